@@ -1,0 +1,273 @@
+// Fused (grouped) relative-position multi-head self-attention for gfx950.
+//
+// Reference: RelPosMultiHeadSelfAttention.forward (models/attentions.py:549-620) and
+// GroupedRelPosMultiHeadSelfAttention.forward (attentions.py:645-718), closed form:
+//
+//     S[b,h,i,j] = (Qu[b,h,i] . K[b,h,j] + Qv[b,h,i] . E[h, Tg-1+j-i]) / sqrt(d)
+//     key group j masked iff G*j >= lens[b];  P = softmax_j(S);  O = P V
+//
+// The reference materialises Q E^T as (T x 2T-1), then realigns it with a pad/reshape/slice
+// ("rel_to_abs", attentions.py:483-547) and builds a (B,1,T,T) float mask every forward
+// (attentions.py:1377-1403).  Here one workgroup owns a 64-query tile of one (b, h):
+//   * keys are streamed in blocks of 64 with an online (flash-style) softmax, fp32 statistics;
+//   * the positional term is computed only on the band of 64+64-1 relative rows a tile touches and
+//     realigned through a per-wave LDS skew buffer (write PE[r'][i], read at r' = j - i + 15);
+//   * MFMA operands are swapped (S^T = K Q^T, O^T = V^T P^T) so that every lane owns ONE query
+//     column: running max / sum / rescale are lane-local and the exponentiated scores feed the
+//     second MFMA straight from registers (the 32-key contraction order is permuted consistently
+//     on both operands instead of shuffling P);
+//   * the key-padding mask is evaluated from lens[b]; fully masked key blocks are skipped;
+//   * group-reshape / head split are index arithmetic (inputs are head-major, output is (B*T, D)).
+// All MFMA are v_mfma_f32_16x16x32_bf16, fp32 accumulation.
+#include "kernels.h"
+
+namespace {
+
+constexpr int BI = 64;          // queries per workgroup (16 per wave)
+constexpr int BJ = 64;          // keys per block
+constexpr int SKEW_LD = 84;     // floats per query row of the skew buffer (>= 80, multiple of 4)
+
+template <int DP>
+struct AttnSmem {
+    static constexpr int KROW = DP * 2 + 16;         // bytes per K / E row
+    static constexpr int VROW = BJ * 2 + 16;         // bytes per V^T row
+    static constexpr int K_BYTES = BJ * KROW;
+    static constexpr int V_BYTES = DP * VROW;
+    static constexpr int E_BYTES = 128 * KROW;
+    static constexpr int S_BYTES = 4 * 16 * SKEW_LD * 4;
+    static constexpr int TOTAL = K_BYTES + V_BYTES + E_BYTES + S_BYTES;
+};
+
+template <int DP>
+__global__ __launch_bounds__(256) void relpos_attention_kernel(const AttnParams p) {
+    using SM = AttnSmem<DP>;
+    constexpr int KS = DP / 32;     // k-steps over the head dim
+    constexpr int DT = DP / 16;     // 16-wide output column tiles
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sK = smem;
+    char* sV = sK + SM::K_BYTES;
+    char* sE = sV + SM::V_BYTES;
+    float* sS = reinterpret_cast<float*>(sE + SM::E_BYTES);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int qtiles = (p.Tg + BI - 1) / BI;
+    int id = blockIdx.x;
+    const int qt = id % qtiles; id /= qtiles;
+    const int h = id % p.H; const int b = id / p.H;
+    const int i0 = qt * BI, iw0 = i0 + wave * 16;
+    const size_t bh = (size_t)b * p.H + h;
+    const bf16_t* Qu = p.qu + bh * p.Tg * DP;
+    const bf16_t* Qv = p.qv + bh * p.Tg * DP;
+    const bf16_t* Kh = p.kh + bh * p.Tg * DP;
+    const bf16_t* Vt = p.vt + bh * (size_t)DP * p.Tgp;
+    const bf16_t* Eh = p.eh + (size_t)h * (2 * p.Tg - 1) * DP;
+
+    int nkeys = (p.lens[b] + p.G - 1) / p.G;          // unmasked key groups: G*j < lens[b]
+    nkeys = nkeys < p.Tg ? nkeys : p.Tg;
+    nkeys = nkeys < 1 ? 1 : nkeys;
+
+    // ---- this lane's query (column c of the wave's 16): B operands of S^T = K Q^T, kept in registers
+    bf16x8 qu[KS], qv[KS];
+    {
+        const int i = iw0 + c;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            uint4 a = make_uint4(0, 0, 0, 0), bq = a;
+            const int x = ks * 32 + g * 8;
+            if (i < p.Tg && x < p.d) {
+                a = mask_chunk(*reinterpret_cast<const uint4*>(Qu + (size_t)i * DP + x), p.d - x);
+                bq = mask_chunk(*reinterpret_cast<const uint4*>(Qv + (size_t)i * DP + x), p.d - x);
+            }
+            qu[ks] = as_bf16x8(a);
+            qv[ks] = as_bf16x8(bq);
+        }
+    }
+
+    f32x4 acc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+    float* skew = sS + wave * 16 * SKEW_LD + c * SKEW_LD;
+    const int woff = 48 - 16 * wave;                  // first band row of this wave inside the workgroup band
+
+    for (int j0 = 0; j0 < nkeys; j0 += BJ) {
+        __syncthreads();                              // previous block's LDS reads are done
+        // ---- stage K block, V^T block and the relative-position band
+        for (int q = tid; q < BJ * (DP / 8); q += 256) {
+            const int r = q / (DP / 8), x = (q - r * (DP / 8)) * 8;
+            const int j = j0 + r;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (j < p.Tg && x < p.d) v = mask_chunk(*reinterpret_cast<const uint4*>(Kh + (size_t)j * DP + x), p.d - x);
+            *reinterpret_cast<uint4*>(sK + r * SM::KROW + x * 2) = v;
+        }
+        for (int q = tid; q < DP * (BJ / 8); q += 256) {
+            const int x = q / (BJ / 8), jc = (q - x * (BJ / 8)) * 8;
+            const int j = j0 + jc;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (x < p.d && j < p.Tg) v = mask_chunk(*reinterpret_cast<const uint4*>(Vt + (size_t)x * p.Tgp + j), p.Tg - j);
+            *reinterpret_cast<uint4*>(sV + x * SM::VROW + jc * 2) = v;
+        }
+        const int rbase = p.Tg - 1 + j0 - i0 - 63;   // E row of band row 0
+        for (int q = tid; q < 128 * (DP / 8); q += 256) {
+            const int rr = q / (DP / 8), x = (q - rr * (DP / 8)) * 8;
+            const int r = rbase + rr;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (r >= 0 && r <= 2 * p.Tg - 2 && x < p.d)
+                v = mask_chunk(*reinterpret_cast<const uint4*>(Eh + (size_t)r * DP + x), p.d - x);
+            *reinterpret_cast<uint4*>(sE + rr * SM::KROW + x * 2) = v;
+        }
+        __syncthreads();
+
+        // ---- S^T tiles: rows = keys (g*4+reg within tile jt), cols = queries (c)
+        f32x4 st[4];
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            st[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(sK + (jt * 16 + c) * SM::KROW + (ks * 32 + g * 8) * 2);
+                st[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qu[ks], st[jt], 0, 0, 0);
+            }
+        }
+        // ---- positional band: PE^T[r'][i] = E[rbase_w + r'] . Qv[i], r' in [0, 80)
+#pragma unroll
+        for (int rt = 0; rt < 5; ++rt) {
+            f32x4 pe = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(sE + (woff + rt * 16 + c) * SM::KROW + (ks * 32 + g * 8) * 2);
+                pe = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qv[ks], pe, 0, 0, 0);
+            }
+            *reinterpret_cast<f32x4*>(skew + rt * 16 + g * 4) = pe;
+        }
+        __syncthreads();                              // skew buffer written (wave-local data; barrier for ordering)
+
+        // ---- realign (r' = j_local - i_local + 15), scale, mask, online softmax
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int jl = jt * 16 + g * 4 + r;
+                float s = (st[jt][r] + skew[jl + 15 - c]) * p.scale;
+                s = (j0 + jl < nkeys) ? s : -INFINITY;
+                st[jt][r] = s;
+                mloc = fmaxf(mloc, s);
+            }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 16));
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+        const float m_new = fmaxf(m_run, mloc);       // finite: key j0 of every visited block is unmasked
+        const float alpha = __expf(m_run - m_new);
+        m_run = m_new;
+        float lsum = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = __expf(st[jt][r] - m_new);
+                st[jt][r] = e;
+                lsum += e;
+            }
+        l_run = l_run * alpha + lsum;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            acc[dt][0] *= alpha; acc[dt][1] *= alpha; acc[dt][2] *= alpha; acc[dt][3] *= alpha;
+        }
+        // ---- O^T += V^T P^T ; contraction slot (g, e) <-> key (2*c2 + (e>>2))*16 + g*4 + (e&3) on both operands
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+            uint4 pb;
+            pb.x = pack_bf2(st[2 * c2][0], st[2 * c2][1]);
+            pb.y = pack_bf2(st[2 * c2][2], st[2 * c2][3]);
+            pb.z = pack_bf2(st[2 * c2 + 1][0], st[2 * c2 + 1][1]);
+            pb.w = pack_bf2(st[2 * c2 + 1][2], st[2 * c2 + 1][3]);
+            const bf16x8 pfrag = as_bf16x8(pb);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const char* vrow = sV + (dt * 16 + c) * SM::VROW;
+                const uint2 lo = *reinterpret_cast<const uint2*>(vrow + ((2 * c2) * 16 + g * 4) * 2);
+                const uint2 hi = *reinterpret_cast<const uint2*>(vrow + ((2 * c2 + 1) * 16 + g * 4) * 2);
+                const bf16x8 a = as_bf16x8(make_uint4(lo.x, lo.y, hi.x, hi.y));
+                acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pfrag, acc[dt], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- normalise and scatter back to the un-grouped (B*T, D) layout
+    float l_tot = l_run + __shfl_xor(l_run, 16);
+    l_tot += __shfl_xor(l_tot, 32);
+    const float inv = 1.0f / l_tot;
+    const int i = iw0 + c;
+    if (i < p.Tg) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int x = dt * 16 + g * 4 + r;
+                if (x >= p.d) continue;
+                int n = h * p.d + x, toff = 0;
+                while (n >= p.D) { n -= p.D; ++toff; }
+                const int t = i * p.G + toff;
+                if (t < p.T) p.out[((size_t)b * p.T + t) * p.ldo + n] = f2bf(acc[dt][r] * inv);
+            }
+    }
+}
+
+__global__ void attn_pad_rows_kernel(GemmParams p, int B) {
+    // rows t in [T, Tp): Q = 0 -> Qu = u, Qv = v;  K = V = 0
+    const int Tp = p.Tg * p.G;
+    const int npad = Tp - p.T;
+    const int total = B * npad * p.D;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int nn = idx % p.D;
+        const int rest = idx / p.D;
+        const int t = p.T + rest % npad, b = rest / npad;
+        const int tq = t / p.G, toff = t - tq * p.G;
+        const int flat = toff * p.D + nn;
+        const int h = flat / p.d, x = flat - h * p.d;
+        const size_t i1 = ((size_t)(b * p.H + h) * p.Tg + tq) * p.dpad + x;
+        p.qu[i1] = f2bf(p.u[nn]);
+        p.qv[i1] = f2bf(p.v[nn]);
+        p.kh[i1] = 0;
+        p.vt[((size_t)(b * p.H + h) * p.dpad + x) * p.Tgp + tq] = 0;
+    }
+}
+
+template <int DP>
+int launch_dp(const AttnParams& p, hipStream_t s) {
+    using SM = AttnSmem<DP>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&relpos_attention_kernel<DP>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, SM::TOTAL);
+        attr_set = true;
+    }
+    const int qtiles = (p.Tg + BI - 1) / BI;
+    hipLaunchKernelGGL((relpos_attention_kernel<DP>), dim3(p.B * p.H * qtiles), dim3(256), SM::TOTAL, s, p);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+}  // namespace
+
+int launch_relpos_attention(const AttnParams& p, hipStream_t s) {
+    if (p.B <= 0 || p.Tg <= 0) return 0;
+    if (p.Tgp % 8 || p.dpad < p.d) return -2;
+    switch (p.dpad) {
+        case 32: return launch_dp<32>(p, s);
+        case 64: return launch_dp<64>(p, s);
+        case 96: return launch_dp<96>(p, s);
+        case 128: return launch_dp<128>(p, s);
+        case 160: return launch_dp<160>(p, s);
+        case 192: return launch_dp<192>(p, s);
+    }
+    return -3;
+}
+
+int launch_attn_pad_rows(const GemmParams& p, int B, hipStream_t s) {
+    const int npad = p.Tg * p.G - p.T;
+    if (npad <= 0 || B <= 0) return 0;
+    const int total = B * npad * p.D;
+    hipLaunchKernelGGL(attn_pad_rows_kernel, dim3((total + 255) / 256), dim3(256), 0, s, p, B);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}

@@ -1,0 +1,55 @@
+// Shared device helpers for the gfx950 (CDNA4 / MI355X) kernels of libeffconf.
+// Wavefront = 64 lanes everywhere in this code base; no other target is supported.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;  // storage type for bfloat16 activations / weights
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define EC_WAVE 64
+
+__device__ __forceinline__ uint16_t f2bf(float f) {   // round-to-nearest-even
+    uint32_t u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float swishf_(float x) { return x * sigmoidf_(x); }
+
+// Zero the bf16 elements with index >= valid (0..8) of a 16-byte chunk of 8 bf16.
+__device__ __forceinline__ uint4 mask_chunk(uint4 v, int valid) {
+    if (valid >= 8) return v;
+    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int rem = valid - 2 * i;
+        w[i] = rem <= 0 ? 0u : (rem == 1 ? (w[i] & 0xFFFFu) : w[i]);
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+__device__ __forceinline__ bf16x8 as_bf16x8(uint4 v) {
+    union { uint4 u; bf16x8 b; } c;
+    c.u = v;
+    return c.b;
+}
+
+// XCD-aware, bijective remap of a linear workgroup id: hardware places block b on XCD b % 8
+// (speed only, never correctness); give every XCD a contiguous chunk of the logical tile space so
+// neighbouring tiles (which share operand panels) hit the same private L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int nx = 8;
+    int xcd = bid % nx, idx = bid / nx;
+    int q = nwg / nx, r = nwg % nx;
+    int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+static inline int ec_round_up(int x, int m) { return (x + m - 1) / m * m; }
+static inline int ec_cdiv(int a, int b) { return (a + b - 1) / b; }

@@ -1,0 +1,666 @@
+// libeffconf host side: weight packing, workspace layout, the encoder forward schedule and the C ABI
+// declared in include/effconf.h.  Everything the forward path does is "enqueue kernels on the
+// caller's stream": no allocation, no synchronisation, no host<->device copies (graph-capturable).
+//
+// The forward schedule follows ConformerEncoder.forward (reference models/encoders.py:97-142) and
+// ConformerBlock.forward (models/blocks.py:119-137); see DESIGN.md for the kernel map.
+#include "kernels.h"
+#include "../../include/effconf.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+int fail(const std::string& m) { g_err = m; return -1; }
+#define EC_TRY(expr) do { int _rc = (expr); if (_rc != 0) return fail(std::string(#expr) + " failed rc=" + std::to_string(_rc)); } while (0)
+
+inline int ld8(int d) { return ec_round_up(d, 8); }
+
+uint16_t h_f2bf(float f) {
+    uint32_t u; memcpy(&u, &f, 4);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+struct HostTensor { std::vector<float> data; std::vector<int64_t> shape; };
+
+struct PackedLinear { const bf16_t* w = nullptr; const float* bias = nullptr; int N = 0, K = 0, ldw = 0; };
+struct LNp { const float* g = nullptr; const float* b = nullptr; };
+
+struct BlockW {
+    LNp ln_ffn1, ln_att, ln_conv, ln_ffn2, ln_out;
+    PackedLinear ffn1_a, ffn1_b, qkv, pos, outp, pw1, pw2, res, ffn2_a, ffn2_b;
+    const float *u = nullptr, *v = nullptr, *dw_w = nullptr, *dw_b = nullptr;
+    const bf16_t* pos_table = nullptr;   // [2*max_pos-1][ld8(D)], row r <-> position max_pos-1-r
+};
+
+struct TraceEntry { char name[64]; int64_t offset, rows, cols, ld; int32_t dtype; };
+struct ProfRec { int cls; double flops, bytes; };
+
+}  // namespace
+
+struct EcEncoder {
+    EcConfig cfg;
+    std::vector<EcBlock> blocks;
+    std::map<std::string, HostTensor> host;
+    bool finalized = false;
+    std::vector<void*> allocs;
+    // packed
+    const float *sub_w9 = nullptr, *sub_b = nullptr;
+    PackedLinear lin;
+    std::vector<BlockW> bw;
+    const float *fc_wt = nullptr, *fc_b = nullptr;
+    const int* block_stride = nullptr;
+    MelTables mel{};
+    // trace
+    char* trace_arena = nullptr; size_t trace_bytes = 0, trace_used = 0;
+    std::vector<TraceEntry> trace;
+    // per-launch event profiler (bench / tuning only; off by default)
+    bool prof_on = false;
+    std::vector<hipEvent_t> prof_ev;          // pairs
+    std::vector<ProfRec> prof_rec;
+    size_t prof_next = 0;
+};
+
+namespace {
+
+template <class T>
+const T* upload(EcEncoder* e, const std::vector<T>& v) {
+    void* d = nullptr;
+    size_t bytes = std::max<size_t>(v.size() * sizeof(T), 16);
+    if (hipMalloc(&d, bytes) != hipSuccess) return nullptr;
+    e->allocs.push_back(d);
+    if (!v.empty() && hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    return reinterpret_cast<const T*>(d);
+}
+
+const HostTensor* find(EcEncoder* e, const std::string& k) {
+    auto it = e->host.find(k);
+    return it == e->host.end() ? nullptr : &it->second;
+}
+
+// [N][K] fp32 (row-major, possibly a gather of rows given by `rows`) -> padded bf16 + padded bias
+bool pack_linear(EcEncoder* e, const std::vector<const float*>& row_ptr, const std::vector<float>& bias, int K, PackedLinear* out) {
+    const int N = (int)row_ptr.size();
+    const int Np = ec_round_up(N, 128), Kp = ec_round_up(K, 64);
+    std::vector<uint16_t> w((size_t)Np * Kp, 0);
+    for (int n = 0; n < N; ++n) {
+        if (!row_ptr[n]) continue;
+        for (int k = 0; k < K; ++k) w[(size_t)n * Kp + k] = h_f2bf(row_ptr[n][k]);
+    }
+    std::vector<float> b(Np, 0.f);
+    for (int n = 0; n < N && n < (int)bias.size(); ++n) b[n] = bias[n];
+    out->w = upload(e, w);
+    out->bias = upload(e, b);
+    out->N = N; out->K = K; out->ldw = Kp;
+    return out->w && out->bias;
+}
+
+bool pack_named_linear(EcEncoder* e, const std::string& prefix, int N, int K, PackedLinear* out, std::string* err) {
+    const HostTensor* w = find(e, prefix + ".weight");
+    const HostTensor* b = find(e, prefix + ".bias");
+    if (!w || !b) { *err = "missing tensor " + prefix + ".weight/.bias"; return false; }
+    if ((int64_t)w->data.size() != (int64_t)N * K || (int)b->data.size() != N) { *err = "shape mismatch for " + prefix; return false; }
+    std::vector<const float*> rows(N);
+    for (int n = 0; n < N; ++n) rows[n] = w->data.data() + (size_t)n * K;
+    return pack_linear(e, rows, b->data, K, out);
+}
+
+bool get_ln(EcEncoder* e, const std::string& prefix, int D, LNp* out, std::string* err) {
+    const HostTensor* g = find(e, prefix + ".weight");
+    const HostTensor* b = find(e, prefix + ".bias");
+    if (!g || !b || (int)g->data.size() != D || (int)b->data.size() != D) { *err = "missing/mis-shaped LayerNorm " + prefix; return false; }
+    out->g = upload(e, g->data);
+    out->b = upload(e, b->data);
+    return out->g && out->b;
+}
+
+// BatchNorm(eval) fold: y = (x - mean) / sqrt(var + 1e-5) * gamma + beta  -> per-channel scale / shift
+bool bn_fold(EcEncoder* e, const std::string& prefix, int C, std::vector<float>* scale, std::vector<float>* shift, std::string* err) {
+    const HostTensor *g = find(e, prefix + ".weight"), *b = find(e, prefix + ".bias");
+    const HostTensor *m = find(e, prefix + ".running_mean"), *v = find(e, prefix + ".running_var");
+    if (!g || !b || !m || !v || (int)g->data.size() != C) { *err = "missing/mis-shaped BatchNorm " + prefix; return false; }
+    scale->resize(C); shift->resize(C);
+    for (int c = 0; c < C; ++c) {
+        const float s = g->data[c] / std::sqrt(v->data[c] + 1e-5f);
+        (*scale)[c] = s;
+        (*shift)[c] = b->data[c] - m->data[c] * s;
+    }
+    return true;
+}
+
+// Relative sinusoid table, fp32 operation order of the reference (attentions.py:1219-1226 / 1275-1284):
+// angle = pos / 10000^(2i/D) in fp32, row r <-> position max_pos-1-r, even cols sin, odd cols cos.
+const bf16_t* build_pos_table(EcEncoder* e, int max_pos, int D) {
+    const int rows = 2 * max_pos - 1, ld = ld8(D);
+    std::vector<uint16_t> t((size_t)rows * ld, 0);
+    std::vector<float> denom(D / 2);
+    for (int i = 0; i < D / 2; ++i) denom[i] = std::pow(10000.0f, (2.0f * (float)i) / (float)D);
+    for (int r = 0; r < rows; ++r) {
+        const float pos = (float)(max_pos - 1 - r);
+        for (int i = 0; i < D / 2; ++i) {
+            const float a = pos / denom[i];
+            t[(size_t)r * ld + 2 * i] = h_f2bf(std::sin(a));
+            t[(size_t)r * ld + 2 * i + 1] = h_f2bf(std::cos(a));
+        }
+    }
+    return upload(e, t);
+}
+
+bool build_mel_tables(EcEncoder* e, std::string* err) {
+    const EcConfig& c = e->cfg;
+    if (c.n_fft != 512) { *err = "only n_fft = 512 is native"; return false; }
+    // Hann(win_length, periodic) centred in n_fft (torch.stft pads the window on both sides)
+    std::vector<float> win(c.n_fft, 0.f);
+    const int off = (c.n_fft - c.win_length) / 2;
+    for (int n = 0; n < c.win_length; ++n) win[off + n] = (float)(0.5 - 0.5 * std::cos(2.0 * M_PI * n / c.win_length));
+    std::vector<float2> tw(c.n_fft / 2);
+    for (int k = 0; k < c.n_fft / 2; ++k) {
+        const double a = -2.0 * M_PI * k / c.n_fft;
+        tw[k] = make_float2((float)std::cos(a), (float)std::sin(a));
+    }
+    // HTK triangular filterbank, f in [0, 8000], no area normalisation (torchaudio melscale_fbanks, modules.py:82)
+    const int nf = c.n_fft / 2 + 1, nm = c.n_mels;
+    const double fmin = 0.0, fmax = 8000.0;
+    auto hz2mel = [](double f) { return 2595.0 * std::log10(1.0 + f / 700.0); };
+    auto mel2hz = [](double m) { return 700.0 * (std::pow(10.0, m / 2595.0) - 1.0); };
+    std::vector<double> fpts(nm + 2);
+    for (int i = 0; i < nm + 2; ++i) fpts[i] = mel2hz(hz2mel(fmin) + (hz2mel(fmax) - hz2mel(fmin)) * i / (nm + 1));
+    std::vector<int> start(nm), count(nm), offs(nm);
+    std::vector<float> wts;
+    for (int m = 0; m < nm; ++m) {
+        int s0 = -1, cnt = 0;
+        std::vector<float> row;
+        for (int k = 0; k < nf; ++k) {
+            const double f = (double)(c.sample_rate / 2) * k / (nf - 1);
+            const double down = (f - fpts[m]) / (fpts[m + 1] - fpts[m]);
+            const double up = (fpts[m + 2] - f) / (fpts[m + 2] - fpts[m + 1]);
+            const double w = std::max(0.0, std::min(down, up));
+            if (w > 0.0) {
+                if (s0 < 0) s0 = k;
+                row.resize(k - s0 + 1, 0.f);
+                row[k - s0] = (float)w;
+                cnt = k - s0 + 1;
+            }
+        }
+        start[m] = s0 < 0 ? 0 : s0; count[m] = cnt; offs[m] = (int)wts.size();
+        wts.insert(wts.end(), row.begin(), row.begin() + cnt);
+    }
+    e->mel.window = upload(e, win);
+    e->mel.twiddle = upload(e, tw);
+    e->mel.fb_start = upload(e, start);
+    e->mel.fb_count = upload(e, count);
+    e->mel.fb_offset = upload(e, offs);
+    e->mel.fb_weight = upload(e, wts);
+    return e->mel.window && e->mel.twiddle && e->mel.fb_weight;
+}
+
+// ------------------------------------------------------------------ shapes + workspace layout
+struct Shapes {
+    int B, Tm, T1;
+    std::vector<int> Tin, Tout;   // frames entering / leaving each block
+};
+
+Shapes make_shapes(const EcEncoder* e, int B, int Tm) {
+    Shapes s; s.B = B; s.Tm = Tm;
+    int t = Tm;
+    for (int i = 0; i < e->cfg.sub_layers; ++i) t = (t - 1) / 2 + 1;
+    s.T1 = t;
+    for (const EcBlock& b : e->blocks) {
+        s.Tin.push_back(t);
+        if (b.conv_stride > 1) t = (t - 1) / b.conv_stride + 1;
+        s.Tout.push_back(t);
+    }
+    return s;
+}
+
+struct Workspace {
+    size_t total = 0;
+    size_t mel, sub, x0, x1, a, hbuf, qu, qv, kh, vt, eh, o, gbuf, cbuf, xs, lens, preds;
+};
+
+inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+
+Workspace make_workspace(const EcEncoder* e, const Shapes& s, bool from_audio) {
+    Workspace w;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += al(bytes); return o; };
+    const size_t B = s.B;
+    size_t mx = 0, ma = 0, mh = 0, mq = 0, mvt = 0, me = 0, mg = 0, mc = 0;
+    for (size_t k = 0; k < e->blocks.size(); ++k) {
+        const EcBlock& b = e->blocks[k];
+        const size_t T = s.Tin[k], To = s.Tout[k], D = b.dim_model, De = b.dim_expand;
+        const size_t Tp = ec_round_up((int)T, b.group_size), Tg = Tp / b.group_size, Tgp = ec_round_up((int)Tg, 8);
+        const size_t d = (size_t)b.group_size * D / b.num_heads, dpad = ec_round_up((int)d, 32);
+        mx = std::max(mx, std::max(B * T * D, B * To * De) * 4);
+        ma = std::max(ma, std::max(B * T * ld8(D), B * To * ld8(De)) * 2);
+        mh = std::max(mh, std::max(B * T * D, B * To * De) * b.ff_ratio * 2);
+        mq = std::max(mq, B * b.num_heads * Tg * dpad * 2);
+        mvt = std::max(mvt, B * b.num_heads * dpad * Tgp * 2);
+        me = std::max(me, (size_t)b.num_heads * (2 * Tg - 1) * dpad * 2);
+        mg = std::max(mg, B * T * ld8(De) * 2);
+        mc = std::max(mc, B * To * ld8(De) * 2);
+    }
+    w.mel = take(from_audio ? B * e->cfg.n_mels * s.Tm * 4 : 0);
+    const int C = e->cfg.sub_filters[e->cfg.sub_layers - 1];
+    int F = e->cfg.n_mels; for (int i = 0; i < e->cfg.sub_layers; ++i) F /= 2;
+    w.sub = take(B * s.T1 * C * F * 2);
+    w.x0 = take(mx); w.x1 = take(mx);
+    w.a = take(ma); w.hbuf = take(mh);
+    w.qu = take(mq); w.qv = take(mq); w.kh = take(mq); w.vt = take(mvt); w.eh = take(me);
+    w.o = take(ma); w.gbuf = take(mg); w.cbuf = take(mc); w.xs = take(ma);
+    w.lens = take((e->blocks.size() + 1) * B * 4);
+    w.preds = take(0);
+    w.total = off;
+    return w;
+}
+
+// ------------------------------------------------------------------ per-launch profiler
+struct ProfScope {
+    EcEncoder* e; hipStream_t st; bool on;
+    ProfScope(EcEncoder* e_, hipStream_t st_, int cls, double flops, double bytes) : e(e_), st(st_), on(e_->prof_on) {
+        if (!on) return;
+        if (e->prof_next + 2 > e->prof_ev.size()) {
+            for (int i = 0; i < 2; ++i) { hipEvent_t ev; (void)hipEventCreate(&ev); e->prof_ev.push_back(ev); }
+        }
+        e->prof_rec.push_back(ProfRec{cls, flops, bytes});
+        (void)hipEventRecord(e->prof_ev[e->prof_next], st);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(e->prof_ev[e->prof_next + 1], st);
+        e->prof_next += 2;
+    }
+};
+#define PROF(cls, flops, bytes) ProfScope _prof_scope(e, st, (cls), (double)(flops), (double)(bytes))
+
+// ------------------------------------------------------------------ forward
+void trace_add(EcEncoder* e, hipStream_t st, const char* name, const void* ptr, int64_t rows, int64_t cols, int64_t ld, int dtype) {
+    if (!e->trace_arena) return;
+    const size_t esz = dtype == 1 ? 2 : 4;
+    const size_t bytes = (size_t)rows * ld * esz;
+    const size_t off = al(e->trace_used);
+    if (off + bytes > e->trace_bytes) return;
+    (void)hipMemcpyAsync(e->trace_arena + off, ptr, bytes, hipMemcpyDeviceToDevice, st);
+    TraceEntry t{};
+    snprintf(t.name, sizeof(t.name), "%s", name);
+    t.offset = (int64_t)off; t.rows = rows; t.cols = cols; t.ld = ld; t.dtype = dtype;
+    e->trace.push_back(t);
+    e->trace_used = off + bytes;
+}
+
+enum ProfClass { PC_MEL = 0, PC_SUBCONV = 1, PC_GEMM_FFN = 2, PC_GEMM_OTHER = 3, PC_LAYERNORM = 4, PC_ATTENTION = 5,
+                 PC_DWCONV = 6, PC_MISC = 7, PC_COUNT = 8 };
+
+int run_gemm(EcEncoder* e, int cls, hipStream_t st, const bf16_t* A, int lda, int M, const PackedLinear& L, int epi, void* C, int ldc,
+             const float* R = nullptr, int ldr = 0, float alpha = 1.f) {
+    const double out_b = (epi == EPI_F32) ? 4.0 : (epi == EPI_RESID_F32 ? 8.0 : 2.0);
+    PROF(cls, 2.0 * M * (double)L.N * L.K, (double)M * L.K * 2 + (double)L.N * L.K * 2 + (double)M * L.N * out_b);
+    GemmParams p{};
+    p.A = A; p.lda = lda; p.W = L.w; p.ldw = L.ldw; p.bias = L.bias;
+    p.M = M; p.N = L.N; p.K = L.K; p.C = C; p.ldc = ldc; p.R = R; p.ldr = ldr; p.alpha = alpha;
+    return launch_gemm(p, epi, st);
+}
+
+int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from_audio, const Shapes& s, const Workspace& w,
+                 char* ws, float* out, int64_t* out_len, hipStream_t st) {
+    const EcConfig& c = e->cfg;
+    const int B = s.B, nb = (int)e->blocks.size();
+    e->trace.clear(); e->trace_used = 0;
+    int* lens = reinterpret_cast<int*>(ws + w.lens);
+    { PROF(PC_MISC, 0, 0); EC_TRY(launch_lengths(in_len, B, from_audio, c.hop_length, c.sub_layers, e->block_stride, nb, lens, out_len, st)); }
+    if (from_audio) trace_add(e, st, "mel", mel, (int64_t)B * c.n_mels, s.Tm, s.Tm, 0);
+
+    // ---- Conv2dSubsampling (modules.py:232-249) + transpose + Linear (encoders.py:113-116)
+    bf16_t* sub = reinterpret_cast<bf16_t*>(ws + w.sub);
+    const int C0 = c.sub_filters[0], F2 = c.n_mels / 2, Ksub = C0 * F2;
+    { PROF(PC_SUBCONV, 2.0 * 9 * B * s.T1 * (double)Ksub, (double)B * c.n_mels * s.Tm * 4 + (double)B * s.T1 * Ksub * 2); EC_TRY(launch_subsample_conv(mel, B, c.n_mels, s.Tm, s.T1, e->sub_w9, e->sub_b, C0, sub, Ksub, st)); }
+    trace_add(e, st, "subsample", sub, (int64_t)B * s.T1, Ksub, Ksub, 1);
+    float* x = reinterpret_cast<float*>(ws + w.x0);
+    float* xalt = reinterpret_cast<float*>(ws + w.x1);
+    EC_TRY(run_gemm(e, PC_GEMM_OTHER, st, sub, Ksub, B * s.T1, e->lin, EPI_F32, x, e->lin.N));
+    trace_add(e, st, "linear", x, (int64_t)B * s.T1, e->lin.N, e->lin.N, 0);
+
+    bf16_t* a = reinterpret_cast<bf16_t*>(ws + w.a);
+    bf16_t* hbuf = reinterpret_cast<bf16_t*>(ws + w.hbuf);
+    bf16_t* o = reinterpret_cast<bf16_t*>(ws + w.o);
+    bf16_t* gbuf = reinterpret_cast<bf16_t*>(ws + w.gbuf);
+    bf16_t* cbuf = reinterpret_cast<bf16_t*>(ws + w.cbuf);
+    bf16_t* xs = reinterpret_cast<bf16_t*>(ws + w.xs);
+    bool have_a = false;
+    char nm[64];
+
+    for (int k = 0; k < nb; ++k) {
+        const EcBlock& b = e->blocks[k];
+        const BlockW& W = e->bw[k];
+        const int T = s.Tin[k], To = s.Tout[k], D = b.dim_model, De = b.dim_expand;
+        const int M = B * T, Mo = B * To;
+        // ---- x += 1/2 FFN1(x)   (blocks.py:122; modules.py:385-392)
+        { PROF(PC_LAYERNORM, 0, (double)M * D * 6); if (!have_a) EC_TRY(launch_layernorm(x, M, D, W.ln_ffn1.g, W.ln_ffn1.b, nullptr, a, ld8(D), nullptr, nullptr, st)); }
+        EC_TRY(run_gemm(e, PC_GEMM_FFN, st, a, ld8(D), M, W.ffn1_a, EPI_SWISH_BF16, hbuf, W.ffn1_a.N));
+        EC_TRY(run_gemm(e, PC_GEMM_FFN, st, hbuf, W.ffn1_a.N, M, W.ffn1_b, EPI_RESID_F32, x, D, x, D, 0.5f));
+        snprintf(nm, sizeof(nm), "blocks.%d.x_ffn1", k); trace_add(e, st, nm, x, M, D, D, 0);
+
+        // ---- x += MHSA(LN(x))   (blocks.py:125-126; modules.py:472-488; attentions.py:549-718)
+        {
+            const int G = b.group_size, H = b.num_heads;
+            const int Tp = ec_round_up(T, G), Tg = Tp / G, Tgp = ec_round_up(Tg, 8);
+            const int d = G * D / H, dpad = ec_round_up(d, 32);
+            { PROF(PC_LAYERNORM, 0, (double)M * D * 6); EC_TRY(launch_layernorm(x, M, D, W.ln_att.g, W.ln_att.b, nullptr, a, ld8(D), nullptr, nullptr, st)); }
+            GemmParams p{};
+            p.A = a; p.lda = ld8(D); p.W = W.qkv.w; p.ldw = W.qkv.ldw; p.bias = W.qkv.bias;
+            p.M = M; p.N = 3 * D; p.K = D;
+            p.T = T; p.G = G; p.H = H; p.D = D; p.d = d; p.dpad = dpad; p.Tg = Tg; p.Tgp = Tgp;
+            p.qu = reinterpret_cast<bf16_t*>(ws + w.qu); p.qv = reinterpret_cast<bf16_t*>(ws + w.qv);
+            p.kh = reinterpret_cast<bf16_t*>(ws + w.kh); p.vt = reinterpret_cast<bf16_t*>(ws + w.vt);
+            p.u = W.u; p.v = W.v;
+            { PROF(PC_GEMM_OTHER, 2.0 * M * 3.0 * D * D, (double)M * D * 2 + 3.0 * D * D * 2 + (double)M * D * 8); EC_TRY(launch_gemm(p, EPI_QKV, st)); }
+            { PROF(PC_MISC, 0, 0); EC_TRY(launch_attn_pad_rows(p, B, st)); }
+            // positional embeddings E = pos_layer(R) (attentions.py:588 / 678): input independent, tiny (2Tp-G rows)
+            GemmParams pe{};
+            const int erows = 2 * Tp - G;
+            pe.A = W.pos_table + (size_t)(b.max_pos - Tp + G / 2) * ld8(D); pe.lda = ld8(D);
+            pe.W = W.pos.w; pe.ldw = W.pos.ldw; pe.bias = W.pos.bias;
+            pe.M = erows; pe.N = D; pe.K = D;
+            pe.T = erows; pe.G = G; pe.H = H; pe.D = D; pe.d = d; pe.dpad = dpad; pe.Tg = 2 * Tg - 1; pe.Tgp = 0;
+            pe.kh = reinterpret_cast<bf16_t*>(ws + w.eh);
+            if (Tp > b.max_pos) return fail("sequence longer than max_pos_encoding");
+            { PROF(PC_GEMM_OTHER, 2.0 * erows * (double)D * D, (double)erows * D * 4 + (double)D * D * 2); EC_TRY(launch_gemm(pe, EPI_HEADS, st)); }
+            AttnParams ap{};
+            ap.qu = p.qu; ap.qv = p.qv; ap.kh = p.kh; ap.vt = p.vt; ap.eh = pe.kh;
+            ap.lens = lens + (size_t)k * B;
+            ap.B = B; ap.H = H; ap.T = T; ap.G = G; ap.D = D; ap.d = d; ap.dpad = dpad; ap.Tg = Tg; ap.Tgp = Tgp;
+            ap.out = o; ap.ldo = ld8(D); ap.scale = 1.0f / std::sqrt((float)d);
+            { PROF(PC_ATTENTION, 2.0 * B * H * (double)Tg * Tg * d * 3.0, (double)M * D * 2 * 5); EC_TRY(launch_relpos_attention(ap, st)); }
+            snprintf(nm, sizeof(nm), "blocks.%d.att_o", k); trace_add(e, st, nm, o, M, D, ld8(D), 1);
+            EC_TRY(run_gemm(e, PC_GEMM_OTHER, st, o, ld8(D), M, W.outp, EPI_RESID_F32, x, D, x, D, 1.0f));
+            snprintf(nm, sizeof(nm), "blocks.%d.x_mhsa", k); trace_add(e, st, nm, x, M, D, D, 0);
+        }
+
+        // ---- x = conv_res(x) + ConvModule(x)   (blocks.py:129; modules.py:511-522)
+        { PROF(PC_LAYERNORM, 0, (double)M * D * 6); EC_TRY(launch_layernorm(x, M, D, W.ln_conv.g, W.ln_conv.b, nullptr, a, ld8(D), nullptr, nullptr, st)); }
+        EC_TRY(run_gemm(e, PC_GEMM_OTHER, st, a, ld8(D), M, W.pw1, EPI_GLU_BF16, gbuf, ld8(De)));
+        { PROF(PC_DWCONV, 2.0 * Mo * (double)De * b.kernel_size, (double)M * De * 2 + (double)Mo * De * 2); EC_TRY(launch_dwconv(gbuf, B, T, To, De, ld8(De), W.dw_w, W.dw_b, b.kernel_size, b.conv_stride, cbuf, st)); }
+        snprintf(nm, sizeof(nm), "blocks.%d.dw", k); trace_add(e, st, nm, cbuf, Mo, De, ld8(De), 1);
+        if (D != De) {   // 1x1 strided conv on frames 0, s, 2s, ...  (blocks.py:106-110)
+            { PROF(PC_MISC, 0, (double)Mo * D * 6); EC_TRY(launch_cast_rows(x, D, T, b.conv_stride, To, B, xs, ld8(D), st)); }
+            EC_TRY(run_gemm(e, PC_GEMM_OTHER, st, xs, ld8(D), Mo, W.res, EPI_F32, xalt, De));
+            std::swap(x, xalt);
+        } else if (b.conv_stride > 1) {
+            return fail("strided block without expansion is not native (no shipped config uses it)");
+        }
+        EC_TRY(run_gemm(e, PC_GEMM_OTHER, st, cbuf, ld8(De), Mo, W.pw2, EPI_RESID_F32, x, De, x, De, 1.0f));
+        snprintf(nm, sizeof(nm), "blocks.%d.x_conv", k); trace_add(e, st, nm, x, Mo, De, De, 0);
+
+        // ---- x += 1/2 FFN2(x); x = LN(x)   (blocks.py:132-135)
+        { PROF(PC_LAYERNORM, 0, (double)Mo * De * 6); EC_TRY(launch_layernorm(x, Mo, De, W.ln_ffn2.g, W.ln_ffn2.b, nullptr, a, ld8(De), nullptr, nullptr, st)); }
+        EC_TRY(run_gemm(e, PC_GEMM_FFN, st, a, ld8(De), Mo, W.ffn2_a, EPI_SWISH_BF16, hbuf, W.ffn2_a.N));
+        EC_TRY(run_gemm(e, PC_GEMM_FFN, st, hbuf, W.ffn2_a.N, Mo, W.ffn2_b, EPI_RESID_F32, x, De, x, De, 0.5f));
+        const bool last = (k == nb - 1);
+        float* xo = last ? out : x;
+        // block-final norm fused with the next block's FFN1 pre-norm (both read the same rows)
+        { PROF(PC_LAYERNORM, 0, (double)Mo * De * 10); EC_TRY(launch_layernorm(x, Mo, De, W.ln_out.g, W.ln_out.b, xo, last ? nullptr : a, ld8(De),
+                                last ? nullptr : e->bw[k + 1].ln_ffn1.g, last ? nullptr : e->bw[k + 1].ln_ffn1.b, st)); }
+        have_a = !last;
+        snprintf(nm, sizeof(nm), "blocks.%d.out", k); trace_add(e, st, nm, xo, Mo, De, De, 0);
+    }
+    return 0;
+}
+
+}  // namespace
+
+// =================================================================== C ABI
+extern "C" {
+
+int effconf_abi_version(void) { return EFFCONF_ABI_VERSION; }
+const char* effconf_last_error(void) { return g_err.c_str(); }
+
+EcEncoder* effconf_encoder_create(const EcConfig* cfg) {
+    if (!cfg || cfg->num_blocks <= 0 || !cfg->blocks) { fail("null / empty config"); return nullptr; }
+    if (cfg->sub_layers != 1) { fail("only one Conv2dSubsampling layer is native (Efficient Conformer configs)"); return nullptr; }
+    if (cfg->n_mels % 4 || cfg->n_mels > 128) { fail("n_mels must be a multiple of 4, <= 128"); return nullptr; }
+    for (int i = 0; i < cfg->num_blocks; ++i) {
+        const EcBlock& b = cfg->blocks[i];
+        if (b.dim_model % 4 || b.dim_expand % 4 || b.kernel_size > 31 || !(b.kernel_size & 1) || !(b.group_size & 1) ||
+            (b.group_size * b.dim_model) % b.num_heads || b.conv_stride < 1 || b.conv_stride > 2 ||
+            ec_round_up(b.group_size * b.dim_model / b.num_heads, 32) > 192) {
+            fail("unsupported block hyper-parameters at block " + std::to_string(i)); return nullptr;
+        }
+    }
+    EcEncoder* e = new EcEncoder();
+    e->cfg = *cfg;
+    e->blocks.assign(cfg->blocks, cfg->blocks + cfg->num_blocks);
+    e->cfg.blocks = e->blocks.data();
+    return e;
+}
+
+void effconf_encoder_destroy(EcEncoder* e) {
+    if (!e) return;
+    for (void* p : e->allocs) (void)hipFree(p);
+    delete e;
+}
+
+int effconf_encoder_load_tensor(EcEncoder* e, const char* key, const float* host, const int64_t* shape, int32_t ndim) {
+    if (!e || !key || !host) return fail("null argument");
+    HostTensor t;
+    int64_t n = 1;
+    for (int i = 0; i < ndim; ++i) { t.shape.push_back(shape[i]); n *= shape[i]; }
+    t.data.assign(host, host + n);
+    e->host[key] = std::move(t);
+    e->finalized = false;
+    return 0;
+}
+
+int effconf_encoder_finalize(EcEncoder* e) {
+    if (!e) return fail("null encoder");
+    for (void* p : e->allocs) (void)hipFree(p);
+    e->allocs.clear();
+    e->bw.assign(e->blocks.size(), BlockW());
+    std::string err;
+    const EcConfig& c = e->cfg;
+    // ---- subsampling conv (C,1,3,3) + BatchNorm2d fold
+    {
+        const int C = c.sub_filters[0];
+        const HostTensor* w = find(e, "subsampling_module.layers.0.0.weight");
+        const HostTensor* b = find(e, "subsampling_module.layers.0.0.bias");
+        std::vector<float> sc, sh;
+        if (!w || !b || (int)w->data.size() != C * 9) return fail("missing subsampling conv weights");
+        if (!bn_fold(e, "subsampling_module.layers.0.1", C, &sc, &sh, &err)) return fail(err);
+        std::vector<float> w9(C * 9), bb(C);
+        for (int ch = 0; ch < C; ++ch) {
+            for (int j = 0; j < 9; ++j) w9[ch * 9 + j] = w->data[ch * 9 + j] * sc[ch];
+            bb[ch] = b->data[ch] * sc[ch] + sh[ch];
+        }
+        e->sub_w9 = upload(e, w9); e->sub_b = upload(e, bb);
+        if (!pack_named_linear(e, "linear", e->blocks[0].dim_model, C * (c.n_mels / 2), &e->lin, &err)) return fail(err);
+    }
+    std::map<std::pair<int, int>, const bf16_t*> tables;
+    std::vector<int> strides;
+    for (size_t k = 0; k < e->blocks.size(); ++k) {
+        const EcBlock& b = e->blocks[k];
+        BlockW& W = e->bw[k];
+        const int D = b.dim_model, De = b.dim_expand, F1 = D * b.ff_ratio, F2 = De * b.ff_ratio;
+        const std::string p = "blocks." + std::to_string(k);
+        strides.push_back(b.conv_stride);
+        bool ok = get_ln(e, p + ".feed_forward_module1.layers.0", D, &W.ln_ffn1, &err) &&
+                  pack_named_linear(e, p + ".feed_forward_module1.layers.1", F1, D, &W.ffn1_a, &err) &&
+                  pack_named_linear(e, p + ".feed_forward_module1.layers.4", D, F1, &W.ffn1_b, &err) &&
+                  get_ln(e, p + ".feed_forward_module2.layers.0", De, &W.ln_ffn2, &err) &&
+                  pack_named_linear(e, p + ".feed_forward_module2.layers.1", F2, De, &W.ffn2_a, &err) &&
+                  pack_named_linear(e, p + ".feed_forward_module2.layers.4", De, F2, &W.ffn2_b, &err) &&
+                  get_ln(e, p + ".norm", De, &W.ln_out, &err);
+        if (!ok) return fail(err);
+        const std::string m = p + ".multi_head_self_attention_module";
+        if (!get_ln(e, m + ".norm", D, &W.ln_att, &err)) return fail(err);
+        {   // Q, K, V stacked into one [3D][D] weight
+            std::vector<const float*> rows; std::vector<float> bias;
+            for (const char* n : {"query_layer", "key_layer", "value_layer"}) {
+                const HostTensor* w = find(e, m + ".mhsa." + n + ".weight");
+                const HostTensor* bb = find(e, m + ".mhsa." + n + ".bias");
+                if (!w || !bb || (int)w->data.size() != D * D) return fail("missing " + m + ".mhsa." + n);
+                for (int r = 0; r < D; ++r) rows.push_back(w->data.data() + (size_t)r * D);
+                bias.insert(bias.end(), bb->data.begin(), bb->data.end());
+            }
+            if (!pack_linear(e, rows, bias, D, &W.qkv)) return fail("upload failed");
+        }
+        if (!pack_named_linear(e, m + ".mhsa.pos_layer", D, D, &W.pos, &err)) return fail(err);
+        if (!pack_named_linear(e, m + ".mhsa.output_layer", D, D, &W.outp, &err)) return fail(err);
+        const HostTensor *u = find(e, m + ".mhsa.u"), *v = find(e, m + ".mhsa.v");
+        if (!u || !v || (int)u->data.size() != D) return fail("missing " + m + ".mhsa.u/v");
+        W.u = upload(e, u->data); W.v = upload(e, v->data);
+        auto key = std::make_pair(b.max_pos, D);
+        if (!tables.count(key)) tables[key] = build_pos_table(e, b.max_pos, D);
+        W.pos_table = tables[key];
+        // ---- convolution module
+        const std::string cm = p + ".convolution_module.layers";
+        if (!get_ln(e, cm + ".0", D, &W.ln_conv, &err)) return fail(err);
+        {   // pointwise-1 (2De, D, 1): GLU halves interleaved in blocks of 32 output channels (a | b)
+            const HostTensor* w = find(e, cm + ".2.weight");
+            const HostTensor* bb = find(e, cm + ".2.bias");
+            if (!w || !bb || (int)w->data.size() != 2 * De * D) return fail("missing " + cm + ".2");
+            const int nblk = ec_cdiv(De, 32);
+            std::vector<const float*> rows(nblk * 64, nullptr); std::vector<float> bias(nblk * 64, 0.f);
+            for (int j = 0; j < De; ++j) {
+                const int jb = j / 32, jj = j % 32;
+                rows[jb * 64 + jj] = w->data.data() + (size_t)j * D;            bias[jb * 64 + jj] = bb->data[j];
+                rows[jb * 64 + 32 + jj] = w->data.data() + (size_t)(De + j) * D; bias[jb * 64 + 32 + jj] = bb->data[De + j];
+            }
+            if (!pack_linear(e, rows, bias, D, &W.pw1)) return fail("upload failed");
+        }
+        {   // depthwise (De, 1, k) + BatchNorm1d fold -> [k][De] fp32
+            const int ks = b.kernel_size;
+            const HostTensor* w = find(e, cm + ".4.weight");
+            const HostTensor* bb = find(e, cm + ".4.bias");
+            std::vector<float> sc, sh;
+            if (!w || !bb || (int)w->data.size() != De * ks) return fail("missing " + cm + ".4");
+            if (!bn_fold(e, cm + ".5", De, &sc, &sh, &err)) return fail(err);
+            std::vector<float> wk((size_t)ks * De), bz(De);
+            for (int ch = 0; ch < De; ++ch) {
+                for (int j = 0; j < ks; ++j) wk[(size_t)j * De + ch] = w->data[(size_t)ch * ks + j] * sc[ch];
+                bz[ch] = bb->data[ch] * sc[ch] + sh[ch];
+            }
+            W.dw_w = upload(e, wk); W.dw_b = upload(e, bz);
+        }
+        if (!pack_named_linear(e, cm + ".7", De, De, &W.pw2, &err)) return fail(err);
+        if (D != De && !pack_named_linear(e, p + ".conv_res.1", De, D, &W.res, &err)) return fail(err);
+    }
+    e->block_stride = upload(e, strides);
+    if (c.vocab_size > 0) {
+        const HostTensor *w = find(e, "fc.weight"), *b = find(e, "fc.bias");
+        const int D = e->blocks.back().dim_expand, V = c.vocab_size;
+        if (w && b) {
+            if ((int)w->data.size() != V * D) return fail("fc.weight shape mismatch");
+            std::vector<float> wt((size_t)D * V);
+            for (int v = 0; v < V; ++v) for (int k = 0; k < D; ++k) wt[(size_t)k * V + v] = w->data[(size_t)v * D + k];
+            e->fc_wt = upload(e, wt); e->fc_b = upload(e, b->data);
+        }
+    }
+    if (!build_mel_tables(e, &err)) return fail(err);
+    for (void* p : e->allocs) if (!p) return fail("device allocation failed");
+    if (hipDeviceSynchronize() != hipSuccess) return fail("upload failed");
+    e->host.clear();
+    e->finalized = true;
+    return 0;
+}
+
+size_t effconf_encoder_workspace_bytes(const EcEncoder* e, int32_t batch, int32_t n, int32_t from_audio) {
+    if (!e || batch <= 0 || n <= 0) return 0;
+    const int Tm = from_audio ? n / e->cfg.hop_length + 1 : n;
+    return make_workspace(e, make_shapes(e, batch, Tm), from_audio != 0).total;
+}
+
+int32_t effconf_encoder_out_frames(const EcEncoder* e, int32_t n, int32_t from_audio) {
+    if (!e || n <= 0) return 0;
+    const int Tm = from_audio ? n / e->cfg.hop_length + 1 : n;
+    return make_shapes(e, 1, Tm).Tout.back();
+}
+
+int effconf_encoder_forward_mel(EcEncoder* e, const float* mel, const int64_t* mel_len, int32_t batch, int32_t n_frames,
+                                float* out, int64_t* out_len, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!e || !e->finalized) return fail("encoder not finalized");
+    if (!mel || !mel_len || !out || !workspace || batch <= 0 || n_frames <= 0) return fail("bad argument");
+    const Shapes s = make_shapes(e, batch, n_frames);
+    const Workspace w = make_workspace(e, s, false);
+    if (workspace_bytes < w.total) return fail("workspace too small");
+    return forward_core(e, mel, mel_len, 0, s, w, reinterpret_cast<char*>(workspace), out, out_len, (hipStream_t)stream);
+}
+
+int effconf_encoder_forward(EcEncoder* e, const float* audio, const int64_t* x_len, int32_t batch, int32_t n_samples,
+                            float* out, int64_t* out_len, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!e || !e->finalized) return fail("encoder not finalized");
+    if (!audio || !x_len || !out || !workspace || batch <= 0 || n_samples <= e->cfg.n_fft / 2) return fail("bad argument");
+    const int Tm = n_samples / e->cfg.hop_length + 1;
+    const Shapes s = make_shapes(e, batch, Tm);
+    const Workspace w = make_workspace(e, s, true);
+    if (workspace_bytes < w.total) return fail("workspace too small");
+    char* ws = reinterpret_cast<char*>(workspace);
+    float* mel = reinterpret_cast<float*>(ws + w.mel);
+    hipStream_t st = (hipStream_t)stream;
+    { PROF(PC_MEL, 0, (double)batch * n_samples * 4 + (double)batch * e->cfg.n_mels * Tm * 4); EC_TRY(launch_mel(audio, batch, n_samples, e->mel, e->cfg.n_fft, e->cfg.hop_length, e->cfg.n_mels, Tm,
+                      e->cfg.normalize, e->cfg.mean, e->cfg.std, mel, st)); }
+    return forward_core(e, mel, x_len, 1, s, w, ws, out, out_len, st);
+}
+
+int effconf_mel_frontend(EcEncoder* e, const float* audio, int32_t batch, int32_t n_samples, float* mel, void* stream) {
+    if (!e || !e->finalized) return fail("encoder not finalized");
+    const int Tm = n_samples / e->cfg.hop_length + 1;
+    EC_TRY(launch_mel(audio, batch, n_samples, e->mel, e->cfg.n_fft, e->cfg.hop_length, e->cfg.n_mels, Tm,
+                      e->cfg.normalize, e->cfg.mean, e->cfg.std, mel, (hipStream_t)stream));
+    return 0;
+}
+
+int effconf_ctc_greedy(EcEncoder* e, const float* enc_out, const int64_t* out_len, int32_t batch, int32_t t_out,
+                       int32_t* labels, int32_t* label_len, float* logits, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!e || !e->finalized) return fail("encoder not finalized");
+    if (!e->fc_wt) return fail("no CTC head (fc.weight / fc.bias) loaded");
+    if (workspace_bytes < (size_t)batch * t_out * 4) return fail("workspace too small");
+    int* preds = reinterpret_cast<int*>(workspace);
+    hipStream_t st = (hipStream_t)stream;
+    EC_TRY(launch_ctc_argmax(enc_out, batch * t_out, e->blocks.back().dim_expand, e->fc_wt, e->fc_b, e->cfg.vocab_size,
+                             preds, logits, st));
+    EC_TRY(launch_ctc_collapse(preds, out_len, batch, t_out, labels, label_len, st));
+    return 0;
+}
+
+int effconf_profile_enable(EcEncoder* e, int32_t enable) {
+    if (!e) return fail("null encoder");
+    e->prof_on = enable != 0; e->prof_next = 0; e->prof_rec.clear();
+    return 0;
+}
+
+int effconf_profile_read(EcEncoder* e, int32_t cls, double* total_ms, int64_t* launches, double* flops, double* bytes) {
+    if (!e || cls < 0 || cls >= PC_COUNT) return fail("bad profile class");
+    if (hipDeviceSynchronize() != hipSuccess) return fail("sync failed");
+    double ms = 0, fl = 0, by = 0; int64_t n = 0;
+    for (size_t i = 0; i < e->prof_rec.size(); ++i) {
+        if (e->prof_rec[i].cls != cls) continue;
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, e->prof_ev[2 * i], e->prof_ev[2 * i + 1]) != hipSuccess) return fail("event read failed");
+        ms += t; fl += e->prof_rec[i].flops; by += e->prof_rec[i].bytes; ++n;
+    }
+    *total_ms = ms; *launches = n; *flops = fl; *bytes = by;
+    return 0;
+}
+
+int effconf_encoder_set_trace(EcEncoder* e, void* dev_arena, size_t bytes) {
+    if (!e) return fail("null encoder");
+    e->trace_arena = reinterpret_cast<char*>(dev_arena); e->trace_bytes = bytes; e->trace_used = 0; e->trace.clear();
+    return 0;
+}
+int32_t effconf_encoder_trace_count(const EcEncoder* e) { return e ? (int32_t)e->trace.size() : 0; }
+int effconf_encoder_trace_entry(const EcEncoder* e, int32_t i, char* name64, int64_t* offset, int64_t* rows, int64_t* cols,
+                                int64_t* ld, int32_t* dtype) {
+    if (!e || i < 0 || i >= (int)e->trace.size()) return fail("bad trace index");
+    const TraceEntry& t = e->trace[i];
+    memcpy(name64, t.name, 64);
+    *offset = t.offset; *rows = t.rows; *cols = t.cols; *ld = t.ld; *dtype = t.dtype;
+    return 0;
+}
+
+}  // extern "C"

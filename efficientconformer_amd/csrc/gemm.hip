@@ -1,0 +1,247 @@
+// bf16 MFMA GEMM with fused epilogues for the Conformer encoder (gfx950).
+//
+//   C[m, n] = sum_k A[m, k] * W[n, k] + bias[n]
+//
+// Replaces every nn.Linear / pointwise Conv1d on the hot path of the reference
+// (models/layers.py:57-67, 122-136; call sites modules.py:378-382, 502-508, attentions.py:57-60, 471;
+// encoders.py:116) together with the element-wise op that follows it (Swish, GLU, residual add,
+// +u/+v and the (B,T,D)->(B,H,T/G,d) head split of attentions.py:674-686).
+//
+// Tiling: 128 x BN x 64 block tile, 4 waves (2x2), each wave 64 x BN/2 built from
+// v_mfma_f32_32x32x16_bf16; register-staged global->LDS double buffer with one barrier per k-tile;
+// LDS rows padded by 16 B (row stride 144 B = 9 x 16 B slots, conflict-free for ds_read_b128).
+// M is large (B*T), N and K are small/odd multiples of 4: A tail chunks are masked in registers,
+// weights are zero-padded once at pack time.
+#include "kernels.h"
+
+namespace {
+
+constexpr int BM = 128;
+constexpr int BK = 64;
+constexpr int LROW = BK * 2 + 16;   // bytes per LDS row
+
+struct FastDiv {   // exact for n * d < 2^32
+    uint32_t mul, d;
+    __host__ __device__ FastDiv() : mul(0), d(1) {}
+    __host__ explicit FastDiv(uint32_t dd) : mul(dd > 1 ? (uint32_t)((1ull << 32) / dd + 1) : 0), d(dd) {}
+    __device__ __forceinline__ uint32_t div(uint32_t n) const { return d == 1 ? n : __umulhi(n, mul); }
+};
+
+struct GemmDev {
+    GemmParams p;
+    FastDiv fG, fD, fd;
+};
+
+template <int BN, int EPI>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmDev gd) {
+    const GemmParams& p = gd.p;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sA = smem;                       // [2][BM][LROW]
+    char* sB = smem + 2 * BM * LROW;       // [2][BN][LROW]
+    constexpr int NB = BN / 32;            // B chunks per thread
+    constexpr int NF = BN / 64;            // 32-col fragments per wave
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int n_tiles = (p.N + BN - 1) / BN;
+    const int m_tiles = (p.M + BM - 1) / BM;
+    const int id = xcd_remap(blockIdx.x, m_tiles * n_tiles);
+    const int tm = id / n_tiles, tn = id - tm * n_tiles;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // ---- staging addresses (constant over the k loop)
+    const int srow = tid >> 3, kc = tid & 7;
+    const bf16_t* a_ptr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int m = m0 + srow + 32 * i;
+        m = m < p.M ? m : p.M - 1;
+        size_t src = m;
+        if (p.a_rows > 0) {
+            int b = m / p.a_rows, r = m - b * p.a_rows;
+            src = (size_t)b * p.a_pitch + (size_t)r * p.a_stride;
+        }
+        a_ptr[i] = p.A + src * p.lda + kc * 8;
+    }
+    const bf16_t* b_ptr[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) b_ptr[i] = p.W + (size_t)(n0 + srow + 32 * i) * p.ldw + kc * 8;
+
+    uint4 ra[4], rb[NB];
+    auto load_tile = [&](int kt) {
+        const int k = kt * BK + kc * 8;
+        const int valid = p.K - k;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (valid > 0) v = mask_chunk(*reinterpret_cast<const uint4*>(a_ptr[i] + kt * BK), valid);
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const uint4*>(b_ptr[i] + kt * BK);
+    };
+    auto store_tile = [&](int buf) {
+        char* a = sA + buf * BM * LROW;
+        char* b = sB + buf * BN * LROW;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(a + (srow + 32 * i) * LROW + kc * 16) = ra[i];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) *reinterpret_cast<uint4*>(b + (srow + 32 * i) * LROW + kc * 16) = rb[i];
+    };
+
+    f32x16 acc[2][NF];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NF; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    const int nk = (p.K + BK - 1) / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    const int frag_off = (lane & 31) * LROW + (lane >> 5) * 16;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);
+        const char* a = sA + buf * BM * LROW + (wm * 64) * LROW + frag_off;
+        const char* b = sB + buf * BN * LROW + (wn * (BN / 2)) * LROW + frag_off;
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            bf16x8 af[2], bf[NF];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) af[mi] = *reinterpret_cast<const bf16x8*>(a + mi * 32 * LROW + kk * 32);
+#pragma unroll
+            for (int ni = 0; ni < NF; ++ni) bf[ni] = *reinterpret_cast<const bf16x8*>(b + ni * 32 * LROW + kk * 32);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NF; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue.  C layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    const int lcol = lane & 31, lrow = 4 * (lane >> 5);
+    if constexpr (EPI == EPI_GLU_BF16) {
+        static_assert(BN == 128, "GLU needs both halves in one wave");
+        const int j = (n0 + wn * 64) / 2 + lcol;           // output channel
+        const float ba = p.bias[n0 + wn * 64 + lcol], bb = p.bias[n0 + wn * 64 + 32 + lcol];
+        bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
+        if (j < p.ldc) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + lrow;
+                    if (m < p.M) C[(size_t)m * p.ldc + j] = f2bf((acc[mi][0][r] + ba) * sigmoidf_(acc[mi][1][r] + bb));
+                }
+        }
+    } else if constexpr (EPI == EPI_QKV || EPI == EPI_HEADS) {
+        // rows m = (b, t); grouped view: t = G*tq + toff; flat = toff*D + nn; head h = flat / d, x = flat % d
+        int b0 = 0, t0 = m0 + wm * 64;
+        if (EPI == EPI_QKV) { b0 = t0 / p.T; t0 -= b0 * p.T; }
+#pragma unroll
+        for (int ni = 0; ni < NF; ++ni) {
+            const int n = n0 + wn * (BN / 2) + ni * 32 + lcol;
+            if (n >= p.N) continue;
+            int which = 1, nn = n;
+            if (EPI == EPI_QKV) { which = gd.fD.div(n); nn = n - which * p.D; }
+            const float bias = p.bias[n];
+            float bu = 0.f, bv = 0.f;
+            if (EPI == EPI_QKV && which == 0) { bu = p.u[nn]; bv = p.v[nn]; }
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rr = mi * 32 + (r & 3) + 8 * (r >> 2) + lrow;
+                    if (m0 + wm * 64 + rr >= p.M) continue;
+                    int b = b0, t = t0 + rr;
+                    if (EPI == EPI_QKV) while (t >= p.T) { t -= p.T; ++b; }
+                    const int tq = gd.fG.div(t), toff = t - tq * p.G;
+                    const int flat = toff * p.D + nn;
+                    const int h = gd.fd.div(flat), x = flat - h * p.d;
+                    const float val = acc[mi][ni][r] + bias;
+                    const size_t idx = ((size_t)(b * p.H + h) * p.Tg + tq) * p.dpad + x;
+                    if (which == 0) { p.qu[idx] = f2bf(val + bu); p.qv[idx] = f2bf(val + bv); }
+                    else if (which == 1) p.kh[idx] = f2bf(val);
+                    else p.vt[((size_t)(b * p.H + h) * p.dpad + x) * p.Tgp + tq] = f2bf(val);
+                }
+        }
+    } else {
+#pragma unroll
+        for (int ni = 0; ni < NF; ++ni) {
+            const int n = n0 + wn * (BN / 2) + ni * 32 + lcol;
+            const bool f32out = (EPI == EPI_F32 || EPI == EPI_RESID_F32);
+            const int nlim = f32out ? p.N : p.ldc;   // bf16 outputs also write their (zero) pad columns
+            if (n >= nlim) continue;
+            const float bias = p.bias[n];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + lrow;
+                    if (m >= p.M) continue;
+                    float val = acc[mi][ni][r] + bias;
+                    if constexpr (EPI == EPI_F32) {
+                        reinterpret_cast<float*>(p.C)[(size_t)m * p.ldc + n] = val;
+                    } else if constexpr (EPI == EPI_RESID_F32) {
+                        reinterpret_cast<float*>(p.C)[(size_t)m * p.ldc + n] = p.R[(size_t)m * p.ldr + n] + p.alpha * val;
+                    } else if constexpr (EPI == EPI_SWISH_BF16) {
+                        reinterpret_cast<bf16_t*>(p.C)[(size_t)m * p.ldc + n] = f2bf(swishf_(val));
+                    } else {
+                        reinterpret_cast<bf16_t*>(p.C)[(size_t)m * p.ldc + n] = f2bf(val);
+                    }
+                }
+        }
+    }
+}
+
+template <int BN, int EPI>
+int launch_t(const GemmDev& gd, hipStream_t s) {
+    const GemmParams& p = gd.p;
+    const int n_tiles = (p.N + BN - 1) / BN, m_tiles = (p.M + BM - 1) / BM;
+    const size_t lds = 2 * (BM + BN) * LROW;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BN, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_kernel<BN, EPI>), dim3(m_tiles * n_tiles), dim3(256), lds, s, gd);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+template <int EPI>
+int launch_bn(const GemmDev& gd, hipStream_t s) {
+    const int n = gd.p.N;
+    // the 64-wide tile wastes less when N just exceeds a multiple of 128 by <= 64
+    if constexpr (EPI != EPI_GLU_BF16) {
+        if (ec_round_up(n, 64) < ec_round_up(n, 128)) return launch_t<64, EPI>(gd, s);
+    }
+    return launch_t<128, EPI>(gd, s);
+}
+
+}  // namespace
+
+int launch_gemm(const GemmParams& p, int epi, hipStream_t s) {
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0) return 0;
+    if (p.lda % 8 || p.ldw % 64) return -2;
+    GemmDev gd;
+    gd.p = p;
+    if (epi == EPI_QKV || epi == EPI_HEADS) {
+        gd.fG = FastDiv(p.G); gd.fD = FastDiv(p.D); gd.fd = FastDiv(p.d);
+    }
+    switch (epi) {
+        case EPI_F32: return launch_bn<EPI_F32>(gd, s);
+        case EPI_BF16: return launch_bn<EPI_BF16>(gd, s);
+        case EPI_SWISH_BF16: return launch_bn<EPI_SWISH_BF16>(gd, s);
+        case EPI_RESID_F32: return launch_bn<EPI_RESID_F32>(gd, s);
+        case EPI_GLU_BF16: return launch_bn<EPI_GLU_BF16>(gd, s);
+        case EPI_QKV: return launch_bn<EPI_QKV>(gd, s);
+        case EPI_HEADS: return launch_bn<EPI_HEADS>(gd, s);
+    }
+    return -3;
+}

@@ -1,0 +1,86 @@
+// Internal launch API of libeffconf: one function per HIP kernel family.  All pointers are device
+// memory owned by the caller; every launch goes to the stream passed in; nothing allocates or syncs.
+#pragma once
+#include "common.h"
+
+// ---------------------------------------------------------------- GEMM  (gemm.hip)
+// C[m, n] = sum_k A[m, k] * W[n, k] + bias[n]   (A bf16 row-major, W bf16 "Linear weight" layout [N][K])
+// W must be packed by pack_weight_bf16(): [round_up(N,128)][round_up(K,64)] zero padded; bias [round_up(N,128)].
+enum GemmEpilogue {
+    EPI_F32 = 0,         // C f32 [M][ldc]            = acc + bias
+    EPI_BF16 = 1,        // C bf16 [M][ldc]           = acc + bias
+    EPI_SWISH_BF16 = 2,  // C bf16 [M][ldc]           = swish(acc + bias)
+    EPI_RESID_F32 = 3,   // C f32 [M][ldc]            = R[m][n] + alpha * (acc + bias)   (R may alias C)
+    EPI_GLU_BF16 = 4,    // C bf16 [M][ldc], N/2 cols = a * sigmoid(b); W rows interleaved in blocks of 32 (a|b)
+    EPI_QKV = 5,         // scatter to head-major Qu, Qv, K and key-major V^T (see GemmParams)
+    EPI_HEADS = 6,       // scatter a single matrix to head-major [H][rows/G][dpad]   (positional E)
+};
+
+struct GemmParams {
+    const bf16_t* A; int lda;          // lda multiple of 8 (16-byte rows); columns >= K are ignored (masked)
+    int a_rows, a_pitch, a_stride;     // row map: src_row(m) = (m / a_rows) * a_pitch + (m % a_rows) * a_stride; a_rows==0: identity
+    const bf16_t* W; int ldw;          // packed weight, ldw = round_up(K, 64)
+    const float* bias;
+    int M, N, K;
+    void* C; int ldc;
+    const float* R; int ldr; float alpha;
+    // EPI_QKV / EPI_HEADS: rows m = (b, t) with t < T; grouped attention view
+    int T, G, H, D, d, dpad, Tg, Tgp;
+    bf16_t *qu, *qv, *kh, *vt;         // [B][H][Tg][dpad] x3, [B][H][dpad][Tgp]
+    const float *u, *v;                // [D] content / position bias (attentions.py:474-475)
+};
+int launch_gemm(const GemmParams& p, int epi, hipStream_t s);
+
+// ---------------------------------------------------------------- normalisation / casts  (norm.hip)
+// y = LayerNorm(x) over the last dim (eps 1e-6), two-pass fp32 statistics, one wave per row.
+// out_bf16 (ld = round_up(D,8), pad columns zeroed) and/or out_f32 (ld = D) may be null.
+// If gamma2 != null a second LayerNorm is applied to the first result and *that* goes to out_bf16
+// (block-final norm fused with the next block's FFN1 pre-norm).
+int launch_layernorm(const float* x, int M, int D, const float* gamma, const float* beta,
+                     float* out_f32, bf16_t* out_bf16, int ld_bf16,
+                     const float* gamma2, const float* beta2, hipStream_t s);
+// out[m][:] = bf16(x[src_row(m)][:])   (strided frame decimation + cast for conv_res, blocks.py:106-110)
+int launch_cast_rows(const float* x, int D, int rows_per_batch, int stride, int out_rows_per_batch, int batch,
+                     bf16_t* out, int ld_out, hipStream_t s);
+
+// ---------------------------------------------------------------- attention  (attention.hip)
+struct AttnParams {
+    const bf16_t *qu, *qv, *kh, *vt, *eh;   // see GemmParams; eh [H][2Tg-1][dpad]
+    const int* lens;                        // [B] valid frames at this stage (keys j with G*j >= lens[b] are masked)
+    int B, H, T, G, D, d, dpad, Tg, Tgp;
+    bf16_t* out; int ldo;                   // [B*T][ldo] un-grouped attention output (rows t >= T dropped)
+    float scale;                            // 1/sqrt(d)
+};
+int launch_relpos_attention(const AttnParams& p, hipStream_t s);
+// rows t in [T, Tp) of the grouped view: Qu=u, Qv=v, K=V=0  (attentions.py:107-138, 671-675)
+int launch_attn_pad_rows(const GemmParams& p, int B, hipStream_t s);
+
+// ---------------------------------------------------------------- convolutions  (conv.hip)
+// mel (B, F, Tm) f32 -> (B*T1, C*F/2) bf16, feature index c*(F/2)+f; 3x3 s2 p1 conv (Cin=1) + folded BN + Swish
+int launch_subsample_conv(const float* mel, int B, int F, int Tm, int T1, const float* w9, const float* bias, int C,
+                          bf16_t* out, int ldo, hipStream_t s);
+// g (B, T, ld) bf16 -> (B, To, ld) bf16: depthwise conv k taps ("same" zero pad), stride s, folded BN, Swish
+int launch_dwconv(const bf16_t* g, int B, int T, int To, int C, int ld, const float* w_kc, const float* bias,
+                  int ksize, int stride, bf16_t* out, hipStream_t s);
+
+// ---------------------------------------------------------------- mel frontend  (mel.hip)
+struct MelTables {                 // device tables built once per encoder
+    const float* window;           // [n_fft] Hann(win_length) centred in n_fft
+    const float2* twiddle;         // [n_fft/2] exp(-2 pi i k / n_fft)
+    const int* fb_start;           // [n_mels] first non-zero bin
+    const int* fb_count;           // [n_mels]
+    const int* fb_offset;          // [n_mels] offset into fb_weight
+    const float* fb_weight;        // packed non-zero triangular weights
+};
+int launch_mel(const float* audio, int B, int L, const MelTables& t, int n_fft, int hop, int n_mels, int Tm,
+               int normalize, float mean, float std, float* mel, hipStream_t s);
+
+// ---------------------------------------------------------------- lengths + CTC head  (ctc.hip)
+// stage lengths: mel frames -> per-stage frame counts (int32), final int64 out_len
+int launch_lengths(const int64_t* x_len, int B, int from_audio, int hop, int sub_layers, const int* block_stride,
+                   int n_blocks, int* stage_lens /*[n_blocks+1][B]*/, int64_t* out_len, hipStream_t s);
+// logits = x W^T + b in fp32 (Wt is [D][V]), argmax per frame (first max), optional logits out
+int launch_ctc_argmax(const float* x, int M, int D, const float* Wt, const float* bias, int V,
+                      int* preds, float* logits_or_null, hipStream_t s);
+// drop blanks (0), collapse repeats, stop at len[b]  (model_ctc.py:99-133)
+int launch_ctc_collapse(const int* preds, const int64_t* lens, int B, int T, int* labels, int* label_len, hipStream_t s);

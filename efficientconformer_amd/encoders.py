@@ -1,0 +1,245 @@
+"""Drop-in for the reference's ``models.encoders.ConformerEncoder`` (reference models/encoders.py:44-142).
+
+Same constructor (``ConformerEncoder(encoder_params: dict)``), same ``forward(x, x_len)`` signature and
+return convention, same ``state_dict`` key names (so reference checkpoints load unchanged:
+models/model.py:361-384, model_ctc.py:77-88) — but ``forward`` runs the hand-written HIP kernels of
+libeffconf.so through the C ABI of include/effconf.h.  The ``nn.Module`` tree below only *holds*
+parameters under the reference's names; none of those sub-modules is ever called, and there is no
+PyTorch/CPU fallback: without the HIP library or without a GPU tensor, ``forward`` raises.
+
+Differences from the reference, by design:
+  * eval-mode only (SpecAugment, dropout, variational noise and BatchNorm statistics updates are
+    training-time features, reference encoders.py:103-104, layers.py:63);
+  * the third return value is a list of ``None`` (the reference returns per-block attention maps that no
+    caller consumes: model_ctc.py:63-68, 93; transducer.py:94, 145);
+  * weights are packed once (BatchNorm folded, bf16, MFMA-friendly padding); call ``repack()`` after
+    mutating parameters in place (``load_state_dict`` / ``.to()`` re-pack automatically).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .config import EncoderPlan, build_plan
+
+
+class _Holder(nn.Module):
+    """Attribute container; exists only so parameter names match the reference."""
+
+
+def _seq(*mods):
+    return nn.Sequential(*[m if m is not None else nn.Identity() for m in mods])
+
+
+def _ffn_holder(d, dff):
+    # reference modules.py:376-383: Sequential(LN, Linear, Swish, Dropout, Linear, Dropout)
+    h = _Holder()
+    h.layers = _seq(nn.LayerNorm(d, eps=1e-6), nn.Linear(d, dff), None, None, nn.Linear(dff, d), None)
+    return h
+
+
+class _BlockHolder(nn.Module):
+    def __init__(self, bp):
+        super().__init__()
+        d, de = bp.dim_model, bp.dim_expand
+        self.feed_forward_module1 = _ffn_holder(d, bp.dim_ffn1)
+        att = _Holder()
+        att.norm = nn.LayerNorm(d, eps=1e-6)
+        mhsa = _Holder()
+        for n in ("query_layer", "key_layer", "value_layer", "output_layer", "pos_layer"):
+            setattr(mhsa, n, nn.Linear(d, d))
+        mhsa.u = nn.Parameter(torch.zeros(d))
+        mhsa.v = nn.Parameter(torch.zeros(d))
+        att.mhsa = mhsa
+        self.multi_head_self_attention_module = att
+        conv = _Holder()
+        # reference modules.py:498-509: LN, Transpose, Conv1d pw, GLU, Conv1d dw, BN, Swish, Conv1d pw, Transpose, Dropout
+        conv.layers = _seq(nn.LayerNorm(d, eps=1e-6), None, nn.Conv1d(d, 2 * de, 1), None,
+                           nn.Conv1d(de, de, bp.kernel_size, groups=de), nn.BatchNorm1d(de), None,
+                           nn.Conv1d(de, de, 1), None, None)
+        self.convolution_module = conv
+        self.feed_forward_module2 = _ffn_holder(de, bp.dim_ffn2)
+        self.norm = nn.LayerNorm(de, eps=1e-6)
+        if bp.transition:   # reference blocks.py:106-110
+            self.conv_res = _seq(None, nn.Conv1d(d, de, 1))
+        self.stride = bp.conv_stride
+
+
+class ConformerEncoder(nn.Module):
+
+    def __init__(self, params: dict):
+        super().__init__()
+        self.params = dict(params)
+        self.plan: EncoderPlan = build_plan(params)
+        plan = self.plan
+        sub = _Holder()
+        layers, cin = [], 1
+        for c in plan.sub_filters[:plan.sub_layers]:
+            layers.append(_seq(nn.Conv2d(cin, c, 3, stride=2, padding=1), nn.BatchNorm2d(c), None))
+            cin = c
+        sub.layers = nn.ModuleList(layers)
+        self.subsampling_module = sub
+        self.linear = nn.Linear(plan.dim_in, plan.blocks[0].dim_model)
+        self.blocks = nn.ModuleList([_BlockHolder(bp) for bp in plan.blocks])
+        self._handle = None
+        self._packed = False
+        object.__setattr__(self, "_head", None)   # not a sub-module: keeps state_dict keys equal to the reference's
+        self._ws: Dict[tuple, torch.Tensor] = {}
+        self.eval()
+
+    # ------------------------------------------------------------------ weights
+    def attach_head(self, fc: Optional[nn.Linear]):
+        """Let the C library also pack the CTC head ``fc`` (reference model_ctc.py:49)."""
+        object.__setattr__(self, "_head", fc)
+        self._packed = False
+
+    def repack(self):
+        self._packed = False
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        # real torchaudio registers frontend buffers the reference checkpoints may carry; the native frontend
+        # builds its own window / filterbank tables, so accept-and-ignore them.
+        sd = {k: v for k, v in state_dict.items() if not k.startswith("preprocessing.")}
+        r = super().load_state_dict(sd, strict=strict, **kw)
+        self._packed = False
+        return r
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self._packed = False
+        return r
+
+    def _make_config(self):
+        plan = self.plan
+        blocks = (_lib.EcBlock * len(plan.blocks))()
+        for i, b in enumerate(plan.blocks):
+            blocks[i] = _lib.EcBlock(b.dim_model, b.dim_expand, b.dim_ffn1 // b.dim_model, b.num_heads, b.kernel_size,
+                                     b.group_size, b.max_pos, b.conv_stride)
+        cfg = _lib.EcConfig()
+        cfg.n_mels, cfg.sample_rate, cfg.n_fft = plan.n_mels, plan.sample_rate, plan.n_fft
+        cfg.win_length, cfg.hop_length = plan.win_length, plan.hop_length
+        cfg.normalize, cfg.mean, cfg.std = int(plan.normalize), plan.mean, plan.std
+        cfg.sub_layers = plan.sub_layers
+        for i in range(4):
+            cfg.sub_filters[i] = plan.sub_filters[i] if i < len(plan.sub_filters) else 0
+        cfg.num_blocks = len(plan.blocks)
+        cfg.blocks = C.cast(blocks, C.POINTER(_lib.EcBlock))
+        cfg.vocab_size = self._head.out_features if self._head is not None else 0
+        return cfg, blocks
+
+    def _ensure_packed(self):
+        if self._packed:
+            return
+        lib = _lib.load()
+        if self._handle is not None:
+            lib.effconf_encoder_destroy(self._handle)
+            self._handle = None
+        cfg, keep = self._make_config()
+        h = lib.effconf_encoder_create(C.byref(cfg))
+        if not h:
+            raise _lib.EffconfError("effconf_encoder_create: %s" % lib.effconf_last_error().decode())
+        self._handle = h
+        tensors = dict(super().state_dict())
+        if self._head is not None:
+            tensors["fc.weight"], tensors["fc.bias"] = self._head.weight, self._head.bias
+        for key, t in tensors.items():
+            if key.endswith("num_batches_tracked"):
+                continue
+            arr = np.ascontiguousarray(t.detach().to("cpu", torch.float32).numpy())
+            shape = (C.c_int64 * max(arr.ndim, 1))(*arr.shape)
+            _lib.check(lib.effconf_encoder_load_tensor(h, key.encode(), arr.ctypes.data_as(C.c_void_p), shape, arr.ndim),
+                       "load_tensor(%s)" % key)
+        _lib.check(lib.effconf_encoder_finalize(h), "finalize")
+        self._packed = True
+
+    def __del__(self):
+        try:
+            if self._handle is not None and _lib._lib is not None:
+                _lib._lib.effconf_encoder_destroy(self._handle)
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ forward
+    def _workspace(self, batch: int, n: int, from_audio: bool, device) -> torch.Tensor:
+        key = (batch, n, from_audio, str(device))
+        ws = self._ws.get(key)
+        if ws is None:
+            nbytes = _lib.load().effconf_encoder_workspace_bytes(self._handle, batch, n, int(from_audio))
+            if len(self._ws) > 8:
+                self._ws.clear()
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            self._ws[key] = ws
+        return ws
+
+    def _run(self, x: torch.Tensor, x_len: Optional[torch.Tensor], from_audio: bool):
+        if self.training:
+            raise RuntimeError("efficientconformer_amd.ConformerEncoder is an inference path: call .eval()")
+        if not x.is_cuda:
+            raise RuntimeError("ConformerEncoder.forward needs a GPU tensor (HIP path only; no CPU fallback)")
+        lib = _lib.load()
+        self._ensure_packed()
+        x = x.contiguous().float()
+        batch, n = (x.shape[0], x.shape[1]) if from_audio else (x.shape[0], x.shape[2])
+        lens_given = x_len is not None
+        lens = (x_len if lens_given else torch.full((batch,), n, dtype=torch.int64)).to(x.device, torch.int64).contiguous()
+        t_out = lib.effconf_encoder_out_frames(self._handle, n, int(from_audio))
+        out = torch.empty(batch, t_out, self.plan.dim_out, dtype=torch.float32, device=x.device)
+        out_len = torch.empty(batch, dtype=torch.int64, device=x.device)
+        ws = self._workspace(batch, n, from_audio, x.device)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        fn = lib.effconf_encoder_forward if from_audio else lib.effconf_encoder_forward_mel
+        _lib.check(fn(self._handle, x.data_ptr(), lens.data_ptr(), batch, n, out.data_ptr(), out_len.data_ptr(),
+                      ws.data_ptr(), ws.numel(), stream), "encoder_forward")
+        return out, (out_len if lens_given else None), [None] * len(self.plan.blocks)
+
+    def forward(self, x: torch.Tensor, x_len: Optional[torch.Tensor] = None):
+        """x: (B, L) raw 16 kHz audio, x_len: (B,) samples -> (x (B, T_out, D_last), x_len, attentions)
+        (reference encoders.py:97-142)."""
+        return self._run(x, x_len, True)
+
+    def forward_mel(self, mel: torch.Tensor, mel_len: Optional[torch.Tensor] = None):
+        """Enter after AudioPreprocessing: mel (B, n_mels, Tm), lengths in frames (the parity boundary)."""
+        return self._run(mel, mel_len, False)
+
+    def mel_frontend(self, x: torch.Tensor, x_len: Optional[torch.Tensor] = None):
+        """AudioPreprocessing.forward (reference modules.py:87-106) on the GPU."""
+        lib = _lib.load()
+        self._ensure_packed()
+        x = x.contiguous().float()
+        tm = x.shape[1] // self.plan.hop_length + 1
+        mel = torch.empty(x.shape[0], self.plan.n_mels, tm, dtype=torch.float32, device=x.device)
+        _lib.check(lib.effconf_mel_frontend(self._handle, x.data_ptr(), x.shape[0], x.shape[1], mel.data_ptr(),
+                                            torch.cuda.current_stream(x.device).cuda_stream), "mel_frontend")
+        if x_len is not None:
+            x_len = torch.div(x_len, self.plan.hop_length, rounding_mode="floor") + 1
+        return mel, x_len
+
+    # ------------------------------------------------------------------ test instrumentation
+    def trace_forward_mel(self, mel: torch.Tensor, mel_len: torch.Tensor, arena_bytes: int = 1 << 28):
+        """Run forward_mel with the debug trace enabled; returns (out, out_len, {name: tensor})."""
+        lib = _lib.load()
+        self._ensure_packed()
+        arena = torch.zeros(arena_bytes, dtype=torch.uint8, device=mel.device)
+        _lib.check(lib.effconf_encoder_set_trace(self._handle, arena.data_ptr(), arena.numel()), "set_trace")
+        try:
+            out, out_len, _ = self.forward_mel(mel, mel_len)
+            torch.cuda.synchronize()
+            res = {}
+            name = C.create_string_buffer(64)
+            off, rows, cols, ld = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+            dt = C.c_int32()
+            for i in range(lib.effconf_encoder_trace_count(self._handle)):
+                _lib.check(lib.effconf_encoder_trace_entry(self._handle, i, name, C.byref(off), C.byref(rows), C.byref(cols),
+                                                           C.byref(ld), C.byref(dt)), "trace_entry")
+                esz, tdt = (2, torch.bfloat16) if dt.value == 1 else (4, torch.float32 if dt.value == 0 else torch.int32)
+                raw = arena[off.value: off.value + rows.value * ld.value * esz]
+                t = raw.view(tdt).view(rows.value, ld.value)[:, :cols.value].float().cpu()
+                res[name.value.decode()] = t
+            return out, out_len, res
+        finally:
+            lib.effconf_encoder_set_trace(self._handle, None, 0)

@@ -1,0 +1,87 @@
+"""CTC model wrapper: the caller side of the hot path (reference models/model_ctc.py:39-136).
+
+``ModelCTC`` keeps the reference's attribute names (``encoder``, ``fc``), state-dict keys
+(``encoder.*``, ``fc.*``) and method names (including the reference's spelling
+``gready_search_decoding``), but the head and the greedy collapse run as HIP kernels
+(effconf_ctc_greedy) instead of ``nn.Linear`` + a Python loop with ``.item()`` per token.
+Training (losses, optimizer, schedules), beam search and WER scoring are out of scope.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .config import load_config
+from .encoders import ConformerEncoder
+
+
+class ModelCTC(nn.Module):
+
+    def __init__(self, encoder_params: dict, tokenizer_params: dict, training_params: Optional[dict] = None,
+                 decoding_params: Optional[dict] = None, name: str = "model", tokenizer=None):
+        super().__init__()
+        if encoder_params.get("arch", "Conformer") != "Conformer":
+            raise Exception("Unknown encoder architecture:", encoder_params.get("arch"))
+        self.encoder = ConformerEncoder(encoder_params)
+        self.fc = nn.Linear(self.encoder.plan.dim_out, tokenizer_params["vocab_size"])
+        self.encoder.attach_head(self.fc)
+        self.tokenizer = tokenizer
+        self.name = name
+        self.eval()
+
+    @classmethod
+    def from_config(cls, cfg, tokenizer=None):
+        cfg = load_config(cfg)
+        return cls(cfg["encoder_params"], cfg["tokenizer_params"], cfg.get("training_params"),
+                   cfg.get("decoding_params"), cfg.get("model_name", "model"), tokenizer)
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        sd = {k.replace(".module.", "."): v for k, v in state_dict.items()        # DDP-saved checkpoints, model.py:367-370
+              if not k.startswith("encoder.preprocessing.")}
+        r = super().load_state_dict(sd, strict=strict, **kw)
+        self.encoder.repack()
+        return r
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self.encoder.repack()
+        return r
+
+    # ---- reference ModelCTC.forward (model_ctc.py:57-68): batch = (x, y, x_len, y_len)
+    def forward(self, batch):
+        x, _, x_len, _ = batch
+        enc, enc_len, attentions = self.encoder(x, x_len)
+        logits, _, _ = self._head(enc, enc_len, want_logits=True)
+        return logits, enc_len, attentions
+
+    def _head(self, enc: torch.Tensor, enc_len: Optional[torch.Tensor], want_logits: bool = False):
+        lib = _lib.load()
+        b, t, _ = enc.shape
+        if enc_len is None:
+            enc_len = torch.full((b,), t, dtype=torch.int64, device=enc.device)
+        labels = torch.empty(b, t, dtype=torch.int32, device=enc.device)
+        label_len = torch.empty(b, dtype=torch.int32, device=enc.device)
+        logits = torch.empty(b, t, self.fc.out_features, dtype=torch.float32, device=enc.device) if want_logits else None
+        ws = torch.empty(b * t * 4, dtype=torch.uint8, device=enc.device)
+        _lib.check(lib.effconf_ctc_greedy(self.encoder._handle, enc.data_ptr(), enc_len.data_ptr(), b, t, labels.data_ptr(),
+                                          label_len.data_ptr(), logits.data_ptr() if want_logits else None, ws.data_ptr(),
+                                          ws.numel(), torch.cuda.current_stream(enc.device).cuda_stream), "ctc_greedy")
+        return logits, labels, label_len
+
+    def greedy_labels(self, x: torch.Tensor, x_len: Optional[torch.Tensor], from_mel: bool = False) -> List[List[int]]:
+        """Greedy CTC label-id sequences (blank 0 removed, repeats collapsed), one list per utterance."""
+        enc, enc_len, _ = self.encoder.forward_mel(x, x_len) if from_mel else self.encoder(x, x_len)
+        _, labels, label_len = self._head(enc, enc_len)
+        labels, label_len = labels.cpu(), label_len.cpu()          # one D2H copy per batch, not one per token
+        return [labels[b, :int(label_len[b])].tolist() for b in range(labels.shape[0])]
+
+    def gready_search_decoding(self, x, x_len):
+        """Reference spelling (model_ctc.py:90).  Returns decoded strings when a tokenizer is attached
+        (``tokenizer.decode(list_of_id_lists)``, model_ctc.py:136), otherwise the id lists."""
+        ids = self.greedy_labels(x, x_len)
+        return self.tokenizer.decode(ids) if self.tokenizer is not None else ids
+
+    greedy_search_decoding = gready_search_decoding

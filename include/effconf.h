@@ -1,0 +1,119 @@
+/* libeffconf — MI355X (gfx950) native Efficient Conformer encoder forward path.  C ABI.
+ *
+ * The reference (burchim/EfficientConformer) has no plugin/FFI layer: its seam for this path is the
+ * Python class models.encoders.ConformerEncoder (reference models/encoders.py:44), constructed from
+ * the `encoder_params` dict (encoders.py:46-95) and called as `encoder(x, x_len)` at
+ * models/model_ctc.py:63, 93, 159, models/transducer.py:94, 145, 206 and models/model.py:552, 639.
+ * This header is what a native replacement of that seam exports; the Python class
+ * efficientconformer_amd.ConformerEncoder binds it with ctypes.
+ *
+ * Conventions
+ *   - every `dev` pointer is caller-owned DEVICE memory (HIP); the library never frees it;
+ *   - packed weights are the only memory the library owns (allocated in effconf_encoder_finalize,
+ *     released by effconf_encoder_destroy);
+ *   - all work is enqueued on the `stream` argument (a hipStream_t passed as void*; NULL = default
+ *     stream); no call synchronises the device or allocates in the forward path (graph-capturable);
+ *   - return value 0 = ok, negative = error, message via effconf_last_error() (thread-local);
+ *   - no C++ exceptions or torch types cross this boundary.
+ */
+#ifndef EFFCONF_H
+#define EFFCONF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EFFCONF_ABI_VERSION 1
+
+/* Per-block hyper-parameters, already resolved from the per-stage lists exactly as
+ * ConformerEncoder.__init__ does (reference encoders.py:80-95). */
+typedef struct EcBlock {
+    int32_t dim_model;    /* D   : input / attention width                                  */
+    int32_t dim_expand;   /* De  : output width (== D except in the two transition blocks)  */
+    int32_t ff_ratio;     /* FFN hidden = ff_ratio * dim                                    */
+    int32_t num_heads;    /* H                                                              */
+    int32_t kernel_size;  /* depthwise conv taps (odd, <= 31)                               */
+    int32_t group_size;   /* attention group size G (odd)                                   */
+    int32_t max_pos;      /* max_pos_encoding of this block's relative table                */
+    int32_t conv_stride;  /* 1 or 2 (progressive downsampling, blocks.py:106-117)           */
+} EcBlock;
+
+/* Mirrors the reference `encoder_params` keys that reach the hot path (encoders.py:50-94). */
+typedef struct EcConfig {
+    int32_t n_mels, sample_rate, n_fft, win_length, hop_length;  /* modules.py:77-85           */
+    int32_t normalize; float mean, std;                          /* modules.py:103-104         */
+    int32_t sub_layers;                                          /* Conv2dSubsampling layers   */
+    int32_t sub_filters[4];                                      /* channels per layer         */
+    int32_t num_blocks;
+    const EcBlock* blocks;
+    int32_t vocab_size;                                          /* >0: CTC head `fc` present  */
+} EcConfig;
+
+typedef struct EcEncoder EcEncoder;
+
+int effconf_abi_version(void);
+const char* effconf_last_error(void);
+
+/* ---- lifetime + weights ------------------------------------------------------------------- */
+EcEncoder* effconf_encoder_create(const EcConfig* cfg);
+void effconf_encoder_destroy(EcEncoder* enc);
+/* Hand over one reference state_dict tensor (HOST fp32, contiguous, reference layout) by its key
+ * without the "encoder." prefix, e.g. "blocks.3.feed_forward_module1.layers.1.weight",
+ * "subsampling_module.layers.0.1.running_var", "fc.weight" (reference models/model.py:361-384,
+ * model_ctc.py:77-88 decide which keys exist).  Unknown keys are rejected (-1). */
+int effconf_encoder_load_tensor(EcEncoder* enc, const char* key, const float* host, const int64_t* shape, int32_t ndim);
+/* Fold BatchNorm(eval) into the convolutions, cast to bf16, pad to MFMA-friendly shapes, build the
+ * sinusoid / window / filterbank tables and upload.  Fails (-1) if a required tensor is missing. */
+int effconf_encoder_finalize(EcEncoder* enc);
+
+/* ---- forward ------------------------------------------------------------------------------ */
+/* Bytes of scratch a forward of this shape needs (n = samples per row if from_audio, else mel frames). */
+size_t effconf_encoder_workspace_bytes(const EcEncoder* enc, int32_t batch, int32_t n, int32_t from_audio);
+/* Output frames T_out for an input of n samples / mel frames (encoders.py:139 bookkeeping). */
+int32_t effconf_encoder_out_frames(const EcEncoder* enc, int32_t n, int32_t from_audio);
+
+/* ConformerEncoder.forward(x, x_len) (reference encoders.py:97-142), eval mode.
+ *   audio   dev f32 (batch, n_samples)   zero-padded rows (utils/preprocessing.py:38)
+ *   x_len   dev i64 (batch)              valid samples per row
+ *   out     dev f32 (batch, T_out, D_last)
+ *   out_len dev i64 (batch)
+ * The third value of the reference's return tuple (attention maps no caller consumes) is not produced. */
+int effconf_encoder_forward(EcEncoder* enc, const float* audio, const int64_t* x_len, int32_t batch, int32_t n_samples,
+                            float* out, int64_t* out_len, void* workspace, size_t workspace_bytes, void* stream);
+/* Same, entered after AudioPreprocessing: mel dev f32 (batch, n_mels, n_frames), mel_len in frames.
+ * This is the parity boundary ("identical mel inputs"). */
+int effconf_encoder_forward_mel(EcEncoder* enc, const float* mel, const int64_t* mel_len, int32_t batch, int32_t n_frames,
+                                float* out, int64_t* out_len, void* workspace, size_t workspace_bytes, void* stream);
+
+/* AudioPreprocessing.forward alone (reference modules.py:87-106): audio -> (batch, n_mels, n//hop+1). */
+int effconf_mel_frontend(EcEncoder* enc, const float* audio, int32_t batch, int32_t n_samples, float* mel, void* stream);
+
+/* CTC head + greedy decode (reference model_ctc.py:49, 90-133): fc, per-frame argmax, drop blanks,
+ * collapse repeats, stop at out_len.  labels dev i32 (batch, T_out) zero-filled tail, label_len dev i32 (batch).
+ * logits (dev f32 (batch, T_out, vocab)) may be NULL.  Needs batch*T_out*4 bytes of workspace. */
+int effconf_ctc_greedy(EcEncoder* enc, const float* enc_out, const int64_t* out_len, int32_t batch, int32_t t_out,
+                       int32_t* labels, int32_t* label_len, float* logits, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- per-launch event profiler (bench / tuning only) --------------------------------------- */
+/* When enabled every kernel launch of the forward is bracketed by two hipEventRecord on the caller's stream.
+ * Classes: 0 mel, 1 subsample conv, 2 FFN GEMMs, 3 other GEMMs, 4 LayerNorm, 5 attention, 6 depthwise conv, 7 misc.
+ * effconf_profile_read synchronises the device and returns, for one class, the summed kernel time, the number of
+ * launches and the summed ALGORITHMIC flops / bytes of those launches since the last enable. */
+int effconf_profile_enable(EcEncoder* enc, int32_t enable);
+int effconf_profile_read(EcEncoder* enc, int32_t cls, double* total_ms, int64_t* launches, double* flops, double* bytes);
+
+/* ---- debug trace (tests only) ------------------------------------------------------------- */
+/* When a trace arena is set, every forward copies its intermediate tensors into it (device-to-device,
+ * same stream).  Entries describe name / byte offset / rows / cols / leading dim / dtype (0=f32, 1=bf16, 2=i32). */
+int effconf_encoder_set_trace(EcEncoder* enc, void* dev_arena, size_t bytes);
+int32_t effconf_encoder_trace_count(const EcEncoder* enc);
+int effconf_encoder_trace_entry(const EcEncoder* enc, int32_t i, char* name64, int64_t* offset, int64_t* rows, int64_t* cols,
+                                int64_t* ld, int32_t* dtype);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EFFCONF_H */

@@ -201,8 +201,10 @@ def conformer_block(x, lens, sd, bp, trace: Optional[dict] = None):
     p = "blocks.%d" % bp.index
     f1 = ffn(x, sd, p + ".feed_forward_module1")
     x = x + 0.5 * f1
+    x_ffn1 = x
     att = mhsa_module(x, lens, sd, p + ".multi_head_self_attention_module", bp.num_heads, bp.group_size)
     x = x + att                                                   # att_res is Identity (att_stride == 1)
+    x_mhsa = x
     c = conv_module(x, sd, p + ".convolution_module", bp.kernel_size, bp.conv_stride)
     if bp.transition:       # 1x1 strided conv on frames 0, s, 2s, ...   blocks.py:106-110
         res = F.linear(x[:, ::bp.conv_stride], _t(sd, p + ".conv_res.1.weight")[:, :, 0], _t(sd, p + ".conv_res.1.bias"))
@@ -211,11 +213,13 @@ def conformer_block(x, lens, sd, bp, trace: Optional[dict] = None):
     else:
         res = x
     x = res + c
+    x_conv = x
     f2 = ffn(x, sd, p + ".feed_forward_module2")
     x = x + 0.5 * f2
     x = F.layer_norm(x, (x.shape[-1],), _t(sd, p + ".norm.weight"), _t(sd, p + ".norm.bias"), LN_EPS)
     if trace is not None:
         trace[p + ".ffn1"], trace[p + ".mhsa"], trace[p + ".conv"], trace[p + ".ffn2"], trace[p + ".out"] = f1, att, c, f2, x
+        trace[p + ".x_ffn1"], trace[p + ".x_mhsa"], trace[p + ".x_conv"] = x_ffn1, x_mhsa, x_conv   # residual stream
     return x
 
 

@@ -1,0 +1,102 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol include/effconf.h declares,
+the host mirror keeps the reference's state-dict surface and config rules, and the product path refuses
+to run without a GPU tensor (no silent fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from efficientconformer_amd import ConformerEncoder, ModelCTC, _lib, named_config, params, synth
+from efficientconformer_amd.config import build_plan
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as ge
+    ge.build()
+    hdr = open(os.path.join(ROOT, "include", "effconf.h")).read()
+    declared = sorted(set(re.findall(r"\b(effconf_[a-z_0-9]+)\s*\(", hdr)))
+    assert len(declared) >= 15
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), "libeffconf.so does not export %s" % name
+    assert sorted(_lib.SIGNATURES) == declared, "ctypes binding out of sync with include/effconf.h"
+    assert _lib.load().effconf_abi_version() == 1
+
+
+def test_create_rejects_bad_config_and_reports_error():
+    lib = _lib.load()
+    cfg = _lib.EcConfig()
+    assert not lib.effconf_encoder_create(ctypes.byref(cfg))
+    assert b"config" in lib.effconf_last_error()
+
+
+@pytest.mark.parametrize("name", ["Tiny", "EfficientConformerCTCSmall", "EfficientConformerCTCMedium",
+                                  "EfficientConformerCTCLarge", "EfficientConformerTransducerMedium"])
+def test_state_dict_surface_matches_reference_keys(name):
+    cfg = named_config(name)
+    m = ModelCTC.from_config(cfg)
+    plan = m.encoder.plan
+    specs = params.param_specs(plan)
+    sd = m.encoder.state_dict()
+    assert list(sd.keys()) == [k for k, _, _ in specs]
+    for k, shape, _ in specs:
+        assert tuple(sd[k].shape) == tuple(shape), k
+    full = synth.make_state_dict(plan, 0, cfg["tokenizer_params"]["vocab_size"], prefix="encoder.")
+    # DDP-saved checkpoints carry ".module." (reference model.py:367-370); torchaudio buffers are ignored
+    ddp = {k.replace("encoder.", "encoder.module.", 1): torch.from_numpy(v) for k, v in full.items()}
+    ddp["encoder.preprocessing.Spectrogram.window"] = torch.zeros(400)
+    m.load_state_dict(ddp)
+    assert torch.equal(m.encoder.linear.weight, torch.from_numpy(full["encoder.linear.weight"]))
+
+
+def test_param_counts_match_reference_readme():
+    # README.md:92-94 / SURVEY.md section 6 (encoder + fc, BatchNorm running stats excluded)
+    for name, want in (("EfficientConformerCTCSmall", 13281856), ("EfficientConformerCTCMedium", 31570932),
+                       ("EfficientConformerCTCLarge", 125675272)):
+        m = ModelCTC.from_config(named_config(name))
+        assert sum(p.numel() for p in m.parameters()) == want
+
+
+def test_block_plan_rule():
+    plan = build_plan(named_config("EfficientConformerCTCSmall")["encoder_params"])
+    b4, b5, b9, b10 = plan.blocks[4], plan.blocks[5], plan.blocks[9], plan.blocks[10]
+    assert (b4.dim_model, b4.dim_expand, b4.group_size, b4.conv_stride, b4.max_pos) == (120, 168, 3, 2, 10000)
+    assert (b5.dim_model, b5.dim_expand, b5.group_size, b5.conv_stride, b5.max_pos) == (168, 168, 1, 1, 5000)
+    assert (b9.dim_model, b9.dim_expand, b9.conv_stride) == (168, 240, 2) and b10.max_pos == 2500
+    assert plan.blocks[0].dim_head == 90 and b5.dim_head == 42 and b10.dim_head == 60
+    assert plan.lengths(160000) == (1001, 501, [501] * 4 + [251] * 5 + [126] * 6)
+
+
+def test_unsupported_configs_raise():
+    p = named_config("EfficientConformerCTCSmall")["encoder_params"]
+    for k, v in (("subsampling_module", "VGG"), ("relative_pos_enc", False), ("causal", True), ("linear_att", True)):
+        q = dict(p); q[k] = v
+        with pytest.raises(NotImplementedError):
+            build_plan(q)
+    q = dict(p); q["subsampling_module"] = "Nope"
+    with pytest.raises(Exception):
+        build_plan(q)
+
+
+def test_no_cpu_fallback():
+    m = ConformerEncoder(named_config("Tiny")["encoder_params"])
+    with pytest.raises(RuntimeError, match="GPU"):
+        m(torch.zeros(2, 16000), torch.tensor([16000, 8000]))
+    m.train()
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(2, 16000))
+
+
+def test_synth_is_deterministic_and_libri_shaped():
+    a = synth.make_tensor("linear.weight", (4, 8), "weight", 0)
+    b = synth.make_tensor("linear.weight", (4, 8), "weight", 0)
+    assert np.array_equal(a, b) and abs(float(a.std()) - 8 ** -0.5) < 0.2
+    lens = synth.libri_lengths(256)
+    assert lens[0] >= lens[-1] and lens.min() >= 24000 and lens.max() <= 256000
+    x = synth.make_audio(lens[:4])
+    assert x.shape == (4, lens[0]) and np.all(x[3, lens[3]:] == 0) and np.abs(x).max() <= 1.0
