@@ -34,6 +34,13 @@ def _err(got, ref):
     return float(d.max()), float(d.mean())
 
 
+def _rel(got, ref):
+    """errors relative to the tensor's magnitude (bf16 storage has ~2^-9 relative rounding)"""
+    mx, mean = _err(got, ref)
+    scale = max(float(ref.abs().max()), 1.0)
+    return mx / scale, mean / scale
+
+
 @pytest.mark.parametrize("tm,lens", [(47, [47, 40, 23]), (100, [100, 77, 52])])
 def test_tiny_every_stage_vs_oracle(tm, lens):
     m, sd = _model("Tiny", 7)
@@ -47,14 +54,14 @@ def test_tiny_every_stage_vs_oracle(tm, lens):
     b = 3
     worst = {}
     sub_ref = trace["subsample"].transpose(1, 2).reshape(-1, trace["subsample"].shape[1])
-    worst["subsample"] = _err(got["subsample"], sub_ref)
-    worst["linear"] = _err(got["linear"], trace["linear"].reshape(-1, trace["linear"].shape[-1]))
+    worst["subsample"] = _rel(got["subsample"], sub_ref)
+    worst["linear"] = _rel(got["linear"], trace["linear"].reshape(-1, trace["linear"].shape[-1]))
     for k in range(len(plan.blocks)):
         for tag in ("x_ffn1", "x_mhsa", "x_conv", "out"):
             r = trace["blocks.%d.%s" % (k, tag)]
-            worst["blocks.%d.%s" % (k, tag)] = _err(got["blocks.%d.%s" % (k, tag)], r.reshape(-1, r.shape[-1]))
+            worst["blocks.%d.%s" % (k, tag)] = _rel(got["blocks.%d.%s" % (k, tag)], r.reshape(-1, r.shape[-1]))
     for k, (mx, mean) in worst.items():
-        assert mx < 0.08 and mean < 0.01, (k, mx, mean, worst)
+        assert mx < 0.02 and mean < 0.003, (k, mx, mean, worst)
     mx, mean = _err(out.cpu(), ref)
     assert mx < 0.08 and mean < 0.01
 
