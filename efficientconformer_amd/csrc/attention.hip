@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const AttnParams 
     const bf16_t* Qu = p.qu + bh * p.Tg * DP;
     const bf16_t* Qv = p.qv + bh * p.Tg * DP;
     const bf16_t* Kh = p.kh + bh * p.Tg * DP;
-    const bf16_t* Vt = p.vt + bh * (size_t)DP * p.Tgp;
+    const bf16_t* Vh = p.vt + bh * p.Tg * DP;          // V, same head-major row-major layout as K
     const bf16_t* Eh = p.eh + (size_t)h * (2 * p.Tg - 1) * DP;
 
     int nkeys = (p.lens[b] + p.G - 1) / p.G;          // unmasked key groups: G*j < lens[b]
@@ -101,12 +101,22 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const AttnParams 
             if (j < p.Tg && x < p.d) v = mask_chunk(*reinterpret_cast<const uint4*>(Kh + (size_t)j * DP + x), p.d - x);
             *reinterpret_cast<uint4*>(sK + r * SM::KROW + x * 2) = v;
         }
-        for (int q = tid; q < DP * (BJ / 8); q += 256) {
-            const int x = q / (BJ / 8), jc = (q - x * (BJ / 8)) * 8;
-            const int j = j0 + jc;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (x < p.d && j < p.Tg) v = mask_chunk(*reinterpret_cast<const uint4*>(Vt + (size_t)x * p.Tgp + j), p.Tg - j);
-            *reinterpret_cast<uint4*>(sV + x * SM::VROW + jc * 2) = v;
+        // V block, transposed into the key-contiguous image sV[x][key]: each thread takes one 8-wide x chunk of a
+        // PAIR of adjacent keys and writes 8 dwords {v[j][x+e], v[j+1][x+e]} (lanes -> consecutive dwords)
+        for (int q = tid; q < (BJ / 2) * (DP / 8); q += 256) {
+            const int pr = q & (BJ / 2 - 1), x = (q / (BJ / 2)) * 8;
+            const int j = j0 + 2 * pr;
+            uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0;
+            if (x < p.d) {
+                if (j < p.Tg) v0 = *reinterpret_cast<const uint4*>(Vh + (size_t)j * DP + x);
+                if (j + 1 < p.Tg) v1 = *reinterpret_cast<const uint4*>(Vh + (size_t)(j + 1) * DP + x);
+            }
+            const uint32_t a[4] = {v0.x, v0.y, v0.z, v0.w}, bq[4] = {v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const uint32_t lo = (a[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu, hi = (bq[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu;
+                *reinterpret_cast<uint32_t*>(sV + (x + e) * SM::VROW + pr * 4) = lo | (hi << 16);
+            }
         }
         const int rbase = p.Tg - 1 + j0 - i0 - 63;   // E row of band row 0
         for (int q = tid; q < 128 * (DP / 8); q += 256) {
@@ -230,7 +240,7 @@ __global__ void attn_pad_rows_kernel(GemmParams p, int B) {
         p.qu[i1] = f2bf(p.u[nn]);
         p.qv[i1] = f2bf(p.v[nn]);
         p.kh[i1] = 0;
-        p.vt[((size_t)(b * p.H + h) * p.dpad + x) * p.Tgp + tq] = 0;
+        p.vt[i1] = 0;
     }
 }
 
@@ -252,7 +262,7 @@ int launch_dp(const AttnParams& p, hipStream_t s) {
 
 int launch_relpos_attention(const AttnParams& p, hipStream_t s) {
     if (p.B <= 0 || p.Tg <= 0) return 0;
-    if (p.Tgp % 8 || p.dpad < p.d) return -2;
+    if (p.dpad < p.d) return -2;
     switch (p.dpad) {
         case 32: return launch_dp<32>(p, s);
         case 64: return launch_dp<64>(p, s);

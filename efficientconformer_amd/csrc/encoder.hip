@@ -36,6 +36,7 @@ struct LNp { const float* g = nullptr; const float* b = nullptr; };
 struct BlockW {
     LNp ln_ffn1, ln_att, ln_conv, ln_ffn2, ln_out;
     PackedLinear ffn1_a, ffn1_b, qkv, pos, outp, pw1, pw2, res, ffn2_a, ffn2_b;
+    const bf16_t *ffn1_bp = nullptr, *ffn2_bp = nullptr;   // W2 with the hidden index permuted per 16 (rsgemm.hip)
     const float *u = nullptr, *v = nullptr, *dw_w = nullptr, *dw_b = nullptr;
     const bf16_t* pos_table = nullptr;   // [2*max_pos-1][ld8(D)], row r <-> position max_pos-1-r
 };
@@ -110,6 +111,22 @@ bool pack_named_linear(EcEncoder* e, const std::string& prefix, int N, int K, Pa
     std::vector<const float*> rows(N);
     for (int n = 0; n < N; ++n) rows[n] = w->data.data() + (size_t)n * K;
     return pack_linear(e, rows, b->data, K, out);
+}
+
+// second FFN weight [D][F] with the hidden (K) index permuted inside every group of 16 so that the first GEMM's
+// accumulator registers are directly the second GEMM's B fragments: position 8h+e <-> 4h + 8(e>>2) + (e&3)
+const bf16_t* pack_ffn2_permuted(EcEncoder* e, const std::string& prefix, int D, int F) {
+    const HostTensor* w = find(e, prefix + ".weight");
+    if (!w || (int64_t)w->data.size() != (int64_t)D * F) return nullptr;
+    const int Np = ec_round_up(D, 128), Kp = ec_round_up(F, 64);
+    std::vector<uint16_t> out((size_t)Np * Kp, 0);
+    for (int n = 0; n < D; ++n)
+        for (int k = 0; k < Kp; ++k) {
+            const int g = k / 16, pp = k % 16, hh = pp >> 3, ee = pp & 7;
+            const int src = g * 16 + 4 * hh + 8 * (ee >> 2) + (ee & 3);
+            if (src < F) out[(size_t)n * Kp + k] = h_f2bf(w->data[(size_t)n * F + src]);
+        }
+    return upload(e, out);
 }
 
 bool get_ln(EcEncoder* e, const std::string& prefix, int D, LNp* out, std::string* err) {
@@ -242,7 +259,7 @@ Workspace make_workspace(const EcEncoder* e, const Shapes& s, bool from_audio) {
         ma = std::max(ma, std::max(B * T * ld8(D), B * To * ld8(De)) * 2);
         mh = std::max(mh, std::max(B * T * D, B * To * De) * b.ff_ratio * 2);
         mq = std::max(mq, B * b.num_heads * Tg * dpad * 2);
-        mvt = std::max(mvt, B * b.num_heads * dpad * Tgp * 2);
+        mvt = std::max(mvt, B * b.num_heads * Tg * dpad * 2);
         me = std::max(me, (size_t)b.num_heads * (2 * Tg - 1) * dpad * 2);
         mg = std::max(mg, B * T * ld8(De) * 2);
         mc = std::max(mc, B * To * ld8(De) * 2);
@@ -308,6 +325,35 @@ int run_gemm(EcEncoder* e, int cls, hipStream_t st, const bf16_t* A, int lda, in
     return launch_gemm(p, epi, st);
 }
 
+// x += alpha * FFN(a)  — fused row-stationary kernel when the width allows, else two tiled GEMMs
+int run_ffn(EcEncoder* e, hipStream_t st, const bf16_t* a, int M, int D, const PackedLinear& L1, const PackedLinear& L2,
+            const bf16_t* w2p, float* x, bf16_t* hbuf) {
+    const int F = L1.N;
+    if (ffn_fused_supported(D)) {
+        PROF(PC_GEMM_FFN, 4.0 * M * (double)D * F, (double)M * D * 10 + 4.0 * D * F);
+        FfnParams p{};
+        p.A = a; p.lda = ld8(D); p.X = x; p.ldx = D; p.Y = x; p.ldy = D;
+        p.W1 = L1.w; p.ldw1 = L1.ldw; p.b1 = L1.bias; p.W2 = w2p; p.ldw2 = L2.ldw; p.b2 = L2.bias;
+        p.M = M; p.D = D; p.Fp = ec_round_up(F, 32); p.alpha = 0.5f;
+        return launch_ffn_fused(p, st);
+    }
+    int rc = run_gemm(e, PC_GEMM_FFN, st, a, ld8(D), M, L1, EPI_SWISH_BF16, hbuf, F);
+    if (rc) return rc;
+    return run_gemm(e, PC_GEMM_FFN, st, hbuf, F, M, L2, EPI_RESID_F32, x, D, x, D, 0.5f);
+}
+
+// row-stationary single GEMM when K <= 384, else the tiled kernel
+int run_rs_or_tiled(EcEncoder* e, int cls, hipStream_t st, const bf16_t* A, int lda, int M, const PackedLinear& L, int rs_epi,
+                    int tiled_epi, void* C, int ldc, const float* R = nullptr, int ldr = 0, float alpha = 1.f) {
+    if (!rs_gemm_supported(L.K)) return run_gemm(e, cls, st, A, lda, M, L, tiled_epi, C, ldc, R, ldr, alpha);
+    const double out_b = (tiled_epi == EPI_F32) ? 4.0 : (tiled_epi == EPI_RESID_F32 ? 8.0 : 2.0);
+    PROF(cls, 2.0 * M * (double)L.N * L.K, (double)M * L.K * 2 + (double)L.N * L.K * 2 + (double)M * L.N * out_b);
+    GemmParams p{};
+    p.A = A; p.lda = lda; p.W = L.w; p.ldw = L.ldw; p.bias = L.bias;
+    p.M = M; p.N = L.N; p.K = L.K; p.C = C; p.ldc = ldc; p.R = R; p.ldr = ldr; p.alpha = alpha;
+    return launch_rs_gemm(p, rs_epi, st);
+}
+
 int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from_audio, const Shapes& s, const Workspace& w,
                  char* ws, float* out, int64_t* out_len, hipStream_t st) {
     const EcConfig& c = e->cfg;
@@ -343,8 +389,7 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
         const int M = B * T, Mo = B * To;
         // ---- x += 1/2 FFN1(x)   (blocks.py:122; modules.py:385-392)
         { PROF(PC_LAYERNORM, 0, (double)M * D * 6); if (!have_a) EC_TRY(launch_layernorm(x, M, D, W.ln_ffn1.g, W.ln_ffn1.b, nullptr, a, ld8(D), nullptr, nullptr, st)); }
-        EC_TRY(run_gemm(e, PC_GEMM_FFN, st, a, ld8(D), M, W.ffn1_a, EPI_SWISH_BF16, hbuf, W.ffn1_a.N));
-        EC_TRY(run_gemm(e, PC_GEMM_FFN, st, hbuf, W.ffn1_a.N, M, W.ffn1_b, EPI_RESID_F32, x, D, x, D, 0.5f));
+        EC_TRY(run_ffn(e, st, a, M, D, W.ffn1_a, W.ffn1_b, W.ffn1_bp, x, hbuf));
         snprintf(nm, sizeof(nm), "blocks.%d.x_ffn1", k); trace_add(e, st, nm, x, M, D, D, 0);
 
         // ---- x += MHSA(LN(x))   (blocks.py:125-126; modules.py:472-488; attentions.py:549-718)
@@ -360,7 +405,8 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
             p.qu = reinterpret_cast<bf16_t*>(ws + w.qu); p.qv = reinterpret_cast<bf16_t*>(ws + w.qv);
             p.kh = reinterpret_cast<bf16_t*>(ws + w.kh); p.vt = reinterpret_cast<bf16_t*>(ws + w.vt);
             p.u = W.u; p.v = W.v;
-            { PROF(PC_GEMM_OTHER, 2.0 * M * 3.0 * D * D, (double)M * D * 2 + 3.0 * D * D * 2 + (double)M * D * 8); EC_TRY(launch_gemm(p, EPI_QKV, st)); }
+            { PROF(PC_GEMM_OTHER, 2.0 * M * 3.0 * D * D, (double)M * D * 2 + 3.0 * D * D * 2 + (double)M * D * 8);
+              if (rs_gemm_supported(D)) EC_TRY(launch_rs_gemm(p, 3, st)); else EC_TRY(launch_gemm(p, EPI_QKV, st)); }
             { PROF(PC_MISC, 0, 0); EC_TRY(launch_attn_pad_rows(p, B, st)); }
             // positional embeddings E = pos_layer(R) (attentions.py:588 / 678): input independent, tiny (2Tp-G rows)
             GemmParams pe{};
@@ -379,29 +425,28 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
             ap.out = o; ap.ldo = ld8(D); ap.scale = 1.0f / std::sqrt((float)d);
             { PROF(PC_ATTENTION, 2.0 * B * H * (double)Tg * Tg * d * 3.0, (double)M * D * 2 * 5); EC_TRY(launch_relpos_attention(ap, st)); }
             snprintf(nm, sizeof(nm), "blocks.%d.att_o", k); trace_add(e, st, nm, o, M, D, ld8(D), 1);
-            EC_TRY(run_gemm(e, PC_GEMM_OTHER, st, o, ld8(D), M, W.outp, EPI_RESID_F32, x, D, x, D, 1.0f));
+            EC_TRY(run_rs_or_tiled(e, PC_GEMM_OTHER, st, o, ld8(D), M, W.outp, 0, EPI_RESID_F32, x, D, x, D, 1.0f));
             snprintf(nm, sizeof(nm), "blocks.%d.x_mhsa", k); trace_add(e, st, nm, x, M, D, D, 0);
         }
 
         // ---- x = conv_res(x) + ConvModule(x)   (blocks.py:129; modules.py:511-522)
         { PROF(PC_LAYERNORM, 0, (double)M * D * 6); EC_TRY(launch_layernorm(x, M, D, W.ln_conv.g, W.ln_conv.b, nullptr, a, ld8(D), nullptr, nullptr, st)); }
-        EC_TRY(run_gemm(e, PC_GEMM_OTHER, st, a, ld8(D), M, W.pw1, EPI_GLU_BF16, gbuf, ld8(De)));
+        EC_TRY(run_rs_or_tiled(e, PC_GEMM_OTHER, st, a, ld8(D), M, W.pw1, 2, EPI_GLU_BF16, gbuf, ld8(De)));
         { PROF(PC_DWCONV, 2.0 * Mo * (double)De * b.kernel_size, (double)M * De * 2 + (double)Mo * De * 2); EC_TRY(launch_dwconv(gbuf, B, T, To, De, ld8(De), W.dw_w, W.dw_b, b.kernel_size, b.conv_stride, cbuf, st)); }
         snprintf(nm, sizeof(nm), "blocks.%d.dw", k); trace_add(e, st, nm, cbuf, Mo, De, ld8(De), 1);
         if (D != De) {   // 1x1 strided conv on frames 0, s, 2s, ...  (blocks.py:106-110)
             { PROF(PC_MISC, 0, (double)Mo * D * 6); EC_TRY(launch_cast_rows(x, D, T, b.conv_stride, To, B, xs, ld8(D), st)); }
-            EC_TRY(run_gemm(e, PC_GEMM_OTHER, st, xs, ld8(D), Mo, W.res, EPI_F32, xalt, De));
+            EC_TRY(run_rs_or_tiled(e, PC_GEMM_OTHER, st, xs, ld8(D), Mo, W.res, 1, EPI_F32, xalt, De));
             std::swap(x, xalt);
         } else if (b.conv_stride > 1) {
             return fail("strided block without expansion is not native (no shipped config uses it)");
         }
-        EC_TRY(run_gemm(e, PC_GEMM_OTHER, st, cbuf, ld8(De), Mo, W.pw2, EPI_RESID_F32, x, De, x, De, 1.0f));
+        EC_TRY(run_rs_or_tiled(e, PC_GEMM_OTHER, st, cbuf, ld8(De), Mo, W.pw2, 0, EPI_RESID_F32, x, De, x, De, 1.0f));
         snprintf(nm, sizeof(nm), "blocks.%d.x_conv", k); trace_add(e, st, nm, x, Mo, De, De, 0);
 
         // ---- x += 1/2 FFN2(x); x = LN(x)   (blocks.py:132-135)
         { PROF(PC_LAYERNORM, 0, (double)Mo * De * 6); EC_TRY(launch_layernorm(x, Mo, De, W.ln_ffn2.g, W.ln_ffn2.b, nullptr, a, ld8(De), nullptr, nullptr, st)); }
-        EC_TRY(run_gemm(e, PC_GEMM_FFN, st, a, ld8(De), Mo, W.ffn2_a, EPI_SWISH_BF16, hbuf, W.ffn2_a.N));
-        EC_TRY(run_gemm(e, PC_GEMM_FFN, st, hbuf, W.ffn2_a.N, Mo, W.ffn2_b, EPI_RESID_F32, x, De, x, De, 0.5f));
+        EC_TRY(run_ffn(e, st, a, Mo, De, W.ffn2_a, W.ffn2_b, W.ffn2_bp, x, hbuf));
         const bool last = (k == nb - 1);
         float* xo = last ? out : x;
         // block-final norm fused with the next block's FFN1 pre-norm (both read the same rows)
@@ -496,6 +541,9 @@ int effconf_encoder_finalize(EcEncoder* e) {
                   pack_named_linear(e, p + ".feed_forward_module2.layers.4", De, F2, &W.ffn2_b, &err) &&
                   get_ln(e, p + ".norm", De, &W.ln_out, &err);
         if (!ok) return fail(err);
+        W.ffn1_bp = pack_ffn2_permuted(e, p + ".feed_forward_module1.layers.4", D, F1);
+        W.ffn2_bp = pack_ffn2_permuted(e, p + ".feed_forward_module2.layers.4", De, F2);
+        if (!W.ffn1_bp || !W.ffn2_bp) return fail("upload failed");
         const std::string m = p + ".multi_head_self_attention_module";
         if (!get_ln(e, m + ".norm", D, &W.ln_att, &err)) return fail(err);
         {   // Q, K, V stacked into one [3D][D] weight

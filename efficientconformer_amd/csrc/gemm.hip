@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDev gd) {
                     const size_t idx = ((size_t)(b * p.H + h) * p.Tg + tq) * p.dpad + x;
                     if (which == 0) { p.qu[idx] = f2bf(val + bu); p.qv[idx] = f2bf(val + bv); }
                     else if (which == 1) p.kh[idx] = f2bf(val);
-                    else p.vt[((size_t)(b * p.H + h) * p.dpad + x) * p.Tgp + tq] = f2bf(val);
+                    else p.vt[idx] = f2bf(val);
                 }
         }
     } else {

@@ -31,6 +31,26 @@ struct GemmParams {
 };
 int launch_gemm(const GemmParams& p, int epi, hipStream_t s);
 
+// ---------------------------------------------------------------- row-stationary fused kernels  (rsgemm.hip)
+// y = x + alpha * (Swish(a W1^T + b1) W2^T + b2);  a = bf16 LayerNorm(x) [M][lda], x/y fp32 [M][ld] (may alias)
+// W1 : bf16 [Fp][ldw1] (rows = hidden units, zero padded to Fp = round_up(F, 32) and ldw1 >= round_up(D, 64))
+// W2 : bf16 [>= round_up(D,128)][ldw2 = Fp], hidden index permuted within groups of 16 (see rsgemm.hip)
+struct FfnParams {
+    const bf16_t* A; int lda;
+    const float* X; int ldx;
+    float* Y; int ldy;
+    const bf16_t* W1; int ldw1; const float* b1;
+    const bf16_t* W2; int ldw2; const float* b2;
+    int M, D, Fp;
+    float alpha;
+};
+// single row-stationary GEMM (K <= 384); epi: 0 residual fp32, 1 fp32, 2 GLU bf16 (N = packed a|b rows), 3 QKV scatter
+// (GemmParams fields as for launch_gemm; `vt` receives V in the SAME head-major row-major layout as K)
+bool rs_gemm_supported(int K);
+int launch_rs_gemm(const GemmParams& p, int epi, hipStream_t s);
+bool ffn_fused_supported(int D);
+int launch_ffn_fused(const FfnParams& p, hipStream_t s);
+
 // ---------------------------------------------------------------- normalisation / casts  (norm.hip)
 // y = LayerNorm(x) over the last dim (eps 1e-6), two-pass fp32 statistics, one wave per row.
 // out_bf16 (ld = round_up(D,8), pad columns zeroed) and/or out_f32 (ld = D) may be null.

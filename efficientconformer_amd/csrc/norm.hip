@@ -3,6 +3,7 @@
 // wavefront shuffles for the row reductions; emits the bf16 A-operand of the following GEMM directly
 // (and, for the block-final norm, also the fp32 residual stream and the *next* block's pre-normed A).
 #include "kernels.h"
+#include <algorithm>
 
 namespace {
 
@@ -47,9 +48,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         float* out_f32, bf16_t* out_bf16, int ld_bf16,
                                                         const float* g2, const float* b2) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
     const int nv = (D / 4 + 63) / 64;
+    // grid-stride over rows: a wave handles many rows so that the launch is not dominated by wave start-up
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += gridDim.x * 4) {
     float4 v[MAXV];
     const float* xr = x + (size_t)row * D;
 #pragma unroll
@@ -74,6 +75,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                 *reinterpret_cast<uint2*>(o + c) = w;
             }
         }
+    }
     }
 }
 
@@ -102,7 +104,8 @@ int launch_layernorm(const float* x, int M, int D, const float* gamma, const flo
                      const float* gamma2, const float* beta2, hipStream_t s) {
     if (M <= 0) return 0;
     if (D % 4 || D > 64 * 4 * MAXV || (out_bf16 && (ld_bf16 % 4 || ld_bf16 < D))) return -2;
-    hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, M, D, gamma, beta,
+    const int blocks = std::min((M + 3) / 4, 256 * 8);
+    hipLaunchKernelGGL(layernorm_kernel, dim3(blocks), dim3(256), 0, s, x, M, D, gamma, beta,
                        out_f32, out_bf16, ld_bf16, gamma2, beta2);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
