@@ -11,15 +11,20 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 #define EC_WAVE 64
 
-__device__ __forceinline__ uint16_t f2bf(float f) {   // round-to-nearest-even
-    uint32_t u = __float_as_uint(f);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+// float -> bf16, round-to-nearest-even in hardware (v_cvt_pk_bf16_f32 on gfx950)
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+    union { bf16x2_t b; uint32_t u; } c;
+    c.b = bf16x2_t{(__bf16)lo, (__bf16)hi};
+    return c.u;
 }
+__device__ __forceinline__ uint16_t f2bf(float f) { return (uint16_t)(pack_bf2(f, 0.f) & 0xFFFFu); }
 __device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
-__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// sigmoid via v_exp_f32 (2^x) + v_rcp_f32: ~1 ulp, no IEEE divide sequence
+__device__ __forceinline__ float sigmoidf_(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896f * x));
+}
 __device__ __forceinline__ float swishf_(float x) { return x * sigmoidf_(x); }
 
 // Zero the bf16 elements with index >= valid (0..8) of a 16-byte chunk of 8 bf16.

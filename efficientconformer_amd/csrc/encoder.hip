@@ -345,7 +345,8 @@ int run_ffn(EcEncoder* e, hipStream_t st, const bf16_t* a, int M, int D, const P
 // row-stationary single GEMM when K <= 384, else the tiled kernel
 int run_rs_or_tiled(EcEncoder* e, int cls, hipStream_t st, const bf16_t* A, int lda, int M, const PackedLinear& L, int rs_epi,
                     int tiled_epi, void* C, int ldc, const float* R = nullptr, int ldr = 0, float alpha = 1.f) {
-    if (!rs_gemm_supported(L.K)) return run_gemm(e, cls, st, A, lda, M, L, tiled_epi, C, ldc, R, ldr, alpha);
+    const bool ok = (rs_epi == 0 || rs_epi == 1) ? rs_gemm_resident_supported(L.K, L.N) : rs_gemm_supported(L.K);
+    if (!ok) return run_gemm(e, cls, st, A, lda, M, L, tiled_epi, C, ldc, R, ldr, alpha);
     const double out_b = (tiled_epi == EPI_F32) ? 4.0 : (tiled_epi == EPI_RESID_F32 ? 8.0 : 2.0);
     PROF(cls, 2.0 * M * (double)L.N * L.K, (double)M * L.K * 2 + (double)L.N * L.K * 2 + (double)M * L.N * out_b);
     GemmParams p{};

@@ -47,6 +47,7 @@ struct FfnParams {
 // single row-stationary GEMM (K <= 384); epi: 0 residual fp32, 1 fp32, 2 GLU bf16 (N = packed a|b rows), 3 QKV scatter
 // (GemmParams fields as for launch_gemm; `vt` receives V in the SAME head-major row-major layout as K)
 bool rs_gemm_supported(int K);
+bool rs_gemm_resident_supported(int K, int N);   // residual / fp32 epilogues keep the whole output row in registers
 int launch_rs_gemm(const GemmParams& p, int epi, hipStream_t s);
 bool ffn_fused_supported(int D);
 int launch_ffn_fused(const FfnParams& p, hipStream_t s);

@@ -1,5 +1,5 @@
 // Row-stationary MFMA kernels for the Conformer block (gfx950): activations stay in registers,
-// weights stream through LDS.
+// weights stream through an LDS-DMA ring.
 //
 // The block's GEMMs are tall and skinny (M = B*T rows in the 10^4..10^5 range, K = D in 120..384,
 // N in D..4D), so the classic C-tile GEMM re-reads A once per N tile and spends most of its time in
@@ -8,8 +8,12 @@
 //   * a wave owns RT*32 activation rows; lane l holds row (l & 31) of each 32-row tile, split in two
 //     halves across lanes l and l+32 -> X is the MFMA *B* operand and lives in registers for the whole kernel
 //     (v_mfma_f32_32x32x16_bf16: B[k][n]: n = lane & 31, k = 8*(lane>>5) + e);
-//   * weight rows are the MFMA *A* operand, staged in 32-row chunks through a double-buffered LDS ring
-//     shared by all waves of the workgroup (every wave needs every weight row exactly once);
+//   * weight rows are the MFMA *A* operand, streamed in 32-row chunks by LDS-DMA
+//     (global_load_lds_dwordx4: no staging registers) into a 3/4-deep ring shared by all waves of the
+//     workgroup, with counted s_waitcnt vmcnt(N) and one raw s_barrier per chunk, so two chunks are always in
+//     flight while one is computed (a one-deep register-staged prefetch was L2-latency bound:
+//     profiles/r1_01_*).  The LDS image is lane-linear, so the bank-conflict swizzle is applied to the
+//     SOURCE address (piece rotation by row) and undone on the read;
 //   * the result tile C^T[n][m] leaves every lane with 16 output columns of ITS OWN row m, so
 //     bias/activation/residual are lane-local, and a second GEMM can consume the first one's
 //     accumulators directly as its B operand: accumulator registers [8s, 8s+8) of a 32-row result tile are,
@@ -19,33 +23,90 @@
 // ffn_fused_kernel: y = x + alpha * (Swish(a W1^T + b1) W2^T + b2)   (a = LayerNorm(x) as bf16)
 //   replaces FeedForwardModule.forward + the half-step residual (reference models/modules.py:385-392,
 //   blocks.py:122, 132); the 4D-wide hidden activation never exists in memory.
+// rs_gemm_kernel: one GEMM with the QKV-scatter / GLU / residual epilogues (see below).
 #include "kernels.h"
 
 namespace {
 
-constexpr int CH = 32;   // weight rows per LDS chunk == hidden units per step
+constexpr int CH = 32;   // weight rows per LDS chunk (== hidden units per FFN step)
 
-template <int KS, int NT2>
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+
+// one wave-wide LDS-DMA: lane i's 16 bytes at g land at lds_wave_base + 16*i
+__device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)g, (lds_void_t*)lds_wave_base, 16, 0, 0);
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N < 64, "vmcnt immediate is 6 bits");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// wait until at most `allowed` chunks (of PER DMA instructions each, issued by this wave) are still in flight
+template <int PER, int MAXC> __device__ __forceinline__ void wait_chunks(int allowed) {
+    if (allowed >= MAXC) wait_vmcnt<PER * MAXC>();
+    else if (MAXC >= 2 && allowed == 1) wait_vmcnt<PER>();
+    else wait_vmcnt<0>();
+}
+__device__ __forceinline__ void wg_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// Issue the DMA for a [32 rows][P pieces of 16 B] weight chunk (row r at src + r*ld elements).  LDS image: piece pc of row r
+// sits at slot r*P + (pc + r) % P.  Wave-instruction i (32*P/64 per chunk) covers slots [64i, 64i+64).
+template <int P> __device__ __forceinline__ void dma_rows32(const bf16_t* src, int ld, char* img, int i, int lane) {
+    const int L = 64 * i + lane;
+    const int r = L / P, q = L - r * P;
+    int pc = q - (r % P);
+    pc += pc < 0 ? P : 0;
+    glds16(src + (size_t)r * ld + pc * 8, img + 64 * i * 16);
+}
+// FFN second weight chunk: [R rows][4 pieces] (32 hidden units), piece pc of row n at slot n*4 + ((pc + (n>>2)) & 3)
+__device__ __forceinline__ void dma_w2(const bf16_t* src, int ld, char* img, int j, int lane) {
+    const int L = 64 * j + lane;
+    const int n = L >> 2, q = L & 3;
+    const int pc = (q - (n >> 2)) & 3;
+    glds16(src + (size_t)n * ld + pc * 8, img + 64 * j * 16);
+}
+
+template <int KS, int NT2, int NBUF>
 struct FfnSmem {
-    static constexpr int W1ROW = KS * 32 + 16;            // bytes per W1 row in LDS (KS*16 bf16 + 16 B pad)
-    static constexpr int W2ROW = CH * 2 + 16;             // 80 B
-    static constexpr int W1_BYTES = CH * W1ROW;
-    static constexpr int W2_BYTES = NT2 * 32 * W2ROW;
-    static constexpr int BUF = W1_BYTES + W2_BYTES + 128;  // + b1 chunk (32 floats)
-    static constexpr int TOTAL = 2 * BUF;
+    static constexpr int P1 = KS * 2;                      // 16-byte pieces per W1 row
+    static constexpr int W1_BYTES = CH * P1 * 16;
+    static constexpr int W2_BYTES = NT2 * 32 * 64;
+    static constexpr int BUF = W1_BYTES + W2_BYTES;
+    static constexpr int RING = NBUF * BUF;
 };
 
-// KS: k16-steps over D (D <= 16*KS), NT2: 32-col tiles over D (D <= 32*NT2), RT: 32-row tiles per wave, NW: waves
-template <int KS, int NT2, int RT, int NW>
+// KS: k16-steps over D (D <= 16*KS), NT2 = KS/2: 32-col tiles over D, RT: 32-row tiles per wave, NW: waves, NBUF: ring depth
+template <int KS, int NT2, int RT, int NW, int NBUF>
 __global__ __launch_bounds__(NW * 64) void ffn_fused_kernel(const FfnParams p) {
-    using SM = FfnSmem<KS, NT2>;
+    using SM = FfnSmem<KS, NT2, NBUF>;
+    static_assert(NT2 * 2 == KS && (2 * KS) % NW == 0, "uniform DMA count per wave");
+    constexpr int PER = 2 * KS / NW;                       // DMA instructions per wave per chunk
+    constexpr int P1 = SM::P1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sb1 = reinterpret_cast<float*>(smem + SM::RING);   // whole first bias in LDS
     constexpr int NTHR = NW * 64;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 31, half = lane >> 5;
     const int m_base = (blockIdx.x * NW + wave) * (RT * 32);
+    const int nchunks = p.Fp / CH;
 
-    // ---- this lane's activation row fragments (B operand of GEMM1), loaded once
+    auto issue = [&](int c) {
+        char* buf = smem + (c % NBUF) * SM::BUF;
+        const bf16_t* w1 = p.W1 + (size_t)c * CH * p.ldw1;
+        const bf16_t* w2 = p.W2 + c * CH;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = wave + NW * k;
+            if (i < KS) dma_rows32<P1>(w1, p.ldw1, buf, i, lane);
+            else dma_w2(w2, p.ldw2, buf + SM::W1_BYTES, i - KS, lane);
+        }
+    };
+
+    // ---- bias -> LDS, this lane's activation row fragments (B operand of GEMM1), then start the weight stream
+    for (int i = tid; i < p.Fp; i += NTHR) sb1[i] = p.b1[i];
     bf16x8 xf[RT][KS];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
@@ -59,6 +120,10 @@ __global__ __launch_bounds__(NW * 64) void ffn_fused_kernel(const FfnParams p) {
             xf[rt][s] = as_bf16x8(v);
         }
     }
+#pragma unroll
+    for (int c = 0; c < NBUF - 1; ++c)
+        if (c < nchunks) issue(c);
+
     f32x16 acc[RT][NT2];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
@@ -67,67 +132,19 @@ __global__ __launch_bounds__(NW * 64) void ffn_fused_kernel(const FfnParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[rt][t][r] = 0.f;
 
-    // ---- weight staging: chunk c = hidden units [32c, 32c+32)
-    constexpr int W1_CHUNKS = CH * KS * 2;                 // 16-byte pieces of a W1 chunk (KS*16 bf16 per row)
-    constexpr int W2_CHUNKS = NT2 * 32 * 4;                // 4 pieces (32 bf16) per W2 row
-    constexpr int N1 = (W1_CHUNKS + NTHR - 1) / NTHR, N2 = (W2_CHUNKS + NTHR - 1) / NTHR;
-    uint4 r1[N1], r2[N2];
-#pragma unroll
-    for (int i = 0; i < N1; ++i) r1[i] = make_uint4(0, 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < N2; ++i) r2[i] = make_uint4(0, 0, 0, 0);
-    float rb = 0.f;
-    auto load_chunk = [&](int c) {
-#pragma unroll
-        for (int i = 0; i < N1; ++i) {
-            const int q = tid + i * NTHR;
-            if (W1_CHUNKS % NTHR == 0 || q < W1_CHUNKS) {
-                const int row = q / (KS * 2), pc = q - row * (KS * 2);
-                r1[i] = *reinterpret_cast<const uint4*>(p.W1 + (size_t)(c * CH + row) * p.ldw1 + pc * 8);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < N2; ++i) {
-            const int q = tid + i * NTHR;
-            if (W2_CHUNKS % NTHR == 0 || q < W2_CHUNKS) {
-                const int row = q >> 2, pc = q & 3;
-                r2[i] = *reinterpret_cast<const uint4*>(p.W2 + (size_t)row * p.ldw2 + c * CH + pc * 8);
-            }
-        }
-        if (tid < CH) rb = p.b1[c * CH + tid];
-    };
-    auto store_chunk = [&](int buf) {
-        char* w1 = smem + buf * SM::BUF;
-        char* w2 = w1 + SM::W1_BYTES;
-#pragma unroll
-        for (int i = 0; i < N1; ++i) {
-            const int q = tid + i * NTHR;
-            if (W1_CHUNKS % NTHR == 0 || q < W1_CHUNKS) {
-                const int row = q / (KS * 2), pc = q - row * (KS * 2);
-                *reinterpret_cast<uint4*>(w1 + row * SM::W1ROW + pc * 16) = r1[i];
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < N2; ++i) {
-            const int q = tid + i * NTHR;
-            if (W2_CHUNKS % NTHR == 0 || q < W2_CHUNKS) {
-                const int row = q >> 2, pc = q & 3;
-                *reinterpret_cast<uint4*>(w2 + row * SM::W2ROW + pc * 16) = r2[i];
-            }
-        }
-        if (tid < CH) reinterpret_cast<float*>(w2 + SM::W2_BYTES)[tid] = rb;
-    };
+    // per-lane read offsets: W1 piece (2s + half) of row lr; W2 pieces of rows 32t + lr
+    const int q0 = (half + lr) % P1;
+    const int k2 = (half + (lr >> 2)) & 3;
+    const int w2off0 = lr * 64 + k2 * 16, w2off1 = lr * 64 + (k2 ^ 2) * 16;
 
-    const int nchunks = p.Fp / CH;
-    load_chunk(0);
-    store_chunk(0);
-    __syncthreads();
     for (int c = 0; c < nchunks; ++c) {
-        const int buf = c & 1;
-        if (c + 1 < nchunks) load_chunk(c + 1);
-        const char* w1 = smem + buf * SM::BUF + lr * SM::W1ROW + half * 16;
-        const char* w2 = smem + buf * SM::BUF + SM::W1_BYTES + lr * SM::W2ROW + half * 16;
-        const float* b1 = reinterpret_cast<const float*>(smem + buf * SM::BUF + SM::W1_BYTES + SM::W2_BYTES);
+        wait_chunks<PER, NBUF - 2>(nchunks - 1 - c);       // chunk c has landed (this wave's pieces)
+        wg_barrier();                                      // ... and everybody's; everybody is done with chunk c-1
+        if (c + NBUF - 1 < nchunks) issue(c + NBUF - 1);   // refill the buffer chunk c-1 used
+        const char* buf = smem + (c % NBUF) * SM::BUF;
+        const char* w1 = buf + lr * (P1 * 16);
+        const char* w2 = buf + SM::W1_BYTES;
+        const float* b1 = sb1 + c * CH;
         // ---- GEMM1: H^T[j][m] = sum_k W1[j][k] a[m][k]
         f32x16 h[RT];
 #pragma unroll
@@ -136,7 +153,9 @@ __global__ __launch_bounds__(NW * 64) void ffn_fused_kernel(const FfnParams p) {
             for (int r = 0; r < 16; ++r) h[rt][r] = 0.f;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(w1 + s * 32);
+            int q = q0 + 2 * s;
+            q -= q >= P1 ? P1 : 0;
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(w1 + q * 16);
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) h[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xf[rt][s], h[rt], 0, 0, 0);
         }
@@ -155,16 +174,15 @@ __global__ __launch_bounds__(NW * 64) void ffn_fused_kernel(const FfnParams p) {
         }
         // ---- GEMM2: Y^T[n][m] += sum_j W2p[n][j] H^T[j][m]
 #pragma unroll
-        for (int t = 0; t < NT2; ++t)
+        for (int t = 0; t < NT2; ++t) {
+            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(w2 + t * 2048 + w2off0);
+            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(w2 + t * 2048 + w2off1);
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(w2 + t * 32 * SM::W2ROW + s2 * 32);
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt)
-                    acc[rt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hf[rt][s2], acc[rt][t], 0, 0, 0);
+            for (int rt = 0; rt < RT; ++rt) {
+                acc[rt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, hf[rt][0], acc[rt][t], 0, 0, 0);
+                acc[rt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, hf[rt][1], acc[rt][t], 0, 0, 0);
             }
-        if (c + 1 < nchunks) store_chunk(buf ^ 1);
-        __syncthreads();
+        }
     }
 
     // ---- epilogue: y[m][n] = x[m][n] + alpha * (acc + b2[n]);  lane owns row m, columns 32t + 8q + 4*half + (0..3)
@@ -192,6 +210,23 @@ __global__ __launch_bounds__(NW * 64) void ffn_fused_kernel(const FfnParams p) {
     }
 }
 
+template <int KS, int NT2, int RT, int NW, int NBUF>
+int launch_ffn_t(const FfnParams& p, hipStream_t s) {
+    using SM = FfnSmem<KS, NT2, NBUF>;
+    const int lds = SM::RING + p.Fp * 4;
+    if (lds > 160 * 1024) return -4;
+    static int attr_set = 0;
+    if (attr_set < lds) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_fused_kernel<KS, NT2, RT, NW, NBUF>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = lds;
+    }
+    const int rows_per_wg = NW * RT * 32;
+    hipLaunchKernelGGL((ffn_fused_kernel<KS, NT2, RT, NW, NBUF>), dim3((p.M + rows_per_wg - 1) / rows_per_wg), dim3(NW * 64),
+                       lds, s, p);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 // ---------------------------------------------------------------------------------------------
 // rs_gemm_kernel: one GEMM, activations stationary:  C^T[n][m] = sum_k W[n][k] a[m][k]  (K = D <= 384)
 //   RS_RESID : y[m][n] = R[m][n] + alpha * (acc + bias[n])      fp32   (attention output projection +
@@ -210,17 +245,35 @@ struct FastDiv32 {   // exact for n * d < 2^32
 };
 struct RsDev { GemmParams p; int nchunks; FastDiv32 fD, fd; };
 
-template <int KS, int RT, int NW, int EPI>
+// G = output tiles (32 columns each) accumulated in registers before they are flushed.  Flushes of the QKV / GLU
+// variants contain only stores and sit at the FRONT of an iteration (before the next DMA issue), so the counted vmcnt
+// never under-waits (memory ops retire in order; extra stores in the FIFO can only make the wait stricter).  The
+// residual variants read R, so they keep the whole row (G >= N/32) and flush once after the loop.
+template <int KS, int G, int RT, int NW, int NBUF, int EPI>
 __global__ __launch_bounds__(NW * 64) void rs_gemm_kernel(const RsDev gd) {
     const GemmParams& p = gd.p;
-    constexpr int WROW = KS * 32 + 16;
-    constexpr int BUF = CH * WROW + 128;
+    static_assert(KS % NW == 0, "uniform DMA count per wave");
+    static_assert(EPI != RS_GLU || G % 2 == 0, "GLU flushes (a, b) pairs");
+    constexpr int PER = KS / NW;
+    constexpr int P1 = KS * 2;
+    constexpr int BUF = CH * P1 * 16;
     constexpr int NTHR = NW * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* sbias = reinterpret_cast<float*>(smem + NBUF * BUF);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 31, half = lane >> 5;
     const int m_base = (blockIdx.x * NW + wave) * (RT * 32);
+    const int nchunks = gd.nchunks;
 
+    auto issue = [&](int c) {
+        char* buf = smem + (c % NBUF) * BUF;
+        const bf16_t* w = p.W + (size_t)c * CH * p.ldw;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) dma_rows32<P1>(w, p.ldw, buf, wave + NW * k, lane);
+    };
+
+    for (int i = tid; i < nchunks * CH; i += NTHR) sbias[i] = p.bias[i];
     bf16x8 xf[RT][KS];
     int rowm[RT];
 #pragma unroll
@@ -249,106 +302,64 @@ __global__ __launch_bounds__(NW * 64) void rs_gemm_kernel(const RsDev gd) {
             qb[rt] = b; qtq[rt] = t / p.G; qtoff[rt] = t - qtq[rt] * p.G;
         }
     }
+#pragma unroll
+    for (int c = 0; c < NBUF - 1; ++c)
+        if (c < nchunks) issue(c);
 
-    constexpr int W_CHUNKS = CH * KS * 2;
-    constexpr int N1 = (W_CHUNKS + NTHR - 1) / NTHR;
-    uint4 r1[N1];
-#pragma unroll
-    for (int i = 0; i < N1; ++i) r1[i] = make_uint4(0, 0, 0, 0);
-    float rb = 0.f;
-    auto load_chunk = [&](int c) {
-#pragma unroll
-        for (int i = 0; i < N1; ++i) {
-            const int q = tid + i * NTHR;
-            if (W_CHUNKS % NTHR == 0 || q < W_CHUNKS) {
-                const int row = q / (KS * 2), pc = q - row * (KS * 2);
-                r1[i] = *reinterpret_cast<const uint4*>(p.W + (size_t)(c * CH + row) * p.ldw + pc * 8);
-            }
-        }
-        if (tid < CH) rb = p.bias[c * CH + tid];
-    };
-    auto store_chunk = [&](int buf) {
-        char* w = smem + buf * BUF;
-#pragma unroll
-        for (int i = 0; i < N1; ++i) {
-            const int q = tid + i * NTHR;
-            if (W_CHUNKS % NTHR == 0 || q < W_CHUNKS) {
-                const int row = q / (KS * 2), pc = q - row * (KS * 2);
-                *reinterpret_cast<uint4*>(w + row * WROW + pc * 16) = r1[i];
-            }
-        }
-        if (tid < CH) reinterpret_cast<float*>(w + CH * WROW)[tid] = rb;
-    };
+    f32x16 acc[RT][G];
 
-    f32x16 prev[RT];   // GLU: the 'a' half of the current channel block
-    load_chunk(0);
-    store_chunk(0);
-    __syncthreads();
-    for (int c = 0; c < gd.nchunks; ++c) {
-        const int buf = c & 1;
-        if (c + 1 < gd.nchunks) load_chunk(c + 1);
-        const char* w = smem + buf * BUF + lr * WROW + half * 16;
-        const float* bias = reinterpret_cast<const float*>(smem + buf * BUF + CH * WROW);
-        f32x16 acc[RT];
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(w + s * 32);
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xf[rt][s], acc[rt], 0, 0, 0);
-        }
-        // ---- epilogue of this 32-column chunk: lane owns row m, columns n = 32c + 8q + 4*half + i
+    // flush tiles [0, ntiles) of the group whose first chunk is c0: lane owns row m, columns 32(c0+g) + 8q + 4*half + i
+    auto flush = [&](int c0, int ntiles) __attribute__((always_inline)) {
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             const int m = rowm[rt];
-            if constexpr (EPI == RS_RESID || EPI == RS_F32) {
-                if (m < p.M) {
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                if (g < ntiles) {
+                const float* bias = sbias + (c0 + g) * CH;
+                if constexpr (EPI == RS_RESID || EPI == RS_F32) {
                     float* yr = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const int nl = q * 8 + half * 4, n = c * CH + nl;
+                        const int nl = q * 8 + half * 4, n = (c0 + g) * CH + nl;
                         if (n >= p.N) continue;
                         float4 o;
-                        o.x = acc[rt][q * 4 + 0] + bias[nl + 0]; o.y = acc[rt][q * 4 + 1] + bias[nl + 1];
-                        o.z = acc[rt][q * 4 + 2] + bias[nl + 2]; o.w = acc[rt][q * 4 + 3] + bias[nl + 3];
+                        o.x = acc[rt][g][q * 4 + 0] + bias[nl + 0]; o.y = acc[rt][g][q * 4 + 1] + bias[nl + 1];
+                        o.z = acc[rt][g][q * 4 + 2] + bias[nl + 2]; o.w = acc[rt][g][q * 4 + 3] + bias[nl + 3];
                         if constexpr (EPI == RS_RESID) {
                             const float4 xv = *reinterpret_cast<const float4*>(p.R + (size_t)m * p.ldr + n);
                             o.x = xv.x + p.alpha * o.x; o.y = xv.y + p.alpha * o.y; o.z = xv.z + p.alpha * o.z; o.w = xv.w + p.alpha * o.w;
                         }
                         *reinterpret_cast<float4*>(yr + n) = o;
                     }
-                }
-            } else if constexpr (EPI == RS_GLU) {
-                if ((c & 1) == 0) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) prev[rt][r] = acc[rt][r] + bias[(r & 3) + 8 * (r >> 2) + 4 * half];
-                } else if (m < p.M) {
+                } else if constexpr (EPI == RS_GLU) {
+                    if ((g & 1) == 0 && g + 1 < G) {                       // tiles (g, g+1) = (a, b) of channel block (c0+g)/2
+                    constexpr int gb = (G > 1) ? 1 : 0;
+                    const float* bias_b = bias + CH;
                     bf16_t* gr = reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const int nl = q * 8 + half * 4, j = (c >> 1) * CH + nl;
+                        const int nl = q * 8 + half * 4, j = ((c0 + g) >> 1) * CH + nl;
                         if (j >= p.ldc) continue;
-                        float g[4];
+                        float o[4];
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) g[i] = prev[rt][q * 4 + i] * sigmoidf_(acc[rt][q * 4 + i] + bias[nl + i]);
-                        *reinterpret_cast<uint2*>(gr + j) = make_uint2(pack_bf2(g[0], g[1]), pack_bf2(g[2], g[3]));
+                        for (int i = 0; i < 4; ++i)
+                            o[i] = (acc[rt][g][q * 4 + i] + bias[nl + i]) * sigmoidf_(acc[rt][(g + gb) % G][q * 4 + i] + bias_b[nl + i]);
+                        *reinterpret_cast<uint2*>(gr + j) = make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
                     }
-                }
-            } else {   // RS_QKV
-                if (m < p.M) {
+                    }
+                } else {   // RS_QKV
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const int nl = q * 8 + half * 4, n0 = c * CH + nl;
+                        const int nl = q * 8 + half * 4, n0 = (c0 + g) * CH + nl;
                         if (n0 >= p.N) continue;
                         // D % 4 == 0: the 4 columns share `which`; heads may split inside the group only between pairs when d is even
                         const int which = gd.fD.div(n0), nn0 = n0 - which * p.D;
                         bf16_t* dst = which == 1 ? p.kh : (which == 2 ? p.vt : p.qu);
 #pragma unroll
                         for (int i2 = 0; i2 < 4; i2 += 2) {
-                            float v0 = acc[rt][q * 4 + i2] + bias[nl + i2], v1 = acc[rt][q * 4 + i2 + 1] + bias[nl + i2 + 1];
+                            const float v0 = acc[rt][g][q * 4 + i2] + bias[nl + i2], v1 = acc[rt][g][q * 4 + i2 + 1] + bias[nl + i2 + 1];
                             const int flat = qtoff[rt] * p.D + nn0 + i2;
                             const int h = gd.fd.div(flat), x = flat - h * p.d;
                             const size_t idx = ((size_t)(qb[rt] * p.H + h) * p.Tg + qtq[rt]) * p.dpad + x;
@@ -372,52 +383,82 @@ __global__ __launch_bounds__(NW * 64) void rs_gemm_kernel(const RsDev gd) {
                         }
                     }
                 }
+                }
             }
         }
-        if (c + 1 < gd.nchunks) store_chunk(buf ^ 1);
-        __syncthreads();
+    };
+
+    const int q0 = (half + lr) % P1;
+    for (int cg = 0; cg < nchunks; cg += G) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int c = cg + g;
+            if (c < nchunks) {
+            wait_chunks<PER, NBUF - 2>(nchunks - 1 - c);
+            wg_barrier();
+            if (g == 0 && cg > 0) flush(cg - G, G);            // stores of the previous group, BEFORE the next DMA issue
+            if (c + NBUF - 1 < nchunks) issue(c + NBUF - 1);
+            const char* w = smem + (c % NBUF) * BUF + lr * (P1 * 16);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[rt][g][r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                int q = q0 + 2 * s;
+                q -= q >= P1 ? P1 : 0;
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(w + q * 16);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc[rt][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xf[rt][s], acc[rt][g], 0, 0, 0);
+            }
+            }
+        }
+    }
+    {   // last (possibly partial) group
+        const int c0 = ((nchunks - 1) / G) * G;
+        flush(c0, nchunks - c0);
     }
 }
 
-template <int KS, int RT, int NW, int EPI>
+template <int KS, int G, int RT, int NW, int NBUF, int EPI>
 int launch_rs_t(const RsDev& gd, hipStream_t s) {
-    constexpr int LDS = 2 * (CH * (KS * 32 + 16) + 128);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rs_gemm_kernel<KS, RT, NW, EPI>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
+    const int lds = NBUF * CH * KS * 32 + gd.nchunks * CH * 4;
+    if (lds > 160 * 1024) return -4;
+    if ((EPI == RS_RESID || EPI == RS_F32) && gd.nchunks > G) return -5;
+    static int attr_set = 0;
+    if (attr_set < lds) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rs_gemm_kernel<KS, G, RT, NW, NBUF, EPI>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = lds;
     }
     const int rows_per_wg = NW * RT * 32;
-    hipLaunchKernelGGL((rs_gemm_kernel<KS, RT, NW, EPI>), dim3((gd.p.M + rows_per_wg - 1) / rows_per_wg), dim3(NW * 64), LDS, s, gd);
+    hipLaunchKernelGGL((rs_gemm_kernel<KS, G, RT, NW, NBUF, EPI>), dim3((gd.p.M + rows_per_wg - 1) / rows_per_wg), dim3(NW * 64), lds, s, gd);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+// configuration class from max(K, N_resident): KS k-steps; residual variants keep KS/2 output tiles, the others 4
 template <int EPI>
 int launch_rs_ks(const RsDev& gd, hipStream_t s) {
-    const int ks = (gd.p.K + 15) / 16;
-    if (ks <= 2) return launch_rs_t<2, 2, 8, EPI>(gd, s);
-    if (ks <= 4) return launch_rs_t<4, 2, 8, EPI>(gd, s);
-    if (ks <= 8) return launch_rs_t<8, 2, 8, EPI>(gd, s);
-    if (ks <= 12) return launch_rs_t<12, 2, 8, EPI>(gd, s);
-    if (ks <= 16) return launch_rs_t<16, 2, 8, EPI>(gd, s);
-    if (ks <= 20) return launch_rs_t<20, 1, 8, EPI>(gd, s);
-    return launch_rs_t<24, 1, 8, EPI>(gd, s);
-}
-
-template <int KS, int NT2, int RT, int NW>
-int launch_ffn_t(const FfnParams& p, hipStream_t s) {
-    using SM = FfnSmem<KS, NT2>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_fused_kernel<KS, NT2, RT, NW>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, SM::TOTAL);
-        attr_set = true;
+    constexpr bool whole = (EPI == RS_RESID || EPI == RS_F32);
+    const int width = whole ? (gd.p.K > gd.p.N ? gd.p.K : gd.p.N) : gd.p.K;
+    const int ks = (width + 15) / 16;
+    if constexpr (whole) {      // KS/2 resident output tiles per row
+        if (ks <= 2) return launch_rs_t<2, 1, 2, 2, 4, EPI>(gd, s);
+        if (ks <= 4) return launch_rs_t<4, 2, 2, 4, 4, EPI>(gd, s);
+        if (ks <= 8) return launch_rs_t<8, 4, 1, 8, 4, EPI>(gd, s);
+        if (ks <= 12) return launch_rs_t<12, 6, 1, 4, 4, EPI>(gd, s);
+        if (ks <= 16) return launch_rs_t<16, 8, 1, 8, 4, EPI>(gd, s);
+        if (ks <= 20) return launch_rs_t<20, 10, 1, 4, 4, EPI>(gd, s);
+        return launch_rs_t<24, 12, 1, 4, 4, EPI>(gd, s);
+    } else {                    // QKV / GLU: groups of 4 tiles, stores only
+        if (ks <= 2) return launch_rs_t<2, 2, 1, 2, 4, EPI>(gd, s);
+        if (ks <= 4) return launch_rs_t<4, 4, 1, 4, 4, EPI>(gd, s);
+        if (ks <= 8) return launch_rs_t<8, 4, 1, 8, 4, EPI>(gd, s);
+        if (ks <= 12) return launch_rs_t<12, 4, 1, 4, 4, EPI>(gd, s);
+        if (ks <= 16) return launch_rs_t<16, 4, 1, 8, 4, EPI>(gd, s);
+        if (ks <= 20) return launch_rs_t<20, 4, 1, 4, 4, EPI>(gd, s);
+        return launch_rs_t<24, 4, 1, 8, 4, EPI>(gd, s);
     }
-    const int rows_per_wg = NW * RT * 32;
-    hipLaunchKernelGGL((ffn_fused_kernel<KS, NT2, RT, NW>), dim3((p.M + rows_per_wg - 1) / rows_per_wg), dim3(NW * 64),
-                       SM::TOTAL, s, p);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 }  // namespace
@@ -429,16 +470,17 @@ int launch_ffn_fused(const FfnParams& p, hipStream_t s) {
     if (!ffn_fused_supported(p.D) || p.Fp % CH || p.lda % 8 || p.ldw1 % 8 || p.ldw2 % 8) return -2;
     const int ks = (p.D + 15) / 16;
     // D <= 128: 8 waves x 32 rows; D <= 256: 4 waves x 64 rows (one wave per SIMD, 512 registers); else 4 x 32
-    if (ks <= 2) return launch_ffn_t<2, 1, 1, 8>(p, s);
-    if (ks <= 4) return launch_ffn_t<4, 2, 1, 8>(p, s);
-    if (ks <= 8) return launch_ffn_t<8, 4, 1, 8>(p, s);
-    if (ks <= 12) return launch_ffn_t<12, 6, 2, 4>(p, s);
-    if (ks <= 16) return launch_ffn_t<16, 8, 2, 4>(p, s);
-    if (ks <= 20) return launch_ffn_t<20, 10, 1, 4>(p, s);
-    return launch_ffn_t<24, 12, 1, 4>(p, s);
+    if (ks <= 2) return launch_ffn_t<2, 1, 1, 4, 4>(p, s);
+    if (ks <= 4) return launch_ffn_t<4, 2, 1, 8, 4>(p, s);
+    if (ks <= 8) return launch_ffn_t<8, 4, 1, 8, 4>(p, s);
+    if (ks <= 12) return launch_ffn_t<12, 6, 2, 4, 4>(p, s);
+    if (ks <= 16) return launch_ffn_t<16, 8, 2, 4, 4>(p, s);
+    if (ks <= 20) return launch_ffn_t<20, 10, 1, 4, 3>(p, s);
+    return launch_ffn_t<24, 12, 1, 4, 3>(p, s);
 }
 
 bool rs_gemm_supported(int K) { return K % 4 == 0 && K <= 384; }
+bool rs_gemm_resident_supported(int K, int N) { return rs_gemm_supported(K) && N <= 384; }
 
 // epi: RS_* (0 resid, 1 f32, 2 glu, 3 qkv).  W packed [>= nchunks*32][ldw >= round_up(K,64)], bias padded likewise.
 int launch_rs_gemm(const GemmParams& p, int epi, hipStream_t s) {
