@@ -8,32 +8,34 @@
 namespace {
 
 constexpr float LN_EPS = 1e-6f;
-constexpr int MAXV = 8;   // float4 per lane: D <= 64 * 4 * 8 = 2048
 
-__device__ __forceinline__ float wave_sum(float v) {
+// LPR lanes cooperate on one row (64/LPR rows per wave): for D = 120..256 a 16-lane group holds the row in <= 4 float4
+// per lane, so every lane of the wave carries loads and a wave keeps 4 rows in flight.
+template <int LPR> __device__ __forceinline__ float group_sum(float v) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
 
-__device__ __forceinline__ void ln_apply(float4 (&x)[MAXV], int nv, int lane, int D, const float* g, const float* b) {
+template <int LPR, int NV>
+__device__ __forceinline__ void ln_apply(float4 (&x)[NV], int sub, int D, const float* g, const float* b) {
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i)
-        if (i < nv && (lane + 64 * i) * 4 < D) s += (x[i].x + x[i].y) + (x[i].z + x[i].w);
-    const float mean = wave_sum(s) / (float)D;
+    for (int i = 0; i < NV; ++i)
+        if ((sub + LPR * i) * 4 < D) s += (x[i].x + x[i].y) + (x[i].z + x[i].w);
+    const float mean = group_sum<LPR>(s) / (float)D;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i)
-        if (i < nv && (lane + 64 * i) * 4 < D) {
-            float a = x[i].x - mean, bb = x[i].y - mean, c = x[i].z - mean, d = x[i].w - mean;
+    for (int i = 0; i < NV; ++i)
+        if ((sub + LPR * i) * 4 < D) {
+            const float a = x[i].x - mean, bb = x[i].y - mean, c = x[i].z - mean, d = x[i].w - mean;
             q += (a * a + bb * bb) + (c * c + d * d);
         }
-    const float rstd = rsqrtf(wave_sum(q) / (float)D + LN_EPS);
+    const float rstd = rsqrtf(group_sum<LPR>(q) / (float)D + LN_EPS);
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i)
-        if (i < nv && (lane + 64 * i) * 4 < D) {
-            const int c = (lane + 64 * i) * 4;
+    for (int i = 0; i < NV; ++i)
+        if ((sub + LPR * i) * 4 < D) {
+            const int c = (sub + LPR * i) * 4;
             const float4 gg = *reinterpret_cast<const float4*>(g + c);
             const float4 bb = *reinterpret_cast<const float4*>(b + c);
             x[i].x = (x[i].x - mean) * rstd * gg.x + bb.x;
@@ -43,39 +45,40 @@ __device__ __forceinline__ void ln_apply(float4 (&x)[MAXV], int nv, int lane, in
         }
 }
 
+template <int LPR, int NV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int M, int D,
                                                         const float* g1, const float* b1,
                                                         float* out_f32, bf16_t* out_bf16, int ld_bf16,
                                                         const float* g2, const float* b2) {
-    const int lane = threadIdx.x & 63;
-    const int nv = (D / 4 + 63) / 64;
-    // grid-stride over rows: a wave handles many rows so that the launch is not dominated by wave start-up
-    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += gridDim.x * 4) {
-    float4 v[MAXV];
-    const float* xr = x + (size_t)row * D;
+    constexpr int RPW = 64 / LPR;                     // rows per wave
+    const int lane = threadIdx.x & 63, sub = lane % LPR;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / LPR;
+    for (int row = row0; row < M; row += gridDim.x * 4 * RPW) {
+        float4 v[NV];
+        const float* xr = x + (size_t)row * D;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i)
-        if (i < nv && (lane + 64 * i) * 4 < D) v[i] = *reinterpret_cast<const float4*>(xr + (lane + 64 * i) * 4);
-    ln_apply(v, nv, lane, D, g1, b1);
-    if (out_f32) {
+        for (int i = 0; i < NV; ++i)
+            if ((sub + LPR * i) * 4 < D) v[i] = *reinterpret_cast<const float4*>(xr + (sub + LPR * i) * 4);
+        ln_apply<LPR, NV>(v, sub, D, g1, b1);
+        if (out_f32) {
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i)
-            if (i < nv && (lane + 64 * i) * 4 < D)
-                *reinterpret_cast<float4*>(out_f32 + (size_t)row * D + (lane + 64 * i) * 4) = v[i];
-    }
-    if (out_bf16) {
-        if (g2) ln_apply(v, nv, lane, D, g2, b2);
-        bf16_t* o = out_bf16 + (size_t)row * ld_bf16;
+            for (int i = 0; i < NV; ++i)
+                if ((sub + LPR * i) * 4 < D)
+                    *reinterpret_cast<float4*>(out_f32 + (size_t)row * D + (sub + LPR * i) * 4) = v[i];
+        }
+        if (out_bf16) {
+            if (g2) ln_apply<LPR, NV>(v, sub, D, g2, b2);
+            bf16_t* o = out_bf16 + (size_t)row * ld_bf16;
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
-            const int c = (lane + 64 * i) * 4;
-            if (i < nv && c < ld_bf16) {
-                uint2 w = make_uint2(0u, 0u);                   // pad columns [D, ld) are written as zeros
-                if (c < D) w = make_uint2(pack_bf2(v[i].x, v[i].y), pack_bf2(v[i].z, v[i].w));
-                *reinterpret_cast<uint2*>(o + c) = w;
+            for (int i = 0; i < NV; ++i) {
+                const int c = (sub + LPR * i) * 4;
+                if (c < ld_bf16) {
+                    uint2 w = make_uint2(0u, 0u);               // pad columns [D, ld) are written as zeros
+                    if (c < D) w = make_uint2(pack_bf2(v[i].x, v[i].y), pack_bf2(v[i].z, v[i].w));
+                    *reinterpret_cast<uint2*>(o + c) = w;
+                }
             }
         }
-    }
     }
 }
 
@@ -103,10 +106,17 @@ int launch_layernorm(const float* x, int M, int D, const float* gamma, const flo
                      float* out_f32, bf16_t* out_bf16, int ld_bf16,
                      const float* gamma2, const float* beta2, hipStream_t s) {
     if (M <= 0) return 0;
-    if (D % 4 || D > 64 * 4 * MAXV || (out_bf16 && (ld_bf16 % 4 || ld_bf16 < D))) return -2;
-    const int blocks = std::min((M + 3) / 4, 256 * 8);
-    hipLaunchKernelGGL(layernorm_kernel, dim3(blocks), dim3(256), 0, s, x, M, D, gamma, beta,
-                       out_f32, out_bf16, ld_bf16, gamma2, beta2);
+    if (D % 4 || D > 2048 || (out_bf16 && (ld_bf16 % 4 || ld_bf16 < D || ld_bf16 > D + 8))) return -2;
+    // NV float4 per lane must also cover the (<= 8) bf16 pad columns: (LPR * NV) * 4 >= ld
+    auto go = [&](auto kern, int rpw) {
+        const int blocks = std::min((M + 4 * rpw - 1) / (4 * rpw), 256 * 8);
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, s, x, M, D, gamma, beta, out_f32, out_bf16, ld_bf16, gamma2, beta2);
+    };
+    if (D <= 120) go(layernorm_kernel<16, 2>, 4);
+    else if (D <= 248) go(layernorm_kernel<16, 4>, 4);
+    else if (D <= 504) go(layernorm_kernel<32, 4>, 2);
+    else if (D <= 1016) go(layernorm_kernel<64, 4>, 1);
+    else go(layernorm_kernel<64, 8>, 1);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

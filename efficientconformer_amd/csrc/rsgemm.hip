@@ -25,6 +25,7 @@
 //   blocks.py:122, 132); the 4D-wide hidden activation never exists in memory.
 // rs_gemm_kernel: one GEMM with the QKV-scatter / GLU / residual epilogues (see below).
 #include "kernels.h"
+#include <cstdlib>
 
 namespace {
 
@@ -437,25 +438,34 @@ int launch_rs_t(const RsDev& gd, hipStream_t s) {
 }
 
 // configuration class from max(K, N_resident): KS k-steps; residual variants keep KS/2 output tiles, the others 4
+inline int env_variant(const char* name) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : -1;
+}
+
+// Shape heuristics (tuned on MI355X, see profiles/): small-N GEMMs are dominated by per-workgroup fixed latency, so
+// they use 4-wave workgroups (128 rows) at several workgroups per CU; variant 1 = 8 waves (256 rows).
 template <int EPI>
 int launch_rs_ks(const RsDev& gd, hipStream_t s) {
     constexpr bool whole = (EPI == RS_RESID || EPI == RS_F32);
     const int width = whole ? (gd.p.K > gd.p.N ? gd.p.K : gd.p.N) : gd.p.K;
     const int ks = (width + 15) / 16;
+    static const int var = env_variant("EFFCONF_RS_VARIANT");
+    const bool big = var == 1;
     if constexpr (whole) {      // KS/2 resident output tiles per row
         if (ks <= 2) return launch_rs_t<2, 1, 2, 2, 4, EPI>(gd, s);
         if (ks <= 4) return launch_rs_t<4, 2, 2, 4, 4, EPI>(gd, s);
-        if (ks <= 8) return launch_rs_t<8, 4, 1, 8, 4, EPI>(gd, s);
+        if (ks <= 8) return big ? launch_rs_t<8, 4, 1, 8, 4, EPI>(gd, s) : launch_rs_t<8, 4, 1, 4, 4, EPI>(gd, s);
         if (ks <= 12) return launch_rs_t<12, 6, 1, 4, 4, EPI>(gd, s);
-        if (ks <= 16) return launch_rs_t<16, 8, 1, 8, 4, EPI>(gd, s);
+        if (ks <= 16) return big ? launch_rs_t<16, 8, 1, 8, 4, EPI>(gd, s) : launch_rs_t<16, 8, 1, 4, 4, EPI>(gd, s);
         if (ks <= 20) return launch_rs_t<20, 10, 1, 4, 4, EPI>(gd, s);
         return launch_rs_t<24, 12, 1, 4, 4, EPI>(gd, s);
     } else {                    // QKV / GLU: groups of 4 tiles, stores only
         if (ks <= 2) return launch_rs_t<2, 2, 1, 2, 4, EPI>(gd, s);
         if (ks <= 4) return launch_rs_t<4, 4, 1, 4, 4, EPI>(gd, s);
-        if (ks <= 8) return launch_rs_t<8, 4, 1, 8, 4, EPI>(gd, s);
+        if (ks <= 8) return big ? launch_rs_t<8, 4, 1, 8, 4, EPI>(gd, s) : launch_rs_t<8, 4, 1, 4, 4, EPI>(gd, s);
         if (ks <= 12) return launch_rs_t<12, 4, 1, 4, 4, EPI>(gd, s);
-        if (ks <= 16) return launch_rs_t<16, 4, 1, 8, 4, EPI>(gd, s);
+        if (ks <= 16) return big ? launch_rs_t<16, 4, 1, 8, 4, EPI>(gd, s) : launch_rs_t<16, 4, 1, 4, 4, EPI>(gd, s);
         if (ks <= 20) return launch_rs_t<20, 4, 1, 4, 4, EPI>(gd, s);
         return launch_rs_t<24, 4, 1, 8, 4, EPI>(gd, s);
     }
@@ -469,12 +479,15 @@ int launch_ffn_fused(const FfnParams& p, hipStream_t s) {
     if (p.M <= 0) return 0;
     if (!ffn_fused_supported(p.D) || p.Fp % CH || p.lda % 8 || p.ldw1 % 8 || p.ldw2 % 8) return -2;
     const int ks = (p.D + 15) / 16;
-    // D <= 128: 8 waves x 32 rows; D <= 256: 4 waves x 64 rows (one wave per SIMD, 512 registers); else 4 x 32
+    // rows per workgroup trade weight re-streaming (LDS-DMA bytes per row) against the number of workgroups:
+    // variant 0 = default heuristic, 1 = force 128-row workgroups, 2 = force the largest
+    static const int var = env_variant("EFFCONF_FFN_VARIANT");
+    const bool small_m = var == 1 || (var != 2 && p.M < 256 * 512);
     if (ks <= 2) return launch_ffn_t<2, 1, 1, 4, 4>(p, s);
     if (ks <= 4) return launch_ffn_t<4, 2, 1, 8, 4>(p, s);
-    if (ks <= 8) return launch_ffn_t<8, 4, 1, 8, 4>(p, s);
-    if (ks <= 12) return launch_ffn_t<12, 6, 2, 4, 4>(p, s);
-    if (ks <= 16) return launch_ffn_t<16, 8, 2, 4, 4>(p, s);
+    if (ks <= 8) return (var == 2) ? launch_ffn_t<8, 4, 2, 8, 4>(p, s) : (var == 1 ? launch_ffn_t<8, 4, 1, 4, 4>(p, s) : launch_ffn_t<8, 4, 1, 8, 4>(p, s));
+    if (ks <= 12) return small_m ? launch_ffn_t<12, 6, 1, 4, 4>(p, s) : launch_ffn_t<12, 6, 2, 4, 4>(p, s);
+    if (ks <= 16) return small_m ? launch_ffn_t<16, 8, 1, 4, 4>(p, s) : launch_ffn_t<16, 8, 2, 4, 4>(p, s);
     if (ks <= 20) return launch_ffn_t<20, 10, 1, 4, 3>(p, s);
     return launch_ffn_t<24, 12, 1, 4, 3>(p, s);
 }
