@@ -70,17 +70,21 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const AttnParams 
     // ---- this lane's query (column c of the wave's 16): B operands of S^T = K Q^T, kept in registers
     bf16x8 qu[KS], qv[KS];
     {
+        // unconditional loads at clamped rows, masked afterwards (a guarded load costs a serialised vmcnt(0) round trip)
         const int i = iw0 + c;
+        const int ic = i < p.Tg ? i : p.Tg - 1;
+        uint4 ra[KS], rb[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            uint4 a = make_uint4(0, 0, 0, 0), bq = a;
             const int x = ks * 32 + g * 8;
-            if (i < p.Tg && x < p.d) {
-                a = mask_chunk(*reinterpret_cast<const uint4*>(Qu + (size_t)i * DP + x), p.d - x);
-                bq = mask_chunk(*reinterpret_cast<const uint4*>(Qv + (size_t)i * DP + x), p.d - x);
-            }
-            qu[ks] = as_bf16x8(a);
-            qv[ks] = as_bf16x8(bq);
+            ra[ks] = *reinterpret_cast<const uint4*>(Qu + (size_t)ic * DP + x);
+            rb[ks] = *reinterpret_cast<const uint4*>(Qv + (size_t)ic * DP + x);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int valid = i < p.Tg ? p.d - (ks * 32 + g * 8) : 0;
+            qu[ks] = as_bf16x8(mask_chunk(ra[ks], valid));
+            qv[ks] = as_bf16x8(mask_chunk(rb[ks], valid));
         }
     }
 
@@ -93,39 +97,59 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const AttnParams 
 
     for (int j0 = 0; j0 < nkeys; j0 += BJ) {
         __syncthreads();                              // previous block's LDS reads are done
-        // ---- stage K block, V^T block and the relative-position band
-        for (int q = tid; q < BJ * (DP / 8); q += 256) {
-            const int r = q / (DP / 8), x = (q - r * (DP / 8)) * 8;
+        // ---- stage K block, V^T block and the relative-position band.  All global loads of a thread are issued first
+        // (unconditionally, at clamped in-bounds rows), then masked and written to LDS.
+        constexpr int CPR = DP / 8;                               // 16-byte chunks per row
+        constexpr int NK = (BJ * CPR + 255) / 256, NV = ((BJ / 2) * CPR + 255) / 256, NE = (128 * CPR + 255) / 256;
+        const int rbase = p.Tg - 1 + j0 - i0 - 63;               // E row of band row 0
+        const int erows = 2 * p.Tg - 1;
+        uint4 lk[NK], lv0[NV], lv1[NV], le[NE];
+#pragma unroll
+        for (int n = 0; n < NK; ++n) {
+            const int q = tid + 256 * n, r = q / CPR, x = (q - r * CPR) * 8;
             const int j = j0 + r;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (j < p.Tg && x < p.d) v = mask_chunk(*reinterpret_cast<const uint4*>(Kh + (size_t)j * DP + x), p.d - x);
-            *reinterpret_cast<uint4*>(sK + r * SM::KROW + x * 2) = v;
+            lk[n] = *reinterpret_cast<const uint4*>(Kh + (size_t)(j < p.Tg ? j : p.Tg - 1) * DP + (x < DP ? x : 0));
+        }
+#pragma unroll
+        for (int n = 0; n < NV; ++n) {
+            const int q = tid + 256 * n, pr = q & (BJ / 2 - 1), x = (q / (BJ / 2)) * 8;
+            const int j = j0 + 2 * pr, xc = x < DP ? x : 0;
+            lv0[n] = *reinterpret_cast<const uint4*>(Vh + (size_t)(j < p.Tg ? j : p.Tg - 1) * DP + xc);
+            lv1[n] = *reinterpret_cast<const uint4*>(Vh + (size_t)(j + 1 < p.Tg ? j + 1 : p.Tg - 1) * DP + xc);
+        }
+#pragma unroll
+        for (int n = 0; n < NE; ++n) {
+            const int q = tid + 256 * n, rr = q / CPR, x = (q - rr * CPR) * 8;
+            int r = rbase + rr;
+            r = r < 0 ? 0 : (r >= erows ? erows - 1 : r);
+            le[n] = *reinterpret_cast<const uint4*>(Eh + (size_t)r * DP + (x < DP ? x : 0));
+        }
+#pragma unroll
+        for (int n = 0; n < NK; ++n) {
+            const int q = tid + 256 * n, r = q / CPR, x = (q - r * CPR) * 8;
+            if (q < BJ * CPR) *reinterpret_cast<uint4*>(sK + r * SM::KROW + x * 2) = mask_chunk(lk[n], (j0 + r < p.Tg) ? p.d - x : 0);
         }
         // V block, transposed into the key-contiguous image sV[x][key]: each thread takes one 8-wide x chunk of a
         // PAIR of adjacent keys and writes 8 dwords {v[j][x+e], v[j+1][x+e]} (lanes -> consecutive dwords)
-        for (int q = tid; q < (BJ / 2) * (DP / 8); q += 256) {
-            const int pr = q & (BJ / 2 - 1), x = (q / (BJ / 2)) * 8;
-            const int j = j0 + 2 * pr;
-            uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0;
-            if (x < p.d) {
-                if (j < p.Tg) v0 = *reinterpret_cast<const uint4*>(Vh + (size_t)j * DP + x);
-                if (j + 1 < p.Tg) v1 = *reinterpret_cast<const uint4*>(Vh + (size_t)(j + 1) * DP + x);
-            }
-            const uint32_t a[4] = {v0.x, v0.y, v0.z, v0.w}, bq[4] = {v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const uint32_t lo = (a[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu, hi = (bq[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu;
-                *reinterpret_cast<uint32_t*>(sV + (x + e) * SM::VROW + pr * 4) = lo | (hi << 16);
+        for (int n = 0; n < NV; ++n) {
+            const int q = tid + 256 * n, pr = q & (BJ / 2 - 1), x = (q / (BJ / 2)) * 8;
+            const int j = j0 + 2 * pr;
+            if (q < (BJ / 2) * CPR) {
+                const uint4 v0 = mask_chunk(lv0[n], (j < p.Tg) ? 8 : 0), v1 = mask_chunk(lv1[n], (j + 1 < p.Tg) ? 8 : 0);
+                const uint32_t a[4] = {v0.x, v0.y, v0.z, v0.w}, bq[4] = {v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const uint32_t lo = (a[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu, hi = (bq[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu;
+                    *reinterpret_cast<uint32_t*>(sV + (x + e) * SM::VROW + pr * 4) = lo | (hi << 16);
+                }
             }
         }
-        const int rbase = p.Tg - 1 + j0 - i0 - 63;   // E row of band row 0
-        for (int q = tid; q < 128 * (DP / 8); q += 256) {
-            const int rr = q / (DP / 8), x = (q - rr * (DP / 8)) * 8;
+#pragma unroll
+        for (int n = 0; n < NE; ++n) {
+            const int q = tid + 256 * n, rr = q / CPR, x = (q - rr * CPR) * 8;
             const int r = rbase + rr;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (r >= 0 && r <= 2 * p.Tg - 2 && x < p.d)
-                v = mask_chunk(*reinterpret_cast<const uint4*>(Eh + (size_t)r * DP + x), p.d - x);
-            *reinterpret_cast<uint4*>(sE + rr * SM::KROW + x * 2) = v;
+            if (q < 128 * CPR) *reinterpret_cast<uint4*>(sE + rr * SM::KROW + x * 2) = mask_chunk(le[n], (r >= 0 && r < erows) ? p.d - x : 0);
         }
         __syncthreads();
 

@@ -27,9 +27,9 @@ __global__ __launch_bounds__(256) void subsample_conv_kernel(const float* __rest
     for (int i = tid; i < (F + 1) * TW; i += 256) {
         const int fr = i / TW, tc = i - fr * TW;
         const int f = fr - 1, t = 2 * t0 - 1 + tc;
-        float v = 0.f;
-        if (f >= 0 && t >= 0 && t < Tm) v = mel[((size_t)b * F + f) * Tm + t];
-        sm[fr * (TW + 1) + tc] = v;
+        const bool ok = f >= 0 && t >= 0 && t < Tm;
+        const float v = mel[((size_t)b * F + (f < 0 ? 0 : f)) * Tm + (t < 0 ? 0 : (t < Tm ? t : Tm - 1))];   // clamped, unconditional
+        sm[fr * (TW + 1) + tc] = ok ? v : 0.f;
     }
     for (int i = tid; i < C * 10; i += 256) {
         const int c = i / 10, j = i - c * 10;
@@ -83,9 +83,9 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const bf16_t* __restrict__ 
     for (int i = tid; i < rows * (DW_CC / 8); i += 256) {
         const int r = i / (DW_CC / 8), ch = (i - r * (DW_CC / 8)) * 8;
         const int t = tin0 + r, c = c0 + ch;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (t >= 0 && t < T && c < ld) v = mask_chunk(*reinterpret_cast<const uint4*>(g + ((size_t)b * T + t) * ld + c), C - c);
-        *reinterpret_cast<uint4*>(sg + r * DW_CC + ch) = v;
+        const int tc = t < 0 ? 0 : (t < T ? t : T - 1), cc = c < ld - 8 ? c : ld - 8;      // clamped, unconditional load
+        const uint4 v = *reinterpret_cast<const uint4*>(g + ((size_t)b * T + tc) * ld + cc);
+        *reinterpret_cast<uint4*>(sg + r * DW_CC + ch) = mask_chunk(v, (t >= 0 && t < T && c < ld) ? C - c : 0);
     }
     __syncthreads();
     const int lane = tid & 63, wave = tid >> 6;

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDev gd) {
             int b = m / p.a_rows, r = m - b * p.a_rows;
             src = (size_t)b * p.a_pitch + (size_t)r * p.a_stride;
         }
-        a_ptr[i] = p.A + src * p.lda + kc * 8;
+        a_ptr[i] = p.A + src * p.lda;
     }
     const bf16_t* b_ptr[NB];
 #pragma unroll
@@ -71,12 +71,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDev gd) {
     auto load_tile = [&](int kt) {
         const int k = kt * BK + kc * 8;
         const int valid = p.K - k;
+        const int kcl = k < p.lda - 8 ? k : p.lda - 8;      // unconditional, clamped (in-bounds) loads; masked below
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (valid > 0) v = mask_chunk(*reinterpret_cast<const uint4*>(a_ptr[i] + kt * BK), valid);
-            ra[i] = v;
-        }
+        for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const uint4*>(a_ptr[i] + kcl);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ra[i] = mask_chunk(ra[i], valid);
 #pragma unroll
         for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const uint4*>(b_ptr[i] + kt * BK);
     };

@@ -1,101 +1,153 @@
 // Log-mel frontend (gfx950): framing with centre reflect padding, Hann(win) centred in n_fft,
-// 512-point FFT in LDS, power spectrum, sparse HTK triangular filterbank, log(x + 1e-9).
+// 512-point FFT, power spectrum, sparse HTK triangular filterbank, log(x + 1e-9).
 //
 // Restates what the reference obtains from torchaudio (models/modules.py:81-82, 90-96:
 // Spectrogram(n_fft, win_length, hop_length, power=2) -> MelScale(n_mels, sr, 0, 8000) -> log).
 // The arithmetic of that dependency is not in the reference repository ("parity unpinned", see
 // oracle/ref_encoder.py); this kernel is validated against the oracle's torch.stft restatement.
 //
-// One workgroup = 16 consecutive frames of one utterance (4 waves x 4 frames), so that the
-// (B, n_mels, Tm) output is written as 64-byte row segments; HBM-bound (640 B in, 320 B out per frame).
+// HBM-bound by design (640 B in, 320 B out per frame), so the FFT is organised to stay out of the way:
+//   * one wave transforms TWO real frames at once as one complex 512-point FFT (z = a + i b) and separates them
+//     with X_a[k] = (Z[k] + conj Z[N-k]) / 2, X_b[k] = (Z[k] - conj Z[N-k]) / 2i;
+//   * 512 = 8 x 8 x 8: three radix-8 passes entirely in registers (8 complex values per lane) with two
+//     exchanges through a per-wave LDS buffer whose pitches (72 / 68 float2) make every access conflict-free;
+//     synchronisation is wave-local (LDS operations of one wave execute in order) — no workgroup barriers
+//     inside the transform (the first version used 9 block-wide barriers per frame: profiles/r1_02_*);
+//   * a workgroup produces 32 consecutive frames of one utterance, staged in LDS and written as 128-byte rows
+//     of the (B, n_mels, Tm) output.
 #include "kernels.h"
 
 namespace {
 
 constexpr int NFFT = 512;
-constexpr int LOGN = 9;
-constexpr int FRAMES_PER_WAVE = 4;
-constexpr int FRAMES_PER_BLOCK = 16;
+constexpr int FRAMES_PER_BLOCK = 32;     // 4 waves x 4 iterations x 2 frames
 constexpr int MAX_MELS = 128;
+constexpr int P1 = 72;                   // float2 pitch of the step-1 exchange buffer [k1][n2*8+n3]
+constexpr int P2 = 68;                   // float2 pitch of the step-2 exchange buffer [n3][k1+8*k2]
 
-__device__ __forceinline__ int bitrev9(int n) { return (int)(__brev((unsigned)n) >> (32 - LOGN)); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }   // a * (-i)
+__device__ __forceinline__ float2 mul_pi(float2 a) { return make_float2(-a.y, a.x); }   // a * (+i)
+
+// in-place 8-point DFT: v[k] <- sum_j v[j] W8^{jk}
+__device__ __forceinline__ void dft8(float2 (&v)[8]) {
+    const float r = 0.70710678118654752f;
+    float2 a[4], b[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { a[j] = cadd(v[j], v[j + 4]); b[j] = csub(v[j], v[j + 4]); }
+    b[1] = make_float2(r * (b[1].x + b[1].y), r * (b[1].y - b[1].x));      // * W8^1 = (1 - i)/sqrt2
+    b[2] = mul_mi(b[2]);                                                   // * W8^2 = -i
+    b[3] = make_float2(r * (b[3].y - b[3].x), -r * (b[3].x + b[3].y));     // * W8^3 = (-1 - i)/sqrt2
+    {
+        const float2 s0 = cadd(a[0], a[2]), s1 = cadd(a[1], a[3]), d0 = csub(a[0], a[2]), d1 = csub(a[1], a[3]);
+        v[0] = cadd(s0, s1); v[4] = csub(s0, s1); v[2] = cadd(d0, mul_mi(d1)); v[6] = cadd(d0, mul_pi(d1));
+    }
+    {
+        const float2 s0 = cadd(b[0], b[2]), s1 = cadd(b[1], b[3]), d0 = csub(b[0], b[2]), d1 = csub(b[1], b[3]);
+        v[1] = cadd(s0, s1); v[5] = csub(s0, s1); v[3] = cadd(d0, mul_mi(d1)); v[7] = cadd(d0, mul_pi(d1));
+    }
+}
+
+// LDS operations of one wave execute in order; this only stops the compiler from reordering across the hand-off
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ audio, int L, MelTables tb, int hop,
                                                   int n_mels, int Tm, int normalize, float mean, float inv_std,
                                                   float* __restrict__ mel) {
-    __shared__ float2 sx[4][NFFT];                               // per-wave FFT buffer (power spectrum aliases .x)
+    __shared__ float2 sbuf[4][2][8 * P1];                        // per wave: exchange buffers A (step 1, Z) and B (step 2, power)
+    __shared__ float2 stw[NFFT];                                 // W512^m
+    __shared__ float swin[NFFT];
     __shared__ float sout[MAX_MELS][FRAMES_PER_BLOCK + 1];
     const int tiles = (Tm + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK;
     const int b = blockIdx.x / tiles, t0 = (blockIdx.x % tiles) * FRAMES_PER_BLOCK;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float2* x = sx[wave];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < NFFT; i += 256) {
+        const float2 w = tb.twiddle[i & 255];                    // table holds W512^k for k < 256; W^(k+256) = -W^k
+        stw[i] = i < 256 ? w : make_float2(-w.x, -w.y);
+        swin[i] = tb.window[i];
+    }
+    __syncthreads();
+    float2* A = sbuf[wave][0];
+    float2* B = sbuf[wave][1];
     const float* a = audio + (size_t)b * L;
 
-    for (int fi = 0; fi < FRAMES_PER_WAVE; ++fi) {
-        const int fl = wave * FRAMES_PER_WAVE + fi;
-        const int t = t0 + fl;
-        const bool live = t < Tm;
-        // ---- frame gather (reflect at both ends of the *padded* waveform, torch.stft center=True) + window
+    for (int it = 0; it < FRAMES_PER_BLOCK / 8; ++it) {
+        const int fl = wave * (FRAMES_PER_BLOCK / 4) + 2 * it;   // local index of the first frame of the pair
+        const int ta = t0 + fl, tbb = ta + 1;
+        // ---- gather both frames (reflect at the ends of the padded waveform, torch.stft center=True) and window them
+        float2 v[8];
 #pragma unroll
-        for (int i = 0; i < NFFT / 64; ++i) {
-            const int n = lane + 64 * i;
-            float v = 0.f;
-            if (live) {
-                int s = t * hop - NFFT / 2 + n;
-                if (s < 0) s = -s;
-                if (s >= L) s = 2 * (L - 1) - s;
-                v = a[s] * tb.window[n];
+        for (int j = 0; j < 8; ++j) {
+            const int n = lane + 64 * j;
+            const float w = swin[n];
+            int sa = ta * hop - NFFT / 2 + n, sb = sa + hop;
+            sa = sa < 0 ? -sa : sa; sa = sa >= L ? 2 * (L - 1) - sa : sa; sa = sa < 0 ? 0 : (sa >= L ? L - 1 : sa);
+            sb = sb < 0 ? -sb : sb; sb = sb >= L ? 2 * (L - 1) - sb : sb; sb = sb < 0 ? 0 : (sb >= L ? L - 1 : sb);
+            const float xa = a[sa], xb = a[sb];                  // unconditional clamped loads
+            v[j] = make_float2(ta < Tm ? xa * w : 0.f, tbb < Tm ? xb * w : 0.f);
+        }
+        // ---- step 1: lane = 8*n2 + n3 holds x[64*n1 + lane]; DFT over n1, twiddle W64^{n2 k1}
+        {
+            const int n2 = lane >> 3;
+            dft8(v);
+#pragma unroll
+            for (int k1 = 0; k1 < 8; ++k1) A[k1 * P1 + lane] = cmul(v[k1], stw[(8 * n2 * k1) & 511]);
+        }
+        wave_sync();
+        // ---- step 2: lane = 8*k1 + n3; DFT over n2, twiddle W512^{n3 (k1 + 8 k2)}
+        {
+            const int k1 = lane >> 3, n3 = lane & 7;
+#pragma unroll
+            for (int n2 = 0; n2 < 8; ++n2) v[n2] = A[k1 * P1 + n2 * 8 + n3];
+            dft8(v);
+#pragma unroll
+            for (int k2 = 0; k2 < 8; ++k2) B[n3 * P2 + k1 + 8 * k2] = cmul(v[k2], stw[(n3 * (k1 + 8 * k2)) & 511]);
+        }
+        wave_sync();
+        // ---- step 3: lane = k1 + 8*k2; DFT over n3 -> Z[lane + 64*k3]
+#pragma unroll
+        for (int n3 = 0; n3 < 8; ++n3) v[n3] = B[n3 * P2 + lane];
+        dft8(v);
+#pragma unroll
+        for (int k3 = 0; k3 < 8; ++k3) A[lane + 64 * k3] = v[k3];
+        wave_sync();
+        // ---- separate the two real spectra, power for bins 0..256 -> B (as floats: [0..256] frame a, [264..520] frame b)
+        float* Pa = reinterpret_cast<float*>(B);
+        float* Pb = Pa + 264;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int k = lane + 64 * j;
+            if (k <= NFFT / 2) {
+                const float2 z = A[k], zc = A[(NFFT - k) & (NFFT - 1)];
+                const float ar = 0.5f * (z.x + zc.x), ai = 0.5f * (z.y - zc.y);     // X_a = (Z[k] + conj Z[N-k]) / 2
+                const float br = 0.5f * (z.y + zc.y), bi = 0.5f * (zc.x - z.x);     // X_b = (Z[k] - conj Z[N-k]) / 2i
+                Pa[k] = ar * ar + ai * ai;
+                Pb[k] = br * br + bi * bi;
             }
-            x[bitrev9(n)] = make_float2(v, 0.f);
         }
-        __syncthreads();
-        // ---- radix-2 decimation-in-time FFT, 9 stages, 256 butterflies per stage (4 per lane)
-#pragma unroll
-        for (int st = 0; st < LOGN; ++st) {
-            const int half = 1 << st;
-#pragma unroll
-            for (int i = 0; i < NFFT / 2 / 64; ++i) {
-                const int q = lane + 64 * i;
-                const int pos = q & (half - 1);
-                const int i0 = ((q >> st) << (st + 1)) + pos, i1 = i0 + half;
-                const float2 w = tb.twiddle[pos << (LOGN - 1 - st)];
-                const float2 u = x[i0], v = x[i1];
-                const float2 tv = make_float2(w.x * v.x - w.y * v.y, w.x * v.y + w.y * v.x);
-                x[i0] = make_float2(u.x + tv.x, u.y + tv.y);
-                x[i1] = make_float2(u.x - tv.x, u.y - tv.y);
-            }
-            __syncthreads();
-        }
-        // ---- power spectrum of bins 0..256 (kept in registers across the barrier, then aliased onto x[].x)
-        float pw[5];
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const int k = lane + 64 * i;
-            pw[i] = 0.f;
-            if (k <= NFFT / 2) { const float2 z = x[k]; pw[i] = z.x * z.x + z.y * z.y; }
-        }
-        __syncthreads();
-        float* P = reinterpret_cast<float*>(x);
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const int k = lane + 64 * i;
-            if (k <= NFFT / 2) P[k] = pw[i];
-        }
-        __syncthreads();
-        // ---- sparse triangular filterbank + log
+        wave_sync();
+        // ---- sparse triangular filterbank + log for both frames
         for (int m = lane; m < n_mels; m += 64) {
             const int s0 = tb.fb_start[m], cnt = tb.fb_count[m];
             const float* w = tb.fb_weight + tb.fb_offset[m];
-            float acc = 0.f;
-            for (int j = 0; j < cnt; ++j) acc = fmaf(P[s0 + j], w[j], acc);
-            float y = logf(acc + 1e-9f);
-            if (normalize) y = (y - mean) * inv_std;
-            sout[m][fl] = y;
+            float ya = 0.f, yb = 0.f;
+            for (int j = 0; j < cnt; ++j) { const float wj = w[j]; ya = fmaf(Pa[s0 + j], wj, ya); yb = fmaf(Pb[s0 + j], wj, yb); }
+            ya = logf(ya + 1e-9f); yb = logf(yb + 1e-9f);
+            if (normalize) { ya = (ya - mean) * inv_std; yb = (yb - mean) * inv_std; }
+            sout[m][fl] = ya;
+            sout[m][fl + 1] = yb;
         }
-        __syncthreads();
+        wave_sync();
     }
+    __syncthreads();
     // ---- coalesced store: rows of FRAMES_PER_BLOCK consecutive frames
-    for (int i = threadIdx.x; i < n_mels * FRAMES_PER_BLOCK; i += 256) {
+    for (int i = tid; i < n_mels * FRAMES_PER_BLOCK; i += 256) {
         const int m = i / FRAMES_PER_BLOCK, fl = i - m * FRAMES_PER_BLOCK;
         if (t0 + fl < Tm) mel[((size_t)b * n_mels + m) * Tm + t0 + fl] = sout[m][fl];
     }

@@ -57,8 +57,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         float4 v[NV];
         const float* xr = x + (size_t)row * D;
 #pragma unroll
-        for (int i = 0; i < NV; ++i)
-            if ((sub + LPR * i) * 4 < D) v[i] = *reinterpret_cast<const float4*>(xr + (sub + LPR * i) * 4);
+        for (int i = 0; i < NV; ++i) {     // unconditional clamped loads (lanes past D re-read the last float4; never used)
+            const int c = (sub + LPR * i) * 4;
+            v[i] = *reinterpret_cast<const float4*>(xr + (c < D - 4 ? c : D - 4));
+        }
         ln_apply<LPR, NV>(v, sub, D, g1, b1);
         if (out_f32) {
 #pragma unroll

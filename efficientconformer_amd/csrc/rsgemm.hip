@@ -87,6 +87,7 @@ __global__ __launch_bounds__(NW * 64) void ffn_fused_kernel(const FfnParams p) {
     constexpr int P1 = SM::P1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sb1 = reinterpret_cast<float*>(smem + SM::RING);   // whole first bias in LDS
+    float* sb2 = sb1 + p.Fp;                                  // second bias, NT2*32 entries
     constexpr int NTHR = NW * 64;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -108,17 +109,25 @@ __global__ __launch_bounds__(NW * 64) void ffn_fused_kernel(const FfnParams p) {
 
     // ---- bias -> LDS, this lane's activation row fragments (B operand of GEMM1), then start the weight stream
     for (int i = tid; i < p.Fp; i += NTHR) sb1[i] = p.b1[i];
+    for (int i = tid; i < NT2 * 32; i += NTHR) sb2[i] = i < p.D ? p.b2[i] : 0.f;
     bf16x8 xf[RT][KS];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
         const int m = m_base + rt * 32 + lr;
         const bf16_t* arow = p.A + (size_t)(m < p.M ? m : p.M - 1) * p.lda;
+        // all loads are issued unconditionally at clamped (in-bounds) addresses and masked afterwards: a guarded load
+        // becomes its own basic block with a full vmcnt(0) round trip (8 serialised L2 latencies here before the fix)
+        uint4 raw[KS];
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const int c0 = s * 16 + half * 8;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (c0 < p.D && m < p.M) v = mask_chunk(*reinterpret_cast<const uint4*>(arow + c0), p.D - c0);
-            xf[rt][s] = as_bf16x8(v);
+            raw[s] = *reinterpret_cast<const uint4*>(arow + (c0 < p.lda - 8 ? c0 : p.lda - 8));
+        }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int c0 = s * 16 + half * 8;
+            const int valid = (m < p.M) ? p.D - c0 : 0;
+            xf[rt][s] = as_bf16x8(mask_chunk(raw[s], valid));
         }
     }
 #pragma unroll
@@ -186,27 +195,34 @@ __global__ __launch_bounds__(NW * 64) void ffn_fused_kernel(const FfnParams p) {
         }
     }
 
-    // ---- epilogue: y[m][n] = x[m][n] + alpha * (acc + b2[n]);  lane owns row m, columns 32t + 8q + 4*half + (0..3)
+    // ---- epilogue: y[m][n] = x[m][n] + alpha * (acc + b2[n]);  lane owns row m, columns 32t + 8q + 4*half + (0..3).
+    // The residual row is fetched with one batch of unconditional (clamped) loads per row tile, then consumed.
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
         const int m = m_base + rt * 32 + lr;
-        if (m >= p.M) continue;
-        const float* xr = p.X + (size_t)m * p.ldx;
-        float* yr = p.Y + (size_t)m * p.ldy;
+        const float* xr = p.X + (size_t)(m < p.M ? m : p.M - 1) * p.ldx;
+        float* yr = p.Y + (size_t)(m < p.M ? m : p.M - 1) * p.ldy;
+        float4 xv[NT2 * 4];
 #pragma unroll
         for (int t = 0; t < NT2; ++t)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int n = t * 32 + q * 8 + half * 4;
-                if (n >= p.D) continue;
-                const float4 xv = *reinterpret_cast<const float4*>(xr + n);
-                const float4 bv = *reinterpret_cast<const float4*>(p.b2 + n);
+                xv[t * 4 + q] = *reinterpret_cast<const float4*>(xr + (n < p.D - 4 ? n : p.D - 4));
+            }
+#pragma unroll
+        for (int t = 0; t < NT2; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = t * 32 + q * 8 + half * 4;
+                const float4 bv = *reinterpret_cast<const float4*>(sb2 + n);
+                const float4 x4 = xv[t * 4 + q];
                 float4 o;
-                o.x = xv.x + p.alpha * (acc[rt][t][q * 4 + 0] + bv.x);
-                o.y = xv.y + p.alpha * (acc[rt][t][q * 4 + 1] + bv.y);
-                o.z = xv.z + p.alpha * (acc[rt][t][q * 4 + 2] + bv.z);
-                o.w = xv.w + p.alpha * (acc[rt][t][q * 4 + 3] + bv.w);
-                *reinterpret_cast<float4*>(yr + n) = o;
+                o.x = x4.x + p.alpha * (acc[rt][t][q * 4 + 0] + bv.x);
+                o.y = x4.y + p.alpha * (acc[rt][t][q * 4 + 1] + bv.y);
+                o.z = x4.z + p.alpha * (acc[rt][t][q * 4 + 2] + bv.z);
+                o.w = x4.w + p.alpha * (acc[rt][t][q * 4 + 3] + bv.w);
+                if (n < p.D && m < p.M) *reinterpret_cast<float4*>(yr + n) = o;
             }
     }
 }
@@ -214,7 +230,7 @@ __global__ __launch_bounds__(NW * 64) void ffn_fused_kernel(const FfnParams p) {
 template <int KS, int NT2, int RT, int NW, int NBUF>
 int launch_ffn_t(const FfnParams& p, hipStream_t s) {
     using SM = FfnSmem<KS, NT2, NBUF>;
-    const int lds = SM::RING + p.Fp * 4;
+    const int lds = SM::RING + p.Fp * 4 + NT2 * 32 * 4;
     if (lds > 160 * 1024) return -4;
     static int attr_set = 0;
     if (attr_set < lds) {
@@ -285,12 +301,16 @@ __global__ __launch_bounds__(NW * 64) void rs_gemm_kernel(const RsDev gd) {
         size_t src = mc;
         if (p.a_rows > 0) { const int b = mc / p.a_rows, r = mc - b * p.a_rows; src = (size_t)b * p.a_pitch + (size_t)r * p.a_stride; }
         const bf16_t* arow = p.A + src * p.lda;
+        uint4 raw[KS];                                   // unconditional clamped loads, masked afterwards (see ffn_fused_kernel)
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const int c0 = s * 16 + half * 8;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (c0 < p.K && m < p.M) v = mask_chunk(*reinterpret_cast<const uint4*>(arow + c0), p.K - c0);
-            xf[rt][s] = as_bf16x8(v);
+            raw[s] = *reinterpret_cast<const uint4*>(arow + (c0 < p.lda - 8 ? c0 : p.lda - 8));
+        }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int c0 = s * 16 + half * 8;
+            xf[rt][s] = as_bf16x8(mask_chunk(raw[s], (m < p.M) ? p.K - c0 : 0));
         }
     }
     // per-row constants of the QKV scatter
@@ -314,26 +334,46 @@ __global__ __launch_bounds__(NW * 64) void rs_gemm_kernel(const RsDev gd) {
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             const int m = rowm[rt];
-            if (m >= p.M) continue;
+            const int mc = m < p.M ? m : p.M - 1;
+            if constexpr (EPI == RS_RESID || EPI == RS_F32) {
+                // whole-row variants: batches of GB tiles — one burst of unconditional clamped residual loads, then consume
+                constexpr int GB = G < 4 ? G : 4;
+                float* yr = reinterpret_cast<float*>(p.C) + (size_t)mc * p.ldc;
+#pragma unroll
+                for (int g0 = 0; g0 < G; g0 += GB) {
+                    float4 rv[GB * 4];
+                    if constexpr (EPI == RS_RESID) {
+#pragma unroll
+                        for (int g = 0; g < GB; ++g)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const int n = (c0 + g0 + g) * CH + q * 8 + half * 4;
+                                rv[g * 4 + q] = *reinterpret_cast<const float4*>(p.R + (size_t)mc * p.ldr + (n < p.N - 4 ? n : p.N - 4));
+                            }
+                    }
+#pragma unroll
+                    for (int g = 0; g < GB; ++g) {
+                        const float* bias = sbias + (c0 + g0 + g) * CH;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int nl = q * 8 + half * 4, n = (c0 + g0 + g) * CH + nl;
+                            float4 o;
+                            o.x = acc[rt][g0 + g][q * 4 + 0] + bias[nl + 0]; o.y = acc[rt][g0 + g][q * 4 + 1] + bias[nl + 1];
+                            o.z = acc[rt][g0 + g][q * 4 + 2] + bias[nl + 2]; o.w = acc[rt][g0 + g][q * 4 + 3] + bias[nl + 3];
+                            if constexpr (EPI == RS_RESID) {
+                                const float4 xv = rv[g * 4 + q];
+                                o.x = xv.x + p.alpha * o.x; o.y = xv.y + p.alpha * o.y; o.z = xv.z + p.alpha * o.z; o.w = xv.w + p.alpha * o.w;
+                            }
+                            if (g0 + g < ntiles && n < p.N && m < p.M) *reinterpret_cast<float4*>(yr + n) = o;
+                        }
+                    }
+                }
+            }
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                if (g < ntiles) {
+                if (g < ntiles && m < p.M) {
                 const float* bias = sbias + (c0 + g) * CH;
                 if constexpr (EPI == RS_RESID || EPI == RS_F32) {
-                    float* yr = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int nl = q * 8 + half * 4, n = (c0 + g) * CH + nl;
-                        if (n >= p.N) continue;
-                        float4 o;
-                        o.x = acc[rt][g][q * 4 + 0] + bias[nl + 0]; o.y = acc[rt][g][q * 4 + 1] + bias[nl + 1];
-                        o.z = acc[rt][g][q * 4 + 2] + bias[nl + 2]; o.w = acc[rt][g][q * 4 + 3] + bias[nl + 3];
-                        if constexpr (EPI == RS_RESID) {
-                            const float4 xv = *reinterpret_cast<const float4*>(p.R + (size_t)m * p.ldr + n);
-                            o.x = xv.x + p.alpha * o.x; o.y = xv.y + p.alpha * o.y; o.z = xv.z + p.alpha * o.z; o.w = xv.w + p.alpha * o.w;
-                        }
-                        *reinterpret_cast<float4*>(yr + n) = o;
-                    }
                 } else if constexpr (EPI == RS_GLU) {
                     if ((g & 1) == 0 && g + 1 < G) {                       // tiles (g, g+1) = (a, b) of channel block (c0+g)/2
                     constexpr int gb = (G > 1) ? 1 : 0;
