@@ -40,6 +40,7 @@ SIGNATURES = {
     "effconf_encoder_forward_mel": (C.c_int, [_P, _F32P, _I64P, _I32, _I32, _F32P, _I64P, _P, _SZ, _P]),
     "effconf_mel_frontend": (C.c_int, [_P, _F32P, _I32, _I32, _F32P, _P]),
     "effconf_ctc_greedy": (C.c_int, [_P, _F32P, _I64P, _I32, _I32, _P, _P, _F32P, _P, _SZ, _P]),
+    "effconf_encoder_set_option": (C.c_int, [_P, C.c_char_p, _I32]),
     "effconf_profile_enable": (C.c_int, [_P, _I32]),
     "effconf_profile_read": (C.c_int, [_P, _I32, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                        C.POINTER(C.c_double)]),

@@ -27,6 +27,13 @@ constexpr int BI = 64;          // queries per workgroup (16 per wave)
 constexpr int BJ = 64;          // keys per block
 constexpr int SKEW_LD = 84;     // floats per query row of the skew buffer (>= 80, multiple of 4)
 
+// 16-byte global load from a (possibly only) 4-byte aligned address (natural layout: head h starts at element h*d)
+__device__ __forceinline__ uint4 ld16(const bf16_t* p) {
+    typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+    const u32x4_a4 v = *reinterpret_cast<const u32x4_a4*>(p);
+    return make_uint4(v[0], v[1], v[2], v[3]);
+}
+
 template <int DP>
 struct AttnSmem {
     static constexpr int KROW = DP * 2 + 16;         // bytes per K / E row
@@ -56,12 +63,13 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const AttnParams 
     const int qt = id % qtiles; id /= qtiles;
     const int h = id % p.H; const int b = id / p.H;
     const int i0 = qt * BI, iw0 = i0 + wave * 16;
-    const size_t bh = (size_t)b * p.H + h;
-    const bf16_t* Qu = p.qu + bh * p.Tg * DP;
-    const bf16_t* Qv = p.qv + bh * p.Tg * DP;
-    const bf16_t* Kh = p.kh + bh * p.Tg * DP;
-    const bf16_t* Vh = p.vt + bh * p.Tg * DP;          // V, same head-major row-major layout as K
-    const bf16_t* Eh = p.eh + (size_t)h * (2 * p.Tg - 1) * DP;
+    const size_t qoff = (size_t)b * p.q_bstride + (size_t)h * p.q_hstride;
+    const bf16_t* Qu = p.qu + qoff;
+    const bf16_t* Qv = p.qv + qoff;
+    const bf16_t* Kh = p.kh + qoff;
+    const bf16_t* Vh = p.vt + qoff;                    // V, same layout as K (transposed at LDS fill)
+    const bf16_t* Eh = p.eh + (size_t)h * p.e_hstride;
+    const int RS = p.q_rowstride, ERS = p.e_rowstride; // row strides (elements); rows may be only 4-byte aligned (natural layout)
 
     int nkeys = (p.lens[b] + p.G - 1) / p.G;          // unmasked key groups: G*j < lens[b]
     nkeys = nkeys < p.Tg ? nkeys : p.Tg;
@@ -77,8 +85,8 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const AttnParams 
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int x = ks * 32 + g * 8;
-            ra[ks] = *reinterpret_cast<const uint4*>(Qu + (size_t)ic * DP + x);
-            rb[ks] = *reinterpret_cast<const uint4*>(Qv + (size_t)ic * DP + x);
+            ra[ks] = ld16(Qu + (size_t)ic * RS + x);
+            rb[ks] = ld16(Qv + (size_t)ic * RS + x);
         }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -108,21 +116,21 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const AttnParams 
         for (int n = 0; n < NK; ++n) {
             const int q = tid + 256 * n, r = q / CPR, x = (q - r * CPR) * 8;
             const int j = j0 + r;
-            lk[n] = *reinterpret_cast<const uint4*>(Kh + (size_t)(j < p.Tg ? j : p.Tg - 1) * DP + (x < DP ? x : 0));
+            lk[n] = ld16(Kh + (size_t)(j < p.Tg ? j : p.Tg - 1) * RS + (x < DP ? x : 0));
         }
 #pragma unroll
         for (int n = 0; n < NV; ++n) {
             const int q = tid + 256 * n, pr = q & (BJ / 2 - 1), x = (q / (BJ / 2)) * 8;
             const int j = j0 + 2 * pr, xc = x < DP ? x : 0;
-            lv0[n] = *reinterpret_cast<const uint4*>(Vh + (size_t)(j < p.Tg ? j : p.Tg - 1) * DP + xc);
-            lv1[n] = *reinterpret_cast<const uint4*>(Vh + (size_t)(j + 1 < p.Tg ? j + 1 : p.Tg - 1) * DP + xc);
+            lv0[n] = ld16(Vh + (size_t)(j < p.Tg ? j : p.Tg - 1) * RS + xc);
+            lv1[n] = ld16(Vh + (size_t)(j + 1 < p.Tg ? j + 1 : p.Tg - 1) * RS + xc);
         }
 #pragma unroll
         for (int n = 0; n < NE; ++n) {
             const int q = tid + 256 * n, rr = q / CPR, x = (q - rr * CPR) * 8;
             int r = rbase + rr;
             r = r < 0 ? 0 : (r >= erows ? erows - 1 : r);
-            le[n] = *reinterpret_cast<const uint4*>(Eh + (size_t)r * DP + (x < DP ? x : 0));
+            le[n] = ld16(Eh + (size_t)r * ERS + (x < DP ? x : 0));
         }
 #pragma unroll
         for (int n = 0; n < NK; ++n) {
@@ -268,6 +276,17 @@ __global__ void attn_pad_rows_kernel(GemmParams p, int B) {
     }
 }
 
+__global__ void attn_pad_rows_nat_kernel(GemmParams p, int B) {
+    const int Tp = p.Tg * p.G, npad = Tp - p.T;
+    const int total = B * npad * p.D;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int nn = idx % p.D, rest = idx / p.D;
+        const int t = p.T + rest % npad, b = rest / npad;
+        const size_t i1 = ((size_t)b * Tp + t) * p.D + nn;
+        p.qu[i1] = f2bf(p.u[nn]); p.qv[i1] = f2bf(p.v[nn]); p.kh[i1] = 0; p.vt[i1] = 0;
+    }
+}
+
 template <int DP>
 int launch_dp(const AttnParams& p, hipStream_t s) {
     using SM = AttnSmem<DP>;
@@ -296,6 +315,14 @@ int launch_relpos_attention(const AttnParams& p, hipStream_t s) {
         case 192: return launch_dp<192>(p, s);
     }
     return -3;
+}
+
+int launch_attn_pad_rows_nat(const GemmParams& p, int B, hipStream_t s) {
+    const int npad = p.Tg * p.G - p.T;
+    if (npad <= 0 || B <= 0) return 0;
+    const int total = B * npad * p.D;
+    hipLaunchKernelGGL(attn_pad_rows_nat_kernel, dim3((total + 255) / 256), dim3(256), 0, s, p, B);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 int launch_attn_pad_rows(const GemmParams& p, int B, hipStream_t s) {

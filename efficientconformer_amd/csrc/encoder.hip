@@ -35,7 +35,7 @@ struct LNp { const float* g = nullptr; const float* b = nullptr; };
 
 struct BlockW {
     LNp ln_ffn1, ln_att, ln_conv, ln_ffn2, ln_out;
-    PackedLinear ffn1_a, ffn1_b, qkv, pos, outp, pw1, pw2, res, ffn2_a, ffn2_b;
+    PackedLinear ffn1_a, ffn1_b, qkv, qkv_nat, pos, outp, pw1, pw2, res, ffn2_a, ffn2_b;
     const bf16_t *ffn1_bp = nullptr, *ffn2_bp = nullptr;   // W2 with the hidden index permuted per 16 (rsgemm.hip)
     const float *u = nullptr, *v = nullptr, *dw_w = nullptr, *dw_b = nullptr;
     const bf16_t* pos_table = nullptr;   // [2*max_pos-1][ld8(D)], row r <-> position max_pos-1-r
@@ -62,6 +62,10 @@ struct EcEncoder {
     // trace
     char* trace_arena = nullptr; size_t trace_bytes = 0, trace_used = 0;
     std::vector<TraceEntry> trace;
+    // positional-embedding cache: E = pos_layer(R) depends only on (block, T); when the caller keeps the SAME workspace
+    // untouched between forwards (opt-in), the 15-18 small E projections are skipped for an unchanged T
+    bool e_cache_on = false;
+    const void* e_cache_ws = nullptr; int e_cache_tm = -1;
     // per-launch event profiler (bench / tuning only; off by default)
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev;          // pairs
@@ -240,6 +244,7 @@ Shapes make_shapes(const EcEncoder* e, int B, int Tm) {
 struct Workspace {
     size_t total = 0;
     size_t mel, sub, x0, x1, a, hbuf, qu, qv, kh, vt, eh, o, gbuf, cbuf, xs, lens, preds;
+    std::vector<size_t> eh_blk;   // per-block E (kept across forwards for the cache)
 };
 
 inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -250,6 +255,7 @@ Workspace make_workspace(const EcEncoder* e, const Shapes& s, bool from_audio) {
     auto take = [&](size_t bytes) { size_t o = off; off += al(bytes); return o; };
     const size_t B = s.B;
     size_t mx = 0, ma = 0, mh = 0, mq = 0, mvt = 0, me = 0, mg = 0, mc = 0;
+    std::vector<size_t> esz;
     for (size_t k = 0; k < e->blocks.size(); ++k) {
         const EcBlock& b = e->blocks[k];
         const size_t T = s.Tin[k], To = s.Tout[k], D = b.dim_model, De = b.dim_expand;
@@ -258,9 +264,10 @@ Workspace make_workspace(const EcEncoder* e, const Shapes& s, bool from_audio) {
         mx = std::max(mx, std::max(B * T * D, B * To * De) * 4);
         ma = std::max(ma, std::max(B * T * ld8(D), B * To * ld8(De)) * 2);
         mh = std::max(mh, std::max(B * T * D, B * To * De) * b.ff_ratio * 2);
-        mq = std::max(mq, B * b.num_heads * Tg * dpad * 2);
-        mvt = std::max(mvt, B * b.num_heads * Tg * dpad * 2);
+        mq = std::max(mq, B * b.num_heads * Tg * dpad * 2 + 512);     // + slack: 16-byte chunk loads may run past a row's head span
+        mvt = std::max(mvt, B * b.num_heads * Tg * dpad * 2 + 512);
         me = std::max(me, (size_t)b.num_heads * (2 * Tg - 1) * dpad * 2);
+        esz.push_back((size_t)b.num_heads * (2 * Tg - 1) * dpad * 2 + 512);
         mg = std::max(mg, B * T * ld8(De) * 2);
         mc = std::max(mc, B * To * ld8(De) * 2);
     }
@@ -273,6 +280,7 @@ Workspace make_workspace(const EcEncoder* e, const Shapes& s, bool from_audio) {
     w.qu = take(mq); w.qv = take(mq); w.kh = take(mq); w.vt = take(mvt); w.eh = take(me);
     w.o = take(ma); w.gbuf = take(mg); w.cbuf = take(mc); w.xs = take(ma);
     w.lens = take((e->blocks.size() + 1) * B * 4);
+    for (size_t k = 0; k < esz.size(); ++k) w.eh_blk.push_back(take(esz[k]));
     w.preds = take(0);
     w.total = off;
     return w;
@@ -382,6 +390,7 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
     bf16_t* xs = reinterpret_cast<bf16_t*>(ws + w.xs);
     bool have_a = false;
     char nm[64];
+    const bool e_cached = e->e_cache_on && e->e_cache_ws == ws && e->e_cache_tm == s.Tm;
 
     for (int k = 0; k < nb; ++k) {
         const EcBlock& b = e->blocks[k];
@@ -399,6 +408,9 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
             const int Tp = ec_round_up(T, G), Tg = Tp / G, Tgp = ec_round_up(Tg, 8);
             const int d = G * D / H, dpad = ec_round_up(d, 32);
             { PROF(PC_LAYERNORM, 0, (double)M * D * 6); EC_TRY(launch_layernorm(x, M, D, W.ln_att.g, W.ln_att.b, nullptr, a, ld8(D), nullptr, nullptr, st)); }
+            // Q/K/V/E layout: "natural" row-major [B*Tp][D] (16-byte row stores from the GEMM, head split = pointer arithmetic in
+            // the attention kernel) whenever the grouped head dim d is even (4-byte aligned head spans); head-major otherwise
+            const bool nat = (d % 2) == 0;
             GemmParams p{};
             p.A = a; p.lda = ld8(D); p.W = W.qkv.w; p.ldw = W.qkv.ldw; p.bias = W.qkv.bias;
             p.M = M; p.N = 3 * D; p.K = D;
@@ -407,8 +419,13 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
             p.kh = reinterpret_cast<bf16_t*>(ws + w.kh); p.vt = reinterpret_cast<bf16_t*>(ws + w.vt);
             p.u = W.u; p.v = W.v;
             { PROF(PC_GEMM_OTHER, 2.0 * M * 3.0 * D * D, (double)M * D * 2 + 3.0 * D * D * 2 + (double)M * D * 8);
-              if (rs_gemm_supported(D)) EC_TRY(launch_rs_gemm(p, 3, st)); else EC_TRY(launch_gemm(p, EPI_QKV, st)); }
-            { PROF(PC_MISC, 0, 0); EC_TRY(launch_attn_pad_rows(p, B, st)); }
+              if (rs_gemm_supported(D)) {
+                  if (nat) { p.W = W.qkv_nat.w; p.ldw = W.qkv_nat.ldw; p.bias = W.qkv_nat.bias; }
+                  EC_TRY(launch_rs_gemm(p, nat ? 4 : 3, st));
+              } else {
+                  EC_TRY(launch_gemm(p, nat ? EPI_QKV_NAT : EPI_QKV, st));
+              } }
+            { PROF(PC_MISC, 0, 0); EC_TRY(nat ? launch_attn_pad_rows_nat(p, B, st) : launch_attn_pad_rows(p, B, st)); }
             // positional embeddings E = pos_layer(R) (attentions.py:588 / 678): input independent, tiny (2Tp-G rows)
             GemmParams pe{};
             const int erows = 2 * Tp - G;
@@ -416,13 +433,18 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
             pe.W = W.pos.w; pe.ldw = W.pos.ldw; pe.bias = W.pos.bias;
             pe.M = erows; pe.N = D; pe.K = D;
             pe.T = erows; pe.G = G; pe.H = H; pe.D = D; pe.d = d; pe.dpad = dpad; pe.Tg = 2 * Tg - 1; pe.Tgp = 0;
-            pe.kh = reinterpret_cast<bf16_t*>(ws + w.eh);
+            pe.kh = reinterpret_cast<bf16_t*>(ws + w.eh_blk[k]);
+            pe.C = pe.kh; pe.ldc = D;
             if (Tp > b.max_pos) return fail("sequence longer than max_pos_encoding");
-            { PROF(PC_GEMM_OTHER, 2.0 * erows * (double)D * D, (double)erows * D * 4 + (double)D * D * 2); EC_TRY(launch_gemm(pe, EPI_HEADS, st)); }
+            if (!e_cached) { PROF(PC_GEMM_OTHER, 2.0 * erows * (double)D * D, (double)erows * D * 4 + (double)D * D * 2);
+                             EC_TRY(launch_gemm(pe, nat ? EPI_BF16 : EPI_HEADS, st)); }
             AttnParams ap{};
             ap.qu = p.qu; ap.qv = p.qv; ap.kh = p.kh; ap.vt = p.vt; ap.eh = pe.kh;
             ap.lens = lens + (size_t)k * B;
             ap.B = B; ap.H = H; ap.T = T; ap.G = G; ap.D = D; ap.d = d; ap.dpad = dpad; ap.Tg = Tg; ap.Tgp = Tgp;
+            if (nat) { ap.q_bstride = (long long)Tp * D; ap.q_hstride = d; ap.q_rowstride = G * D; ap.e_hstride = d; ap.e_rowstride = G * D; }
+            else { ap.q_bstride = (long long)H * Tg * dpad; ap.q_hstride = (long long)Tg * dpad; ap.q_rowstride = dpad;
+                   ap.e_hstride = (long long)(2 * Tg - 1) * dpad; ap.e_rowstride = dpad; }
             ap.out = o; ap.ldo = ld8(D); ap.scale = 1.0f / std::sqrt((float)d);
             { PROF(PC_ATTENTION, 2.0 * B * H * (double)Tg * Tg * d * 3.0, (double)M * D * 2 * 5); EC_TRY(launch_relpos_attention(ap, st)); }
             snprintf(nm, sizeof(nm), "blocks.%d.att_o", k); trace_add(e, st, nm, o, M, D, ld8(D), 1);
@@ -456,6 +478,7 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
         have_a = !last;
         snprintf(nm, sizeof(nm), "blocks.%d.out", k); trace_add(e, st, nm, xo, Mo, De, De, 0);
     }
+    e->e_cache_ws = ws; e->e_cache_tm = s.Tm;
     return 0;
 }
 
@@ -557,6 +580,17 @@ int effconf_encoder_finalize(EcEncoder* e) {
                 bias.insert(bias.end(), bb->data.begin(), bb->data.end());
             }
             if (!pack_linear(e, rows, bias, D, &W.qkv)) return fail("upload failed");
+            // natural-layout variant for the row-stationary kernel: rows permuted inside every chunk of 32 so that a lane's
+            // 16 accumulators are 16 consecutive output columns (chunk row j <-> column 16((j>>2)&1) + 4(j>>3) + (j&3))
+            const int np = ec_round_up(3 * D, 32);
+            std::vector<const float*> prow(np, nullptr); std::vector<float> pbias(np, 0.f);
+            for (int n = 0; n < np; ++n) {
+                const int c = n / 32, j = n % 32;
+                const int src = c * 32 + 16 * ((j >> 2) & 1) + 4 * (j >> 3) + (j & 3);
+                if (src < 3 * D) { prow[n] = rows[src]; pbias[n] = bias[src]; }
+            }
+            if (!pack_linear(e, prow, pbias, D, &W.qkv_nat)) return fail("upload failed");
+            W.qkv_nat.N = 3 * D;
         }
         if (!pack_named_linear(e, m + ".mhsa.pos_layer", D, D, &W.pos, &err)) return fail(err);
         if (!pack_named_linear(e, m + ".mhsa.output_layer", D, D, &W.outp, &err)) return fail(err);
@@ -614,6 +648,7 @@ int effconf_encoder_finalize(EcEncoder* e) {
     for (void* p : e->allocs) if (!p) return fail("device allocation failed");
     if (hipDeviceSynchronize() != hipSuccess) return fail("upload failed");
     e->host.clear();
+    e->e_cache_ws = nullptr; e->e_cache_tm = -1;
     e->finalized = true;
     return 0;
 }
@@ -675,6 +710,12 @@ int effconf_ctc_greedy(EcEncoder* e, const float* enc_out, const int64_t* out_le
                              preds, logits, st));
     EC_TRY(launch_ctc_collapse(preds, out_len, batch, t_out, labels, label_len, st));
     return 0;
+}
+
+int effconf_encoder_set_option(EcEncoder* e, const char* name, int32_t value) {
+    if (!e || !name) return fail("null argument");
+    if (!strcmp(name, "cache_pos_embeddings")) { e->e_cache_on = value != 0; e->e_cache_ws = nullptr; e->e_cache_tm = -1; return 0; }
+    return fail(std::string("unknown option ") + name);
 }
 
 int effconf_profile_enable(EcEncoder* e, int32_t enable) {

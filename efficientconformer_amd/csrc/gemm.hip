@@ -170,6 +170,32 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDev gd) {
                     else p.vt[idx] = f2bf(val);
                 }
         }
+    } else if constexpr (EPI == EPI_QKV_NAT) {
+        // natural layout: out[which][(b*Tp + t)][nn], which = n / D; rows m = (b, t)
+        const int Tp = p.Tg * p.G;
+        int b0 = (m0 + wm * 64) / p.T, t0 = (m0 + wm * 64) - b0 * p.T;
+#pragma unroll
+        for (int ni = 0; ni < NF; ++ni) {
+            const int n = n0 + wn * (BN / 2) + ni * 32 + lcol;
+            if (n >= p.N) continue;
+            const int which = gd.fD.div(n), nn = n - which * p.D;
+            const float bias = p.bias[n];
+            const float bu = which == 0 ? p.u[nn] : 0.f, bv = which == 0 ? p.v[nn] : 0.f;
+            bf16_t* dst = which == 1 ? p.kh : (which == 2 ? p.vt : p.qu);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rr = mi * 32 + (r & 3) + 8 * (r >> 2) + lrow;
+                    if (m0 + wm * 64 + rr >= p.M) continue;
+                    int b = b0, t = t0 + rr;
+                    while (t >= p.T) { t -= p.T; ++b; }
+                    const size_t idx = ((size_t)b * Tp + t) * p.D + nn;
+                    const float val = acc[mi][ni][r] + bias;
+                    if (which == 0) { p.qu[idx] = f2bf(val + bu); p.qv[idx] = f2bf(val + bv); }
+                    else dst[idx] = f2bf(val);
+                }
+        }
     } else {
 #pragma unroll
         for (int ni = 0; ni < NF; ++ni) {
@@ -230,7 +256,7 @@ int launch_gemm(const GemmParams& p, int epi, hipStream_t s) {
     if (p.lda % 8 || p.ldw % 64) return -2;
     GemmDev gd;
     gd.p = p;
-    if (epi == EPI_QKV || epi == EPI_HEADS) {
+    if (epi == EPI_QKV || epi == EPI_HEADS || epi == EPI_QKV_NAT) {
         gd.fG = FastDiv(p.G); gd.fD = FastDiv(p.D); gd.fd = FastDiv(p.d);
     }
     switch (epi) {
@@ -241,6 +267,7 @@ int launch_gemm(const GemmParams& p, int epi, hipStream_t s) {
         case EPI_GLU_BF16: return launch_bn<EPI_GLU_BF16>(gd, s);
         case EPI_QKV: return launch_bn<EPI_QKV>(gd, s);
         case EPI_HEADS: return launch_bn<EPI_HEADS>(gd, s);
+        case EPI_QKV_NAT: return launch_bn<EPI_QKV_NAT>(gd, s);
     }
     return -3;
 }

@@ -14,6 +14,7 @@ enum GemmEpilogue {
     EPI_GLU_BF16 = 4,    // C bf16 [M][ldc], N/2 cols = a * sigmoid(b); W rows interleaved in blocks of 32 (a|b)
     EPI_QKV = 5,         // scatter to head-major Qu, Qv, K and key-major V^T (see GemmParams)
     EPI_HEADS = 6,       // scatter a single matrix to head-major [H][rows/G][dpad]   (positional E)
+    EPI_QKV_NAT = 7,     // Q+u, Q+v, K, V as plain row-major [B*Tp][D] bf16 ("natural" layout; attention does the head split)
 };
 
 struct GemmParams {
@@ -44,7 +45,8 @@ struct FfnParams {
     int M, D, Fp;
     float alpha;
 };
-// single row-stationary GEMM (K <= 384); epi: 0 residual fp32, 1 fp32, 2 GLU bf16 (N = packed a|b rows), 3 QKV scatter
+// single row-stationary GEMM (K <= 384); epi: 0 residual fp32, 1 fp32, 2 GLU bf16 (N = packed a|b rows), 3 QKV head-major
+// scatter, 4 QKV natural layout (weight rows permuted inside every 32-row chunk, see pack_linear_chunkperm)
 // (GemmParams fields as for launch_gemm; `vt` receives V in the SAME head-major row-major layout as K)
 bool rs_gemm_supported(int K);
 bool rs_gemm_resident_supported(int K, int N);   // residual / fp32 epilogues keep the whole output row in registers
@@ -67,6 +69,10 @@ int launch_cast_rows(const float* x, int D, int rows_per_batch, int stride, int 
 // ---------------------------------------------------------------- attention  (attention.hip)
 struct AttnParams {
     const bf16_t *qu, *qv, *kh, *vt, *eh;   // see GemmParams; eh [H][2Tg-1][dpad]
+    // element strides: row (b, h, tq) of Q/K/V starts at b*q_bstride + h*q_hstride + tq*q_rowstride; E row r of head h at
+    // h*e_hstride + r*e_rowstride.  head-major: (H*Tg*dpad, Tg*dpad, dpad) / ((2Tg-1)*dpad, dpad);
+    // natural [B*Tp][D]: (Tp*D, d, G*D) / (d, G*D) — a grouped row is G consecutive rows, head h is the span [h*d, (h+1)*d)
+    long long q_bstride, q_hstride, e_hstride; int q_rowstride, e_rowstride;
     const int* lens;                        // [B] valid frames at this stage (keys j with G*j >= lens[b] are masked)
     int B, H, T, G, D, d, dpad, Tg, Tgp;
     bf16_t* out; int ldo;                   // [B*T][ldo] un-grouped attention output (rows t >= T dropped)
@@ -74,7 +80,8 @@ struct AttnParams {
 };
 int launch_relpos_attention(const AttnParams& p, hipStream_t s);
 // rows t in [T, Tp) of the grouped view: Qu=u, Qv=v, K=V=0  (attentions.py:107-138, 671-675)
-int launch_attn_pad_rows(const GemmParams& p, int B, hipStream_t s);
+int launch_attn_pad_rows(const GemmParams& p, int B, hipStream_t s);       // head-major buffers
+int launch_attn_pad_rows_nat(const GemmParams& p, int B, hipStream_t s);   // natural [B*Tp][D] buffers
 
 // ---------------------------------------------------------------- convolutions  (conv.hip)
 // mel (B, F, Tm) f32 -> (B*T1, C*F/2) bf16, feature index c*(F/2)+f; 3x3 s2 p1 conv (Cin=1) + folded BN + Swish

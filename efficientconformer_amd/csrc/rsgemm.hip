@@ -251,8 +251,11 @@ int launch_ffn_t(const FfnParams& p, hipStream_t s) {
 //   RS_F32   : y[m][n] = acc + bias[n]                          fp32   (conv_res 1x1 strided conv, blocks.py:106-110)
 //   RS_GLU   : g[m][j] = (acc_a + b_a) * sigmoid(acc_b + b_b)   bf16   (pointwise-1 + GLU, modules.py:513-514;
 //              weight rows interleaved per 32 channels: chunk 2i = a, chunk 2i+1 = b)
-//   RS_QKV   : Q+u, Q+v, K, V scattered to head-major [B][H][Tg][dpad] (attentions.py:651-686)
-enum { RS_RESID = 0, RS_F32 = 1, RS_GLU = 2, RS_QKV = 3 };
+//   RS_QKV   : Q+u, Q+v, K, V scattered to head-major [B][H][Tg][dpad] (attentions.py:651-686)   (odd d fallback)
+//   RS_QKV_NAT: Q+u, Q+v, K, V as plain rows [B*Tp][D] with 8-byte row-contiguous stores; the weight rows of every
+//              32-row chunk are permuted at pack time (row j <-> column 16((j>>2)&1) + 4(j>>3) + (j&3)) so that a
+//              lane's 16 accumulators are 16 CONSECUTIVE output columns 32c + 16*half + r
+enum { RS_RESID = 0, RS_F32 = 1, RS_GLU = 2, RS_QKV = 3, RS_QKV_NAT = 4 };
 
 struct FastDiv32 {   // exact for n * d < 2^32
     uint32_t mul, d;
@@ -266,8 +269,11 @@ struct RsDev { GemmParams p; int nchunks; FastDiv32 fD, fd; };
 // variants contain only stores and sit at the FRONT of an iteration (before the next DMA issue), so the counted vmcnt
 // never under-waits (memory ops retire in order; extra stores in the FIFO can only make the wait stricter).  The
 // residual variants read R, so they keep the whole row (G >= N/32) and flush once after the loop.
+// second launch-bounds argument = minimum waves per SIMD: small workgroups want several co-resident per CU so that one
+// workgroup's prologue / flush memory phases overlap another's MFMA phase
 template <int KS, int G, int RT, int NW, int NBUF, int EPI>
-__global__ __launch_bounds__(NW * 64) void rs_gemm_kernel(const RsDev gd) {
+__global__ __launch_bounds__(NW * 64, (NW == 4 && RT == 1) ? (KS <= 8 ? 3 : (KS <= 16 ? 2 : 1)) : (NW == 8 ? 2 : 1))
+void rs_gemm_kernel(const RsDev gd) {
     const GemmParams& p = gd.p;
     static_assert(KS % NW == 0, "uniform DMA count per wave");
     static_assert(EPI != RS_GLU || G % 2 == 0, "GLU flushes (a, b) pairs");
@@ -315,6 +321,15 @@ __global__ __launch_bounds__(NW * 64) void rs_gemm_kernel(const RsDev gd) {
     }
     // per-row constants of the QKV scatter
     int qb[RT], qtq[RT], qtoff[RT];
+    size_t qrow[RT];
+    if constexpr (EPI == RS_QKV_NAT) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const int m = rowm[rt] < p.M ? rowm[rt] : p.M - 1;
+            const int b = m / p.T, t = m - b * p.T;
+            qrow[rt] = ((size_t)b * (p.Tg * p.G) + t) * p.D;
+        }
+    }
     if constexpr (EPI == RS_QKV) {
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
@@ -389,6 +404,26 @@ __global__ __launch_bounds__(NW * 64) void rs_gemm_kernel(const RsDev gd) {
                             o[i] = (acc[rt][g][q * 4 + i] + bias[nl + i]) * sigmoidf_(acc[rt][(g + gb) % G][q * 4 + i] + bias_b[nl + i]);
                         *reinterpret_cast<uint2*>(gr + j) = make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
                     }
+                    }
+                } else if constexpr (EPI == RS_QKV_NAT) {
+#pragma unroll
+                    for (int r0 = 0; r0 < 16; r0 += 4) {
+                        const int n0 = (c0 + g) * CH + 16 * half + r0;          // 4 consecutive columns, one `which` (D % 4 == 0)
+                        if (n0 < p.N) {
+                            const int which = gd.fD.div(n0), nn0 = n0 - which * p.D;
+                            float v[4];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) v[i] = acc[rt][g][r0 + i] + bias[(i) + 8 * (r0 >> 2) + 4 * half];
+                            const size_t idx = qrow[rt] + nn0;
+                            if (which == 0) {
+                                const float4 u4 = *reinterpret_cast<const float4*>(p.u + nn0), v4 = *reinterpret_cast<const float4*>(p.v + nn0);
+                                *reinterpret_cast<uint2*>(p.qu + idx) = make_uint2(pack_bf2(v[0] + u4.x, v[1] + u4.y), pack_bf2(v[2] + u4.z, v[3] + u4.w));
+                                *reinterpret_cast<uint2*>(p.qv + idx) = make_uint2(pack_bf2(v[0] + v4.x, v[1] + v4.y), pack_bf2(v[2] + v4.z, v[3] + v4.w));
+                            } else {
+                                bf16_t* dst = which == 1 ? p.kh : p.vt;
+                                *reinterpret_cast<uint2*>(dst + idx) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                            }
+                        }
                     }
                 } else {   // RS_QKV
 #pragma unroll
@@ -519,15 +554,28 @@ int launch_ffn_fused(const FfnParams& p, hipStream_t s) {
     if (p.M <= 0) return 0;
     if (!ffn_fused_supported(p.D) || p.Fp % CH || p.lda % 8 || p.ldw1 % 8 || p.ldw2 % 8) return -2;
     const int ks = (p.D + 15) / 16;
-    // rows per workgroup trade weight re-streaming (LDS-DMA bytes per row) against the number of workgroups:
-    // variant 0 = default heuristic, 1 = force 128-row workgroups, 2 = force the largest
+    // rows per workgroup / waves per SIMD trade-offs, selected per width class (EFFCONF_FFN_VARIANT overrides for tuning)
     static const int var = env_variant("EFFCONF_FFN_VARIANT");
-    const bool small_m = var == 1 || (var != 2 && p.M < 256 * 512);
     if (ks <= 2) return launch_ffn_t<2, 1, 1, 4, 4>(p, s);
     if (ks <= 4) return launch_ffn_t<4, 2, 1, 8, 4>(p, s);
-    if (ks <= 8) return (var == 2) ? launch_ffn_t<8, 4, 2, 8, 4>(p, s) : (var == 1 ? launch_ffn_t<8, 4, 1, 4, 4>(p, s) : launch_ffn_t<8, 4, 1, 8, 4>(p, s));
-    if (ks <= 12) return small_m ? launch_ffn_t<12, 6, 1, 4, 4>(p, s) : launch_ffn_t<12, 6, 2, 4, 4>(p, s);
-    if (ks <= 16) return small_m ? launch_ffn_t<16, 8, 1, 4, 4>(p, s) : launch_ffn_t<16, 8, 2, 4, 4>(p, s);
+    if (ks <= 8) {
+        if (var == 1) return launch_ffn_t<8, 4, 1, 4, 3>(p, s);      // 128 rows, 3 workgroups per CU
+        if (var == 2) return launch_ffn_t<8, 4, 1, 4, 4>(p, s);
+        if (var == 3) return launch_ffn_t<8, 4, 2, 8, 4>(p, s);      // 512 rows
+        return launch_ffn_t<8, 4, 1, 8, 4>(p, s);
+    }
+    if (ks <= 12) {
+        if (var == 1) return launch_ffn_t<12, 6, 1, 4, 4>(p, s);
+        if (var == 2) return launch_ffn_t<12, 6, 2, 4, 4>(p, s);
+        if (var == 3) return launch_ffn_t<12, 6, 1, 8, 3>(p, s);
+        return launch_ffn_t<12, 6, 1, 8, 4>(p, s);                   // 2 waves per SIMD, 256 rows: 48 vs 67 us (profiles/r1_04)
+    }
+    if (ks <= 16) {
+        if (var == 1) return launch_ffn_t<16, 8, 1, 8, 4>(p, s);
+        if (var == 2) return launch_ffn_t<16, 8, 2, 4, 4>(p, s);
+        if (var == 3) return launch_ffn_t<16, 8, 1, 8, 3>(p, s);
+        return launch_ffn_t<16, 8, 1, 4, 4>(p, s);
+    }
     if (ks <= 20) return launch_ffn_t<20, 10, 1, 4, 3>(p, s);
     return launch_ffn_t<24, 12, 1, 4, 3>(p, s);
 }
@@ -542,12 +590,13 @@ int launch_rs_gemm(const GemmParams& p, int epi, hipStream_t s) {
     RsDev gd;
     gd.p = p;
     gd.nchunks = (p.N + CH - 1) / CH;
-    if (epi == RS_QKV) { gd.fD = FastDiv32(p.D); gd.fd = FastDiv32(p.d); }
+    if (epi == RS_QKV || epi == RS_QKV_NAT) { gd.fD = FastDiv32(p.D); gd.fd = FastDiv32(p.d); }
     switch (epi) {
         case RS_RESID: return launch_rs_ks<RS_RESID>(gd, s);
         case RS_F32: return launch_rs_ks<RS_F32>(gd, s);
         case RS_GLU: return launch_rs_ks<RS_GLU>(gd, s);
         case RS_QKV: return launch_rs_ks<RS_QKV>(gd, s);
+        case RS_QKV_NAT: return launch_rs_ks<RS_QKV_NAT>(gd, s);
     }
     return -3;
 }

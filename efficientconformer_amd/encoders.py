@@ -155,6 +155,9 @@ class ConformerEncoder(nn.Module):
             _lib.check(lib.effconf_encoder_load_tensor(h, key.encode(), arr.ctypes.data_as(C.c_void_p), shape, arr.ndim),
                        "load_tensor(%s)" % key)
         _lib.check(lib.effconf_encoder_finalize(h), "finalize")
+        # this wrapper owns its workspaces exclusively, so the input-independent positional projections may be cached
+        _lib.check(lib.effconf_encoder_set_option(h, b"cache_pos_embeddings", 1), "set_option")
+        self._ws.clear()
         self._packed = True
 
     def __del__(self):

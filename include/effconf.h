@@ -97,6 +97,11 @@ int effconf_mel_frontend(EcEncoder* enc, const float* audio, int32_t batch, int3
 int effconf_ctc_greedy(EcEncoder* enc, const float* enc_out, const int64_t* out_len, int32_t batch, int32_t t_out,
                        int32_t* labels, int32_t* label_len, float* logits, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Options.  "cache_pos_embeddings" = 1: the positional projections E = pos_layer(R) (reference attentions.py:588, 678)
+ * are input independent; they live in the workspace and are recomputed only when the workspace pointer or the number
+ * of frames changes.  Enable ONLY if the caller passes the same workspace and leaves it untouched between forwards. */
+int effconf_encoder_set_option(EcEncoder* enc, const char* name, int32_t value);
+
 /* ---- per-launch event profiler (bench / tuning only) --------------------------------------- */
 /* When enabled every kernel launch of the forward is bracketed by two hipEventRecord on the caller's stream.
  * Classes: 0 mel, 1 subsample conv, 2 FFN GEMMs, 3 other GEMMs, 4 LayerNorm, 5 attention, 6 depthwise conv, 7 misc.
