@@ -61,51 +61,91 @@ __global__ __launch_bounds__(256) void subsample_conv_kernel(const float* __rest
     }
 }
 
-constexpr int DW_TT = 64;   // output frames per workgroup
-constexpr int DW_CC = 64;   // channels per workgroup (one per lane)
+// ---- depthwise conv: block = 128 output frames x 64 channels; thread = 8 channels (one 16-byte vector) x 4 consecutive
+// output frames with a sliding window over the input rows, so every input row is read once from LDS (as one ds_read_b128)
+// and every tap weight once per 4 outputs; global loads and stores are 16 bytes per lane, 128 contiguous bytes per row.
+constexpr int DW_NT = 4;                       // outputs per thread
+constexpr int DW_TT = 32 * DW_NT;              // output frames per workgroup
+constexpr int DW_CC = 64;                      // channels per workgroup
+constexpr int DW_PITCH = DW_CC * 2 + 16;       // bytes per LDS row (144: 4-row-strided b128 reads spread over all 16 slots)
 
+template <int KSZ, int STRIDE>
 __global__ __launch_bounds__(256) void dwconv_kernel(const bf16_t* __restrict__ g, int T, int To, int C, int ld,
-                                                     const float* __restrict__ w_kc, const float* __restrict__ bias,
-                                                     int ksize, int stride, bf16_t* out) {
+                                                     const float* __restrict__ w_kc, const float* __restrict__ bias, bf16_t* out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16_t* sg = reinterpret_cast<bf16_t*>(smem);       // [rows][DW_CC]
+    constexpr int ROWS = (DW_TT - 1) * STRIDE + KSZ;
+    char* sg = smem;                                                        // [ROWS][DW_PITCH] bf16 rows
+    float* sw = reinterpret_cast<float*>(smem + ROWS * DW_PITCH);           // [KSZ][64] folded weights, then [64] bias
     const int ctiles = (C + DW_CC - 1) / DW_CC;
     const int ttiles = (To + DW_TT - 1) / DW_TT;
     int id = blockIdx.x;
     const int ct = id % ctiles; id /= ctiles;
     const int tt = id % ttiles; const int b = id / ttiles;
     const int c0 = ct * DW_CC, to0 = tt * DW_TT;
-    const int half = (ksize - 1) / 2;
-    const int rows = (DW_TT - 1) * stride + ksize;
-    const int tin0 = to0 * stride - half;
+    constexpr int HALF = (KSZ - 1) / 2;
+    const int tin0 = to0 * STRIDE - HALF;
     const int tid = threadIdx.x;
-    // stage rows tin0 .. tin0+rows-1, channels c0..c0+63 (16-byte chunks of 8 channels)
-    for (int i = tid; i < rows * (DW_CC / 8); i += 256) {
-        const int r = i / (DW_CC / 8), ch = (i - r * (DW_CC / 8)) * 8;
+    for (int i = tid; i < ROWS * (DW_CC / 8); i += 256) {
+        const int r = i >> 3, ch = (i & 7) * 8;
         const int t = tin0 + r, c = c0 + ch;
         const int tc = t < 0 ? 0 : (t < T ? t : T - 1), cc = c < ld - 8 ? c : ld - 8;      // clamped, unconditional load
         const uint4 v = *reinterpret_cast<const uint4*>(g + ((size_t)b * T + tc) * ld + cc);
-        *reinterpret_cast<uint4*>(sg + r * DW_CC + ch) = mask_chunk(v, (t >= 0 && t < T && c < ld) ? C - c : 0);
+        *reinterpret_cast<uint4*>(sg + r * DW_PITCH + ch * 2) = mask_chunk(v, (t >= 0 && t < T && c < ld) ? C - c : 0);
+    }
+    for (int i = tid; i < (KSZ + 1) * DW_CC; i += 256) {
+        const int j = i / DW_CC, ch = i - j * DW_CC, c = c0 + ch;
+        sw[i] = c < C ? (j < KSZ ? w_kc[j * C + c] : bias[c]) : 0.f;
     }
     __syncthreads();
-    const int lane = tid & 63, wave = tid >> 6;
-    const int c = c0 + lane;
-    if (c >= ld) return;
-    const bool live = c < C;
-    float wreg[31];
+    const int cc = tid & 7, tg = tid >> 3;
+    float acc[DW_NT][8];
 #pragma unroll
-    for (int j = 0; j < 31; ++j) wreg[j] = (live && j < ksize) ? w_kc[j * C + c] : 0.f;
-    const float bz = live ? bias[c] : 0.f;
-    for (int tl = wave; tl < DW_TT; tl += 4) {
-        const int to = to0 + tl;
-        if (to >= To) break;
-        float a = bz;
-        const bf16_t* p = sg + (tl * stride) * DW_CC + lane;
-#pragma unroll
-        for (int j = 0; j < 31; ++j)
-            if (j < ksize) a = fmaf(wreg[j], bf2f(p[j * DW_CC]), a);
-        out[((size_t)b * To + to) * ld + c] = live ? f2bf(swishf_(a)) : (bf16_t)0;
+    for (int o = 0; o < DW_NT; ++o) {
+        const float4 b0 = *reinterpret_cast<const float4*>(sw + KSZ * DW_CC + cc * 8), b1 = *reinterpret_cast<const float4*>(sw + KSZ * DW_CC + cc * 8 + 4);
+        acc[o][0] = b0.x; acc[o][1] = b0.y; acc[o][2] = b0.z; acc[o][3] = b0.w;
+        acc[o][4] = b1.x; acc[o][5] = b1.y; acc[o][6] = b1.z; acc[o][7] = b1.w;
     }
+    const char* base = sg + (tg * DW_NT * STRIDE) * DW_PITCH + cc * 16;
+    // tap loop kept rolled: fully unrolled the compiler keeps every window row / tap weight live (> 256 VGPRs)
+#pragma unroll 1
+    for (int tap = 0; tap < KSZ; ++tap) {
+        const float4 w0 = *reinterpret_cast<const float4*>(sw + tap * DW_CC + cc * 8), w1 = *reinterpret_cast<const float4*>(sw + tap * DW_CC + cc * 8 + 4);
+#pragma unroll
+        for (int o = 0; o < DW_NT; ++o) {
+            const uint4 raw = *reinterpret_cast<const uint4*>(base + (tap + o * STRIDE) * DW_PITCH);
+            acc[o][0] = fmaf(w0.x, __uint_as_float(raw.x << 16), acc[o][0]); acc[o][1] = fmaf(w0.y, __uint_as_float(raw.x & 0xFFFF0000u), acc[o][1]);
+            acc[o][2] = fmaf(w0.z, __uint_as_float(raw.y << 16), acc[o][2]); acc[o][3] = fmaf(w0.w, __uint_as_float(raw.y & 0xFFFF0000u), acc[o][3]);
+            acc[o][4] = fmaf(w1.x, __uint_as_float(raw.z << 16), acc[o][4]); acc[o][5] = fmaf(w1.y, __uint_as_float(raw.z & 0xFFFF0000u), acc[o][5]);
+            acc[o][6] = fmaf(w1.z, __uint_as_float(raw.w << 16), acc[o][6]); acc[o][7] = fmaf(w1.w, __uint_as_float(raw.w & 0xFFFF0000u), acc[o][7]);
+        }
+    }
+    const int c = c0 + cc * 8;
+    if (c < ld) {
+#pragma unroll
+        for (int o = 0; o < DW_NT; ++o) {
+            const int to = to0 + tg * DW_NT + o;
+            if (to < To) {
+                uint4 w;                                   // channels >= C have zero weights and bias: swish(0) = 0 keeps the pad columns zero
+                w.x = pack_bf2(swishf_(acc[o][0]), swishf_(acc[o][1])); w.y = pack_bf2(swishf_(acc[o][2]), swishf_(acc[o][3]));
+                w.z = pack_bf2(swishf_(acc[o][4]), swishf_(acc[o][5])); w.w = pack_bf2(swishf_(acc[o][6]), swishf_(acc[o][7]));
+                *reinterpret_cast<uint4*>(out + ((size_t)b * To + to) * ld + c) = w;
+            }
+        }
+    }
+}
+
+template <int KSZ, int STRIDE>
+int launch_dw_t(const bf16_t* g, int B, int T, int To, int C, int ld, const float* w_kc, const float* bias, bf16_t* out, hipStream_t s) {
+    const int ctiles = (C + DW_CC - 1) / DW_CC, ttiles = (To + DW_TT - 1) / DW_TT;
+    constexpr int ROWS = (DW_TT - 1) * STRIDE + KSZ;
+    const size_t lds = (size_t)ROWS * DW_PITCH + (size_t)(KSZ + 1) * DW_CC * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv_kernel<KSZ, STRIDE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((dwconv_kernel<KSZ, STRIDE>), dim3(B * ttiles * ctiles), dim3(256), lds, s, g, T, To, C, ld, w_kc, bias, out);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 }  // namespace
@@ -123,11 +163,13 @@ int launch_subsample_conv(const float* mel, int B, int F, int Tm, int T1, const 
 int launch_dwconv(const bf16_t* g, int B, int T, int To, int C, int ld, const float* w_kc, const float* bias,
                   int ksize, int stride, bf16_t* out, hipStream_t s) {
     if (B <= 0 || To <= 0) return 0;
-    if (ksize > 31 || ksize < 1 || (ksize & 1) == 0 || ld % 8) return -2;
-    const int ctiles = (C + DW_CC - 1) / DW_CC, ttiles = (To + DW_TT - 1) / DW_TT;
-    const int rows = (DW_TT - 1) * stride + ksize;
-    const size_t lds = (size_t)rows * DW_CC * sizeof(bf16_t);
-    hipLaunchKernelGGL(dwconv_kernel, dim3(B * ttiles * ctiles), dim3(256), lds, s, g, T, To, C, ld, w_kc, bias,
-                       ksize, stride, out);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    if (ld % 8 || ld < C) return -2;
+    // taps are fully unrolled per (kernel size, stride); the shipped configs use k = 15 (Efficient Conformer) and 31 (Conformer)
+    if (ksize == 15 && stride == 1) return launch_dw_t<15, 1>(g, B, T, To, C, ld, w_kc, bias, out, s);
+    if (ksize == 15 && stride == 2) return launch_dw_t<15, 2>(g, B, T, To, C, ld, w_kc, bias, out, s);
+    if (ksize == 31 && stride == 1) return launch_dw_t<31, 1>(g, B, T, To, C, ld, w_kc, bias, out, s);
+    if (ksize == 31 && stride == 2) return launch_dw_t<31, 2>(g, B, T, To, C, ld, w_kc, bias, out, s);
+    if (ksize == 7 && stride == 1) return launch_dw_t<7, 1>(g, B, T, To, C, ld, w_kc, bias, out, s);
+    if (ksize == 7 && stride == 2) return launch_dw_t<7, 2>(g, B, T, To, C, ld, w_kc, bias, out, s);
+    return -3;
 }

@@ -27,7 +27,7 @@ __global__ void lengths_kernel(const int64_t* __restrict__ x_len, int B, int fro
     if (out_len) out_len[b] = l;
 }
 
-constexpr int CTC_ROWS = 32;   // rows per workgroup: the [D][V] weight is re-streamed from L2 once per 32 frames
+constexpr int CTC_ROWS = 8;
 
 __global__ __launch_bounds__(256) void ctc_argmax_kernel(const float* __restrict__ x, int M, int D,
                                                          const float* __restrict__ Wt, const float* __restrict__ bias,

@@ -272,7 +272,7 @@ struct RsDev { GemmParams p; int nchunks; FastDiv32 fD, fd; };
 // second launch-bounds argument = minimum waves per SIMD: small workgroups want several co-resident per CU so that one
 // workgroup's prologue / flush memory phases overlap another's MFMA phase
 template <int KS, int G, int RT, int NW, int NBUF, int EPI>
-__global__ __launch_bounds__(NW * 64, (NW == 4 && RT == 1) ? (KS <= 8 ? 3 : (KS <= 16 ? 2 : 1)) : (NW == 8 ? 2 : 1))
+__global__ __launch_bounds__(NW * 64, (NW == 4 && RT == 1 && EPI != RS_RESID) ? (KS <= 8 ? 3 : (KS <= 12 ? 2 : 1)) : (NW == 8 ? 2 : 1))
 void rs_gemm_kernel(const RsDev gd) {
     const GemmParams& p = gd.p;
     static_assert(KS % NW == 0, "uniform DMA count per wave");
@@ -406,22 +406,52 @@ void rs_gemm_kernel(const RsDev gd) {
                     }
                     }
                 } else if constexpr (EPI == RS_QKV_NAT) {
+                    // columns 32(c0+g) + 16*half + r: two runs of 8 consecutive columns -> 16-byte stores when D % 8 == 0
+                    // (a run never straddles the Q|K|V boundary), else four runs of 4 (8-byte stores)
+                    if ((p.D & 7) == 0) {
 #pragma unroll
-                    for (int r0 = 0; r0 < 16; r0 += 4) {
-                        const int n0 = (c0 + g) * CH + 16 * half + r0;          // 4 consecutive columns, one `which` (D % 4 == 0)
-                        if (n0 < p.N) {
-                            const int which = gd.fD.div(n0), nn0 = n0 - which * p.D;
-                            float v[4];
+                        for (int r0 = 0; r0 < 16; r0 += 8) {
+                            const int n0 = (c0 + g) * CH + 16 * half + r0;
+                            if (n0 < p.N) {
+                                const int which = gd.fD.div(n0), nn0 = n0 - which * p.D;
+                                float v[8];
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) v[i] = acc[rt][g][r0 + i] + bias[(i) + 8 * (r0 >> 2) + 4 * half];
-                            const size_t idx = qrow[rt] + nn0;
-                            if (which == 0) {
-                                const float4 u4 = *reinterpret_cast<const float4*>(p.u + nn0), v4 = *reinterpret_cast<const float4*>(p.v + nn0);
-                                *reinterpret_cast<uint2*>(p.qu + idx) = make_uint2(pack_bf2(v[0] + u4.x, v[1] + u4.y), pack_bf2(v[2] + u4.z, v[3] + u4.w));
-                                *reinterpret_cast<uint2*>(p.qv + idx) = make_uint2(pack_bf2(v[0] + v4.x, v[1] + v4.y), pack_bf2(v[2] + v4.z, v[3] + v4.w));
-                            } else {
-                                bf16_t* dst = which == 1 ? p.kh : p.vt;
-                                *reinterpret_cast<uint2*>(dst + idx) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                                for (int i = 0; i < 8; ++i) v[i] = acc[rt][g][r0 + i] + bias[(i & 3) + 8 * ((r0 + i) >> 2) + 4 * half];
+                                const size_t idx = qrow[rt] + nn0;
+                                if (which == 0) {
+                                    float uu[8], vv[8];
+                                    *reinterpret_cast<float4*>(uu) = *reinterpret_cast<const float4*>(p.u + nn0);
+                                    *reinterpret_cast<float4*>(uu + 4) = *reinterpret_cast<const float4*>(p.u + nn0 + 4);
+                                    *reinterpret_cast<float4*>(vv) = *reinterpret_cast<const float4*>(p.v + nn0);
+                                    *reinterpret_cast<float4*>(vv + 4) = *reinterpret_cast<const float4*>(p.v + nn0 + 4);
+                                    *reinterpret_cast<uint4*>(p.qu + idx) = make_uint4(pack_bf2(v[0] + uu[0], v[1] + uu[1]), pack_bf2(v[2] + uu[2], v[3] + uu[3]),
+                                                                                     pack_bf2(v[4] + uu[4], v[5] + uu[5]), pack_bf2(v[6] + uu[6], v[7] + uu[7]));
+                                    *reinterpret_cast<uint4*>(p.qv + idx) = make_uint4(pack_bf2(v[0] + vv[0], v[1] + vv[1]), pack_bf2(v[2] + vv[2], v[3] + vv[3]),
+                                                                                     pack_bf2(v[4] + vv[4], v[5] + vv[5]), pack_bf2(v[6] + vv[6], v[7] + vv[7]));
+                                } else {
+                                    bf16_t* dst = which == 1 ? p.kh : p.vt;
+                                    *reinterpret_cast<uint4*>(dst + idx) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+                                }
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int r0 = 0; r0 < 16; r0 += 4) {
+                            const int n0 = (c0 + g) * CH + 16 * half + r0;          // 4 consecutive columns, one `which` (D % 4 == 0)
+                            if (n0 < p.N) {
+                                const int which = gd.fD.div(n0), nn0 = n0 - which * p.D;
+                                float v[4];
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) v[i] = acc[rt][g][r0 + i] + bias[(i) + 8 * (r0 >> 2) + 4 * half];
+                                const size_t idx = qrow[rt] + nn0;
+                                if (which == 0) {
+                                    const float4 u4 = *reinterpret_cast<const float4*>(p.u + nn0), v4 = *reinterpret_cast<const float4*>(p.v + nn0);
+                                    *reinterpret_cast<uint2*>(p.qu + idx) = make_uint2(pack_bf2(v[0] + u4.x, v[1] + u4.y), pack_bf2(v[2] + u4.z, v[3] + u4.w));
+                                    *reinterpret_cast<uint2*>(p.qv + idx) = make_uint2(pack_bf2(v[0] + v4.x, v[1] + v4.y), pack_bf2(v[2] + v4.z, v[3] + v4.w));
+                                } else {
+                                    bf16_t* dst = which == 1 ? p.kh : p.vt;
+                                    *reinterpret_cast<uint2*>(dst + idx) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                                }
                             }
                         }
                     }
