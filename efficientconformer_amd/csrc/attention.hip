@@ -34,6 +34,13 @@ __device__ __forceinline__ uint4 ld16(const bf16_t* p) {
     return make_uint4(v[0], v[1], v[2], v[3]);
 }
 
+// per-wave LDS hand-off: LDS operations of one wave execute in order, only the compiler must not reorder across it
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <int DP>
 struct AttnSmem {
     static constexpr int KROW = DP * 2 + 16;         // bytes per K / E row
@@ -103,15 +110,14 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const AttnParams 
     float* skew = sS + wave * 16 * SKEW_LD + c * SKEW_LD;
     const int woff = 48 - 16 * wave;                  // first band row of this wave inside the workgroup band
 
-    for (int j0 = 0; j0 < nkeys; j0 += BJ) {
-        __syncthreads();                              // previous block's LDS reads are done
-        // ---- stage K block, V^T block and the relative-position band.  All global loads of a thread are issued first
-        // (unconditionally, at clamped in-bounds rows), then masked and written to LDS.
-        constexpr int CPR = DP / 8;                               // 16-byte chunks per row
-        constexpr int NK = (BJ * CPR + 255) / 256, NV = ((BJ / 2) * CPR + 255) / 256, NE = (128 * CPR + 255) / 256;
-        const int rbase = p.Tg - 1 + j0 - i0 - 63;               // E row of band row 0
-        const int erows = 2 * p.Tg - 1;
-        uint4 lk[NK], lv0[NV], lv1[NV], le[NE];
+    // ---- K / V / E staging, software pipelined: the global loads of key block j+1 are issued (unconditionally, at clamped
+    // in-bounds rows) right after block j has been written to LDS and are consumed one iteration later
+    constexpr int CPR = DP / 8;                               // 16-byte chunks per row
+    constexpr int NK = (BJ * CPR + 255) / 256, NV = ((BJ / 2) * CPR + 255) / 256, NE = (128 * CPR + 255) / 256;
+    const int erows = 2 * p.Tg - 1;
+    uint4 lk[NK], lv0[NV], lv1[NV], le[NE];
+    auto load_block = [&](int j0) __attribute__((always_inline)) {
+        const int rbase = p.Tg - 1 + j0 - i0 - 63;           // E row of band row 0
 #pragma unroll
         for (int n = 0; n < NK; ++n) {
             const int q = tid + 256 * n, r = q / CPR, x = (q - r * CPR) * 8;
@@ -132,6 +138,9 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const AttnParams 
             r = r < 0 ? 0 : (r >= erows ? erows - 1 : r);
             le[n] = ld16(Eh + (size_t)r * ERS + (x < DP ? x : 0));
         }
+    };
+    auto store_block = [&](int j0) __attribute__((always_inline)) {
+        const int rbase = p.Tg - 1 + j0 - i0 - 63;
 #pragma unroll
         for (int n = 0; n < NK; ++n) {
             const int q = tid + 256 * n, r = q / CPR, x = (q - r * CPR) * 8;
@@ -159,7 +168,14 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const AttnParams 
             const int r = rbase + rr;
             if (q < 128 * CPR) *reinterpret_cast<uint4*>(sE + rr * SM::KROW + x * 2) = mask_chunk(le[n], (r >= 0 && r < erows) ? p.d - x : 0);
         }
+    };
+
+    load_block(0);
+    for (int j0 = 0; j0 < nkeys; j0 += BJ) {
+        __syncthreads();                              // previous block's LDS reads are done
+        store_block(j0);
         __syncthreads();
+        if (j0 + BJ < nkeys) load_block(j0 + BJ);     // in flight during this block's MFMA / softmax work
 
         // ---- S^T tiles: rows = keys (g*4+reg within tile jt), cols = queries (c)
         f32x4 st[4];
@@ -183,7 +199,7 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const AttnParams 
             }
             *reinterpret_cast<f32x4*>(skew + rt * 16 + g * 4) = pe;
         }
-        __syncthreads();                              // skew buffer written (wave-local data; barrier for ordering)
+        wave_sync();                                  // skew buffer is per wave: LDS ops of one wave execute in order
 
         // ---- realign (r' = j_local - i_local + 15), scale, mask, online softmax
         float mloc = -INFINITY;
