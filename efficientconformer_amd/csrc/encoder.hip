@@ -334,8 +334,9 @@ int run_gemm(EcEncoder* e, int cls, hipStream_t st, const bf16_t* A, int lda, in
 }
 
 // x += alpha * FFN(a)  — fused row-stationary kernel when the width allows, else two tiled GEMMs
+// ln != null: the pre-norm is computed inside the fused kernel's prologue (a is not read); the tiled fallback needs `a`
 int run_ffn(EcEncoder* e, hipStream_t st, const bf16_t* a, int M, int D, const PackedLinear& L1, const PackedLinear& L2,
-            const bf16_t* w2p, float* x, bf16_t* hbuf) {
+            const bf16_t* w2p, float* x, bf16_t* hbuf, const LNp* ln = nullptr) {
     const int F = L1.N;
     if (ffn_fused_supported(D)) {
         PROF(PC_GEMM_FFN, 4.0 * M * (double)D * F, (double)M * D * 10 + 4.0 * D * F);
@@ -343,6 +344,7 @@ int run_ffn(EcEncoder* e, hipStream_t st, const bf16_t* a, int M, int D, const P
         p.A = a; p.lda = ld8(D); p.X = x; p.ldx = D; p.Y = x; p.ldy = D;
         p.W1 = L1.w; p.ldw1 = L1.ldw; p.b1 = L1.bias; p.W2 = w2p; p.ldw2 = L2.ldw; p.b2 = L2.bias;
         p.M = M; p.D = D; p.Fp = ec_round_up(F, 32); p.alpha = 0.5f;
+        if (ln) { p.ln_g = ln->g; p.ln_b = ln->b; }
         return launch_ffn_fused(p, st);
     }
     int rc = run_gemm(e, PC_GEMM_FFN, st, a, ld8(D), M, L1, EPI_SWISH_BF16, hbuf, F);
@@ -352,7 +354,8 @@ int run_ffn(EcEncoder* e, hipStream_t st, const bf16_t* a, int M, int D, const P
 
 // row-stationary single GEMM when K <= 384, else the tiled kernel
 int run_rs_or_tiled(EcEncoder* e, int cls, hipStream_t st, const bf16_t* A, int lda, int M, const PackedLinear& L, int rs_epi,
-                    int tiled_epi, void* C, int ldc, const float* R = nullptr, int ldr = 0, float alpha = 1.f) {
+                    int tiled_epi, void* C, int ldc, const float* R = nullptr, int ldr = 0, float alpha = 1.f,
+                    const float* lnX = nullptr, const LNp* ln = nullptr) {
     const bool ok = (rs_epi == 0 || rs_epi == 1) ? rs_gemm_resident_supported(L.K, L.N) : rs_gemm_supported(L.K);
     if (!ok) return run_gemm(e, cls, st, A, lda, M, L, tiled_epi, C, ldc, R, ldr, alpha);
     const double out_b = (tiled_epi == EPI_F32) ? 4.0 : (tiled_epi == EPI_RESID_F32 ? 8.0 : 2.0);
@@ -360,6 +363,7 @@ int run_rs_or_tiled(EcEncoder* e, int cls, hipStream_t st, const bf16_t* A, int 
     GemmParams p{};
     p.A = A; p.lda = lda; p.W = L.w; p.ldw = L.ldw; p.bias = L.bias;
     p.M = M; p.N = L.N; p.K = L.K; p.C = C; p.ldc = ldc; p.R = R; p.ldr = ldr; p.alpha = alpha;
+    if (lnX && ln) { p.X = lnX; p.ldx = L.K; p.ln_g = ln->g; p.ln_b = ln->b; }
     return launch_rs_gemm(p, rs_epi, st);
 }
 
@@ -407,7 +411,8 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
             const int G = b.group_size, H = b.num_heads;
             const int Tp = ec_round_up(T, G), Tg = Tp / G, Tgp = ec_round_up(Tg, 8);
             const int d = G * D / H, dpad = ec_round_up(d, 32);
-            { PROF(PC_LAYERNORM, 0, (double)M * D * 6); EC_TRY(launch_layernorm(x, M, D, W.ln_att.g, W.ln_att.b, nullptr, a, ld8(D), nullptr, nullptr, st)); }
+            const bool ln_fused = rs_gemm_supported(D);      // pre-norm computed in the QKV kernel's prologue
+            if (!ln_fused) { PROF(PC_LAYERNORM, 0, (double)M * D * 6); EC_TRY(launch_layernorm(x, M, D, W.ln_att.g, W.ln_att.b, nullptr, a, ld8(D), nullptr, nullptr, st)); }
             // Q/K/V/E layout: "natural" row-major [B*Tp][D] (16-byte row stores from the GEMM, head split = pointer arithmetic in
             // the attention kernel) whenever the grouped head dim d is even (4-byte aligned head spans); head-major otherwise
             const bool nat = (d % 2) == 0;
@@ -421,6 +426,7 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
             { PROF(PC_GEMM_OTHER, 2.0 * M * 3.0 * D * D, (double)M * D * 2 + 3.0 * D * D * 2 + (double)M * D * 8);
               if (rs_gemm_supported(D)) {
                   if (nat) { p.W = W.qkv_nat.w; p.ldw = W.qkv_nat.ldw; p.bias = W.qkv_nat.bias; }
+                  p.X = x; p.ldx = D; p.ln_g = W.ln_att.g; p.ln_b = W.ln_att.b;
                   EC_TRY(launch_rs_gemm(p, nat ? 4 : 3, st));
               } else {
                   EC_TRY(launch_gemm(p, nat ? EPI_QKV_NAT : EPI_QKV, st));
@@ -453,8 +459,12 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
         }
 
         // ---- x = conv_res(x) + ConvModule(x)   (blocks.py:129; modules.py:511-522)
-        { PROF(PC_LAYERNORM, 0, (double)M * D * 6); EC_TRY(launch_layernorm(x, M, D, W.ln_conv.g, W.ln_conv.b, nullptr, a, ld8(D), nullptr, nullptr, st)); }
-        EC_TRY(run_rs_or_tiled(e, PC_GEMM_OTHER, st, a, ld8(D), M, W.pw1, 2, EPI_GLU_BF16, gbuf, ld8(De)));
+        if (rs_gemm_supported(D)) {
+            EC_TRY(run_rs_or_tiled(e, PC_GEMM_OTHER, st, a, ld8(D), M, W.pw1, 2, EPI_GLU_BF16, gbuf, ld8(De), nullptr, 0, 1.f, x, &W.ln_conv));
+        } else {
+            { PROF(PC_LAYERNORM, 0, (double)M * D * 6); EC_TRY(launch_layernorm(x, M, D, W.ln_conv.g, W.ln_conv.b, nullptr, a, ld8(D), nullptr, nullptr, st)); }
+            EC_TRY(run_rs_or_tiled(e, PC_GEMM_OTHER, st, a, ld8(D), M, W.pw1, 2, EPI_GLU_BF16, gbuf, ld8(De)));
+        }
         { PROF(PC_DWCONV, 2.0 * Mo * (double)De * b.kernel_size, (double)M * De * 2 + (double)Mo * De * 2); EC_TRY(launch_dwconv(gbuf, B, T, To, De, ld8(De), W.dw_w, W.dw_b, b.kernel_size, b.conv_stride, cbuf, st)); }
         snprintf(nm, sizeof(nm), "blocks.%d.dw", k); trace_add(e, st, nm, cbuf, Mo, De, ld8(De), 1);
         if (D != De) {   // 1x1 strided conv on frames 0, s, 2s, ...  (blocks.py:106-110)
@@ -468,8 +478,12 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
         snprintf(nm, sizeof(nm), "blocks.%d.x_conv", k); trace_add(e, st, nm, x, Mo, De, De, 0);
 
         // ---- x += 1/2 FFN2(x); x = LN(x)   (blocks.py:132-135)
-        { PROF(PC_LAYERNORM, 0, (double)Mo * De * 6); EC_TRY(launch_layernorm(x, Mo, De, W.ln_ffn2.g, W.ln_ffn2.b, nullptr, a, ld8(De), nullptr, nullptr, st)); }
-        EC_TRY(run_ffn(e, st, a, Mo, De, W.ffn2_a, W.ffn2_b, W.ffn2_bp, x, hbuf));
+        if (ffn_fused_supported(De)) {
+            EC_TRY(run_ffn(e, st, a, Mo, De, W.ffn2_a, W.ffn2_b, W.ffn2_bp, x, hbuf, &W.ln_ffn2));
+        } else {
+            { PROF(PC_LAYERNORM, 0, (double)Mo * De * 6); EC_TRY(launch_layernorm(x, Mo, De, W.ln_ffn2.g, W.ln_ffn2.b, nullptr, a, ld8(De), nullptr, nullptr, st)); }
+            EC_TRY(run_ffn(e, st, a, Mo, De, W.ffn2_a, W.ffn2_b, W.ffn2_bp, x, hbuf));
+        }
         const bool last = (k == nb - 1);
         float* xo = last ? out : x;
         // block-final norm fused with the next block's FFN1 pre-norm (both read the same rows)

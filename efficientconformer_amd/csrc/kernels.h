@@ -29,6 +29,9 @@ struct GemmParams {
     int T, G, H, D, d, dpad, Tg, Tgp;
     bf16_t *qu, *qv, *kh, *vt;         // [B][H][Tg][dpad] x3, [B][H][dpad][Tgp]
     const float *u, *v;                // [D] content / position bias (attentions.py:474-475)
+    // row-stationary kernels only: if X != null the A operand is LayerNorm(X[m][0..K)) (eps 1e-6, fp32 two-pass statistics)
+    // computed in the prologue from the fp32 residual stream instead of being read from A
+    const float* X; int ldx; const float *ln_g, *ln_b;
 };
 int launch_gemm(const GemmParams& p, int epi, hipStream_t s);
 
@@ -44,6 +47,7 @@ struct FfnParams {
     const bf16_t* W2; int ldw2; const float* b2;
     int M, D, Fp;
     float alpha;
+    const float *ln_g, *ln_b;          // if non-null: a = LayerNorm(X) computed in the prologue (A is ignored)
 };
 // single row-stationary GEMM (K <= 384); epi: 0 residual fp32, 1 fp32, 2 GLU bf16 (N = packed a|b rows), 3 QKV head-major
 // scatter, 4 QKV natural layout (weight rows permuted inside every 32-row chunk, see pack_linear_chunkperm)

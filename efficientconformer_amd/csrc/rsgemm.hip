@@ -69,6 +69,50 @@ __device__ __forceinline__ void dma_w2(const bf16_t* src, int ld, char* img, int
     glds16(src + (size_t)n * ld + pc * 8, img + 64 * j * 16);
 }
 
+// ---- LayerNorm in the prologue: lane (row m, half) owns columns 16s + 8*half + e of its row; row statistics need the
+// partner half-lane only (one xor-32 shuffle).  eps 1e-6, two-pass fp32 (reference modules.py:377, 447, 500).
+template <int KS>
+__device__ __forceinline__ void load_row_layernorm(const float* xrow, int D, bool live, int half, const float* sg, const float* sb,
+                                                   bf16x8 (&xf)[KS]) {
+    float4 ra[KS], rb[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {                      // unconditional clamped loads
+        const int c0 = s * 16 + half * 8;
+        ra[s] = *reinterpret_cast<const float4*>(xrow + (c0 < D - 4 ? c0 : D - 4));
+        rb[s] = *reinterpret_cast<const float4*>(xrow + (c0 + 4 < D - 4 ? c0 + 4 : D - 4));
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int c0 = s * 16 + half * 8;
+        if (c0 >= D) ra[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c0 + 4 >= D) rb[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+        sum += (ra[s].x + ra[s].y) + (ra[s].z + ra[s].w) + (rb[s].x + rb[s].y) + (rb[s].z + rb[s].w);
+    }
+    const float mean = (sum + __shfl_xor(sum, 32)) / (float)D;
+    float var = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int c0 = s * 16 + half * 8;
+        if (c0 < D) { const float a = ra[s].x - mean, b = ra[s].y - mean, c = ra[s].z - mean, d = ra[s].w - mean; var += (a * a + b * b) + (c * c + d * d); }
+        if (c0 + 4 < D) { const float a = rb[s].x - mean, b = rb[s].y - mean, c = rb[s].z - mean, d = rb[s].w - mean; var += (a * a + b * b) + (c * c + d * d); }
+    }
+    const float rstd = rsqrtf((var + __shfl_xor(var, 32)) / (float)D + 1e-6f);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int c0 = s * 16 + half * 8;               // gamma / beta live in LDS, zero padded to KS*16 columns
+        const float4 g0 = *reinterpret_cast<const float4*>(sg + c0), g1 = *reinterpret_cast<const float4*>(sg + c0 + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(sb + c0), b1 = *reinterpret_cast<const float4*>(sb + c0 + 4);
+        const bool va = live && c0 < D, vb = live && c0 + 4 < D;
+        uint4 w;
+        w.x = va ? pack_bf2((ra[s].x - mean) * rstd * g0.x + b0.x, (ra[s].y - mean) * rstd * g0.y + b0.y) : 0u;
+        w.y = va ? pack_bf2((ra[s].z - mean) * rstd * g0.z + b0.z, (ra[s].w - mean) * rstd * g0.w + b0.w) : 0u;
+        w.z = vb ? pack_bf2((rb[s].x - mean) * rstd * g1.x + b1.x, (rb[s].y - mean) * rstd * g1.y + b1.y) : 0u;
+        w.w = vb ? pack_bf2((rb[s].z - mean) * rstd * g1.z + b1.z, (rb[s].w - mean) * rstd * g1.w + b1.w) : 0u;
+        xf[s] = as_bf16x8(w);
+    }
+}
+
 template <int KS, int NT2, int NBUF>
 struct FfnSmem {
     static constexpr int P1 = KS * 2;                      // 16-byte pieces per W1 row
@@ -88,6 +132,8 @@ __global__ __launch_bounds__(NW * 64) void ffn_fused_kernel(const FfnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sb1 = reinterpret_cast<float*>(smem + SM::RING);   // whole first bias in LDS
     float* sb2 = sb1 + p.Fp;                                  // second bias, NT2*32 entries
+    float* sgam = sb2 + NT2 * 32;                             // LayerNorm gamma | beta (KS*16 each, zero padded)
+    float* sbet = sgam + KS * 16;
     constexpr int NTHR = NW * 64;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -110,10 +156,19 @@ __global__ __launch_bounds__(NW * 64) void ffn_fused_kernel(const FfnParams p) {
     // ---- bias -> LDS, this lane's activation row fragments (B operand of GEMM1), then start the weight stream
     for (int i = tid; i < p.Fp; i += NTHR) sb1[i] = p.b1[i];
     for (int i = tid; i < NT2 * 32; i += NTHR) sb2[i] = i < p.D ? p.b2[i] : 0.f;
+    const bool fuse_ln = p.ln_g != nullptr;
+    if (fuse_ln) {
+        for (int i = tid; i < KS * 16; i += NTHR) { sgam[i] = i < p.D ? p.ln_g[i] : 0.f; sbet[i] = i < p.D ? p.ln_b[i] : 0.f; }
+        __syncthreads();
+    }
     bf16x8 xf[RT][KS];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
         const int m = m_base + rt * 32 + lr;
+        if (fuse_ln) {
+            load_row_layernorm<KS>(p.X + (size_t)(m < p.M ? m : p.M - 1) * p.ldx, p.D, m < p.M, half, sgam, sbet, xf[rt]);
+            continue;
+        }
         const bf16_t* arow = p.A + (size_t)(m < p.M ? m : p.M - 1) * p.lda;
         // all loads are issued unconditionally at clamped (in-bounds) addresses and masked afterwards: a guarded load
         // becomes its own basic block with a full vmcnt(0) round trip (8 serialised L2 latencies here before the fix)
@@ -230,7 +285,7 @@ __global__ __launch_bounds__(NW * 64) void ffn_fused_kernel(const FfnParams p) {
 template <int KS, int NT2, int RT, int NW, int NBUF>
 int launch_ffn_t(const FfnParams& p, hipStream_t s) {
     using SM = FfnSmem<KS, NT2, NBUF>;
-    const int lds = SM::RING + p.Fp * 4 + NT2 * 32 * 4;
+    const int lds = SM::RING + p.Fp * 4 + NT2 * 32 * 4 + KS * 32 * 4;
     if (lds > 160 * 1024) return -4;
     static int attr_set = 0;
     if (attr_set < lds) {
@@ -297,6 +352,13 @@ void rs_gemm_kernel(const RsDev gd) {
     };
 
     for (int i = tid; i < nchunks * CH; i += NTHR) sbias[i] = p.bias[i];
+    float* sgam = sbias + nchunks * CH;                       // LayerNorm gamma | beta (KS*16 each, zero padded)
+    float* sbet = sgam + KS * 16;
+    const bool fuse_ln = p.X != nullptr;
+    if (fuse_ln) {
+        for (int i = tid; i < KS * 16; i += NTHR) { sgam[i] = i < p.K ? p.ln_g[i] : 0.f; sbet[i] = i < p.K ? p.ln_b[i] : 0.f; }
+        __syncthreads();
+    }
     bf16x8 xf[RT][KS];
     int rowm[RT];
 #pragma unroll
@@ -304,6 +366,10 @@ void rs_gemm_kernel(const RsDev gd) {
         const int m = m_base + rt * 32 + lr;
         rowm[rt] = m;
         const int mc = m < p.M ? m : p.M - 1;
+        if (fuse_ln) {
+            load_row_layernorm<KS>(p.X + (size_t)mc * p.ldx, p.K, m < p.M, half, sgam, sbet, xf[rt]);
+            continue;
+        }
         size_t src = mc;
         if (p.a_rows > 0) { const int b = mc / p.a_rows, r = mc - b * p.a_rows; src = (size_t)b * p.a_pitch + (size_t)r * p.a_stride; }
         const bf16_t* arow = p.A + src * p.lda;
@@ -528,7 +594,7 @@ void rs_gemm_kernel(const RsDev gd) {
 
 template <int KS, int G, int RT, int NW, int NBUF, int EPI>
 int launch_rs_t(const RsDev& gd, hipStream_t s) {
-    const int lds = NBUF * CH * KS * 32 + gd.nchunks * CH * 4;
+    const int lds = NBUF * CH * KS * 32 + gd.nchunks * CH * 4 + KS * 32 * 4;
     if (lds > 160 * 1024) return -4;
     if ((EPI == RS_RESID || EPI == RS_F32) && gd.nchunks > G) return -5;
     static int attr_set = 0;
