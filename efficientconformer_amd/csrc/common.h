@@ -27,16 +27,11 @@ __device__ __forceinline__ float sigmoidf_(float x) {
 }
 __device__ __forceinline__ float swishf_(float x) { return x * sigmoidf_(x); }
 
-// Zero the bf16 elements with index >= valid (0..8) of a 16-byte chunk of 8 bf16.
+// Zero the bf16 elements with index >= valid of a 16-byte chunk of 8 bf16 (valid may be <= 0 or >= 8).
+// Written without a local array: an indexed temporary made the compiler park whole staging arrays in scratch memory.
+__device__ __forceinline__ uint32_t mask_dw(uint32_t w, int rem) { return rem <= 0 ? 0u : (rem == 1 ? (w & 0xFFFFu) : w); }
 __device__ __forceinline__ uint4 mask_chunk(uint4 v, int valid) {
-    if (valid >= 8) return v;
-    uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int rem = valid - 2 * i;
-        w[i] = rem <= 0 ? 0u : (rem == 1 ? (w[i] & 0xFFFFu) : w[i]);
-    }
-    return make_uint4(w[0], w[1], w[2], w[3]);
+    return make_uint4(mask_dw(v.x, valid), mask_dw(v.y, valid - 2), mask_dw(v.z, valid - 4), mask_dw(v.w, valid - 6));
 }
 
 __device__ __forceinline__ bf16x8 as_bf16x8(uint4 v) {

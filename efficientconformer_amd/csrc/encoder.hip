@@ -55,6 +55,8 @@ struct EcEncoder {
     // packed
     const float *sub_w9 = nullptr, *sub_b = nullptr;
     PackedLinear lin;
+    const bf16_t* lin_fused = nullptr; int lin_fused_ld = 0;   // Linear weight in the fused kernel's K order (sublinear.hip)
+    bool fuse_subsample = true;
     std::vector<BlockW> bw;
     const float *fc_wt = nullptr, *fc_b = nullptr;
     const int* block_stride = nullptr;
@@ -379,11 +381,18 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
     // ---- Conv2dSubsampling (modules.py:232-249) + transpose + Linear (encoders.py:113-116)
     bf16_t* sub = reinterpret_cast<bf16_t*>(ws + w.sub);
     const int C0 = c.sub_filters[0], F2 = c.n_mels / 2, Ksub = C0 * F2;
-    { PROF(PC_SUBCONV, 2.0 * 9 * B * s.T1 * (double)Ksub, (double)B * c.n_mels * s.Tm * 4 + (double)B * s.T1 * Ksub * 2); EC_TRY(launch_subsample_conv(mel, B, c.n_mels, s.Tm, s.T1, e->sub_w9, e->sub_b, C0, sub, Ksub, st)); }
-    trace_add(e, st, "subsample", sub, (int64_t)B * s.T1, Ksub, Ksub, 1);
     float* x = reinterpret_cast<float*>(ws + w.x0);
     float* xalt = reinterpret_cast<float*>(ws + w.x1);
-    EC_TRY(run_gemm(e, PC_GEMM_OTHER, st, sub, Ksub, B * s.T1, e->lin, EPI_F32, x, e->lin.N));
+    if (e->fuse_subsample && e->lin_fused) {
+        PROF(PC_SUBCONV, 2.0 * 9 * B * s.T1 * (double)Ksub + 2.0 * B * s.T1 * (double)Ksub * e->lin.N,
+             (double)B * c.n_mels * s.Tm * 4 + (double)B * s.T1 * e->lin.N * 4);
+        EC_TRY(launch_sublinear_fused(mel, B, c.n_mels, s.Tm, s.T1, e->sub_w9, e->sub_b, C0, e->lin_fused, e->lin_fused_ld,
+                                      e->lin.bias, e->lin.N, x, e->lin.N, st));
+    } else {
+        { PROF(PC_SUBCONV, 2.0 * 9 * B * s.T1 * (double)Ksub, (double)B * c.n_mels * s.Tm * 4 + (double)B * s.T1 * Ksub * 2); EC_TRY(launch_subsample_conv(mel, B, c.n_mels, s.Tm, s.T1, e->sub_w9, e->sub_b, C0, sub, Ksub, st)); }
+        trace_add(e, st, "subsample", sub, (int64_t)B * s.T1, Ksub, Ksub, 1);
+        EC_TRY(run_gemm(e, PC_GEMM_OTHER, st, sub, Ksub, B * s.T1, e->lin, EPI_F32, x, e->lin.N));
+    }
     trace_add(e, st, "linear", x, (int64_t)B * s.T1, e->lin.N, e->lin.N, 0);
 
     bf16_t* a = reinterpret_cast<bf16_t*>(ws + w.a);
@@ -562,6 +571,19 @@ int effconf_encoder_finalize(EcEncoder* e) {
         }
         e->sub_w9 = upload(e, w9); e->sub_b = upload(e, bb);
         if (!pack_named_linear(e, "linear", e->blocks[0].dim_model, C * (c.n_mels / 2), &e->lin, &err)) return fail(err);
+        if (sublinear_fused_supported(c.n_mels, e->blocks[0].dim_model)) {
+            // K' = (fc*Cp + ch)*8 + e  <->  reference feature ch*(F/2) + 8*fc + e   (sublinear.hip)
+            const HostTensor* lw = find(e, "linear.weight");
+            const int N = e->blocks[0].dim_model, F2 = c.n_mels / 2, Cp = ec_round_up(C, 8), Kp = (F2 / 8) * Cp * 8;
+            const int Np = ec_round_up(N, 128);
+            std::vector<uint16_t> wf((size_t)Np * Kp, 0);
+            for (int n = 0; n < N; ++n)
+                for (int fc = 0; fc < F2 / 8; ++fc)
+                    for (int ch = 0; ch < C; ++ch)
+                        for (int ee = 0; ee < 8; ++ee)
+                            wf[(size_t)n * Kp + ((size_t)fc * Cp + ch) * 8 + ee] = h_f2bf(lw->data[(size_t)n * (C * F2) + ch * F2 + fc * 8 + ee]);
+            e->lin_fused = upload(e, wf); e->lin_fused_ld = Kp;
+        }
     }
     std::map<std::pair<int, int>, const bf16_t*> tables;
     std::vector<int> strides;
@@ -728,6 +750,7 @@ int effconf_ctc_greedy(EcEncoder* e, const float* enc_out, const int64_t* out_le
 
 int effconf_encoder_set_option(EcEncoder* e, const char* name, int32_t value) {
     if (!e || !name) return fail("null argument");
+    if (!strcmp(name, "fuse_subsample")) { e->fuse_subsample = value != 0; return 0; }
     if (!strcmp(name, "cache_pos_embeddings")) { e->e_cache_on = value != 0; e->e_cache_ws = nullptr; e->e_cache_tm = -1; return 0; }
     return fail(std::string("unknown option ") + name);
 }

@@ -67,27 +67,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDev gd) {
 #pragma unroll
     for (int i = 0; i < NB; ++i) b_ptr[i] = p.W + (size_t)(n0 + srow + 32 * i) * p.ldw + kc * 8;
 
-    uint4 ra[4], rb[NB];
-    auto load_tile = [&](int kt) {
-        const int k = kt * BK + kc * 8;
-        const int valid = p.K - k;
-        const int kcl = k < p.lda - 8 ? k : p.lda - 8;      // unconditional, clamped (in-bounds) loads; masked below
-#pragma unroll
-        for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const uint4*>(a_ptr[i] + kcl);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) ra[i] = mask_chunk(ra[i], valid);
-#pragma unroll
-        for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const uint4*>(b_ptr[i] + kt * BK);
-    };
-    auto store_tile = [&](int buf) {
-        char* a = sA + buf * BM * LROW;
-        char* b = sB + buf * BN * LROW;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(a + (srow + 32 * i) * LROW + kc * 16) = ra[i];
-#pragma unroll
-        for (int i = 0; i < NB; ++i) *reinterpret_cast<uint4*>(b + (srow + 32 * i) * LROW + kc * 16) = rb[i];
-    };
-
     f32x16 acc[2][NF];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
@@ -97,29 +76,53 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDev gd) {
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
     const int nk = (p.K + BK - 1) / BK;
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
     const int frag_off = (lane & 31) * LROW + (lane >> 5) * 16;
-    for (int kt = 0; kt < nk; ++kt) {
+    // one staging site (iteration -1 is the prologue): global loads of tile kt+1, MFMA on tile kt, then publish tile kt+1.
+    // (staging arrays written inside lambdas end up in scratch memory; keep this inline)
+    for (int kt = -1; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
-        const char* a = sA + buf * BM * LROW + (wm * 64) * LROW + frag_off;
-        const char* b = sB + buf * BN * LROW + (wn * (BN / 2)) * LROW + frag_off;
+        const bool more = kt + 1 < nk;
+        uint4 ra[4], rb[NB];
 #pragma unroll
-        for (int kk = 0; kk < BK / 16; ++kk) {
-            bf16x8 af[2], bf[NF];
+        for (int i = 0; i < 4; ++i) ra[i] = make_uint4(0, 0, 0, 0);
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) af[mi] = *reinterpret_cast<const bf16x8*>(a + mi * 32 * LROW + kk * 32);
+        for (int i = 0; i < NB; ++i) rb[i] = make_uint4(0, 0, 0, 0);
+        if (more) {
+            const int k = (kt + 1) * BK + kc * 8;
+            const int valid = p.K - k;
+            const int kcl = k < p.lda - 8 ? k : p.lda - 8;      // unconditional, clamped (in-bounds) loads; masked below
 #pragma unroll
-            for (int ni = 0; ni < NF; ++ni) bf[ni] = *reinterpret_cast<const bf16x8*>(b + ni * 32 * LROW + kk * 32);
+            for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const uint4*>(a_ptr[i] + kcl);
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const uint4*>(b_ptr[i] + (kt + 1) * BK);
 #pragma unroll
-                for (int ni = 0; ni < NF; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+            for (int i = 0; i < 4; ++i) ra[i] = mask_chunk(ra[i], valid);
         }
-        if (kt + 1 < nk) store_tile(buf ^ 1);
+        if (kt >= 0) {
+            const char* a = sA + buf * BM * LROW + (wm * 64) * LROW + frag_off;
+            const char* b = sB + buf * BN * LROW + (wn * (BN / 2)) * LROW + frag_off;
+#pragma unroll
+            for (int kk = 0; kk < BK / 16; ++kk) {
+                bf16x8 af[2], bf[NF];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) af[mi] = *reinterpret_cast<const bf16x8*>(a + mi * 32 * LROW + kk * 32);
+#pragma unroll
+                for (int ni = 0; ni < NF; ++ni) bf[ni] = *reinterpret_cast<const bf16x8*>(b + ni * 32 * LROW + kk * 32);
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NF; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+            }
+        }
+        if (more) {
+            char* a = sA + (buf ^ 1) * BM * LROW;
+            char* b = sB + (buf ^ 1) * BN * LROW;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(a + (srow + 32 * i) * LROW + kc * 16) = ra[i];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) *reinterpret_cast<uint4*>(b + (srow + 32 * i) * LROW + kc * 16) = rb[i];
+        }
         __syncthreads();
     }
 

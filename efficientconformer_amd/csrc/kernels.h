@@ -91,6 +91,10 @@ int launch_attn_pad_rows_nat(const GemmParams& p, int B, hipStream_t s);   // na
 // mel (B, F, Tm) f32 -> (B*T1, C*F/2) bf16, feature index c*(F/2)+f; 3x3 s2 p1 conv (Cin=1) + folded BN + Swish
 int launch_subsample_conv(const float* mel, int B, int F, int Tm, int T1, const float* w9, const float* bias, int C,
                           bf16_t* out, int ldo, hipStream_t s);
+// fused subsampling conv + Linear (sublinear.hip): mel (B, F, Tm) -> out fp32 (B*T1, N); W packed in (f-chunk, channel, f) K order
+bool sublinear_fused_supported(int F, int N);
+int launch_sublinear_fused(const float* mel, int B, int F, int Tm, int T1, const float* w9, const float* cbias, int C,
+                           const bf16_t* W, int ldw, const float* bias, int N, float* out, int ldc, hipStream_t s);
 // g (B, T, ld) bf16 -> (B, To, ld) bf16: depthwise conv k taps ("same" zero pad), stride s, folded BN, Swish
 int launch_dwconv(const bf16_t* g, int B, int T, int To, int C, int ld, const float* w_kc, const float* bias,
                   int ksize, int stride, bf16_t* out, hipStream_t s);

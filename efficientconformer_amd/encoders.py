@@ -101,6 +101,11 @@ class ConformerEncoder(nn.Module):
     def repack(self):
         self._packed = False
 
+    def set_option(self, name: str, value: int):
+        """Forward a tuning / test option to the C library (see effconf_encoder_set_option)."""
+        self._ensure_packed()
+        _lib.check(_lib.load().effconf_encoder_set_option(self._handle, name.encode(), int(value)), "set_option(%s)" % name)
+
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
         # real torchaudio registers frontend buffers the reference checkpoints may carry; the native frontend
         # builds its own window / filterbank tables, so accept-and-ignore them.
@@ -177,6 +182,8 @@ class ConformerEncoder(nn.Module):
                 self._ws.clear()
             ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
             self._ws[key] = ws
+            # a fresh workspace has no valid positional-embedding cache, even if the allocator reuses an old address
+            _lib.check(_lib.load().effconf_encoder_set_option(self._handle, b"cache_pos_embeddings", 1), "set_option")
         return ws
 
     def _run(self, x: torch.Tensor, x_len: Optional[torch.Tensor], from_audio: bool):

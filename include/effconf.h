@@ -99,7 +99,8 @@ int effconf_ctc_greedy(EcEncoder* enc, const float* enc_out, const int64_t* out_
 
 /* Options.  "cache_pos_embeddings" = 1: the positional projections E = pos_layer(R) (reference attentions.py:588, 678)
  * are input independent; they live in the workspace and are recomputed only when the workspace pointer or the number
- * of frames changes.  Enable ONLY if the caller passes the same workspace and leaves it untouched between forwards. */
+ * of frames changes.  Enable ONLY if the caller passes the same workspace and leaves it untouched between forwards.
+ * "fuse_subsample" (default 1): 0 selects the unfused conv-subsampling + Linear kernels (kept for tests / odd shapes). */
 int effconf_encoder_set_option(EcEncoder* enc, const char* name, int32_t value);
 
 /* ---- per-launch event profiler (bench / tuning only) --------------------------------------- */

@@ -41,9 +41,11 @@ def _rel(got, ref):
     return mx / scale, mean / scale
 
 
+@pytest.mark.parametrize("fuse", [1, 0])
 @pytest.mark.parametrize("tm,lens", [(47, [47, 40, 23]), (100, [100, 77, 52])])
-def test_tiny_every_stage_vs_oracle(tm, lens):
+def test_tiny_every_stage_vs_oracle(tm, lens, fuse):
     m, sd = _model("Tiny", 7)
+    m.encoder.set_option("fuse_subsample", fuse)       # fused conv+Linear kernel / separate conv and GEMM kernels
     plan = m.encoder.plan
     mel, ln = synth.make_mel(3, 80, tm, lens, seed=4321 + tm)
     trace = {}
@@ -54,7 +56,8 @@ def test_tiny_every_stage_vs_oracle(tm, lens):
     b = 3
     worst = {}
     sub_ref = trace["subsample"].transpose(1, 2).reshape(-1, trace["subsample"].shape[1])
-    worst["subsample"] = _rel(got["subsample"], sub_ref)
+    if not fuse:
+        worst["subsample"] = _rel(got["subsample"], sub_ref)
     worst["linear"] = _rel(got["linear"], trace["linear"].reshape(-1, trace["linear"].shape[-1]))
     for k in range(len(plan.blocks)):
         for tag in ("x_ffn1", "x_mhsa", "x_conv", "out"):
