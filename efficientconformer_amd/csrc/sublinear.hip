@@ -168,7 +168,8 @@ int launch_t(const float* mel, int B, int F, int Tm, int T1, const float* w9, co
 
 }  // namespace
 
-bool sublinear_fused_supported(int F, int N) { return F == 80 && N <= 384; }
+// N <= 256: two 128-wide output tiles keep the double-buffered A/B tiles + conv weights inside the 160 KB LDS
+bool sublinear_fused_supported(int F, int N) { return F == 80 && N <= 256; }
 
 // W: packed [round_up(N,128)][ldw] bf16 in K' order (see file header), ldw = 5*Cp*8
 int launch_sublinear_fused(const float* mel, int B, int F, int Tm, int T1, const float* w9, const float* cbias, int C,
@@ -178,6 +179,5 @@ int launch_sublinear_fused(const float* mel, int B, int F, int Tm, int T1, const
     const int Cp = ec_round_up(C, 8);
     if (ldw != 5 * Cp * 8 || ldw % 64) return -2;
     if (N <= 128) return launch_t<1>(mel, B, F, Tm, T1, w9, cbias, C, Cp, W, ldw, bias, N, out, ldc, s);
-    if (N <= 256) return launch_t<2>(mel, B, F, Tm, T1, w9, cbias, C, Cp, W, ldw, bias, N, out, ldc, s);
-    return launch_t<3>(mel, B, F, Tm, T1, w9, cbias, C, Cp, W, ldw, bias, N, out, ldc, s);
+    return launch_t<2>(mel, B, F, Tm, T1, w9, cbias, C, Cp, W, ldw, bias, N, out, ldc, s);
 }
