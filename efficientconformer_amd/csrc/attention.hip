@@ -20,6 +20,7 @@
 //   * group-reshape / head split are index arithmetic (inputs are head-major, output is (B*T, D)).
 // All MFMA are v_mfma_f32_16x16x32_bf16, fp32 accumulation.
 #include "kernels.h"
+#include <cstdlib>
 
 namespace {
 
@@ -41,22 +42,32 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int DP>
+
+template <int DP, int NWV>
 struct AttnSmem {
+    static constexpr int ERING = NWV * 32;           // rows of the rolling relative-position ring (power of two >= BI + BJ - 1)
     static constexpr int KROW = DP * 2 + 16;         // bytes per K / E row
     static constexpr int VROW = BJ * 2 + 16;         // bytes per V^T row
     static constexpr int K_BYTES = BJ * KROW;
     static constexpr int V_BYTES = DP * VROW;
-    static constexpr int E_BYTES = 128 * KROW;
-    static constexpr int S_BYTES = 4 * 16 * SKEW_LD * 4;
+    static constexpr int E_BYTES = ERING * KROW;
+    static constexpr int S_BYTES = NWV * 16 * SKEW_LD * 4;
     static constexpr int TOTAL = K_BYTES + V_BYTES + E_BYTES + S_BYTES;
 };
 
-template <int DP>
-__global__ __launch_bounds__(256) void relpos_attention_kernel(const AttnParams p) {
-    using SM = AttnSmem<DP>;
+// NWV waves = NWV*16 queries per workgroup.  K and V blocks are staged once per 16*NWV queries; the positional band
+// (BI + 63 rows per key block, shifting by 64 rows per block) lives in a ring indexed by the absolute E row, so only the
+// 64 NEW rows are staged per key block.  Staging is software pipelined through registers (loads of block j+1 are in
+// flight during block j's MFMA / softmax work) and all loads are unconditional at clamped addresses.
+template <int DP, int NWV>
+__global__ __launch_bounds__(NWV * 64) void relpos_attention_kernel(const AttnParams p) {
+    using SM = AttnSmem<DP, NWV>;
     constexpr int KS = DP / 32;     // k-steps over the head dim
     constexpr int DT = DP / 16;     // 16-wide output column tiles
+    constexpr int BI = NWV * 16;
+    constexpr int NTHR = NWV * 64;
+    constexpr int CPR = DP / 8;     // 16-byte chunks per row
+    constexpr int ERING = SM::ERING;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sK = smem;
     char* sV = sK + SM::K_BYTES;
@@ -77,6 +88,7 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const AttnParams 
     const bf16_t* Vh = p.vt + qoff;                    // V, same layout as K (transposed at LDS fill)
     const bf16_t* Eh = p.eh + (size_t)h * p.e_hstride;
     const int RS = p.q_rowstride, ERS = p.e_rowstride; // row strides (elements); rows may be only 4-byte aligned (natural layout)
+    const int erows = 2 * p.Tg - 1;
 
     int nkeys = (p.lens[b] + p.G - 1) / p.G;          // unmasked key groups: G*j < lens[b]
     nkeys = nkeys < p.Tg ? nkeys : p.Tg;
@@ -85,7 +97,6 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const AttnParams 
     // ---- this lane's query (column c of the wave's 16): B operands of S^T = K Q^T, kept in registers
     bf16x8 qu[KS], qv[KS];
     {
-        // unconditional loads at clamped rows, masked afterwards (a guarded load costs a serialised vmcnt(0) round trip)
         const int i = iw0 + c;
         const int ic = i < p.Tg ? i : p.Tg - 1;
         uint4 ra[KS], rb[KS];
@@ -102,80 +113,95 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const AttnParams 
             qv[ks] = as_bf16x8(mask_chunk(rb[ks], valid));
         }
     }
+    // ---- first positional band: rows R0 .. R0 + BI + 62 (absolute E rows), staged directly
+    const int R0 = p.Tg - 1 - i0 - (BI - 1);           // E row of band row 0 for key block 0
+    for (int q = tid; q < (BI + 63) * CPR; q += NTHR) {
+        const int rr = q / CPR, x = (q - rr * CPR) * 8;
+        const int r = R0 + rr;
+        const int rc = r < 0 ? 0 : (r >= erows ? erows - 1 : r);
+        const uint4 v = ld16(Eh + (size_t)rc * ERS + x);
+        *reinterpret_cast<uint4*>(sE + ((r + 8192) & (ERING - 1)) * SM::KROW + x * 2) = mask_chunk(v, (r >= 0 && r < erows) ? p.d - x : 0);
+    }
 
     f32x4 acc[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_run = 0.f;
     float* skew = sS + wave * 16 * SKEW_LD + c * SKEW_LD;
-    const int woff = 48 - 16 * wave;                  // first band row of this wave inside the workgroup band
+    const int woff = BI - 16 - 16 * wave;             // first band row of this wave inside the workgroup band
 
-    // ---- K / V / E staging, software pipelined: the global loads of key block j+1 are issued (unconditionally, at clamped
-    // in-bounds rows) right after block j has been written to LDS and are consumed one iteration later
-    constexpr int CPR = DP / 8;                               // 16-byte chunks per row
-    constexpr int NK = (BJ * CPR + 255) / 256, NV = ((BJ / 2) * CPR + 255) / 256, NE = (128 * CPR + 255) / 256;
-    const int erows = 2 * p.Tg - 1;
+    // ---- K / V / new-E staging registers (zero-initialised: conditionally written arrays end up in scratch otherwise)
+    constexpr int NK = (BJ * CPR + NTHR - 1) / NTHR, NV = ((BJ / 2) * CPR + NTHR - 1) / NTHR, NE = (64 * CPR + NTHR - 1) / NTHR;
     uint4 lk[NK], lv0[NV], lv1[NV], le[NE];
-    auto load_block = [&](int j0) __attribute__((always_inline)) {
-        const int rbase = p.Tg - 1 + j0 - i0 - 63;           // E row of band row 0
 #pragma unroll
-        for (int n = 0; n < NK; ++n) {
-            const int q = tid + 256 * n, r = q / CPR, x = (q - r * CPR) * 8;
-            const int j = j0 + r;
-            lk[n] = ld16(Kh + (size_t)(j < p.Tg ? j : p.Tg - 1) * RS + (x < DP ? x : 0));
+    for (int n = 0; n < NK; ++n) lk[n] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int n = 0; n < NV; ++n) { lv0[n] = make_uint4(0, 0, 0, 0); lv1[n] = lv0[n]; }
+#pragma unroll
+    for (int n = 0; n < NE; ++n) le[n] = make_uint4(0, 0, 0, 0);
+
+    for (int j0 = -BJ; j0 < nkeys; j0 += BJ) {        // iteration -BJ is the prologue (loads of block 0 only)
+        const int jn = j0 + BJ;                       // block whose loads are issued in this iteration
+        if (j0 >= 0) {
+            __syncthreads();                          // previous block's LDS reads are done
+            // ---- publish block j0: K rows, transposed V, and (for j0 > 0) the 64 new band rows
+#pragma unroll
+            for (int n = 0; n < NK; ++n) {
+                const int q = tid + NTHR * n, r = q / CPR, x = (q - r * CPR) * 8;
+                if (q < BJ * CPR) *reinterpret_cast<uint4*>(sK + r * SM::KROW + x * 2) = mask_chunk(lk[n], (j0 + r < p.Tg) ? p.d - x : 0);
+            }
+#pragma unroll
+            for (int n = 0; n < NV; ++n) {
+                const int q = tid + NTHR * n, pr = q & (BJ / 2 - 1), x = (q / (BJ / 2)) * 8;
+                const int j = j0 + 2 * pr;
+                if (q < (BJ / 2) * CPR) {
+                    const uint4 v0 = mask_chunk(lv0[n], (j < p.Tg) ? 8 : 0), v1 = mask_chunk(lv1[n], (j + 1 < p.Tg) ? 8 : 0);
+                    const uint32_t a[4] = {v0.x, v0.y, v0.z, v0.w}, bq[4] = {v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const uint32_t lo = (a[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu, hi = (bq[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu;
+                        *reinterpret_cast<uint32_t*>(sV + (x + e) * SM::VROW + pr * 4) = lo | (hi << 16);
+                    }
+                }
+            }
+            if (j0 > 0) {
+                const int rnew = R0 + j0 + BI - 1;    // first new absolute E row of this block
+#pragma unroll
+                for (int n = 0; n < NE; ++n) {
+                    const int q = tid + NTHR * n, rr = q / CPR, x = (q - rr * CPR) * 8;
+                    const int r = rnew + rr;
+                    if (q < 64 * CPR)
+                        *reinterpret_cast<uint4*>(sE + ((r + 8192) & (ERING - 1)) * SM::KROW + x * 2) = mask_chunk(le[n], (r >= 0 && r < erows) ? p.d - x : 0);
+                }
+            }
+            __syncthreads();
         }
+        if (jn < nkeys) {                             // loads of the next block: in flight during this block's compute
 #pragma unroll
-        for (int n = 0; n < NV; ++n) {
-            const int q = tid + 256 * n, pr = q & (BJ / 2 - 1), x = (q / (BJ / 2)) * 8;
-            const int j = j0 + 2 * pr, xc = x < DP ? x : 0;
-            lv0[n] = ld16(Vh + (size_t)(j < p.Tg ? j : p.Tg - 1) * RS + xc);
-            lv1[n] = ld16(Vh + (size_t)(j + 1 < p.Tg ? j + 1 : p.Tg - 1) * RS + xc);
-        }
+            for (int n = 0; n < NK; ++n) {
+                const int q = tid + NTHR * n, r = q / CPR, x = (q - r * CPR) * 8;
+                const int j = jn + r;
+                lk[n] = ld16(Kh + (size_t)(j < p.Tg ? j : p.Tg - 1) * RS + (x < DP ? x : 0));
+            }
 #pragma unroll
-        for (int n = 0; n < NE; ++n) {
-            const int q = tid + 256 * n, rr = q / CPR, x = (q - rr * CPR) * 8;
-            int r = rbase + rr;
-            r = r < 0 ? 0 : (r >= erows ? erows - 1 : r);
-            le[n] = ld16(Eh + (size_t)r * ERS + (x < DP ? x : 0));
-        }
-    };
-    auto store_block = [&](int j0) __attribute__((always_inline)) {
-        const int rbase = p.Tg - 1 + j0 - i0 - 63;
+            for (int n = 0; n < NV; ++n) {
+                const int q = tid + NTHR * n, pr = q & (BJ / 2 - 1), x = (q / (BJ / 2)) * 8;
+                const int j = jn + 2 * pr, xc = x < DP ? x : 0;
+                lv0[n] = ld16(Vh + (size_t)(j < p.Tg ? j : p.Tg - 1) * RS + xc);
+                lv1[n] = ld16(Vh + (size_t)(j + 1 < p.Tg ? j + 1 : p.Tg - 1) * RS + xc);
+            }
+            if (jn > 0) {
+                const int rnew = R0 + jn + BI - 1;
 #pragma unroll
-        for (int n = 0; n < NK; ++n) {
-            const int q = tid + 256 * n, r = q / CPR, x = (q - r * CPR) * 8;
-            if (q < BJ * CPR) *reinterpret_cast<uint4*>(sK + r * SM::KROW + x * 2) = mask_chunk(lk[n], (j0 + r < p.Tg) ? p.d - x : 0);
-        }
-        // V block, transposed into the key-contiguous image sV[x][key]: each thread takes one 8-wide x chunk of a
-        // PAIR of adjacent keys and writes 8 dwords {v[j][x+e], v[j+1][x+e]} (lanes -> consecutive dwords)
-#pragma unroll
-        for (int n = 0; n < NV; ++n) {
-            const int q = tid + 256 * n, pr = q & (BJ / 2 - 1), x = (q / (BJ / 2)) * 8;
-            const int j = j0 + 2 * pr;
-            if (q < (BJ / 2) * CPR) {
-                const uint4 v0 = mask_chunk(lv0[n], (j < p.Tg) ? 8 : 0), v1 = mask_chunk(lv1[n], (j + 1 < p.Tg) ? 8 : 0);
-                const uint32_t a[4] = {v0.x, v0.y, v0.z, v0.w}, bq[4] = {v1.x, v1.y, v1.z, v1.w};
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const uint32_t lo = (a[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu, hi = (bq[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu;
-                    *reinterpret_cast<uint32_t*>(sV + (x + e) * SM::VROW + pr * 4) = lo | (hi << 16);
+                for (int n = 0; n < NE; ++n) {
+                    const int q = tid + NTHR * n, rr = q / CPR, x = (q - rr * CPR) * 8;
+                    int r = rnew + rr;
+                    r = r < 0 ? 0 : (r >= erows ? erows - 1 : r);
+                    le[n] = ld16(Eh + (size_t)r * ERS + (x < DP ? x : 0));
                 }
             }
         }
-#pragma unroll
-        for (int n = 0; n < NE; ++n) {
-            const int q = tid + 256 * n, rr = q / CPR, x = (q - rr * CPR) * 8;
-            const int r = rbase + rr;
-            if (q < 128 * CPR) *reinterpret_cast<uint4*>(sE + rr * SM::KROW + x * 2) = mask_chunk(le[n], (r >= 0 && r < erows) ? p.d - x : 0);
-        }
-    };
-
-    load_block(0);
-    for (int j0 = 0; j0 < nkeys; j0 += BJ) {
-        __syncthreads();                              // previous block's LDS reads are done
-        store_block(j0);
-        __syncthreads();
-        if (j0 + BJ < nkeys) load_block(j0 + BJ);     // in flight during this block's MFMA / softmax work
+        if (j0 < 0) continue;
 
         // ---- S^T tiles: rows = keys (g*4+reg within tile jt), cols = queries (c)
         f32x4 st[4];
@@ -188,13 +214,15 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const AttnParams 
                 st[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qu[ks], st[jt], 0, 0, 0);
             }
         }
-        // ---- positional band: PE^T[r'][i] = E[rbase_w + r'] . Qv[i], r' in [0, 80)
+        // ---- positional band: PE^T[r'][i] = E[rw0 + r'] . Qv[i], r' in [0, 80); rw0 = absolute E row of this wave's band row 0
+        const int rw0 = R0 + j0 + woff + 8192;
 #pragma unroll
         for (int rt = 0; rt < 5; ++rt) {
             f32x4 pe = f32x4{0.f, 0.f, 0.f, 0.f};
+            const char* erow = sE + ((rw0 + rt * 16 + c) & (ERING - 1)) * SM::KROW + g * 16;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(sE + (woff + rt * 16 + c) * SM::KROW + (ks * 32 + g * 8) * 2);
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(erow + ks * 64);
                 pe = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qv[ks], pe, 0, 0, 0);
             }
             *reinterpret_cast<f32x4*>(skew + rt * 16 + g * 4) = pe;
@@ -208,10 +236,10 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const AttnParams 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int jl = jt * 16 + g * 4 + r;
-                float s = (st[jt][r] + skew[jl + 15 - c]) * p.scale;
-                s = (j0 + jl < nkeys) ? s : -INFINITY;
-                st[jt][r] = s;
-                mloc = fmaxf(mloc, s);
+                float sc = (st[jt][r] + skew[jl + 15 - c]) * p.scale;
+                sc = (j0 + jl < nkeys) ? sc : -INFINITY;
+                st[jt][r] = sc;
+                mloc = fmaxf(mloc, sc);
             }
         mloc = fmaxf(mloc, __shfl_xor(mloc, 16));
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
@@ -252,23 +280,40 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const AttnParams 
         }
     }
 
-    // ---- normalise and scatter back to the un-grouped (B*T, D) layout
+    // ---- normalise and scatter back to the un-grouped (B*T, D) layout: 4 consecutive head columns per store when they
+    // stay inside one original frame (8-byte stores), element-wise otherwise
     float l_tot = l_run + __shfl_xor(l_run, 16);
     l_tot += __shfl_xor(l_tot, 32);
     const float inv = 1.0f / l_tot;
     const int i = iw0 + c;
     if (i < p.Tg) {
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
+        for (int dt = 0; dt < DT; ++dt) {
+            const int x0 = dt * 16 + g * 4;
+            if (x0 >= p.d) continue;
+            int n0 = h * p.d + x0, toff = 0;
+            while (n0 >= p.D) { n0 -= p.D; ++toff; }
+            const int t0 = i * p.G + toff;
+            if (x0 + 3 < p.d && n0 + 3 < p.D && (n0 & 1) == 0) {
+                if (t0 < p.T) {
+                    typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+                    u32x2_a4 w;
+                    w[0] = pack_bf2(acc[dt][0] * inv, acc[dt][1] * inv);
+                    w[1] = pack_bf2(acc[dt][2] * inv, acc[dt][3] * inv);
+                    *reinterpret_cast<u32x2_a4*>(p.out + ((size_t)b * p.T + t0) * p.ldo + n0) = w;
+                }
+            } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int x = dt * 16 + g * 4 + r;
-                if (x >= p.d) continue;
-                int n = h * p.d + x, toff = 0;
-                while (n >= p.D) { n -= p.D; ++toff; }
-                const int t = i * p.G + toff;
-                if (t < p.T) p.out[((size_t)b * p.T + t) * p.ldo + n] = f2bf(acc[dt][r] * inv);
+                for (int r = 0; r < 4; ++r) {
+                    const int x = x0 + r;
+                    if (x >= p.d) continue;
+                    int n = h * p.d + x, tf = 0;
+                    while (n >= p.D) { n -= p.D; ++tf; }
+                    const int t = i * p.G + tf;
+                    if (t < p.T) p.out[((size_t)b * p.T + t) * p.ldo + n] = f2bf(acc[dt][r] * inv);
+                }
             }
+        }
     }
 }
 
@@ -303,18 +348,29 @@ __global__ void attn_pad_rows_nat_kernel(GemmParams p, int B) {
     }
 }
 
-template <int DP>
-int launch_dp(const AttnParams& p, hipStream_t s) {
-    using SM = AttnSmem<DP>;
+template <int DP, int NWV>
+int launch_dp_w(const AttnParams& p, hipStream_t s) {
+    using SM = AttnSmem<DP, NWV>;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&relpos_attention_kernel<DP>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&relpos_attention_kernel<DP, NWV>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, SM::TOTAL);
         attr_set = true;
     }
-    const int qtiles = (p.Tg + BI - 1) / BI;
-    hipLaunchKernelGGL((relpos_attention_kernel<DP>), dim3(p.B * p.H * qtiles), dim3(256), SM::TOTAL, s, p);
+    const int qtiles = (p.Tg + NWV * 16 - 1) / (NWV * 16);
+    hipLaunchKernelGGL((relpos_attention_kernel<DP, NWV>), dim3(p.B * p.H * qtiles), dim3(NWV * 64), SM::TOTAL, s, p);
     return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+template <int DP>
+int launch_dp(const AttnParams& p, hipStream_t s) {
+    // 128-query workgroups halve the K / V staging per query; short sequences keep 64-query workgroups
+    static const char* ev = getenv("EFFCONF_ATTN_WAVES");
+    const int force = ev ? atoi(ev) : 0;
+    constexpr bool fits8 = AttnSmem<DP, 8>::TOTAL <= 160 * 1024;
+    if constexpr (fits8)
+        if ((p.Tg > 96 && force != 4) || force == 8) return launch_dp_w<DP, 8>(p, s);
+    return launch_dp_w<DP, 4>(p, s);
 }
 
 }  // namespace
