@@ -151,3 +151,52 @@ def test_other_configs_vs_reference_golden(golden_dir, name, tm):
     mx, mean = _err(out[:, ::8].cpu(), torch.from_numpy(g["out_rows"]))
     print("%s err max %.4f mean %.5f" % (name, mx, mean))
     assert mx < 0.15 and mean < 0.015
+
+
+def test_batch_rows_are_independent_given_the_padded_length():
+    """Size-independent property: utterance b's output depends only on its own row and on the padded
+    length, so running rows alone (same L_pad) must reproduce the batched result bit for bit; this is what makes
+    data-parallel sharding exact."""
+    m, _ = _model("Tiny", 7)
+    lens = np.array([30000, 22000, 9000], dtype=np.int64)
+    audio = torch.from_numpy(synth.make_audio(lens, seed=21)).cuda()
+    ln = torch.from_numpy(lens).cuda()
+    full, full_len, _ = m.encoder(audio, ln)
+    for b in range(3):
+        one, one_len, _ = m.encoder(audio[b:b + 1].contiguous(), ln[b:b + 1].contiguous())
+        assert torch.equal(one[0], full[b]) and int(one_len[0]) == int(full_len[b])
+
+
+def test_single_short_utterance():
+    m, sd = _model("Tiny", 7)
+    lens = np.array([3000], dtype=np.int64)            # 19 mel frames -> 10 -> 5 -> 3 encoder frames
+    audio = torch.from_numpy(synth.make_audio(lens, seed=4))
+    with torch.no_grad():
+        ref, ref_len = R.encoder(audio, torch.from_numpy(lens), sd, m.encoder.plan)
+    out, out_len, _ = m.encoder(audio.cuda(), torch.from_numpy(lens).cuda())
+    assert out.shape == ref.shape and out_len.cpu().tolist() == ref_len.tolist()
+    assert _rel(out.cpu(), ref)[0] < 0.02
+
+
+def test_ctc_collapse_kernel_edge_cases():
+    """effconf_ctc_greedy on hand-made frames: all blanks, repeats with and without separating blanks, length cut-off,
+    ties (first maximum wins, like torch.argmax).  Labels are integers: exact."""
+    cfg = named_config("Tiny")
+    m = ModelCTC.from_config(cfg).cuda()
+    d, v = m.fc.in_features, m.fc.out_features           # 48, 32
+    with torch.no_grad():
+        m.fc.weight.zero_(); m.fc.bias.zero_()
+        for k in range(v):
+            m.fc.weight[k, k] = 1.0                       # logits[k] = x[k]
+    m.encoder.repack(); m.encoder._ensure_packed()
+    seqs = [[0, 0, 0, 0, 0, 0, 0, 0], [5, 5, 0, 5, 7, 7, 7, 0], [3, 3, 3, 3, 3, 3, 3, 3], [1, 2, 1, 2, 0, 0, 9, 9]]
+    lens = [8, 8, 3, 7]
+    x = torch.zeros(4, 8, d)
+    for b, s in enumerate(seqs):
+        for t, k in enumerate(s):
+            x[b, t, k] = 2.0
+    x[2, 1, 4] = 2.0                                       # tie between classes 3 and 4 at (2, 1): class 3 (first) wins
+    logits, labels, label_len = m._head(x.cuda(), torch.tensor(lens).cuda(), want_logits=True)
+    got = [labels[b, :int(label_len[b])].cpu().tolist() for b in range(4)]
+    assert got == [[], [5, 5, 7], [3], [1, 2, 1, 2, 9]]
+    assert got == R.ctc_greedy(logits.cpu(), torch.tensor(lens))
