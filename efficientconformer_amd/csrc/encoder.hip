@@ -617,12 +617,12 @@ int effconf_encoder_finalize(EcEncoder* e) {
             }
             if (!pack_linear(e, rows, bias, D, &W.qkv)) return fail("upload failed");
             // natural-layout variant for the row-stationary kernel: rows permuted inside every chunk of 32 so that a lane's
-            // 16 accumulators are 16 consecutive output columns (chunk row j <-> column 16((j>>2)&1) + 4(j>>3) + (j&3))
+            // accumulators are row-contiguous runs of 8 columns (chunk row j <-> column 16(j>>4) + 8((j>>2)&1) + 4((j>>3)&1) + (j&3))
             const int np = ec_round_up(3 * D, 32);
             std::vector<const float*> prow(np, nullptr); std::vector<float> pbias(np, 0.f);
             for (int n = 0; n < np; ++n) {
                 const int c = n / 32, j = n % 32;
-                const int src = c * 32 + 16 * ((j >> 2) & 1) + 4 * (j >> 3) + (j & 3);
+                const int src = c * 32 + 16 * (j >> 4) + 8 * ((j >> 2) & 1) + 4 * ((j >> 3) & 1) + (j & 3);
                 if (src < 3 * D) { prow[n] = rows[src]; pbias[n] = bias[src]; }
             }
             if (!pack_linear(e, prow, pbias, D, &W.qkv_nat)) return fail("upload failed");

@@ -216,13 +216,22 @@ __global__ __launch_bounds__(NW * 64) void ffn_fused_kernel(const FfnParams p) {
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) h[rt][r] = 0.f;
+        // fragments are fetched in batches of FB before the MFMAs that consume them, so the LDS latency is paid once per
+        // batch instead of once per MFMA pair (matters most at one wave per SIMD)
+        constexpr int FB = KS < 8 ? KS : 8;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            int q = q0 + 2 * s;
-            q -= q >= P1 ? P1 : 0;
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(w1 + q * 16);
+        for (int s0 = 0; s0 < KS; s0 += FB) {
+            bf16x8 wa[FB];
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) h[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xf[rt][s], h[rt], 0, 0, 0);
+            for (int i = 0; i < FB; ++i) {
+                int q = q0 + 2 * (s0 + i);
+                q -= q >= P1 ? P1 : 0;
+                wa[i] = *reinterpret_cast<const bf16x8*>(w1 + q * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < FB; ++i)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) h[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[i], xf[rt][s0 + i], h[rt], 0, 0, 0);
         }
         // ---- bias + Swish, pack to bf16: registers [8s, 8s+8) are the B fragment of k-step s of GEMM2
         bf16x8 hf[RT][2];
@@ -238,15 +247,22 @@ __global__ __launch_bounds__(NW * 64) void ffn_fused_kernel(const FfnParams p) {
             hf[rt][1] = as_bf16x8(make_uint4(w[4], w[5], w[6], w[7]));
         }
         // ---- GEMM2: Y^T[n][m] += sum_j W2p[n][j] H^T[j][m]
+        constexpr int TB = NT2 < 4 ? NT2 : 4;
 #pragma unroll
-        for (int t = 0; t < NT2; ++t) {
-            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(w2 + t * 2048 + w2off0);
-            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(w2 + t * 2048 + w2off1);
+        for (int t0 = 0; t0 < NT2; t0 += TB) {
+            bf16x8 wb[TB][2];
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-                acc[rt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, hf[rt][0], acc[rt][t], 0, 0, 0);
-                acc[rt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, hf[rt][1], acc[rt][t], 0, 0, 0);
+            for (int i = 0; i < TB; ++i) {
+                wb[i][0] = *reinterpret_cast<const bf16x8*>(w2 + (t0 + i) * 2048 + w2off0);
+                wb[i][1] = *reinterpret_cast<const bf16x8*>(w2 + (t0 + i) * 2048 + w2off1);
             }
+#pragma unroll
+            for (int i = 0; i < TB; ++i)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    acc[rt][t0 + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[i][0], hf[rt][0], acc[rt][t0 + i], 0, 0, 0);
+                    acc[rt][t0 + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[i][1], hf[rt][1], acc[rt][t0 + i], 0, 0, 0);
+                }
         }
     }
 
@@ -308,8 +324,9 @@ int launch_ffn_t(const FfnParams& p, hipStream_t s) {
 //              weight rows interleaved per 32 channels: chunk 2i = a, chunk 2i+1 = b)
 //   RS_QKV   : Q+u, Q+v, K, V scattered to head-major [B][H][Tg][dpad] (attentions.py:651-686)   (odd d fallback)
 //   RS_QKV_NAT: Q+u, Q+v, K, V as plain rows [B*Tp][D] with 8-byte row-contiguous stores; the weight rows of every
-//              32-row chunk are permuted at pack time (row j <-> column 16((j>>2)&1) + 4(j>>3) + (j&3)) so that a
-//              lane's 16 accumulators are 16 CONSECUTIVE output columns 32c + 16*half + r
+//              32-row chunk are permuted at pack time (row j <-> column 16(j>>4) + 8((j>>2)&1) + 4((j>>3)&1) + (j&3)) so that
+//              a lane's accumulators r = 0..7 / 8..15 are the columns 32c + 16(r>>3) + 8*half + (r&7): each 16-byte store of a
+//              lane pair fills one 32-byte sector per row (half-filled sectors doubled the HBM write traffic: profiles/r1_06)
 enum { RS_RESID = 0, RS_F32 = 1, RS_GLU = 2, RS_QKV = 3, RS_QKV_NAT = 4 };
 
 struct FastDiv32 {   // exact for n * d < 2^32
@@ -477,7 +494,7 @@ void rs_gemm_kernel(const RsDev gd) {
                     if ((p.D & 7) == 0) {
 #pragma unroll
                         for (int r0 = 0; r0 < 16; r0 += 8) {
-                            const int n0 = (c0 + g) * CH + 16 * half + r0;
+                            const int n0 = (c0 + g) * CH + 16 * (r0 >> 3) + 8 * half;   // lane pair -> one full 32-byte sector per row
                             if (n0 < p.N) {
                                 const int which = gd.fD.div(n0), nn0 = n0 - which * p.D;
                                 float v[8];
@@ -503,7 +520,7 @@ void rs_gemm_kernel(const RsDev gd) {
                     } else {
 #pragma unroll
                         for (int r0 = 0; r0 < 16; r0 += 4) {
-                            const int n0 = (c0 + g) * CH + 16 * half + r0;          // 4 consecutive columns, one `which` (D % 4 == 0)
+                            const int n0 = (c0 + g) * CH + 16 * (r0 >> 3) + 8 * half + (r0 & 7);   // 4 consecutive columns, one `which`
                             if (n0 < p.N) {
                                 const int which = gd.fD.div(n0), nn0 = n0 - which * p.D;
                                 float v[4];
@@ -575,13 +592,20 @@ void rs_gemm_kernel(const RsDev gd) {
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[rt][g][r] = 0.f;
+            constexpr int FB = KS < 8 ? KS : 8;         // fragment batches, see ffn_fused_kernel
 #pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                int q = q0 + 2 * s;
-                q -= q >= P1 ? P1 : 0;
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(w + q * 16);
+            for (int s0 = 0; s0 < KS; s0 += FB) {
+                bf16x8 wa[FB];
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt) acc[rt][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xf[rt][s], acc[rt][g], 0, 0, 0);
+                for (int i = 0; i < FB; ++i) {
+                    int q = q0 + 2 * (s0 + i);
+                    q -= q >= P1 ? P1 : 0;
+                    wa[i] = *reinterpret_cast<const bf16x8*>(w + q * 16);
+                }
+#pragma unroll
+                for (int i = 0; i < FB; ++i)
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) acc[rt][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[i], xf[rt][s0 + i], acc[rt][g], 0, 0, 0);
             }
             }
         }

@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Per-kernel FETCH_SIZE / WRITE_SIZE (KB, as reported by rocprofv3 --pmc) -> text summary for profiles/.
+gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports 1/2 of the bytes of a wide coalesced stream
+(TCC_EA0_RDREQ tallied at 64 B for 128-B requests) -> the 'fetch_x2' column doubles it; WRITE_SIZE is uncalibrated."""
+import sqlite3
+import sys
+from collections import defaultdict
+
+
+def load(db, counter):
+    c = sqlite3.connect(db)
+    agg = defaultdict(lambda: [0, 0.0])
+    for name, val in c.execute("select name, counter_value from pmc_events where counter_name = ?", (counter,)):
+        a = agg[name]
+        a[0] += 1
+        a[1] += val
+    return agg
+
+
+def main():
+    fetch, write, out = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE"), sys.argv[3]
+    note = sys.argv[4] if len(sys.argv) > 4 else ""
+    with open(out, "w") as f:
+        f.write("# rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes), per-dispatch averages in MB\n# %s\n" % note)
+        f.write("%-100s %7s %12s %12s %12s\n" % ("kernel", "calls", "fetch_MB", "fetch_x2_MB", "write_MB"))
+        for name in sorted(fetch, key=lambda k: -fetch[k][1]):
+            n, kb = fetch[name]
+            wn, wkb = write.get(name, [1, 0.0])
+            f.write("%-100s %7d %12.2f %12.2f %12.2f\n" % (name[:100], n, kb / n / 1024, 2 * kb / n / 1024, wkb / max(wn, 1) / 1024))
+    print(open(out).read())
+
+
+if __name__ == "__main__":
+    main()
