@@ -218,7 +218,7 @@ __global__ __launch_bounds__(NW * 64) void ffn_fused_kernel(const FfnParams p) {
             for (int r = 0; r < 16; ++r) h[rt][r] = 0.f;
         // fragments are fetched in batches of FB before the MFMAs that consume them, so the LDS latency is paid once per
         // batch instead of once per MFMA pair (matters most at one wave per SIMD)
-        constexpr int FB = KS < 8 ? KS : 8;
+        constexpr int FB = (KS % 8 == 0) ? 8 : ((KS % 4 == 0) ? 4 : KS);     // must divide KS
 #pragma unroll
         for (int s0 = 0; s0 < KS; s0 += FB) {
             bf16x8 wa[FB];
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(NW * 64) void ffn_fused_kernel(const FfnParams p) {
             hf[rt][1] = as_bf16x8(make_uint4(w[4], w[5], w[6], w[7]));
         }
         // ---- GEMM2: Y^T[n][m] += sum_j W2p[n][j] H^T[j][m]
-        constexpr int TB = NT2 < 4 ? NT2 : 4;
+        constexpr int TB = (NT2 % 4 == 0) ? 4 : ((NT2 % 2 == 0) ? 2 : 1);    // must divide NT2
 #pragma unroll
         for (int t0 = 0; t0 < NT2; t0 += TB) {
             bf16x8 wb[TB][2];
@@ -592,7 +592,7 @@ void rs_gemm_kernel(const RsDev gd) {
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[rt][g][r] = 0.f;
-            constexpr int FB = KS < 8 ? KS : 8;         // fragment batches, see ffn_fused_kernel
+            constexpr int FB = (KS % 8 == 0) ? 8 : ((KS % 4 == 0) ? 4 : KS);   // fragment batches (divisor of KS), see ffn_fused_kernel
 #pragma unroll
             for (int s0 = 0; s0 < KS; s0 += FB) {
                 bf16x8 wa[FB];
