@@ -57,6 +57,8 @@ struct EcEncoder {
     PackedLinear lin;
     const bf16_t* lin_fused = nullptr; int lin_fused_ld = 0;   // Linear weight in the fused kernel's K order (sublinear.hip)
     bool fuse_subsample = true;
+    // two-layer subsampler (plain Conformer configs): layer-2 implicit-GEMM weight [N][9*Cp] (tap, c_in), folded bias, Cp
+    const bf16_t* sub2_w = nullptr; const float* sub2_b = nullptr; int sub2_cp = 0;
     std::vector<BlockW> bw;
     const float *fc_wt = nullptr, *fc_b = nullptr;
     const int* block_stride = nullptr;
@@ -245,7 +247,7 @@ Shapes make_shapes(const EcEncoder* e, int B, int Tm) {
 
 struct Workspace {
     size_t total = 0;
-    size_t mel, sub, x0, x1, a, hbuf, qu, qv, kh, vt, eh, o, gbuf, cbuf, xs, lens, preds;
+    size_t mel, sub, sub1, x0, x1, a, hbuf, qu, qv, kh, vt, eh, o, gbuf, cbuf, xs, lens, preds;
     std::vector<size_t> eh_blk;   // per-block E (kept across forwards for the cache)
 };
 
@@ -277,6 +279,10 @@ Workspace make_workspace(const EcEncoder* e, const Shapes& s, bool from_audio) {
     const int C = e->cfg.sub_filters[e->cfg.sub_layers - 1];
     int F = e->cfg.n_mels; for (int i = 0; i < e->cfg.sub_layers; ++i) F /= 2;
     w.sub = take(B * s.T1 * C * F * 2);
+    {   // two-layer subsampler: channel-last layer-1 activation [B][F/2][T after layer 1][Cp]
+        const size_t tl1 = (s.Tm - 1) / 2 + 1;
+        w.sub1 = take(e->cfg.sub_layers == 2 ? B * (e->cfg.n_mels / 2) * tl1 * ec_round_up(e->cfg.sub_filters[0], 64) * 2 : 0);
+    }
     w.x0 = take(mx); w.x1 = take(mx);
     w.a = take(ma); w.hbuf = take(mh);
     w.qu = take(mq); w.qv = take(mq); w.kh = take(mq); w.vt = take(mvt); w.eh = take(me);
@@ -383,7 +389,16 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
     const int C0 = c.sub_filters[0], F2 = c.n_mels / 2, Ksub = C0 * F2;
     float* x = reinterpret_cast<float*>(ws + w.x0);
     float* xalt = reinterpret_cast<float*>(ws + w.x1);
-    if (e->fuse_subsample && e->lin_fused) {
+    if (c.sub_layers == 2) {
+        const int Tl1 = (s.Tm - 1) / 2 + 1, F1 = c.n_mels / 2, F2q = c.n_mels / 4, C1 = c.sub_filters[1];
+        bf16_t* act1 = reinterpret_cast<bf16_t*>(ws + w.sub1);
+        { PROF(PC_SUBCONV, 2.0 * 9 * B * Tl1 * (double)C0 * F1, (double)B * c.n_mels * s.Tm * 4 + (double)B * Tl1 * F1 * e->sub2_cp * 2);
+          EC_TRY(launch_subsample_conv_cl(mel, B, c.n_mels, s.Tm, Tl1, e->sub_w9, e->sub_b, C0, e->sub2_cp, act1, st)); }
+        { PROF(PC_GEMM_OTHER, 2.0 * 9 * (double)B * F2q * s.T1 * C0 * C1, (double)B * Tl1 * F1 * e->sub2_cp * 2 + (double)B * s.T1 * F2q * C1 * 2);
+          EC_TRY(launch_conv2_igemm(act1, B, F1, Tl1, e->sub2_cp, e->sub2_w, 9 * e->sub2_cp, e->sub2_b, C1, F2q, s.T1, sub, st)); }
+        trace_add(e, st, "subsample", sub, (int64_t)B * s.T1, F2q * C1, F2q * C1, 1);
+        EC_TRY(run_gemm(e, PC_GEMM_OTHER, st, sub, F2q * C1, B * s.T1, e->lin, EPI_F32, x, e->lin.N));
+    } else if (e->fuse_subsample && e->lin_fused) {
         PROF(PC_SUBCONV, 2.0 * 9 * B * s.T1 * (double)Ksub + 2.0 * B * s.T1 * (double)Ksub * e->lin.N,
              (double)B * c.n_mels * s.Tm * 4 + (double)B * s.T1 * e->lin.N * 4);
         EC_TRY(launch_sublinear_fused(mel, B, c.n_mels, s.Tm, s.T1, e->sub_w9, e->sub_b, C0, e->lin_fused, e->lin_fused_ld,
@@ -515,7 +530,8 @@ const char* effconf_last_error(void) { return g_err.c_str(); }
 
 EcEncoder* effconf_encoder_create(const EcConfig* cfg) {
     if (!cfg || cfg->num_blocks <= 0 || !cfg->blocks) { fail("null / empty config"); return nullptr; }
-    if (cfg->sub_layers != 1) { fail("only one Conv2dSubsampling layer is native (Efficient Conformer configs)"); return nullptr; }
+    if (cfg->sub_layers < 1 || cfg->sub_layers > 2) { fail("Conv2dSubsampling with 1 or 2 layers is native"); return nullptr; }
+    if (cfg->sub_layers == 2 && (cfg->sub_filters[0] % 8 || cfg->sub_filters[1] % 8 || cfg->n_mels % 16)) { fail("two-layer subsampler needs filters % 8 == 0, n_mels % 16 == 0"); return nullptr; }
     if (cfg->n_mels % 4 || cfg->n_mels > 128) { fail("n_mels must be a multiple of 4, <= 128"); return nullptr; }
     for (int i = 0; i < cfg->num_blocks; ++i) {
         const EcBlock& b = cfg->blocks[i];
@@ -570,8 +586,40 @@ int effconf_encoder_finalize(EcEncoder* e) {
             bb[ch] = b->data[ch] * sc[ch] + sh[ch];
         }
         e->sub_w9 = upload(e, w9); e->sub_b = upload(e, bb);
-        if (!pack_named_linear(e, "linear", e->blocks[0].dim_model, C * (c.n_mels / 2), &e->lin, &err)) return fail(err);
-        if (sublinear_fused_supported(c.n_mels, e->blocks[0].dim_model)) {
+        if (c.sub_layers == 1) {
+            if (!pack_named_linear(e, "linear", e->blocks[0].dim_model, C * (c.n_mels / 2), &e->lin, &err)) return fail(err);
+        } else {
+            // ---- layer 2: (C1, C, 3, 3) conv + BatchNorm2d fold -> implicit-GEMM weight [C1][9*Cp], K order (tap, c_in)
+            const int C1 = c.sub_filters[1], Cp = ec_round_up(C, 64), F2 = c.n_mels / 4;
+            const HostTensor* w2 = find(e, "subsampling_module.layers.1.0.weight");
+            const HostTensor* b2 = find(e, "subsampling_module.layers.1.0.bias");
+            std::vector<float> sc2, sh2;
+            if (!w2 || !b2 || (int64_t)w2->data.size() != (int64_t)C1 * C * 9) return fail("missing subsampling layer-2 conv weights");
+            if (!bn_fold(e, "subsampling_module.layers.1.1", C1, &sc2, &sh2, &err)) return fail(err);
+            const int Np = ec_round_up(C1, 128);
+            std::vector<uint16_t> wp((size_t)Np * 9 * Cp, 0);
+            std::vector<float> bp(Np, 0.f);
+            for (int n = 0; n < C1; ++n) {
+                for (int ci = 0; ci < C; ++ci)
+                    for (int tap = 0; tap < 9; ++tap)
+                        wp[(size_t)n * 9 * Cp + (size_t)tap * Cp + ci] = h_f2bf(w2->data[((size_t)n * C + ci) * 9 + tap] * sc2[n]);
+                bp[n] = b2->data[n] * sc2[n] + sh2[n];
+            }
+            e->sub2_w = upload(e, wp); e->sub2_b = upload(e, bp); e->sub2_cp = Cp;
+            // ---- Linear with its K axis in (f2, c) order (reference feature index c*F2 + f2, modules.py:247)
+            const HostTensor* lw = find(e, "linear.weight");
+            const HostTensor* lb = find(e, "linear.bias");
+            const int N = e->blocks[0].dim_model, K = C1 * F2;
+            if (!lw || !lb || (int64_t)lw->data.size() != (int64_t)N * K) return fail("missing / mis-shaped linear.weight");
+            std::vector<float> perm((size_t)N * K);
+            for (int n = 0; n < N; ++n)
+                for (int f2 = 0; f2 < F2; ++f2)
+                    for (int ch = 0; ch < C1; ++ch) perm[(size_t)n * K + (size_t)f2 * C1 + ch] = lw->data[(size_t)n * K + (size_t)ch * F2 + f2];
+            std::vector<const float*> rows(N);
+            for (int n = 0; n < N; ++n) rows[n] = perm.data() + (size_t)n * K;
+            if (!pack_linear(e, rows, lb->data, K, &e->lin)) return fail("upload failed");
+        }
+        if (c.sub_layers == 1 && sublinear_fused_supported(c.n_mels, e->blocks[0].dim_model)) {
             // K' = (fc*Cp + ch)*8 + e  <->  reference feature ch*(F/2) + 8*fc + e   (sublinear.hip)
             const HostTensor* lw = find(e, "linear.weight");
             const int N = e->blocks[0].dim_model, F2 = c.n_mels / 2, Cp = ec_round_up(C, 8), Kp = (F2 / 8) * Cp * 8;

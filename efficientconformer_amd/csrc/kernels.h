@@ -95,6 +95,11 @@ int launch_subsample_conv(const float* mel, int B, int F, int Tm, int T1, const 
 bool sublinear_fused_supported(int F, int N);
 int launch_sublinear_fused(const float* mel, int B, int F, int Tm, int T1, const float* w9, const float* cbias, int C,
                            const bf16_t* W, int ldw, const float* bias, int N, float* out, int ldc, hipStream_t s);
+// two-layer subsampling (conv2.hip): layer 1 channel-last, layer 2 implicit GEMM
+int launch_subsample_conv_cl(const float* mel, int B, int F, int Tm, int T1, const float* w9, const float* bias, int C, int Cp,
+                             bf16_t* out, hipStream_t s);
+int launch_conv2_igemm(const bf16_t* act1, int B, int F1, int T1, int Cp, const bf16_t* W, int ldw, const float* bias,
+                       int N, int F2, int T2, bf16_t* out, hipStream_t s);
 // g (B, T, ld) bf16 -> (B, To, ld) bf16: depthwise conv k taps ("same" zero pad), stride s, folded BN, Swish
 int launch_dwconv(const bf16_t* g, int B, int T, int To, int C, int ld, const float* w_kc, const float* bias,
                   int ksize, int stride, bf16_t* out, hipStream_t s);

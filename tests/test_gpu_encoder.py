@@ -141,7 +141,7 @@ def test_audio_entry_and_none_lengths():
 
 
 @pytest.mark.parametrize("name,tm", [("EfficientConformerCTCMedium", 1001), ("EfficientConformerCTCLarge", 1001),
-                                     ("EfficientConformerTransducerMedium", 1001)])
+                                     ("EfficientConformerTransducerMedium", 1001), ("ConformerCTCLarge", 501)])
 def test_other_configs_vs_reference_golden(golden_dir, name, tm):
     g = np.load(os.path.join(golden_dir, name + "_B2.npz"))
     m, sd = _model(name, int(g["weight_seed"]))
