@@ -7,5 +7,6 @@ csrc/.  See DESIGN.md / INTEGRATION.md.
 from .config import build_plan, load_config, named_config  # noqa: F401
 from .encoders import ConformerEncoder  # noqa: F401
 from .model_ctc import ModelCTC  # noqa: F401
+from .transducer import Transducer  # noqa: F401
 
-__all__ = ["ConformerEncoder", "ModelCTC", "build_plan", "load_config", "named_config"]
+__all__ = ["ConformerEncoder", "ModelCTC", "Transducer", "build_plan", "load_config", "named_config"]

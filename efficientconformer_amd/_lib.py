@@ -25,6 +25,11 @@ class EcConfig(C.Structure):
                 ("blocks", C.POINTER(EcBlock)), ("vocab_size", C.c_int32)]
 
 
+class EcRnntConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("dim_encoder", "dim_decoder", "dim_joint", "vocab_size", "num_layers",
+                                            "max_consec_dec_step", "joint_mode", "joint_act")]
+
+
 # name -> (restype, argtypes); the symbol list tests/test_abi.py checks against include/effconf.h
 _P, _I32, _I64P, _F32P, _SZ = C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t
 SIGNATURES = {
@@ -40,6 +45,13 @@ SIGNATURES = {
     "effconf_encoder_forward_mel": (C.c_int, [_P, _F32P, _I64P, _I32, _I32, _F32P, _I64P, _P, _SZ, _P]),
     "effconf_mel_frontend": (C.c_int, [_P, _F32P, _I32, _I32, _F32P, _P]),
     "effconf_ctc_greedy": (C.c_int, [_P, _F32P, _I64P, _I32, _I32, _P, _P, _F32P, _P, _SZ, _P]),
+    "effconf_rnnt_create": (_P, [C.POINTER(EcRnntConfig)]),
+    "effconf_rnnt_destroy": (None, [_P]),
+    "effconf_rnnt_load_tensor": (C.c_int, [_P, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), _I32]),
+    "effconf_rnnt_finalize": (C.c_int, [_P]),
+    "effconf_rnnt_workspace_bytes": (_SZ, [_P, _I32, _I32]),
+    "effconf_rnnt_max_tokens": (_I32, [_P, _I32]),
+    "effconf_rnnt_greedy": (C.c_int, [_P, _F32P, _I64P, _I32, _I32, _P, _P, _I32, _P, _SZ, _P]),
     "effconf_encoder_set_option": (C.c_int, [_P, C.c_char_p, _I32]),
     "effconf_profile_enable": (C.c_int, [_P, _I32]),
     "effconf_profile_read": (C.c_int, [_P, _I32, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),

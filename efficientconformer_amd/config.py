@@ -192,7 +192,12 @@ _NAMED = {
     "ConformerCTCLarge": ("CTC", _plain(512, 8, 18), 256),
     # not a shipped model: small dims for unit tests (exercises grouping, T % G != 0, both transitions)
     "Tiny": ("CTC", dict(_eff([24, 32, 48], 4, 6, [1, 3], 24), max_pos_encoding=2000), 32),
+    "TinyTransducer": ("Transducer", dict(_eff([24, 32, 48], 4, 6, [1, 3], 24), max_pos_encoding=2000), 40),
 }
+
+# decoder_params["dim_model"] == joint_params["dim_model"] of the shipped Transducer configs
+# (reference configs/*Transducer*.json: 640 for Medium / Large, 320 for Small)
+_RNNT_DIM = {"EfficientConformerTransducerMedium": 640, "EfficientConformerTransducerLarge": 640, "TinyTransducer": 32}
 
 
 def named_config(name: str) -> dict:
@@ -200,8 +205,13 @@ def named_config(name: str) -> dict:
     if name not in _NAMED:
         raise KeyError("unknown model %r; known: %s" % (name, sorted(_NAMED)))
     mtype, enc, vocab = _NAMED[name]
-    return {"model_name": name, "model_type": mtype, "encoder_params": copy.deepcopy(enc),
-            "tokenizer_params": {"vocab_type": "bpe", "vocab_size": vocab}}
+    cfg = {"model_name": name, "model_type": mtype, "encoder_params": copy.deepcopy(enc),
+           "tokenizer_params": {"vocab_type": "bpe", "vocab_size": vocab}}
+    if mtype == "Transducer":
+        d = _RNNT_DIM[name]
+        cfg["decoder_params"] = {"arch": "RNN", "num_layers": 1, "dim_model": d, "vocab_size": vocab}
+        cfg["joint_params"] = {"joint_mode": "sum", "dim_model": d, "act": "tanh"}
+    return cfg
 
 
 def load_config(cfg) -> dict:

@@ -46,6 +46,9 @@ struct ProfRec { int cls; double flops, bytes; };
 
 }  // namespace
 
+int ec_fail(const char* msg) { return fail(msg ? msg : "error"); }   // shared with rnnt.hip
+
+
 struct EcEncoder {
     EcConfig cfg;
     std::vector<EcBlock> blocks;

@@ -17,7 +17,7 @@ from typing import List, Tuple
 from .config import EncoderPlan
 
 # kinds: how synth.py initialises, and how the C packer interprets the tensor
-W, B, GAMMA, BETA, RMEAN, RVAR, NBT, UV = "weight", "bias", "gamma", "beta", "running_mean", "running_var", "num_batches_tracked", "uv"
+W, B, GAMMA, BETA, RMEAN, RVAR, NBT, UV, EMB = "weight", "bias", "gamma", "beta", "running_mean", "running_var", "num_batches_tracked", "uv", "embedding"
 
 Spec = Tuple[str, Tuple[int, ...], str]
 
@@ -75,3 +75,16 @@ def param_specs(plan: EncoderPlan) -> List[Spec]:
 def head_specs(plan: EncoderPlan, vocab: int) -> List[Spec]:
     """CTC head ``fc`` (reference model_ctc.py:49)."""
     return _lin("fc", vocab, plan.dim_out)
+
+
+def transducer_specs(dim_encoder: int, decoder_params: dict, joint_params: dict) -> List[Spec]:
+    """Prediction + joint network state_dict (reference decoders.py:46-47 -> ``decoder.embedding`` / ``decoder.rnn``;
+    joint_networks.py:41-52 -> ``joint_network.linear_{encoder,decoder,joint}``), RNN decoder, one layer."""
+    v, h, j = int(decoder_params["vocab_size"]), int(decoder_params["dim_model"]), int(joint_params["dim_model"])
+    out: List[Spec] = [("decoder.embedding.weight", (v, h), EMB)]
+    out += [("decoder.rnn.weight_ih_l0", (4 * h, h), W), ("decoder.rnn.weight_hh_l0", (4 * h, h), W),
+            ("decoder.rnn.bias_ih_l0", (4 * h,), B), ("decoder.rnn.bias_hh_l0", (4 * h,), B)]
+    out += _lin("joint_network.linear_encoder", j, dim_encoder)
+    out += _lin("joint_network.linear_decoder", j, h)
+    out += _lin("joint_network.linear_joint", v, j)
+    return out

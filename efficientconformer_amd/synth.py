@@ -48,6 +48,10 @@ def make_tensor(key: str, shape, kind: str, seed: int) -> np.ndarray:
         return np.zeros(shape, dtype=np.int64)
     if kind == P.UV:
         return (0.1 * g.standard_normal(shape)).astype(np.float32)
+    if kind == P.EMB:                      # nn.Embedding init N(0, 1) with the padding_idx = 0 row zeroed (decoders.py:46)
+        e = g.standard_normal(shape).astype(np.float32)
+        e[0] = 0.0
+        return e
     raise ValueError(kind)
 
 
@@ -59,6 +63,20 @@ def make_state_dict(plan: EncoderPlan, seed: int = 0, vocab: int | None = None, 
     if vocab is not None:
         for key, shape, kind in P.head_specs(plan, vocab):
             sd[key] = make_tensor(key, shape, kind, seed)
+    return sd
+
+
+def make_transducer_state_dict(dim_encoder: int, decoder_params: dict, joint_params: dict, seed: int = 0,
+                               blank_bias: float = 0.0) -> Dict[str, np.ndarray]:
+    """Key-seeded prediction / joint network weights (keys ``decoder.*`` / ``joint_network.*``).
+
+    ``blank_bias`` is added to the blank logit's bias: with purely random weights the blank wins 1/V of the decisions and
+    greedy decoding emits ``max_consec_dec_step`` tokens on every frame (a useful stress case, but not what a trained
+    model does); ~1.2 gives the roughly 1 token per 3-4 encoder frames of a trained LibriSpeech model."""
+    sd = {}
+    for key, shape, kind in P.transducer_specs(dim_encoder, decoder_params, joint_params):
+        sd[key] = make_tensor(key, shape, kind, seed)
+    sd["joint_network.linear_joint.bias"][0] += np.float32(blank_bias)
     return sd
 
 

@@ -63,7 +63,8 @@ void effconf_encoder_destroy(EcEncoder* enc);
 /* Hand over one reference state_dict tensor (HOST fp32, contiguous, reference layout) by its key
  * without the "encoder." prefix, e.g. "blocks.3.feed_forward_module1.layers.1.weight",
  * "subsampling_module.layers.0.1.running_var", "fc.weight" (reference models/model.py:361-384,
- * model_ctc.py:77-88 decide which keys exist).  Unknown keys are rejected (-1). */
+ * model_ctc.py:77-88 decide which keys exist).  Keys the packer does not know are kept and ignored;
+ * effconf_encoder_finalize reports the first REQUIRED key that is missing or mis-shaped. */
 int effconf_encoder_load_tensor(EcEncoder* enc, const char* key, const float* host, const int64_t* shape, int32_t ndim);
 /* Fold BatchNorm(eval) into the convolutions, cast to bf16, pad to MFMA-friendly shapes, build the
  * sinusoid / window / filterbank tables and upload.  Fails (-1) if a required tensor is missing. */
@@ -96,6 +97,40 @@ int effconf_mel_frontend(EcEncoder* enc, const float* audio, int32_t batch, int3
  * logits (dev f32 (batch, T_out, vocab)) may be NULL.  Needs batch*T_out*4 bytes of workspace. */
 int effconf_ctc_greedy(EcEncoder* enc, const float* enc_out, const int64_t* out_len, int32_t batch, int32_t t_out,
                        int32_t* labels, int32_t* label_len, float* logits, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- RNN-T greedy decode (next row after the encoder: BASELINE.json configs[3]) ------------------ */
+/* Replaces Transducer.gready_search_decoding's per-utterance Python loop (reference models/transducer.py:139-186) for
+ * the shipped Transducer configs: RnnDecoder = Embedding + 1-layer LSTM (models/decoders.py:41-70) and
+ * JointNetwork(joint_mode "sum", act "tanh", models/joint_networks.py:35-104).  All arithmetic fp32. */
+typedef struct EcRnntConfig {
+    int32_t dim_encoder;          /* encoder_params["dim_model"][-1]                (transducer.py:76)  */
+    int32_t dim_decoder;          /* decoder_params["dim_model"] (embedding = LSTM hidden, decoders.py:46-47) */
+    int32_t dim_joint;            /* joint_params["dim_model"]                      (joint_networks.py:41) */
+    int32_t vocab_size;           /* decoder_params["vocab_size"]; token 0 = blank / start (transducer.py:151, 167) */
+    int32_t num_layers;           /* decoder_params["num_layers"]: 1 is native                                   */
+    int32_t max_consec_dec_step;  /* decoder_params.get("max_consec_dec_step", 5)  (transducer.py:83)            */
+    int32_t joint_mode;           /* 0 = "sum" (native); "concat" is rejected                                    */
+    int32_t joint_act;            /* 0 = "tanh" (native); others rejected                                        */
+} EcRnntConfig;
+
+typedef struct EcRnnt EcRnnt;
+
+EcRnnt* effconf_rnnt_create(const EcRnntConfig* cfg);
+void effconf_rnnt_destroy(EcRnnt* r);
+/* state_dict tensors (HOST fp32) by reference key: "decoder.embedding.weight", "decoder.rnn.{weight,bias}_{ih,hh}_l0",
+ * "joint_network.linear_{encoder,decoder,joint}.{weight,bias}". */
+int effconf_rnnt_load_tensor(EcRnnt* r, const char* key, const float* host, const int64_t* shape, int32_t ndim);
+/* Builds the per-token LSTM input table Gin[y] = W_ih emb[y] + b_ih + b_hh and the k-major weight images; uploads. */
+int effconf_rnnt_finalize(EcRnnt* r);
+size_t effconf_rnnt_workspace_bytes(const EcRnnt* r, int32_t batch, int32_t t_out);
+/* Upper bound of emitted tokens per utterance: max_consec_dec_step * T_out (transducer.py:167-176). */
+int32_t effconf_rnnt_max_tokens(const EcRnnt* r, int32_t t_out);
+/* enc_out dev f32 (batch, T_out, dim_encoder), out_len dev i64 (batch) -> tokens dev i32 (batch, max_tokens), zero-filled
+ * tails (the leading start token of the reference's `y` is not included: transducer.py:179 decodes y[:, 1:]),
+ * token_len dev i32 (batch). */
+int effconf_rnnt_greedy(EcRnnt* r, const float* enc_out, const int64_t* out_len, int32_t batch, int32_t t_out,
+                        int32_t* tokens, int32_t* token_len, int32_t max_tokens, void* workspace, size_t workspace_bytes,
+                        void* stream);
 
 /* Options.  "cache_pos_embeddings" = 1: the positional projections E = pos_layer(R) (reference attentions.py:588, 678)
  * are input independent; they live in the workspace and are recomputed only when the workspace pointer or the number

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from efficientconformer_amd import ConformerEncoder, ModelCTC, _lib, named_config, params, synth
+from efficientconformer_amd import ConformerEncoder, ModelCTC, Transducer, _lib, named_config, params, synth
 from efficientconformer_amd.config import build_plan
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -100,3 +100,27 @@ def test_synth_is_deterministic_and_libri_shaped():
     assert lens[0] >= lens[-1] and lens.min() >= 24000 and lens.max() <= 256000
     x = synth.make_audio(lens[:4])
     assert x.shape == (4, lens[0]) and np.all(x[3, lens[3]:] == 0) and np.abs(x).max() <= 1.0
+
+
+def test_transducer_state_dict_surface_and_config_checks():
+    """decoder.* / joint_network.* keys as the reference registers them (decoders.py:46-47, joint_networks.py:41-52)."""
+    cfg = named_config("EfficientConformerTransducerMedium")
+    m = Transducer.from_config(cfg)
+    specs = params.transducer_specs(m.encoder.plan.dim_out, cfg["decoder_params"], cfg["joint_params"])
+    sd = m.state_dict()
+    for k, shape, _ in specs:
+        assert tuple(sd[k].shape) == tuple(shape), k
+    assert [k for k in sd if not k.startswith("encoder.")] == [k for k, _, _ in specs]
+    syn = synth.make_transducer_state_dict(m.encoder.plan.dim_out, cfg["decoder_params"], cfg["joint_params"], 0, blank_bias=1.2)
+    assert np.all(syn["decoder.embedding.weight"][0] == 0)
+    with pytest.raises(NotImplementedError):
+        Transducer.from_config(dict(cfg, joint_params={"joint_mode": "concat", "dim_model": 640, "act": "tanh"}))
+    with pytest.raises(NotImplementedError):
+        Transducer.from_config(dict(cfg, decoder_params=dict(cfg["decoder_params"], arch="Transformer")))
+    with pytest.raises(NotImplementedError):
+        m.forward(None)
+    with pytest.raises(RuntimeError):
+        m.decode_encoded(torch.zeros(1, 4, 360), None)          # CPU tensor: no fallback
+    lib = _lib.load()
+    bad = _lib.EcRnntConfig(360, 640, 640, 1000, 2, 5, 0, 0)
+    assert not lib.effconf_rnnt_create(ctypes.byref(bad)) and b"num_layers" in lib.effconf_last_error()

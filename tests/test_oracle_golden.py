@@ -120,3 +120,29 @@ def test_mel_frontend_against_independent_dft():
     # zero-padded tail frames: exactly log(1e-9) once the 400-tap window has left the audio
     short, _ = R.mel_frontend(torch.from_numpy(audio), torch.from_numpy(lens))
     assert np.allclose(short[1, :, 19:24].numpy(), np.log(np.float32(1e-9)), atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["TinyTransducer", "EfficientConformerTransducerMedium"])
+def test_rnnt_greedy_oracle_matches_reference_tokens(golden_dir, name):
+    """oracle/ref_transducer.greedy_decode vs the reference's own Transducer.gready_search_decoding
+    (tools/make_goldens.py: reference_rnnt_greedy) on the reference encoder's outputs: identical token lists,
+    both for purely random joint weights (max_consec_dec_step fires on every frame) and with a boosted blank."""
+    from efficientconformer_amd.config import named_config
+    from oracle import ref_transducer as RT
+    g = np.load(os.path.join(golden_dir, "rnnt_%s.npz" % name))
+    cfg = named_config(name)
+    f, f_len = torch.from_numpy(g["f"]), g["f_len"]
+    if name != "TinyTransducer":          # keep the CPU suite short: first utterance's first 40 frames decide the same way
+        f_len = np.minimum(f_len, 40)
+    for tag in ("rand", "blank"):
+        sd = synth.make_transducer_state_dict(f.shape[-1], cfg["decoder_params"], cfg["joint_params"], int(g["weight_seed"]),
+                                              blank_bias=float(g["blank_bias_" + tag]))
+        toks = RT.greedy_decode(sd, f, f_len, 5)
+        offs = g["offsets_" + tag]
+        for b, t in enumerate(toks):
+            want = g["tokens_" + tag][offs[b]:offs[b + 1]].tolist()
+            if name == "TinyTransducer":
+                assert t == want, (tag, b)
+            else:                          # greedy decoding is causal in the frame index: a prefix of frames gives a prefix of tokens
+                assert t == want[:len(t)], (tag, b)
+                assert tag != "rand" or len(t) == 5 * int(f_len[b]), (tag, b)

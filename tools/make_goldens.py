@@ -51,6 +51,39 @@ def import_reference():
     return enc, att
 
 
+def reference_rnnt_greedy(f, f_len, dec_params, joint_params, sd):
+    """Execute the reference's own Transducer.gready_search_decoding (transducer.py:139-186) on given encoder
+    outputs: a Transducer object is assembled around the reference's RnnDecoder / JointNetwork classes (without
+    Model.__init__: no tokenizer file, optimizer or loss here) and its real method is called."""
+    for n, attrs in (("jiwer", ()), ("kenlm", ()), ("warp_rnnt", ("rnnt_loss",)), ("ctcdecode", ("CTCBeamDecoder",)),
+                     ("torch.utils.tensorboard", ("SummaryWriter",)), ("sentencepiece", ("SentencePieceProcessor", "SentencePieceTrainer"))):
+        if n not in sys.modules or n == "sentencepiece":
+            m = types.ModuleType(n)
+            for a in attrs:
+                setattr(m, a, object)
+            sys.modules.setdefault(n, m)
+    import models.transducer as tr
+    import models.decoders as dec
+    import models.joint_networks as jn
+    obj = tr.Transducer.__new__(tr.Transducer)
+    nn.Module.__init__(obj)
+    obj.decoder = dec.RnnDecoder(dec_params).eval()
+    obj.joint_network = jn.JointNetwork(f.shape[-1], dec_params["dim_model"], dec_params["vocab_size"], joint_params).eval()
+    obj.decoder.load_state_dict(to_torch({k[len("decoder."):]: v for k, v in sd.items() if k.startswith("decoder.")}), strict=True)
+    obj.joint_network.load_state_dict(to_torch({k[len("joint_network."):]: v for k, v in sd.items() if k.startswith("joint_network.")}), strict=True)
+    obj.max_consec_dec_step = dec_params.get("max_consec_dec_step", 5)
+
+    class _Ids:                                   # tokenizer.decode(list of id lists) -> keep the ids
+        @staticmethod
+        def decode(lists):
+            return [list(map(int, l)) for l in lists]
+    obj.tokenizer = _Ids()
+    object.__setattr__(obj, "encoder", lambda x, x_len: (f, f_len, None))
+    obj.eval()
+    with torch.no_grad():
+        return obj.gready_search_decoding(torch.zeros(f.shape[0], 1), f_len)
+
+
 def to_torch(sd):
     return {k: torch.from_numpy(v.copy()) for k, v in sd.items()}
 
@@ -127,10 +160,31 @@ def save(name, **arrays):
     print("wrote %s (%.1f KB)" % (path, os.path.getsize(path) / 1024))
 
 
+def rnnt_goldens(enc_mod):
+    """RNN-T greedy decode (BASELINE.json configs[3]): the reference encoder's own output f -> the reference's greedy
+    token lists, for purely random joint weights (blank almost never wins: the max_consec_dec_step rule fires on every
+    frame) and with a boosted blank bias (trained-model-like token rate)."""
+    for name, tm, lens, seed in (("TinyTransducer", 100, [100, 77, 52, 9], 7), ("EfficientConformerTransducerMedium", 1001, [1001, 640], 0)):
+        cfg = named_config(name)
+        mel, ln = synth.make_mel(len(lens), 80, tm, lens, seed=4321)
+        plan, f, f_len, _, _, _ = run_encoder(enc_mod, name, mel, ln, seed=seed)
+        arrs = {"mel_seed": np.int64(4321), "weight_seed": np.int64(seed), "mel_len": ln, "f": f.numpy(), "f_len": f_len.numpy()}
+        for tag, bb in (("rand", 0.0), ("blank", 1.2)):
+            sd = synth.make_transducer_state_dict(plan.dim_out, cfg["decoder_params"], cfg["joint_params"], seed, blank_bias=bb)
+            toks = reference_rnnt_greedy(f, f_len, cfg["decoder_params"], cfg["joint_params"], sd)
+            flat, offs = pack_labels(toks)
+            arrs["tokens_" + tag], arrs["offsets_" + tag], arrs["blank_bias_" + tag] = flat, offs, np.float32(bb)
+            print("  %s/%s: tokens per utterance %s (frames %s)" % (name, tag, [len(t) for t in toks], f_len.tolist()))
+        save("rnnt_" + name, **arrs)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     enc_mod, att_mod = import_reference()
+    if "--only-rnnt" in sys.argv:
+        return rnnt_goldens(enc_mod)
+    rnnt_goldens(enc_mod)
 
     # ---- 1. tiny config: every module output, two sequence lengths (T1 % 3 == 0 and != 0)
     for tm, lens in ((47, [47, 40, 23]), (100, [100, 77, 52])):
