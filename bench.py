@@ -26,7 +26,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from efficientconformer_amd import ModelCTC, _lib, named_config, synth  # noqa: E402
+from efficientconformer_amd import ModelCTC, Transducer, _lib, named_config, synth  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0     # dense MFMA bf16, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
@@ -47,10 +47,19 @@ def parse():
     return ap.parse_args()
 
 
+RNNT_BLANK_BIAS = 1.2         # synthetic joint bias of the blank: ~1 token per 3 encoder frames (synth.make_transducer_state_dict)
+
+
 def build_model(name):
     cfg = named_config(name)
-    model = ModelCTC.from_config(cfg)
-    sd = synth.make_state_dict(model.encoder.plan, 0, cfg["tokenizer_params"]["vocab_size"], prefix="encoder.")
+    if cfg["model_type"] == "Transducer":
+        model = Transducer.from_config(cfg)
+        sd = synth.make_state_dict(model.encoder.plan, 0, None, prefix="encoder.")
+        sd.update(synth.make_transducer_state_dict(model.encoder.plan.dim_out, cfg["decoder_params"], cfg["joint_params"], 0,
+                                                   blank_bias=RNNT_BLANK_BIAS))
+    else:
+        model = ModelCTC.from_config(cfg)
+        sd = synth.make_state_dict(model.encoder.plan, 0, cfg["tokenizer_params"]["vocab_size"], prefix="encoder.")
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     return cfg, model, sd
 
@@ -65,7 +74,10 @@ def make_batch(args, rank):
 
 def step(model, audio, lens):
     enc, enc_len, _ = model.encoder(audio, lens)
-    _, labels, label_len = model._head(enc, enc_len)
+    if isinstance(model, Transducer):
+        labels, label_len = model.decode_encoded(enc, enc_len)       # RNN-T greedy (transducer.py:139-186)
+    else:
+        _, labels, label_len = model._head(enc, enc_len)             # fc + argmax + CTC collapse (model_ctc.py:90-133)
     return enc, enc_len, labels, label_len
 
 
@@ -79,9 +91,15 @@ def cpu_baseline(sd, plan, audio_np, lens_np, budget_s=12.0):
     frames = int((lens // plan.hop_length + 1).sum())
     threads = torch.get_num_threads()
 
+    rnnt = "decoder.embedding.weight" in sd
+    if rnnt:
+        from oracle import ref_transducer as RT
+
     def run():
         with torch.no_grad():
             x, l = R.encoder(audio, lens, osd, plan)
+            if rnnt:
+                return RT.greedy_decode(osd, x, l, 5)
             return R.ctc_greedy(R.ctc_logits(x, osd), l)
     run()
     t0, n = time.perf_counter(), 0
@@ -92,6 +110,24 @@ def cpu_baseline(sd, plan, audio_np, lens_np, budget_s=12.0):
     return {"value": frames * n / dt, "unit": "mel-frames/s", "cores": threads, "kind": "port",
             "sample": "4 of the %d utterances of rank 0's batch (evenly spaced over the length-sorted batch), %d forward passes "
                       "of the fp32 torch oracle in %.1f s" % (len(lens_np), n, dt)}
+
+
+def pmc_traffic(args, kernel_prefix):
+    """HBM bytes per launch of the dominant kernel class from the committed PMC passes (profiles/pmc_traffic.json, written
+    by tools/pmc_summary.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command).  Counters
+    cannot be read from inside the timed process, so this is only filled when the run matches the profiled configuration."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    d = json.load(open(path))
+    if (d.get("model"), d.get("batch"), d.get("workload")) != (args.model, args.batch, args.workload):
+        return None
+    calls = tot = 0
+    for name, k in d["kernels"].items():
+        if kernel_prefix in name:
+            calls += k["calls"]
+            tot += k["calls"] * (k["fetch_x2_bytes"] + k["write_bytes"])
+    return tot / calls if calls else None
 
 
 def main():
@@ -163,10 +199,11 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "%s: %s, B=%d utterances/GPU, %s lengths, audio in HBM -> encoder out + greedy CTC labels"
+            "config": {"workload": "%s: %s, B=%d utterances/GPU, %s lengths, audio in HBM -> encoder out + greedy %s"
                                    % (args.model, "bf16 operands / fp32 accumulate", args.batch,
                                       "lognormal 1.5-16 s (LibriSpeech-shaped), sorted desc, zero-padded to the batch max"
-                                      if args.workload == "libri" else "10 s"),
+                                      if args.workload == "libri" else "10 s",
+                                      "RNN-T token ids (synthetic blank bias %.1f)" % RNNT_BLANK_BIAS if isinstance(model, Transducer) else "CTC labels"),
                        "global_batch": args.batch * world, "padded_frames_per_s": all_padded * args.steps / elapsed,
                        "parallelism": "dp%d (utterance shards, all-gather of encoder outputs)" % world},
         }
@@ -191,9 +228,21 @@ def main():
         n_l = max(dom["launches_per_step"], 1)
         avg_ms = dom["ms_per_step"] / n_l
         ach = dom["gflop_per_step"] / max(dom["ms_per_step"], 1e-9)          # GFLOP/ms == TFLOP/s
-        result["roofline"] = {"kernel": "gemm_kernel (FFN1/FFN2 launches: LN'd x -> 4D Swish -> D + half-step residual)",
+        if isinstance(model, Transducer):      # decode leg on its own (torch events: it is launched on torch's current stream)
+            enc, enc_len, _ = model.encoder(audio, lens)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(nprof):
+                toks, tok_len = model.decode_encoded(enc, enc_len)
+            e1.record()
+            torch.cuda.synchronize()
+            per["rnnt_greedy"] = {"ms_per_step": e0.elapsed_time(e1) / nprof, "launches_per_step": 2,
+                                  "tokens_per_step": int(tok_len.sum()), "encoder_frames_per_step": int(enc_len.sum())}
+        result["roofline"] = {"kernel": "ffn_fused_kernel / gemm_kernel FFN launches (LN'd x -> 4D Swish -> D + half-step residual)",
                               "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                              "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
+                              "frac": ach / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(args, "ffn_fused_kernel"),
+                              "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/pmc_traffic.json)",
+                              "alg_bytes_per_launch": 1e6 * dom["alg_mb_per_step"] / n_l,
                               "avg_launch_ms": avg_ms, "launches_per_step": n_l,
                               "alg_gflop_per_launch": dom["gflop_per_step"] / n_l,
                               "alg_hbm_gbs": dom["alg_mb_per_step"] / max(dom["ms_per_step"], 1e-9),

@@ -2,6 +2,7 @@
 """Per-kernel FETCH_SIZE / WRITE_SIZE (KB, as reported by rocprofv3 --pmc) -> text summary for profiles/.
 gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports 1/2 of the bytes of a wide coalesced stream
 (TCC_EA0_RDREQ tallied at 64 B for 128-B requests) -> the 'fetch_x2' column doubles it; WRITE_SIZE is uncalibrated."""
+import json
 import sqlite3
 import sys
 from collections import defaultdict
@@ -28,6 +29,12 @@ def main():
             wn, wkb = write.get(name, [1, 0.0])
             f.write("%-100s %7d %12.2f %12.2f %12.2f\n" % (name[:100], n, kb / n / 1024, 2 * kb / n / 1024, wkb / max(wn, 1) / 1024))
     print(open(out).read())
+    if len(sys.argv) > 5:          # machine-readable copy for bench.py's roofline.traffic: argv[5] = json path, argv[6..8] = model batch workload
+        kern = {name: {"calls": fetch[name][0], "fetch_x2_bytes": 2 * 1024 * fetch[name][1] / fetch[name][0],
+                       "write_bytes": 1024 * write.get(name, [1, 0.0])[1] / max(write.get(name, [1, 0.0])[0], 1)} for name in fetch}
+        json.dump({"source": out, "model": sys.argv[6], "batch": int(sys.argv[7]), "workload": sys.argv[8],
+                   "correction": "FETCH_SIZE x2 (gfx950: 128-B read requests tallied as 64 B), WRITE_SIZE as reported; KB -> bytes",
+                   "kernels": kern}, open(sys.argv[5], "w"), indent=1)
 
 
 if __name__ == "__main__":
