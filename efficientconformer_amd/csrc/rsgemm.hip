@@ -25,52 +25,18 @@
 //   blocks.py:122, 132); the 4D-wide hidden activation never exists in memory.
 // rs_gemm_kernel: one GEMM with the QKV-scatter / GLU / residual epilogues (see below).
 #include "kernels.h"
+#include "rowstat.h"
+#include <cstdio>
 #include <cstdlib>
 
 namespace {
 
-constexpr int CH = 32;   // weight rows per LDS chunk (== hidden units per FFN step)
-
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef __attribute__((address_space(1))) const void gbl_void_t;
-
-// one wave-wide LDS-DMA: lane i's 16 bytes at g land at lds_wave_base + 16*i
-__device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((gbl_void_t*)g, (lds_void_t*)lds_wave_base, 16, 0, 0);
-}
-template <int N> __device__ __forceinline__ void wait_vmcnt() {
-    static_assert(N >= 0 && N < 64, "vmcnt immediate is 6 bits");
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-// wait until at most `allowed` chunks (of PER DMA instructions each, issued by this wave) are still in flight
-template <int PER, int MAXC> __device__ __forceinline__ void wait_chunks(int allowed) {
-    if (allowed >= MAXC) wait_vmcnt<PER * MAXC>();
-    else if (MAXC >= 2 && allowed == 1) wait_vmcnt<PER>();
-    else wait_vmcnt<0>();
-}
-__device__ __forceinline__ void wg_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-// Issue the DMA for a [32 rows][P pieces of 16 B] weight chunk (row r at src + r*ld elements).  LDS image: piece pc of row r
-// sits at slot r*P + (pc + r) % P.  Wave-instruction i (32*P/64 per chunk) covers slots [64i, 64i+64).
-template <int P> __device__ __forceinline__ void dma_rows32(const bf16_t* src, int ld, char* img, int i, int lane) {
-    const int L = 64 * i + lane;
-    const int r = L / P, q = L - r * P;
-    int pc = q - (r % P);
-    pc += pc < 0 ? P : 0;
-    glds16(src + (size_t)r * ld + pc * 8, img + 64 * i * 16);
-}
-// FFN second weight chunk: [R rows][4 pieces] (32 hidden units), piece pc of row n at slot n*4 + ((pc + (n>>2)) & 3)
-__device__ __forceinline__ void dma_w2(const bf16_t* src, int ld, char* img, int j, int lane) {
-    const int L = 64 * j + lane;
-    const int n = L >> 2, q = L & 3;
-    const int pc = (q - (n >> 2)) & 3;
-    glds16(src + (size_t)n * ld + pc * 8, img + 64 * j * 16);
-}
-
 // ---- LayerNorm in the prologue: lane (row m, half) owns columns 16s + 8*half + e of its row; row statistics need the
 // partner half-lane only (one xor-32 shuffle).  eps 1e-6, two-pass fp32 (reference modules.py:377, 447, 500).
+template <int KS>
+__device__ __forceinline__ void layernorm_regs(float4 (&ra)[KS], float4 (&rb)[KS], int D, bool live, int half, const float* sg, const float* sb,
+                                               bf16x8 (&xf)[KS]);
+
 template <int KS>
 __device__ __forceinline__ void load_row_layernorm(const float* xrow, int D, bool live, int half, const float* sg, const float* sb,
                                                    bf16x8 (&xf)[KS]) {
@@ -81,6 +47,12 @@ __device__ __forceinline__ void load_row_layernorm(const float* xrow, int D, boo
         ra[s] = *reinterpret_cast<const float4*>(xrow + (c0 < D - 4 ? c0 : D - 4));
         rb[s] = *reinterpret_cast<const float4*>(xrow + (c0 + 4 < D - 4 ? c0 + 4 : D - 4));
     }
+    layernorm_regs<KS>(ra, rb, D, live, half, sg, sb, xf);
+}
+
+template <int KS>
+__device__ __forceinline__ void layernorm_regs(float4 (&ra)[KS], float4 (&rb)[KS], int D, bool live, int half, const float* sg, const float* sb,
+                                               bf16x8 (&xf)[KS]) {
     float sum = 0.f;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
@@ -113,6 +85,54 @@ __device__ __forceinline__ void load_row_layernorm(const float* xrow, int D, boo
     }
 }
 
+
+// y = x + alpha * (acc + b2) on a pair of 64-column windows: x in through the staging region, updated in place, y out
+template <int KS, int NT2, int W>
+__device__ __forceinline__ void ffn_epilogue_window(char* stg, int lr, int half, const float* sb2, float alpha, const f32x16 (&acc)[NT2]) {
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        if (2 * W + tt < NT2) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4* cell = reinterpret_cast<float4*>(stg + lr * STG_ROW + (tt * 32 + q * 8 + half * 4) * 4);
+                const float4 bv = *reinterpret_cast<const float4*>(sb2 + (2 * W + tt) * 32 + q * 8 + half * 4);
+                const float4 x4 = *cell;
+                float4 o;
+                o.x = x4.x + alpha * (acc[2 * W + tt][q * 4 + 0] + bv.x);
+                o.y = x4.y + alpha * (acc[2 * W + tt][q * 4 + 1] + bv.y);
+                o.z = x4.z + alpha * (acc[2 * W + tt][q * 4 + 2] + bv.z);
+                o.w = x4.w + alpha * (acc[2 * W + tt][q * 4 + 3] + bv.w);
+                *cell = o;
+            }
+        }
+    }
+}
+template <int KS, int NT2, int W0>
+__device__ __forceinline__ void ffn_epilogue_pair(const char* xb, char* yb, size_t xpitch, size_t ypitch, int row_bytes, int m_base, int M,
+                                                  char* stg, int lane, const float* sb2, float alpha, const f32x16 (&acc)[NT2]) {
+    constexpr int NWIN = (NT2 + 1) / 2;
+    if constexpr (W0 < NWIN) {
+        u32x4 v[16] = {};
+        stage_load<0>(xb, xpitch, row_bytes, m_base, M, 256 * W0, lane, v);
+        if constexpr (W0 + 1 < NWIN) stage_load<8>(xb, xpitch, row_bytes, m_base, M, 256 * (W0 + 1), lane, v);
+        wave_sync();
+        stage_put<0>(stg, lane, v);
+        wave_sync();
+        ffn_epilogue_window<KS, NT2, W0>(stg, lane & 31, lane >> 5, sb2, alpha, acc);
+        wave_sync();
+        stage_store(stg, yb, ypitch, row_bytes, m_base, M, 256 * W0, lane);
+        if constexpr (W0 + 1 < NWIN) {
+            wave_sync();
+            stage_put<8>(stg, lane, v);
+            wave_sync();
+            ffn_epilogue_window<KS, NT2, W0 + 1>(stg, lane & 31, lane >> 5, sb2, alpha, acc);
+            wave_sync();
+            stage_store(stg, yb, ypitch, row_bytes, m_base, M, 256 * (W0 + 1), lane);
+        }
+        ffn_epilogue_pair<KS, NT2, W0 + 2>(xb, yb, xpitch, ypitch, row_bytes, m_base, M, stg, lane, sb2, alpha, acc);
+    }
+}
+
 template <int KS, int NT2, int NBUF>
 struct FfnSmem {
     static constexpr int P1 = KS * 2;                      // 16-byte pieces per W1 row
@@ -121,10 +141,25 @@ struct FfnSmem {
     static constexpr int BUF = W1_BYTES + W2_BYTES;
     static constexpr int RING = NBUF * BUF;
 };
+// Staging region of the coalesced prologue / epilogue: its own LDS when that fits next to the ring, otherwise it aliases the last
+// ring buffer (free until the first in-loop DMA issue, which follows a workgroup barrier; all ring buffers are free after the loop)
+template <int KS, int NT2, int NW, int NBUF>
+struct FfnStage {
+    using SM = FfnSmem<KS, NT2, NBUF>;
+    static constexpr int BYTES = NW * STG_BYTES;
+    static constexpr int MISC = (KS * 16 * 4 /*Fp*/ + NT2 * 32 + KS * 32) * 4;
+    static constexpr bool ALIAS = SM::RING + BYTES + MISC > 160 * 1024;
+    static_assert(!ALIAS || SM::BUF >= BYTES, "staging region must fit one ring buffer");
+};
 
 // KS: k16-steps over D (D <= 16*KS), NT2 = KS/2: 32-col tiles over D, RT: 32-row tiles per wave, NW: waves, NBUF: ring depth
-template <int KS, int NT2, int RT, int NW, int NBUF>
-__global__ __launch_bounds__(NW * 64) void ffn_fused_kernel(const FfnParams p) {
+// PROF: per-phase s_memtime accounting (tuning only, EFFCONF_FFN_PHASES=1): 0 prologue, 1 chunk wait + barrier, 2 DMA issue,
+// 3 GEMM1, 4 bias + Swish + pack, 5 GEMM2, 6 epilogue, 7 waves
+template <int KS, int NT2, int RT, int NW, int NBUF, bool PROF = false>
+__global__ __launch_bounds__(NW * 64) void ffn_fused_kernel(const FfnParams p, unsigned long long* prof = nullptr) {
+    unsigned long long ph[7] = {0, 0, 0, 0, 0, 0, 0}, t0 = 0;
+    if constexpr (PROF) t0 = __builtin_readcyclecounter();
+#define FFN_TICK(i) do { if constexpr (PROF) { asm volatile("" ::: "memory"); const unsigned long long t1_ = __builtin_readcyclecounter(); ph[i] += t1_ - t0; t0 = t1_; } } while (0)
     using SM = FfnSmem<KS, NT2, NBUF>;
     static_assert(NT2 * 2 == KS && (2 * KS) % NW == 0, "uniform DMA count per wave");
     constexpr int PER = 2 * KS / NW;                       // DMA instructions per wave per chunk
@@ -140,6 +175,9 @@ __global__ __launch_bounds__(NW * 64) void ffn_fused_kernel(const FfnParams p) {
     const int lr = lane & 31, half = lane >> 5;
     const int m_base = (blockIdx.x * NW + wave) * (RT * 32);
     const int nchunks = p.Fp / CH;
+    using ST = FfnStage<KS, NT2, NW, NBUF>;
+    static_assert(RT == 1, "one 32-row tile per wave");
+    char* stg = (ST::ALIAS ? smem + (NBUF - 1) * SM::BUF : reinterpret_cast<char*>(sbet + KS * 16)) + wave * STG_BYTES;
 
     auto issue = [&](int c) {
         char* buf = smem + (c % NBUF) * SM::BUF;
@@ -161,33 +199,23 @@ __global__ __launch_bounds__(NW * 64) void ffn_fused_kernel(const FfnParams p) {
         for (int i = tid; i < KS * 16; i += NTHR) { sgam[i] = i < p.D ? p.ln_g[i] : 0.f; sbet[i] = i < p.D ? p.ln_b[i] : 0.f; }
         __syncthreads();
     }
+#pragma unroll
+    for (int c = 0; c < NBUF - 1; ++c)                     // start the weight stream, then fetch this wave's rows
+        if (c < nchunks) issue(c);
     bf16x8 xf[RT][KS];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-        const int m = m_base + rt * 32 + lr;
+    {
+        const bool live = m_base + lr < p.M;
         if (fuse_ln) {
-            load_row_layernorm<KS>(p.X + (size_t)(m < p.M ? m : p.M - 1) * p.ldx, p.D, m < p.M, half, sgam, sbet, xf[rt]);
-            continue;
-        }
-        const bf16_t* arow = p.A + (size_t)(m < p.M ? m : p.M - 1) * p.lda;
-        // all loads are issued unconditionally at clamped (in-bounds) addresses and masked afterwards: a guarded load
-        // becomes its own basic block with a full vmcnt(0) round trip (8 serialised L2 latencies here before the fix)
-        uint4 raw[KS];
+            float4 ra[KS], rb[KS];
+            fetch_row_f32<KS>(p.X, p.ldx, p.D, m_base, p.M, stg, lane, ra, rb);
+            layernorm_regs<KS>(ra, rb, p.D, live, half, sgam, sbet, xf[0]);
+        } else {
+            uint4 raw[KS];
+            fetch_row_bf16<KS>(p.A, p.lda, m_base, p.M, stg, lane, raw);
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const int c0 = s * 16 + half * 8;
-            raw[s] = *reinterpret_cast<const uint4*>(arow + (c0 < p.lda - 8 ? c0 : p.lda - 8));
-        }
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const int c0 = s * 16 + half * 8;
-            const int valid = (m < p.M) ? p.D - c0 : 0;
-            xf[rt][s] = as_bf16x8(mask_chunk(raw[s], valid));
+            for (int s = 0; s < KS; ++s) xf[0][s] = as_bf16x8(mask_chunk(raw[s], live ? p.D - (s * 16 + half * 8) : 0));
         }
     }
-#pragma unroll
-    for (int c = 0; c < NBUF - 1; ++c)
-        if (c < nchunks) issue(c);
 
     f32x16 acc[RT][NT2];
 #pragma unroll
@@ -196,6 +224,7 @@ __global__ __launch_bounds__(NW * 64) void ffn_fused_kernel(const FfnParams p) {
         for (int t = 0; t < NT2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[rt][t][r] = 0.f;
+    FFN_TICK(0);
 
     // per-lane read offsets: W1 piece (2s + half) of row lr; W2 pieces of rows 32t + lr
     const int q0 = (half + lr) % P1;
@@ -205,7 +234,9 @@ __global__ __launch_bounds__(NW * 64) void ffn_fused_kernel(const FfnParams p) {
     for (int c = 0; c < nchunks; ++c) {
         wait_chunks<PER, NBUF - 2>(nchunks - 1 - c);       // chunk c has landed (this wave's pieces)
         wg_barrier();                                      // ... and everybody's; everybody is done with chunk c-1
+        FFN_TICK(1);
         if (c + NBUF - 1 < nchunks) issue(c + NBUF - 1);   // refill the buffer chunk c-1 used
+        FFN_TICK(2);
         const char* buf = smem + (c % NBUF) * SM::BUF;
         const char* w1 = buf + lr * (P1 * 16);
         const char* w2 = buf + SM::W1_BYTES;
@@ -233,6 +264,8 @@ __global__ __launch_bounds__(NW * 64) void ffn_fused_kernel(const FfnParams p) {
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) h[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[i], xf[rt][s0 + i], h[rt], 0, 0, 0);
         }
+        if constexpr (PROF) { asm volatile("s_nop 0" :: "v"(h[0][0]), "v"(h[0][15])); }   // GEMM1 results retired before the tick
+        FFN_TICK(3);
         // ---- bias + Swish, pack to bf16: registers [8s, 8s+8) are the B fragment of k-step s of GEMM2
         bf16x8 hf[RT][2];
 #pragma unroll
@@ -246,6 +279,8 @@ __global__ __launch_bounds__(NW * 64) void ffn_fused_kernel(const FfnParams p) {
             hf[rt][0] = as_bf16x8(make_uint4(w[0], w[1], w[2], w[3]));
             hf[rt][1] = as_bf16x8(make_uint4(w[4], w[5], w[6], w[7]));
         }
+        if constexpr (PROF) { asm volatile("s_nop 0" :: "v"(hf[0][0]), "v"(hf[0][1])); }
+        FFN_TICK(4);
         // ---- GEMM2: Y^T[n][m] += sum_j W2p[n][j] H^T[j][m]
         constexpr int TB = (NT2 % 4 == 0) ? 4 : ((NT2 % 2 == 0) ? 2 : 1);    // must divide NT2
 #pragma unroll
@@ -264,54 +299,73 @@ __global__ __launch_bounds__(NW * 64) void ffn_fused_kernel(const FfnParams p) {
                     acc[rt][t0 + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[i][1], hf[rt][1], acc[rt][t0 + i], 0, 0, 0);
                 }
         }
+        if constexpr (PROF) { asm volatile("s_nop 0" :: "v"(acc[0][NT2 - 1][0]), "v"(acc[0][0][0])); }
+        FFN_TICK(5);
     }
 
     // ---- epilogue: y[m][n] = x[m][n] + alpha * (acc + b2[n]);  lane owns row m, columns 32t + 8q + 4*half + (0..3).
-    // The residual row is fetched with one batch of unconditional (clamped) loads per row tile, then consumed.
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-        const int m = m_base + rt * 32 + lr;
-        const float* xr = p.X + (size_t)(m < p.M ? m : p.M - 1) * p.ldx;
-        float* yr = p.Y + (size_t)(m < p.M ? m : p.M - 1) * p.ldy;
-        float4 xv[NT2 * 4];
-#pragma unroll
-        for (int t = 0; t < NT2; ++t)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = t * 32 + q * 8 + half * 4;
-                xv[t * 4 + q] = *reinterpret_cast<const float4*>(xr + (n < p.D - 4 ? n : p.D - 4));
-            }
-#pragma unroll
-        for (int t = 0; t < NT2; ++t)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = t * 32 + q * 8 + half * 4;
-                const float4 bv = *reinterpret_cast<const float4*>(sb2 + n);
-                const float4 x4 = xv[t * 4 + q];
-                float4 o;
-                o.x = x4.x + p.alpha * (acc[rt][t][q * 4 + 0] + bv.x);
-                o.y = x4.y + p.alpha * (acc[rt][t][q * 4 + 1] + bv.y);
-                o.z = x4.z + p.alpha * (acc[rt][t][q * 4 + 2] + bv.z);
-                o.w = x4.w + p.alpha * (acc[rt][t][q * 4 + 3] + bv.w);
-                if (n < p.D && m < p.M) *reinterpret_cast<float4*>(yr + n) = o;
-            }
+    // Per 64-column window: the residual tile comes in coalesced through the staging region, every lane updates its own
+    // elements in place, and the tile leaves coalesced.
+    if constexpr (ST::ALIAS) wg_barrier();                 // every wave is done with the ring before it becomes staging memory
+    {
+        constexpr int NWIN = (NT2 + 1) / 2;
+        const char* xb = reinterpret_cast<const char*>(p.X);
+        char* yb = reinterpret_cast<char*>(p.Y);
+        ffn_epilogue_pair<KS, NT2, 0>(xb, yb, (size_t)p.ldx * 4, (size_t)p.ldy * 4, p.D * 4, m_base, p.M, stg, lane, sb2, p.alpha, acc[0]);
+    }
+    if constexpr (PROF) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        FFN_TICK(6);
+        if (lane == 0) {
+            for (int i = 0; i < 7; ++i) atomicAdd(prof + i, ph[i]);
+            atomicAdd(prof + 7, 1ull);
+        }
+    }
+#undef FFN_TICK
+}
+
+unsigned long long* g_ffn_prof = nullptr;     // EFFCONF_FFN_PHASES=1: device counters, dumped at exit
+void ffn_prof_dump() {
+    unsigned long long all[8 * 8];
+    if (!g_ffn_prof || hipMemcpy(all, g_ffn_prof, sizeof(all), hipMemcpyDeviceToHost) != hipSuccess) return;
+    static const char* names[7] = {"prologue", "wait+barrier", "dma_issue", "gemm1", "swish", "gemm2", "epilogue"};
+    for (int c = 0; c < 8; ++c) {
+        const unsigned long long* h = all + 8 * c;
+        if (!h[7]) continue;
+        unsigned long long tot = 0;
+        for (int i = 0; i < 7; ++i) tot += h[i];
+        fprintf(stderr, "[ffn phases] KS=%d: waves %llu, cycles/wave %.0f\n", 4 * c, h[7], (double)tot / h[7]);
+        for (int i = 0; i < 7; ++i) fprintf(stderr, "[ffn phases]   %-13s %10.0f cyc/wave  %5.1f%%\n", names[i], (double)h[i] / h[7], 100.0 * h[i] / tot);
     }
 }
 
 template <int KS, int NT2, int RT, int NW, int NBUF>
 int launch_ffn_t(const FfnParams& p, hipStream_t s) {
     using SM = FfnSmem<KS, NT2, NBUF>;
-    const int lds = SM::RING + p.Fp * 4 + NT2 * 32 * 4 + KS * 32 * 4;
+    using ST = FfnStage<KS, NT2, NW, NBUF>;
+    const int lds = SM::RING + p.Fp * 4 + NT2 * 32 * 4 + KS * 32 * 4 + (ST::ALIAS ? 0 : ST::BYTES);
     if (lds > 160 * 1024) return -4;
     static int attr_set = 0;
     if (attr_set < lds) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_fused_kernel<KS, NT2, RT, NW, NBUF>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_fused_kernel<KS, NT2, RT, NW, NBUF, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_fused_kernel<KS, NT2, RT, NW, NBUF, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = lds;
     }
     const int rows_per_wg = NW * RT * 32;
-    hipLaunchKernelGGL((ffn_fused_kernel<KS, NT2, RT, NW, NBUF>), dim3((p.M + rows_per_wg - 1) / rows_per_wg), dim3(NW * 64),
-                       lds, s, p);
+    static const bool prof = getenv("EFFCONF_FFN_PHASES") != nullptr;
+    if (prof) {
+        if (!g_ffn_prof) {
+            if (hipMalloc(&g_ffn_prof, 512) != hipSuccess || hipMemset(g_ffn_prof, 0, 512) != hipSuccess) return -1;
+            atexit(ffn_prof_dump);
+        }
+        hipLaunchKernelGGL((ffn_fused_kernel<KS, NT2, RT, NW, NBUF, true>), dim3((p.M + rows_per_wg - 1) / rows_per_wg),
+                           dim3(NW * 64), lds, s, p, g_ffn_prof + 8 * ((KS / 4) & 7));
+        return hipGetLastError() == hipSuccess ? 0 : -1;
+    }
+    hipLaunchKernelGGL((ffn_fused_kernel<KS, NT2, RT, NW, NBUF, false>), dim3((p.M + rows_per_wg - 1) / rows_per_wg), dim3(NW * 64),
+                       lds, s, p, nullptr);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -329,12 +383,6 @@ int launch_ffn_t(const FfnParams& p, hipStream_t s) {
 //              lane pair fills one 32-byte sector per row (half-filled sectors doubled the HBM write traffic: profiles/r1_06)
 enum { RS_RESID = 0, RS_F32 = 1, RS_GLU = 2, RS_QKV = 3, RS_QKV_NAT = 4 };
 
-struct FastDiv32 {   // exact for n * d < 2^32
-    uint32_t mul, d;
-    __host__ __device__ FastDiv32() : mul(0), d(1) {}
-    __host__ explicit FastDiv32(uint32_t dd) : mul(dd > 1 ? (uint32_t)((1ull << 32) / dd + 1) : 0), d(dd) {}
-    __device__ __forceinline__ uint32_t div(uint32_t n) const { return d == 1 ? n : __umulhi(n, mul); }
-};
 struct RsDev { GemmParams p; int nchunks; FastDiv32 fD, fd; };
 
 // G = output tiles (32 columns each) accumulated in registers before they are flushed.  Flushes of the QKV / GLU
@@ -681,21 +729,13 @@ int launch_ffn_fused(const FfnParams& p, hipStream_t s) {
     if (ks <= 8) {
         if (var == 1) return launch_ffn_t<8, 4, 1, 4, 3>(p, s);      // 128 rows, 3 workgroups per CU
         if (var == 2) return launch_ffn_t<8, 4, 1, 4, 4>(p, s);
-        if (var == 3) return launch_ffn_t<8, 4, 2, 8, 4>(p, s);      // 512 rows
         return launch_ffn_t<8, 4, 1, 8, 4>(p, s);
     }
     if (ks <= 12) {
         if (var == 1) return launch_ffn_t<12, 6, 1, 4, 4>(p, s);
-        if (var == 2) return launch_ffn_t<12, 6, 2, 4, 4>(p, s);
-        if (var == 3) return launch_ffn_t<12, 6, 1, 8, 3>(p, s);
-        return launch_ffn_t<12, 6, 1, 8, 4>(p, s);                   // 2 waves per SIMD, 256 rows: 48 vs 67 us (profiles/r1_04)
+        return launch_ffn_t<12, 6, 1, 8, 3>(p, s);                   // 2 waves per SIMD, 256 rows; ring of 3 leaves room for the staging region
     }
-    if (ks <= 16) {
-        if (var == 1) return launch_ffn_t<16, 8, 1, 8, 4>(p, s);
-        if (var == 2) return launch_ffn_t<16, 8, 2, 4, 4>(p, s);
-        if (var == 3) return launch_ffn_t<16, 8, 1, 8, 3>(p, s);
-        return launch_ffn_t<16, 8, 1, 4, 4>(p, s);
-    }
+    if (ks <= 16) return launch_ffn_t<16, 8, 1, 4, 3>(p, s);
     if (ks <= 20) return launch_ffn_t<20, 10, 1, 4, 3>(p, s);
     return launch_ffn_t<24, 12, 1, 4, 3>(p, s);
 }
