@@ -1,0 +1,569 @@
+// Fused row-local chains of the Conformer block (gfx950).
+//
+// Between the two operations of a Conformer block that mix frames (attention and the depthwise convolution) everything is
+// row-local: for one frame, the attention output projection + residual, the conv-module LayerNorm, pointwise-1 + GLU
+// (reference models/attentions.py:716, blocks.py:125-129, modules.py:511-514) — "chain B" — and, across the block boundary,
+// pointwise-2 + residual, FFN2 with its pre-norm and half-step residual, the block's final LayerNorm, then the NEXT block's
+// FFN1 (pre-norm, half-step residual), the attention pre-norm and the stacked Q/K/V projection (modules.py:519-522,
+// 385-392; blocks.py:129-137, 119-126; attentions.py:651-686) — "chain A".  As separate kernels every step re-reads and
+// re-writes the fp32 residual row (4D bytes each way) in an HBM burst that no compute overlaps: the s_memtime phase profile
+// of the FFN kernel shows the load/store phases, not the MFMA loop, as ~2/3 of a wave's life (profiles/r1_09_*).
+//
+// Here a wave keeps its 32 residual rows in registers, in the MFMA C layout of the row-stationary scheme (rsgemm.hip):
+//     xc[t][r]  <->  row (lane & 31), column 32t + (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+// and walks the whole chain on them:
+//   * a residual GEMM accumulates straight into xc (the accumulator is initialised with xc + bias; the FFN's 1/2 is folded
+//     into its second weight and bias at pack time, exact in bf16);
+//   * LayerNorm needs the partner half-lane only (one xor-32 shuffle per statistic);
+//   * registers [8j, 8j+8) of tile t, rounded to bf16, ARE the B fragment of k-step 2t+j of the next GEMM, provided that GEMM's
+//     weight has its K index permuted within every group of 16 (position 8h+e <-> column 4h + 8(e>>2) + (e&3)) — done once at
+//     pack time for every weight of a chain, so no data ever moves between lanes;
+//   * all weights of the chain stream through ONE LDS-DMA ring as uniform chunks (a 64-row slab of a D-wide weight, or 32
+//     hidden units' W1 rows + W2 columns of an FFN: both 2*KS KiB and 2*KS wave-DMAs), so the counted-vmcnt protocol of
+//     rsgemm.hip carries over unchanged across stage boundaries;
+//   * global memory is touched once per tensor, through the coalesced staging of rowstat.h: x in, A (bf16) in, x out, and the
+//     bf16 products (Q+u, Q+v, K, V rows, or the GLU output) out.
+// HBM bytes per row: chain A 4D (x) + 2D (A) in, 4D (x) + 8D (Q+u, Q+v, K, V) out; chain B 6D in, 4D + 2D out — against
+// ~74D for the unfused block.
+#include "kernels.h"
+#include "rowstat.h"
+
+#include <cstdlib>
+
+namespace {
+
+template <int KS>
+struct Geo {
+    static_assert(KS % 2 == 0, "two k-steps per 32-column tile");
+    static constexpr int NT = KS / 2;               // 32-column tiles of the residual row
+    static constexpr int DP = 32 * NT;              // padded width
+    static constexpr int P1 = KS * 2;               // 16-byte pieces per weight row
+    static constexpr int HALF = CH * P1 * 16;       // one 32-row slab (= one FFN W2 slab): KS KiB
+    static constexpr int BUF = 2 * HALF;
+};
+
+struct ChainDev {
+    ChainParams p;
+    FastDiv32 fT, fD;
+    int nf[8];            // float offsets of the LDS constant arrays (see launch)
+};
+
+// ---- C-layout helpers -----------------------------------------------------------------------------------------------------
+template <int NT>
+__device__ __forceinline__ void add_cvec(f32x16 (&xc)[NT], const float* sv, int half) {    // xc[t][r] += sv[column]
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(sv + 32 * t + 8 * q + 4 * half);
+            xc[t][4 * q + 0] += v.x; xc[t][4 * q + 1] += v.y; xc[t][4 * q + 2] += v.z; xc[t][4 * q + 3] += v.w;
+        }
+}
+// two-pass statistics over the D valid columns (pad columns hold exact zeros); eps 1e-6 (reference modules.py:377, 447; blocks.py:97)
+template <int NT>
+__device__ __forceinline__ void ln_stats(const f32x16 (&xc)[NT], int D, float& mean, float& rstd) {
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; r += 4) sum += (xc[t][r] + xc[t][r + 1]) + (xc[t][r + 2] + xc[t][r + 3]);
+    mean = (sum + __shfl_xor(sum, 32)) / (float)D;
+    float var = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; r += 4) {
+            const float a = xc[t][r] - mean, b = xc[t][r + 1] - mean, c = xc[t][r + 2] - mean, d = xc[t][r + 3] - mean;
+            var += (a * a + b * b) + (c * c + d * d);
+        }
+    var += __shfl_xor(var, 32);
+    var -= (float)(32 * NT - D) * mean * mean;           // the zero pad columns contributed (0 - mean)^2 each
+    rstd = rsqrtf(fmaxf(var, 0.f) / (float)D + 1e-6f);
+}
+// xf = bf16(LayerNorm(xc)) as the K-permuted B fragments of the next GEMM; gamma / beta zero padded (pad columns -> 0)
+template <int KS>
+__device__ __forceinline__ void ln_frags(const f32x16 (&xc)[KS / 2], float mean, float rstd, const float* sg, const float* sb, int half,
+                                         bf16x8 (&xf)[KS]) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        uint32_t w[4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = 32 * (s >> 1) + 8 * (2 * (s & 1) + j) + 4 * half;
+            const float4 g = *reinterpret_cast<const float4*>(sg + col), b = *reinterpret_cast<const float4*>(sb + col);
+            const int r = 8 * (s & 1) + 4 * j;
+            w[2 * j + 0] = pack_bf2((xc[s >> 1][r + 0] - mean) * rstd * g.x + b.x, (xc[s >> 1][r + 1] - mean) * rstd * g.y + b.y);
+            w[2 * j + 1] = pack_bf2((xc[s >> 1][r + 2] - mean) * rstd * g.z + b.z, (xc[s >> 1][r + 3] - mean) * rstd * g.w + b.w);
+        }
+        xf[s] = as_bf16x8(make_uint4(w[0], w[1], w[2], w[3]));
+    }
+}
+template <int NT>
+__device__ __forceinline__ void ln_inplace(f32x16 (&xc)[NT], float mean, float rstd, const float* sg, const float* sb, int half) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 g = *reinterpret_cast<const float4*>(sg + 32 * t + 8 * q + 4 * half), b = *reinterpret_cast<const float4*>(sb + 32 * t + 8 * q + 4 * half);
+            xc[t][4 * q + 0] = (xc[t][4 * q + 0] - mean) * rstd * g.x + b.x;
+            xc[t][4 * q + 1] = (xc[t][4 * q + 1] - mean) * rstd * g.y + b.y;
+            xc[t][4 * q + 2] = (xc[t][4 * q + 2] - mean) * rstd * g.z + b.z;
+            xc[t][4 * q + 3] = (xc[t][4 * q + 3] - mean) * rstd * g.w + b.w;
+        }
+}
+
+// ---- global <-> registers through the staging region ----------------------------------------------------------------------
+// residual rows -> xc (pairs of 64-column windows; pad columns zeroed)
+template <int NT, int W0>
+__device__ __forceinline__ void load_x(const char* xb, size_t pitch, int D, int m_base, int M, char* stg, int lane, f32x16 (&xc)[NT]) {
+    constexpr int NWIN = (NT + 1) / 2;
+    if constexpr (W0 < NWIN) {
+        const int lr = lane & 31, half = lane >> 5;
+        u32x4 v[16] = {};
+        stage_load<0>(xb, pitch, D * 4, m_base, M, 256 * W0, lane, v);
+        if constexpr (W0 + 1 < NWIN) stage_load<8>(xb, pitch, D * 4, m_base, M, 256 * (W0 + 1), lane, v);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (W0 + k < NWIN) {
+                wave_sync();
+                if (k == 0) stage_put<0>(stg, lane, v);
+                else stage_put<8>(stg, lane, v);
+                wave_sync();
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    const int t = 2 * (W0 + k) + tt;
+                    if (t < NT) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int col = 32 * t + 8 * q + 4 * half;
+                            float4 x4 = *reinterpret_cast<const float4*>(stg + lr * STG_ROW + (tt * 32 + q * 8 + half * 4) * 4);
+                            if (col >= D) x4 = make_float4(0.f, 0.f, 0.f, 0.f);      // D % 4 == 0: a piece is valid or not as a whole
+                            xc[t][4 * q + 0] = x4.x; xc[t][4 * q + 1] = x4.y; xc[t][4 * q + 2] = x4.z; xc[t][4 * q + 3] = x4.w;
+                        }
+                    }
+                }
+            }
+        }
+        load_x<NT, W0 + 2>(xb, pitch, D, m_base, M, stg, lane, xc);
+    }
+}
+template <int NT, int W>
+__device__ __forceinline__ void store_x(char* yb, size_t pitch, int D, int m_base, int M, char* stg, int lane, const f32x16 (&xc)[NT]) {
+    constexpr int NWIN = (NT + 1) / 2;
+    if constexpr (W < NWIN) {
+        const int lr = lane & 31, half = lane >> 5;
+        wave_sync();
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int t = 2 * W + tt;
+            if (t < NT) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(stg + lr * STG_ROW + (tt * 32 + q * 8 + half * 4) * 4) =
+                        make_float4(xc[t][4 * q + 0], xc[t][4 * q + 1], xc[t][4 * q + 2], xc[t][4 * q + 3]);
+            }
+        }
+        wave_sync();
+        stage_store(stg, yb, pitch, D * 4, m_base, M, 256 * W, lane);
+        store_x<NT, W + 1>(yb, pitch, D, m_base, M, stg, lane, xc);
+    }
+}
+// bf16 rows (natural column order) -> K-permuted B fragments: k-step s of half h = columns 16s + 4h + {0..3} and 16s + 8 + 4h + {0..3}
+template <int KS, int W>
+__device__ __forceinline__ void load_a(const char* ab, size_t pitch, int row_bytes, int D, int m_base, int M, char* stg, int lane, bf16x8 (&xf)[KS]) {
+    constexpr int NWIN = (KS + 7) / 8;                  // 128 columns per window
+    if constexpr (W < NWIN) {
+        const int lr = lane & 31, half = lane >> 5;
+        u32x4 v[8] = {};
+        stage_load<0>(ab, pitch, row_bytes, m_base, M, 256 * W, lane, v);
+        wave_sync();
+        stage_put<0>(stg, lane, v);
+        wave_sync();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int s = 8 * W + j;
+            if (s < KS) {
+                const char* src = stg + lr * STG_ROW + (16 * j + 4 * half) * 2;
+                uint2 lo = *reinterpret_cast<const uint2*>(src), hi = *reinterpret_cast<const uint2*>(src + 16);
+                const int c0 = 16 * s + 4 * half;           // D % 4 == 0: each 4-column piece is valid or not as a whole
+                if (c0 >= D || m_base + lr >= M) lo = make_uint2(0u, 0u);
+                if (c0 + 8 >= D || m_base + lr >= M) hi = make_uint2(0u, 0u);
+                xf[s] = as_bf16x8(make_uint4(lo.x, lo.y, hi.x, hi.y));
+            }
+        }
+        load_a<KS, W + 1>(ab, pitch, row_bytes, D, m_base, M, stg, lane, xf);
+    }
+}
+
+template <int KS, int NW, int NBUF, int KIND>
+__global__ __launch_bounds__(NW * 64) void chain_kernel(const ChainDev cd) {
+    using G = Geo<KS>;
+    constexpr int NT = G::NT, P1 = G::P1, HALF = G::HALF, BUF = G::BUF;
+    constexpr bool ISB = KIND == CHAIN_B;
+    constexpr bool PRE = KIND == CHAIN_A_FULL || KIND == CHAIN_A_TAIL;     // previous block's tail: pw2, FFN2, block norm
+    constexpr bool POST = KIND == CHAIN_A_FULL || KIND == CHAIN_A_HEAD;    // this block's head: FFN1, QKV
+    static_assert((2 * KS) % NW == 0, "uniform DMA count per wave");
+    constexpr int PER = 2 * KS / NW;
+    constexpr int NTHR = NW * 64;
+    const ChainParams& p = cd.p;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* stg_base = smem + NBUF * BUF;
+    float* sf = reinterpret_cast<float*>(stg_base + NW * STG_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, half = lane >> 5;
+    const int m_base = (blockIdx.x * NW + wave) * 32;
+    char* stg = stg_base + wave * STG_BYTES;
+    const int D = p.D;
+
+    // ---- chunk schedule: [g0] [ffn0] [ffn1] [g1]
+    const int n_g0 = (ISB || PRE) ? (NT + 1) / 2 : 0;
+    const int n_f0 = PRE ? p.f[0].Fp / CH : 0;
+    const int n_f1 = POST ? p.f[1].Fp / CH : 0;
+    const int n_g1 = (ISB || POST) ? p.g1.nchunks : 0;
+    const int e0 = n_g0, e1 = e0 + n_f0, e2 = e1 + n_f1, total = e2 + n_g1;
+
+    auto issue = [&](int c) __attribute__((always_inline)) {
+        char* buf = smem + (c % NBUF) * BUF;
+        const bool ffn = c >= e0 && c < e2;
+        if (ffn) {
+            const ChainFfn& f = p.f[(c >= e1) ? 1 : 0];
+            const int cc = c - ((c >= e1) ? e1 : e0);
+            const bf16_t* w1 = f.w1 + (size_t)cc * CH * f.ldw1;
+            const bf16_t* w2 = f.w2 + cc * CH;
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const int i = wave + NW * k;
+                if (i < KS) dma_rows32<P1>(w1, f.ldw1, buf, i, lane);
+                else dma_w2(w2, f.ldw2, buf + HALF, i - KS, lane);
+            }
+        } else {
+            const ChainGemm& g = (c < e0) ? p.g0 : p.g1;
+            const int cc = (c < e0) ? c : c - e2;
+            const bf16_t* w = g.w + (size_t)cc * 64 * g.ldw;
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const int i = wave + NW * k;
+                if (i < KS) dma_rows32<P1>(w, g.ldw, buf, i, lane);
+                else dma_rows32<P1>(w + (size_t)32 * g.ldw, g.ldw, buf + HALF, i - KS, lane);
+            }
+        }
+    };
+    int gc = 0;                                            // next chunk to consume
+    auto advance = [&]() __attribute__((always_inline)) -> const char* {
+        wait_chunks<PER, NBUF - 2>(total - 1 - gc);        // chunk gc has landed (this wave's pieces)
+        wg_barrier();                                      // ... and everybody's; everybody is done with chunk gc-1
+        if (gc + NBUF - 1 < total) issue(gc + NBUF - 1);
+        const char* buf = smem + (gc % NBUF) * BUF;
+        ++gc;
+        return buf;
+    };
+
+    // ---- constants -> LDS (zero padded so that pad columns stay exactly zero through every stage)
+    float* s_b0 = sf + cd.nf[0];                           // g0 bias [DP]
+    float* s_ln = sf + cd.nf[1];                           // LayerNorms: [i][gamma DP | beta DP]
+    float* s_f0b1 = sf + cd.nf[2];                         // ffn0 b1 [Fp], b2 [DP]
+    float* s_f0b2 = sf + cd.nf[3];
+    float* s_f1b1 = sf + cd.nf[4];
+    float* s_f1b2 = sf + cd.nf[5];
+    float* s_g1b = sf + cd.nf[6];                          // g1 bias [64 * n_g1]
+    float* s_uv = sf + cd.nf[7];                           // u [DP] | v [DP]
+    constexpr int DP = G::DP;
+    constexpr int NLN = ISB ? 1 : 4;
+    if (ISB || PRE) for (int i = tid; i < DP; i += NTHR) s_b0[i] = i < D ? p.g0.bias[i] : 0.f;
+    for (int i = tid; i < NLN * 2 * DP; i += NTHR) {
+        const int l = i / (2 * DP), j = i - l * 2 * DP, col = j < DP ? j : j - DP;
+        const bool used = ISB ? true : ((l < 2) ? PRE : POST);
+        s_ln[i] = (used && col < D) ? (j < DP ? p.ln[l].g[col] : p.ln[l].b[col]) : 0.f;
+    }
+    if (PRE) {
+        for (int i = tid; i < p.f[0].Fp; i += NTHR) s_f0b1[i] = p.f[0].b1[i];
+        for (int i = tid; i < DP; i += NTHR) s_f0b2[i] = i < D ? p.f[0].b2[i] : 0.f;
+    }
+    if (POST) {
+        for (int i = tid; i < p.f[1].Fp; i += NTHR) s_f1b1[i] = p.f[1].b1[i];
+        for (int i = tid; i < DP; i += NTHR) s_f1b2[i] = i < D ? p.f[1].b2[i] : 0.f;
+        for (int i = tid; i < 2 * DP; i += NTHR) { const int col = i < DP ? i : i - DP; s_uv[i] = col < D ? (i < DP ? p.u[col] : p.v[col]) : 0.f; }
+    }
+    if (ISB || POST) for (int i = tid; i < 64 * n_g1; i += NTHR) s_g1b[i] = p.g1.bias[i];
+    __syncthreads();
+
+#pragma unroll
+    for (int c = 0; c < NBUF - 1; ++c)
+        if (c < total) issue(c);
+
+    // ---- this wave's rows
+    f32x16 xc[NT];
+    bf16x8 xf[KS];
+    load_x<NT, 0>(reinterpret_cast<const char*>(p.X), (size_t)p.ldx * 4, D, m_base, p.M, stg, lane, xc);
+    if constexpr (ISB || PRE) load_a<KS, 0>(reinterpret_cast<const char*>(p.A), (size_t)p.lda * 2, p.lda * 2, D, m_base, p.M, stg, lane, xf);
+
+    const int q0 = (half + lr) % P1;
+    const int w1row = lr * (P1 * 16);
+    auto wfrag = [&](const char* slab, int s) __attribute__((always_inline)) {
+        int q = q0 + 2 * s;
+        q -= q >= P1 ? P1 : 0;
+        return *reinterpret_cast<const bf16x8*>(slab + w1row + q * 16);
+    };
+    const int k2 = (half + (lr >> 2)) & 3;
+    const int w2off0 = lr * 64 + k2 * 16, w2off1 = lr * 64 + (k2 ^ 2) * 16;
+
+    // ---- stage: x += g0(A)   (alpha = 1: the accumulator starts at x + bias)
+    if constexpr (ISB || PRE) {
+        add_cvec<NT>(xc, s_b0, half);
+#pragma unroll
+        for (int c = 0; c < (NT + 1) / 2; ++c) {
+            const char* buf = advance();
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (2 * c + j < NT) {
+                    constexpr int FB = (KS % 8 == 0) ? 8 : ((KS % 4 == 0) ? 4 : KS);
+#pragma unroll
+                    for (int s0 = 0; s0 < KS; s0 += FB) {
+                        bf16x8 wa[FB];
+#pragma unroll
+                        for (int i = 0; i < FB; ++i) wa[i] = wfrag(buf + j * HALF, s0 + i);
+#pragma unroll
+                        for (int i = 0; i < FB; ++i) xc[2 * c + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[i], xf[s0 + i], xc[2 * c + j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- FFN stage: x += 1/2 FFN(LN(x))  (the 1/2 lives in W2 / b2)
+    auto ffn_stage = [&](const float* sg, const float* sb, const float* sb1, const float* sb2, int nchunks) __attribute__((always_inline)) {
+        float mean, rstd;
+        ln_stats<NT>(xc, D, mean, rstd);
+        ln_frags<KS>(xc, mean, rstd, sg, sb, half, xf);
+        add_cvec<NT>(xc, sb2, half);
+        for (int c = 0; c < nchunks; ++c) {
+            const char* buf = advance();
+            const float* b1 = sb1 + c * CH + 4 * half;
+            f32x16 h;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(b1 + 8 * q);
+                h[4 * q + 0] = v.x; h[4 * q + 1] = v.y; h[4 * q + 2] = v.z; h[4 * q + 3] = v.w;
+            }
+            constexpr int FB = (KS % 8 == 0) ? 8 : ((KS % 4 == 0) ? 4 : KS);
+#pragma unroll
+            for (int s0 = 0; s0 < KS; s0 += FB) {
+                bf16x8 wa[FB];
+#pragma unroll
+                for (int i = 0; i < FB; ++i) wa[i] = wfrag(buf, s0 + i);
+#pragma unroll
+                for (int i = 0; i < FB; ++i) h = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[i], xf[s0 + i], h, 0, 0, 0);
+            }
+            uint32_t w[8];
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) w[r >> 1] = pack_bf2(swishf_(h[r]), swishf_(h[r + 1]));
+            const bf16x8 hf0 = as_bf16x8(make_uint4(w[0], w[1], w[2], w[3])), hf1 = as_bf16x8(make_uint4(w[4], w[5], w[6], w[7]));
+            const char* w2 = buf + HALF;
+            constexpr int TB = (NT % 4 == 0) ? 4 : ((NT % 2 == 0) ? 2 : 1);
+#pragma unroll
+            for (int t0 = 0; t0 < NT; t0 += TB) {
+                bf16x8 wb[TB][2];
+#pragma unroll
+                for (int i = 0; i < TB; ++i) {
+                    wb[i][0] = *reinterpret_cast<const bf16x8*>(w2 + (t0 + i) * 2048 + w2off0);
+                    wb[i][1] = *reinterpret_cast<const bf16x8*>(w2 + (t0 + i) * 2048 + w2off1);
+                }
+#pragma unroll
+                for (int i = 0; i < TB; ++i) {
+                    xc[t0 + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[i][0], hf0, xc[t0 + i], 0, 0, 0);
+                    xc[t0 + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[i][1], hf1, xc[t0 + i], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    if constexpr (ISB) {
+        // ---- conv-module pre-norm, pointwise-1 + GLU -> bf16 rows (modules.py:512-514)
+        float mean, rstd;
+        ln_stats<NT>(xc, D, mean, rstd);
+        ln_frags<KS>(xc, mean, rstd, s_ln, s_ln + DP, half, xf);
+        for (int c = 0; c < n_g1; ++c) {
+            const char* buf = advance();
+            f32x16 acc[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = *reinterpret_cast<const float4*>(s_g1b + 64 * c + 32 * j + 8 * q + 4 * half);
+                    acc[j][4 * q + 0] = v.x; acc[j][4 * q + 1] = v.y; acc[j][4 * q + 2] = v.z; acc[j][4 * q + 3] = v.w;
+                }
+            constexpr int FB = 2;
+#pragma unroll
+            for (int s0 = 0; s0 < KS; s0 += FB) {
+                bf16x8 wa[2][FB];
+#pragma unroll
+                for (int i = 0; i < FB; ++i) { wa[0][i] = wfrag(buf, s0 + i); wa[1][i] = wfrag(buf + HALF, s0 + i); }
+#pragma unroll
+                for (int i = 0; i < FB; ++i) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0][i], xf[s0 + i], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[1][i], xf[s0 + i], acc[1], 0, 0, 0);
+                }
+            }
+            // a * sigmoid(b) for channels 32c + (r&3) + 8(r>>2) + 4*half -> staging (64 B per row) -> coalesced store
+            wave_sync();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float o[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = acc[0][4 * q + i] * sigmoidf_(acc[1][4 * q + i]);
+                *reinterpret_cast<uint2*>(stg + lr * STG_ROW + (8 * q + 4 * half) * 2) = make_uint2(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]));
+            }
+            wave_sync();
+            const int col = 32 * c + 8 * (lane & 3);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = 16 * i + (lane >> 2), m = m_base + row;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(stg + row * STG_ROW + 16 * (lane & 3));
+                if (m < p.M && col < p.Ng) *reinterpret_cast<u32x4*>(p.glu + (size_t)m * p.ldg + col) = v;
+            }
+        }
+    } else {
+        if constexpr (PRE) {
+            ffn_stage(s_ln, s_ln + DP, s_f0b1, s_f0b2, n_f0);                       // FFN2 of the previous block
+            float mean, rstd;
+            ln_stats<NT>(xc, D, mean, rstd);
+            ln_inplace<NT>(xc, mean, rstd, s_ln + 2 * DP, s_ln + 3 * DP, half);     // block output = LayerNorm(x)  (blocks.py:135)
+        }
+        if constexpr (POST) {
+            ffn_stage(s_ln + 4 * DP, s_ln + 5 * DP, s_f1b1, s_f1b2, n_f1);          // FFN1 of this block
+            float mean, rstd;
+            ln_stats<NT>(xc, D, mean, rstd);
+            ln_frags<KS>(xc, mean, rstd, s_ln + 6 * DP, s_ln + 7 * DP, half, xf);   // attention pre-norm
+            // x is final here (the Q/K/V projection only reads it): store it now so that its registers are free during the last stage
+            store_x<NT, 0>(reinterpret_cast<char*>(p.Y), (size_t)p.ldy * 4, D, m_base, p.M, stg, lane, xc);
+            // destination row offsets of the 4 rows this lane stores per window instruction: (b, t) -> (b*Tp + t)*D
+            size_t qoff[4];
+            bool qok[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = m_base + 8 * i + (lane >> 3);
+                const int mc = m < p.M ? m : p.M - 1;
+                const int b = cd.fT.div(mc), t = mc - b * p.T;
+                qoff[i] = ((size_t)b * p.Tp + t) * D;
+                qok[i] = m < p.M;
+            }
+            const int pc8 = 8 * (lane & 7);
+            for (int c = 0; c < n_g1; ++c) {
+                const char* buf = advance();
+                f32x16 acc[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 v = *reinterpret_cast<const float4*>(s_g1b + 64 * c + 32 * j + 8 * q + 4 * half);
+                        acc[j][4 * q + 0] = v.x; acc[j][4 * q + 1] = v.y; acc[j][4 * q + 2] = v.z; acc[j][4 * q + 3] = v.w;
+                    }
+                constexpr int FB = 2;
+#pragma unroll
+                for (int s0 = 0; s0 < KS; s0 += FB) {
+                    bf16x8 wa[2][FB];
+#pragma unroll
+                    for (int i = 0; i < FB; ++i) { wa[0][i] = wfrag(buf, s0 + i); wa[1][i] = wfrag(buf + HALF, s0 + i); }
+#pragma unroll
+                    for (int i = 0; i < FB; ++i) {
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0][i], xf[s0 + i], acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[1][i], xf[s0 + i], acc[1], 0, 0, 0);
+                    }
+                }
+                // registers r = 8g .. 8g+7 of tile j are the columns 64c + 32j + 16g + 8*half + (0..7) of the stacked [Q | K | V]
+                // (row permutation of pack_linear_chunkperm).  Variant 0: Q + u | K | V, variant 1: Q + v (only Q columns stored).
+                const int nvar = (64 * c < D) ? 2 : 1;
+                for (int var = 0; var < nvar; ++var) {
+                    const float* su = s_uv + var * DP;
+                    wave_sync();
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int g = 0; g < 2; ++g) {
+                            const int n0 = 64 * c + 32 * j + 16 * g + 8 * half;
+                            float4 ua = make_float4(0.f, 0.f, 0.f, 0.f), ub = ua;
+                            if (n0 < D) { ua = *reinterpret_cast<const float4*>(su + n0); ub = *reinterpret_cast<const float4*>(su + n0 + 4); }
+                            *reinterpret_cast<uint4*>(stg + lr * STG_ROW + (32 * j + 16 * g + 8 * half) * 2) =
+                                make_uint4(pack_bf2(acc[j][8 * g + 0] + ua.x, acc[j][8 * g + 1] + ua.y), pack_bf2(acc[j][8 * g + 2] + ua.z, acc[j][8 * g + 3] + ua.w),
+                                           pack_bf2(acc[j][8 * g + 4] + ub.x, acc[j][8 * g + 5] + ub.y), pack_bf2(acc[j][8 * g + 6] + ub.z, acc[j][8 * g + 7] + ub.w));
+                        }
+                    wave_sync();
+                    const int n0 = 64 * c + pc8;
+                    const int which = cd.fD.div(n0), nn0 = n0 - which * D;
+                    bf16_t* dst = which == 0 ? (var == 0 ? p.qu : p.qv) : (which == 1 ? p.kh : p.vt);
+                    const bool colok = n0 < 3 * D && (var == 0 || which == 0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const u32x4 v = *reinterpret_cast<const u32x4*>(stg + (8 * i + (lane >> 3)) * STG_ROW + 16 * (lane & 7));
+                        if (colok && qok[i]) *reinterpret_cast<u32x4*>(dst + qoff[i] + nn0) = v;
+                    }
+                }
+            }
+        }
+    }
+    // ---- residual rows out
+    if constexpr (!POST) store_x<NT, 0>(reinterpret_cast<char*>(p.Y), (size_t)p.ldy * 4, D, m_base, p.M, stg, lane, xc);
+}
+
+// LDS float-region layout shared by kernel and launcher
+inline int chain_float_layout(const ChainParams& p, int kind, int DP, int (&nf)[8]) {
+    const bool isb = kind == CHAIN_B, pre = kind == CHAIN_A_FULL || kind == CHAIN_A_TAIL, post = kind == CHAIN_A_FULL || kind == CHAIN_A_HEAD;
+    int o = 0;
+    nf[0] = o; o += (isb || pre) ? DP : 0;
+    nf[1] = o; o += (isb ? 1 : 4) * 2 * DP;
+    nf[2] = o; o += pre ? p.f[0].Fp : 0;
+    nf[3] = o; o += pre ? DP : 0;
+    nf[4] = o; o += post ? p.f[1].Fp : 0;
+    nf[5] = o; o += post ? DP : 0;
+    nf[6] = o; o += (isb || post) ? 64 * p.g1.nchunks : 0;
+    nf[7] = o; o += post ? 2 * DP : 0;
+    return o;
+}
+
+template <int KS, int NW, int NBUF, int KIND>
+int launch_chain_t(const ChainParams& p, hipStream_t s) {
+    using G = Geo<KS>;
+    ChainDev cd;
+    cd.p = p;
+    cd.fT = FastDiv32(p.T > 0 ? p.T : 1);
+    cd.fD = FastDiv32(p.D);
+    const int nfl = chain_float_layout(p, KIND, G::DP, cd.nf);
+    const int lds = NBUF * G::BUF + NW * STG_BYTES + nfl * 4;
+    if (lds > 160 * 1024) return -4;
+    static int attr_set = 0;
+    if (attr_set < lds) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_kernel<KS, NW, NBUF, KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = lds;
+    }
+    const int rows_per_wg = NW * 32;
+    hipLaunchKernelGGL((chain_kernel<KS, NW, NBUF, KIND>), dim3((p.M + rows_per_wg - 1) / rows_per_wg), dim3(NW * 64), lds, s, cd);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+template <int KIND>
+int launch_chain_kind(const ChainParams& p, hipStream_t s) {
+    const int ks = 2 * ((p.D + 31) / 32);
+    if (ks <= 2) return launch_chain_t<2, 4, 4, KIND>(p, s);
+    if (ks <= 4) return launch_chain_t<4, 8, 4, KIND>(p, s);
+    if (ks <= 8) return launch_chain_t<8, 8, 4, KIND>(p, s);
+    if (ks <= 12) return launch_chain_t<12, 4, 4, KIND>(p, s);
+    return launch_chain_t<16, 4, 3, KIND>(p, s);
+}
+
+}  // namespace
+
+// D % 8 == 0: 16-byte bf16 pieces never straddle the Q | K | V boundaries; D <= 256: the residual row fits the register file
+bool chain_supported(int D) { return D % 8 == 0 && D >= 16 && D <= 256; }
+
+int launch_chain(const ChainParams& p, int kind, hipStream_t s) {
+    if (p.M <= 0) return 0;
+    if (!chain_supported(p.D)) return -2;
+    switch (kind) {
+        case CHAIN_B: return launch_chain_kind<CHAIN_B>(p, s);
+        case CHAIN_A_FULL: return launch_chain_kind<CHAIN_A_FULL>(p, s);
+        case CHAIN_A_HEAD: return launch_chain_kind<CHAIN_A_HEAD>(p, s);
+        case CHAIN_A_TAIL: return launch_chain_kind<CHAIN_A_TAIL>(p, s);
+    }
+    return -3;
+}

@@ -39,6 +39,11 @@ struct BlockW {
     const bf16_t *ffn1_bp = nullptr, *ffn2_bp = nullptr;   // W2 with the hidden index permuted per 16 (rsgemm.hip)
     const float *u = nullptr, *v = nullptr, *dw_w = nullptr, *dw_b = nullptr;
     const bf16_t* pos_table = nullptr;   // [2*max_pos-1][ld8(D)], row r <-> position max_pos-1-r
+    // fused row-local chains (chain.hip): every weight with its K index permuted per 16; FFN second weight / bias pre-scaled by 1/2
+    bool chain_in = false, chain_out = false;          // chain-packed weights exist for the D-wide / De-wide parts of the block
+    PackedLinear c_outp, c_pw1, c_pw2, c_qkv, c_f1a, c_f2a;
+    const bf16_t *c_f1b = nullptr, *c_f2b = nullptr; const float *c_f1b2 = nullptr, *c_f2b2 = nullptr;
+    int c_qkv_chunks = 0, c_pw1_chunks = 0;
 };
 
 struct TraceEntry { char name[64]; int64_t offset, rows, cols, ld; int32_t dtype; };
@@ -60,6 +65,7 @@ struct EcEncoder {
     PackedLinear lin;
     const bf16_t* lin_fused = nullptr; int lin_fused_ld = 0;   // Linear weight in the fused kernel's K order (sublinear.hip)
     bool fuse_subsample = true;
+    bool fuse_chain = true;                  // row-local chains (chain.hip) where supported
     // two-layer subsampler (plain Conformer configs): layer-2 implicit-GEMM weight [N][9*Cp] (tap, c_in), folded bias, Cp
     const bf16_t* sub2_w = nullptr; const float* sub2_b = nullptr; int sub2_cp = 0;
     std::vector<BlockW> bw;
@@ -98,13 +104,20 @@ const HostTensor* find(EcEncoder* e, const std::string& k) {
 }
 
 // [N][K] fp32 (row-major, possibly a gather of rows given by `rows`) -> padded bf16 + padded bias
-bool pack_linear(EcEncoder* e, const std::vector<const float*>& row_ptr, const std::vector<float>& bias, int K, PackedLinear* out) {
+// kperm: K index permuted inside every group of 16 (packed position 8h+e holds column 4h + 8(e>>2) + (e&3)): the B fragments of
+// chain.hip are LayerNorm-ed accumulator registers in MFMA C order
+bool pack_linear(EcEncoder* e, const std::vector<const float*>& row_ptr, const std::vector<float>& bias, int K, PackedLinear* out,
+                 bool kperm = false) {
     const int N = (int)row_ptr.size();
     const int Np = ec_round_up(N, 128), Kp = ec_round_up(K, 64);
     std::vector<uint16_t> w((size_t)Np * Kp, 0);
     for (int n = 0; n < N; ++n) {
         if (!row_ptr[n]) continue;
-        for (int k = 0; k < K; ++k) w[(size_t)n * Kp + k] = h_f2bf(row_ptr[n][k]);
+        for (int k = 0; k < Kp; ++k) {
+            int src = k;
+            if (kperm) { const int g = k / 16, pp = k % 16, hh = pp >> 3, ee = pp & 7; src = g * 16 + 4 * hh + 8 * (ee >> 2) + (ee & 3); }
+            if (src < K) w[(size_t)n * Kp + k] = h_f2bf(row_ptr[n][src]);
+        }
     }
     std::vector<float> b(Np, 0.f);
     for (int n = 0; n < N && n < (int)bias.size(); ++n) b[n] = bias[n];
@@ -114,19 +127,19 @@ bool pack_linear(EcEncoder* e, const std::vector<const float*>& row_ptr, const s
     return out->w && out->bias;
 }
 
-bool pack_named_linear(EcEncoder* e, const std::string& prefix, int N, int K, PackedLinear* out, std::string* err) {
+bool pack_named_linear(EcEncoder* e, const std::string& prefix, int N, int K, PackedLinear* out, std::string* err, bool kperm = false) {
     const HostTensor* w = find(e, prefix + ".weight");
     const HostTensor* b = find(e, prefix + ".bias");
     if (!w || !b) { *err = "missing tensor " + prefix + ".weight/.bias"; return false; }
     if ((int64_t)w->data.size() != (int64_t)N * K || (int)b->data.size() != N) { *err = "shape mismatch for " + prefix; return false; }
     std::vector<const float*> rows(N);
     for (int n = 0; n < N; ++n) rows[n] = w->data.data() + (size_t)n * K;
-    return pack_linear(e, rows, b->data, K, out);
+    return pack_linear(e, rows, b->data, K, out, kperm);
 }
 
 // second FFN weight [D][F] with the hidden (K) index permuted inside every group of 16 so that the first GEMM's
 // accumulator registers are directly the second GEMM's B fragments: position 8h+e <-> 4h + 8(e>>2) + (e&3)
-const bf16_t* pack_ffn2_permuted(EcEncoder* e, const std::string& prefix, int D, int F) {
+const bf16_t* pack_ffn2_permuted(EcEncoder* e, const std::string& prefix, int D, int F, float scale = 1.0f) {
     const HostTensor* w = find(e, prefix + ".weight");
     if (!w || (int64_t)w->data.size() != (int64_t)D * F) return nullptr;
     const int Np = ec_round_up(D, 128), Kp = ec_round_up(F, 64);
@@ -135,7 +148,7 @@ const bf16_t* pack_ffn2_permuted(EcEncoder* e, const std::string& prefix, int D,
         for (int k = 0; k < Kp; ++k) {
             const int g = k / 16, pp = k % 16, hh = pp >> 3, ee = pp & 7;
             const int src = g * 16 + 4 * hh + 8 * (ee >> 2) + (ee & 3);
-            if (src < F) out[(size_t)n * Kp + k] = h_f2bf(w->data[(size_t)n * F + src]);
+            if (src < F) out[(size_t)n * Kp + k] = h_f2bf(scale * w->data[(size_t)n * F + src]);
         }
     return upload(e, out);
 }
@@ -346,6 +359,18 @@ int run_gemm(EcEncoder* e, int cls, hipStream_t st, const bf16_t* A, int lda, in
 
 // x += alpha * FFN(a)  — fused row-stationary kernel when the width allows, else two tiled GEMMs
 // ln != null: the pre-norm is computed inside the fused kernel's prologue (a is not read); the tiled fallback needs `a`
+inline int F1c(const EcBlock& b) { return ec_round_up(b.dim_model * b.ff_ratio, 32); }
+
+// POST half of a chain A: the block's FFN1 (pre-norm ln[2]), attention pre-norm ln[3] and stacked Q/K/V projection
+void fill_chain_head(ChainParams& cp, const BlockW& W, int D, int Fp, int T, int Tp, const GemmParams& q) {
+    cp.D = D;
+    cp.ln[2] = ChainLn{W.ln_ffn1.g, W.ln_ffn1.b};
+    cp.ln[3] = ChainLn{W.ln_att.g, W.ln_att.b};
+    cp.f[1] = ChainFfn{W.c_f1a.w, W.c_f1a.ldw, W.c_f1a.bias, W.c_f1b, W.ffn1_b.ldw, W.c_f1b2, Fp};
+    cp.g1 = ChainGemm{W.c_qkv.w, W.c_qkv.ldw, W.c_qkv.bias, W.c_qkv_chunks};
+    cp.qu = q.qu; cp.qv = q.qv; cp.kh = q.kh; cp.vt = q.vt; cp.u = W.u; cp.v = W.v; cp.T = T; cp.Tp = Tp;
+}
+
 int run_ffn(EcEncoder* e, hipStream_t st, const bf16_t* a, int M, int D, const PackedLinear& L1, const PackedLinear& L2,
             const bf16_t* w2p, float* x, bf16_t* hbuf, const LNp* ln = nullptr) {
     const int F = L1.N;
@@ -419,7 +444,7 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
     bf16_t* gbuf = reinterpret_cast<bf16_t*>(ws + w.gbuf);
     bf16_t* cbuf = reinterpret_cast<bf16_t*>(ws + w.cbuf);
     bf16_t* xs = reinterpret_cast<bf16_t*>(ws + w.xs);
-    bool have_a = false;
+    bool have_a = false, head_done = false;
     char nm[64];
     const bool e_cached = e->e_cache_on && e->e_cache_ws == ws && e->e_cache_tm == s.Tm;
 
@@ -428,28 +453,37 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
         const BlockW& W = e->bw[k];
         const int T = s.Tin[k], To = s.Tout[k], D = b.dim_model, De = b.dim_expand;
         const int M = B * T, Mo = B * To;
-        // ---- x += 1/2 FFN1(x)   (blocks.py:122; modules.py:385-392)
-        { PROF(PC_LAYERNORM, 0, (double)M * D * 6); if (!have_a) EC_TRY(launch_layernorm(x, M, D, W.ln_ffn1.g, W.ln_ffn1.b, nullptr, a, ld8(D), nullptr, nullptr, st)); }
-        EC_TRY(run_ffn(e, st, a, M, D, W.ffn1_a, W.ffn1_b, W.ffn1_bp, x, hbuf));
-        snprintf(nm, sizeof(nm), "blocks.%d.x_ffn1", k); trace_add(e, st, nm, x, M, D, D, 0);
-
-        // ---- x += MHSA(LN(x))   (blocks.py:125-126; modules.py:472-488; attentions.py:549-718)
-        {
-            const int G = b.group_size, H = b.num_heads;
-            const int Tp = ec_round_up(T, G), Tg = Tp / G, Tgp = ec_round_up(Tg, 8);
-            const int d = G * D / H, dpad = ec_round_up(d, 32);
+        const int G = b.group_size, H = b.num_heads;
+        const int Tp = ec_round_up(T, G), Tg = Tp / G, Tgp = ec_round_up(Tg, 8);
+        const int d = G * D / H, dpad = ec_round_up(d, 32);
+        // Q/K/V/E layout: "natural" row-major [B*Tp][D] (16-byte row stores from the GEMM, head split = pointer arithmetic in
+        // the attention kernel) whenever the grouped head dim d is even (4-byte aligned head spans); head-major otherwise
+        const bool nat = (d % 2) == 0;
+        const bool chain_head = e->fuse_chain && W.chain_in && nat;          // FFN1 + QKV of this block as a fused chain
+        const bool chain_b = e->fuse_chain && W.chain_in;                      // out-proj + LN + pointwise-1/GLU
+        const bool chain_tail = e->fuse_chain && W.chain_out;                  // pointwise-2 + FFN2 + block norm (+ next block's head)
+        GemmParams p{};
+        p.A = a; p.lda = ld8(D); p.W = W.qkv.w; p.ldw = W.qkv.ldw; p.bias = W.qkv.bias;
+        p.M = M; p.N = 3 * D; p.K = D;
+        p.T = T; p.G = G; p.H = H; p.D = D; p.d = d; p.dpad = dpad; p.Tg = Tg; p.Tgp = Tgp;
+        p.qu = reinterpret_cast<bf16_t*>(ws + w.qu); p.qv = reinterpret_cast<bf16_t*>(ws + w.qv);
+        p.kh = reinterpret_cast<bf16_t*>(ws + w.kh); p.vt = reinterpret_cast<bf16_t*>(ws + w.vt);
+        p.u = W.u; p.v = W.v;
+        if (head_done) {
+            // FFN1 and the Q/K/V projection of this block already ran inside the previous block's tail chain
+        } else if (chain_head) {
+            ChainParams cp{};
+            fill_chain_head(cp, W, D, F1c(b), T, Tp, p);
+            cp.M = M; cp.X = x; cp.ldx = D; cp.Y = x; cp.ldy = D;
+            PROF(PC_GEMM_FFN, 2.0 * M * (double)D * (2.0 * D * b.ff_ratio + 3.0 * D), (double)M * D * 16 + 22.0 * D * D);
+            EC_TRY(launch_chain(cp, CHAIN_A_HEAD, st));
+        } else {
+            // ---- x += 1/2 FFN1(x)   (blocks.py:122; modules.py:385-392)
+            { PROF(PC_LAYERNORM, 0, (double)M * D * 6); if (!have_a) EC_TRY(launch_layernorm(x, M, D, W.ln_ffn1.g, W.ln_ffn1.b, nullptr, a, ld8(D), nullptr, nullptr, st)); }
+            EC_TRY(run_ffn(e, st, a, M, D, W.ffn1_a, W.ffn1_b, W.ffn1_bp, x, hbuf));
+            // ---- Q/K/V of LN(x)   (modules.py:472-488; attentions.py:651-686)
             const bool ln_fused = rs_gemm_supported(D);      // pre-norm computed in the QKV kernel's prologue
             if (!ln_fused) { PROF(PC_LAYERNORM, 0, (double)M * D * 6); EC_TRY(launch_layernorm(x, M, D, W.ln_att.g, W.ln_att.b, nullptr, a, ld8(D), nullptr, nullptr, st)); }
-            // Q/K/V/E layout: "natural" row-major [B*Tp][D] (16-byte row stores from the GEMM, head split = pointer arithmetic in
-            // the attention kernel) whenever the grouped head dim d is even (4-byte aligned head spans); head-major otherwise
-            const bool nat = (d % 2) == 0;
-            GemmParams p{};
-            p.A = a; p.lda = ld8(D); p.W = W.qkv.w; p.ldw = W.qkv.ldw; p.bias = W.qkv.bias;
-            p.M = M; p.N = 3 * D; p.K = D;
-            p.T = T; p.G = G; p.H = H; p.D = D; p.d = d; p.dpad = dpad; p.Tg = Tg; p.Tgp = Tgp;
-            p.qu = reinterpret_cast<bf16_t*>(ws + w.qu); p.qv = reinterpret_cast<bf16_t*>(ws + w.qv);
-            p.kh = reinterpret_cast<bf16_t*>(ws + w.kh); p.vt = reinterpret_cast<bf16_t*>(ws + w.vt);
-            p.u = W.u; p.v = W.v;
             { PROF(PC_GEMM_OTHER, 2.0 * M * 3.0 * D * D, (double)M * D * 2 + 3.0 * D * D * 2 + (double)M * D * 8);
               if (rs_gemm_supported(D)) {
                   if (nat) { p.W = W.qkv_nat.w; p.ldw = W.qkv_nat.ldw; p.bias = W.qkv_nat.bias; }
@@ -458,6 +492,11 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
               } else {
                   EC_TRY(launch_gemm(p, nat ? EPI_QKV_NAT : EPI_QKV, st));
               } }
+        }
+        snprintf(nm, sizeof(nm), "blocks.%d.x_ffn1", k); trace_add(e, st, nm, x, M, D, D, 0);
+
+        // ---- x += MHSA(LN(x))   (blocks.py:125-126; attentions.py:549-718)
+        {
             { PROF(PC_MISC, 0, 0); EC_TRY(nat ? launch_attn_pad_rows_nat(p, B, st) : launch_attn_pad_rows(p, B, st)); }
             // positional embeddings E = pos_layer(R) (attentions.py:588 / 678): input independent, tiny (2Tp-G rows)
             GemmParams pe{};
@@ -481,12 +520,24 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
             ap.out = o; ap.ldo = ld8(D); ap.scale = 1.0f / std::sqrt((float)d);
             { PROF(PC_ATTENTION, 2.0 * B * H * (double)Tg * Tg * d * 3.0, (double)M * D * 2 * 5); EC_TRY(launch_relpos_attention(ap, st)); }
             snprintf(nm, sizeof(nm), "blocks.%d.att_o", k); trace_add(e, st, nm, o, M, D, ld8(D), 1);
-            EC_TRY(run_rs_or_tiled(e, PC_GEMM_OTHER, st, o, ld8(D), M, W.outp, 0, EPI_RESID_F32, x, D, x, D, 1.0f));
+            if (chain_b) {
+                ChainParams cp{};
+                cp.M = M; cp.D = D; cp.X = x; cp.ldx = D; cp.Y = x; cp.ldy = D; cp.A = o; cp.lda = ld8(D);
+                cp.g0 = ChainGemm{W.c_outp.w, W.c_outp.ldw, W.c_outp.bias, 0};
+                cp.ln[0] = ChainLn{W.ln_conv.g, W.ln_conv.b};
+                cp.g1 = ChainGemm{W.c_pw1.w, W.c_pw1.ldw, W.c_pw1.bias, W.c_pw1_chunks};
+                cp.glu = gbuf; cp.ldg = ld8(De); cp.Ng = De; cp.T = T; cp.Tp = Tp;
+                PROF(PC_GEMM_OTHER, 2.0 * M * (double)D * (D + 2.0 * De), (double)M * D * 10 + (double)M * De * 2 + 2.0 * D * (D + 2.0 * De));
+                EC_TRY(launch_chain(cp, CHAIN_B, st));
+            } else {
+                EC_TRY(run_rs_or_tiled(e, PC_GEMM_OTHER, st, o, ld8(D), M, W.outp, 0, EPI_RESID_F32, x, D, x, D, 1.0f));
+            }
             snprintf(nm, sizeof(nm), "blocks.%d.x_mhsa", k); trace_add(e, st, nm, x, M, D, D, 0);
         }
 
         // ---- x = conv_res(x) + ConvModule(x)   (blocks.py:129; modules.py:511-522)
-        if (rs_gemm_supported(D)) {
+        if (chain_b) {
+        } else if (rs_gemm_supported(D)) {
             EC_TRY(run_rs_or_tiled(e, PC_GEMM_OTHER, st, a, ld8(D), M, W.pw1, 2, EPI_GLU_BF16, gbuf, ld8(De), nullptr, 0, 1.f, x, &W.ln_conv));
         } else {
             { PROF(PC_LAYERNORM, 0, (double)M * D * 6); EC_TRY(launch_layernorm(x, M, D, W.ln_conv.g, W.ln_conv.b, nullptr, a, ld8(D), nullptr, nullptr, st)); }
@@ -501,6 +552,37 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
         } else if (b.conv_stride > 1) {
             return fail("strided block without expansion is not native (no shipped config uses it)");
         }
+        const bool last = (k == nb - 1);
+        float* xo = last ? out : x;
+        if (chain_tail) {
+            bool next_head = false;
+            if (!last) {
+                const EcBlock& nbk = e->blocks[k + 1];
+                next_head = e->bw[k + 1].chain_in && ((nbk.group_size * nbk.dim_model / nbk.num_heads) % 2) == 0 && nbk.dim_model == De;
+            }
+            ChainParams cp{};
+            cp.M = Mo; cp.D = De; cp.X = x; cp.ldx = De; cp.Y = xo; cp.ldy = De; cp.A = cbuf; cp.lda = ld8(De);
+            cp.g0 = ChainGemm{W.c_pw2.w, W.c_pw2.ldw, W.c_pw2.bias, 0};
+            cp.ln[0] = ChainLn{W.ln_ffn2.g, W.ln_ffn2.b};
+            cp.ln[1] = ChainLn{W.ln_out.g, W.ln_out.b};
+            cp.f[0] = ChainFfn{W.c_f2a.w, W.c_f2a.ldw, W.c_f2a.bias, W.c_f2b, W.ffn2_b.ldw, W.c_f2b2, ec_round_up(De * b.ff_ratio, 32)};
+            double fl = 2.0 * Mo * (double)De * (De + 2.0 * De * b.ff_ratio), by = (double)Mo * De * 10 + 2.0 * De * De * (1 + 2.0 * b.ff_ratio);
+            if (next_head) {
+                const EcBlock& nbk = e->blocks[k + 1];
+                const int Tn = s.Tin[k + 1], Gn = nbk.group_size, Tpn = ec_round_up(Tn, Gn);
+                GemmParams pn{};
+                pn.qu = reinterpret_cast<bf16_t*>(ws + w.qu); pn.qv = reinterpret_cast<bf16_t*>(ws + w.qv);
+                pn.kh = reinterpret_cast<bf16_t*>(ws + w.kh); pn.vt = reinterpret_cast<bf16_t*>(ws + w.vt);
+                fill_chain_head(cp, e->bw[k + 1], De, F1c(nbk), Tn, Tpn, pn);
+                fl += 2.0 * Mo * (double)De * (2.0 * De * nbk.ff_ratio + 3.0 * De); by += (double)Mo * De * 8 + 2.0 * De * De * (3 + 2.0 * nbk.ff_ratio);
+            }
+            { PROF(PC_GEMM_FFN, fl, by); EC_TRY(launch_chain(cp, next_head ? CHAIN_A_FULL : CHAIN_A_TAIL, st)); }
+            head_done = next_head;
+            have_a = false;
+            if (last) { snprintf(nm, sizeof(nm), "blocks.%d.out", k); trace_add(e, st, nm, xo, Mo, De, De, 0); }
+            continue;
+        }
+        head_done = false;
         EC_TRY(run_rs_or_tiled(e, PC_GEMM_OTHER, st, cbuf, ld8(De), Mo, W.pw2, 0, EPI_RESID_F32, x, De, x, De, 1.0f));
         snprintf(nm, sizeof(nm), "blocks.%d.x_conv", k); trace_add(e, st, nm, x, Mo, De, De, 0);
 
@@ -511,8 +593,6 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
             { PROF(PC_LAYERNORM, 0, (double)Mo * De * 6); EC_TRY(launch_layernorm(x, Mo, De, W.ln_ffn2.g, W.ln_ffn2.b, nullptr, a, ld8(De), nullptr, nullptr, st)); }
             EC_TRY(run_ffn(e, st, a, Mo, De, W.ffn2_a, W.ffn2_b, W.ffn2_bp, x, hbuf));
         }
-        const bool last = (k == nb - 1);
-        float* xo = last ? out : x;
         // block-final norm fused with the next block's FFN1 pre-norm (both read the same rows)
         { PROF(PC_LAYERNORM, 0, (double)Mo * De * 10); EC_TRY(launch_layernorm(x, Mo, De, W.ln_out.g, W.ln_out.b, xo, last ? nullptr : a, ld8(De),
                                 last ? nullptr : e->bw[k + 1].ln_ffn1.g, last ? nullptr : e->bw[k + 1].ln_ffn1.b, st)); }
@@ -678,6 +758,30 @@ int effconf_encoder_finalize(EcEncoder* e) {
             }
             if (!pack_linear(e, prow, pbias, D, &W.qkv_nat)) return fail("upload failed");
             W.qkv_nat.N = 3 * D;
+            if (chain_supported(D)) {
+                if (!pack_linear(e, prow, pbias, D, &W.c_qkv, true)) return fail("upload failed");
+                W.c_qkv_chunks = ec_cdiv(3 * D, 64);
+            }
+        }
+        if (chain_supported(D)) {      // D-wide part of the block: FFN1, attention output projection (pointwise-1 below)
+            const HostTensor* b2 = find(e, p + ".feed_forward_module1.layers.4.bias");
+            if (!b2 || !pack_named_linear(e, p + ".feed_forward_module1.layers.1", F1, D, &W.c_f1a, &err, true) ||
+                !pack_named_linear(e, m + ".mhsa.output_layer", D, D, &W.c_outp, &err, true)) return fail("chain packing failed: " + err);
+            W.c_f1b = pack_ffn2_permuted(e, p + ".feed_forward_module1.layers.4", D, F1, 0.5f);
+            std::vector<float> hb(b2->data); for (float& x : hb) x *= 0.5f;
+            W.c_f1b2 = upload(e, hb);
+            if (!W.c_f1b || !W.c_f1b2) return fail("upload failed");
+            W.chain_in = true;
+        }
+        if (chain_supported(De)) {     // De-wide part: pointwise-2, FFN2
+            const HostTensor* b2 = find(e, p + ".feed_forward_module2.layers.4.bias");
+            if (!b2 || !pack_named_linear(e, p + ".feed_forward_module2.layers.1", F2, De, &W.c_f2a, &err, true) ||
+                !pack_named_linear(e, p + ".convolution_module.layers.7", De, De, &W.c_pw2, &err, true)) return fail("chain packing failed: " + err);
+            W.c_f2b = pack_ffn2_permuted(e, p + ".feed_forward_module2.layers.4", De, F2, 0.5f);
+            std::vector<float> hb(b2->data); for (float& x : hb) x *= 0.5f;
+            W.c_f2b2 = upload(e, hb);
+            if (!W.c_f2b || !W.c_f2b2) return fail("upload failed");
+            W.chain_out = true;
         }
         if (!pack_named_linear(e, m + ".mhsa.pos_layer", D, D, &W.pos, &err)) return fail(err);
         if (!pack_named_linear(e, m + ".mhsa.output_layer", D, D, &W.outp, &err)) return fail(err);
@@ -702,6 +806,10 @@ int effconf_encoder_finalize(EcEncoder* e) {
                 rows[jb * 64 + 32 + jj] = w->data.data() + (size_t)(De + j) * D; bias[jb * 64 + 32 + jj] = bb->data[De + j];
             }
             if (!pack_linear(e, rows, bias, D, &W.pw1)) return fail("upload failed");
+            if (chain_supported(D)) {
+                if (!pack_linear(e, rows, bias, D, &W.c_pw1, true)) return fail("upload failed");
+                W.c_pw1_chunks = nblk;
+            }
         }
         {   // depthwise (De, 1, k) + BatchNorm1d fold -> [k][De] fp32
             const int ks = b.kernel_size;
@@ -802,6 +910,7 @@ int effconf_ctc_greedy(EcEncoder* e, const float* enc_out, const int64_t* out_le
 int effconf_encoder_set_option(EcEncoder* e, const char* name, int32_t value) {
     if (!e || !name) return fail("null argument");
     if (!strcmp(name, "fuse_subsample")) { e->fuse_subsample = value != 0; return 0; }
+    if (!strcmp(name, "fuse_chain")) { e->fuse_chain = value != 0; return 0; }
     if (!strcmp(name, "cache_pos_embeddings")) { e->e_cache_on = value != 0; e->e_cache_ws = nullptr; e->e_cache_tm = -1; return 0; }
     return fail(std::string("unknown option ") + name);
 }

@@ -58,6 +58,29 @@ int launch_rs_gemm(const GemmParams& p, int epi, hipStream_t s);
 bool ffn_fused_supported(int D);
 int launch_ffn_fused(const FfnParams& p, hipStream_t s);
 
+
+// ---------------------------------------------------------------- fused row-local chains  (chain.hip)
+// One kernel runs a whole row-local stretch of the Conformer block on a 32-row tile per wave, the fp32 residual row staying in
+// registers between GEMMs (see chain.hip).  All weights are K-permuted per 16 (pack_linear_kperm), rows padded to 64.
+struct ChainGemm { const bf16_t* w; int ldw; const float* bias; int nchunks; };        // nchunks = 64-row chunks
+struct ChainFfn { const bf16_t* w1; int ldw1; const float* b1; const bf16_t* w2; int ldw2; const float* b2; int Fp; };   // w2, b2 pre-scaled by 1/2
+struct ChainLn { const float* g; const float* b; };
+struct ChainParams {
+    int M, D;
+    const float* X; int ldx;            // residual stream in
+    float* Y; int ldy;                  // residual stream out (may alias X)
+    const bf16_t* A; int lda;           // bf16 activation feeding g0 (depthwise-conv output / attention output)
+    ChainGemm g0;                       // pointwise-2 or attention output projection: x += g0(A)
+    ChainLn ln[4];                      // chain A: ffn2 pre-norm, block norm, ffn1 pre-norm, attention pre-norm; chain B: [0] = conv-module norm
+    ChainFfn f[2];                      // chain A: ffn2, ffn1 (of the next block)
+    ChainGemm g1;                       // chain A: stacked QKV (natural layout, chunk-permuted rows); chain B: pointwise-1 (a|b interleaved per 32)
+    bf16_t *qu, *qv, *kh, *vt; const float *u, *v; int T, Tp;     // QKV outputs: rows (b, t) -> (b*Tp + t)*D
+    bf16_t* glu; int ldg, Ng;           // GLU output [M][ldg], Ng channels
+};
+enum { CHAIN_B = 0, CHAIN_A_FULL = 1, CHAIN_A_HEAD = 2, CHAIN_A_TAIL = 3 };   // HEAD: first block (no previous tail); TAIL: last block (no next head)
+bool chain_supported(int D);
+int launch_chain(const ChainParams& p, int kind, hipStream_t s);
+
 // ---------------------------------------------------------------- normalisation / casts  (norm.hip)
 // y = LayerNorm(x) over the last dim (eps 1e-6), two-pass fp32 statistics, one wave per row.
 // out_bf16 (ld = round_up(D,8), pad columns zeroed) and/or out_f32 (ld = D) may be null.
