@@ -79,37 +79,43 @@ __device__ __forceinline__ void ln_stats(const f32x16 (&xc)[NT], int D, float& m
     var += __shfl_xor(var, 32);
     var -= (float)(32 * NT - D) * mean * mean;           // the zero pad columns contributed (0 - mean)^2 each
     rstd = rsqrtf(fmaxf(var, 0.f) / (float)D + 1e-6f);
+    // opaque copy: keeps the compiler from carrying all (x - mean) differences of the variance pass into the normalisation
+    // (64-128 extra live registers pushed loop-invariant addresses into scratch, and scratch reloads share the vmcnt FIFO with
+    // the weight DMAs: every reload in a chunk loop waited for the whole prefetch queue)
+    asm volatile("" : "+v"(mean));
 }
-// xf = bf16(LayerNorm(xc)) as the K-permuted B fragments of the next GEMM; gamma / beta zero padded (pad columns -> 0)
+// xf = bf16((xc - mean) * rstd) as the K-permuted B fragments of the next GEMM.  The LayerNorm's gamma / beta are folded into that
+// GEMM at pack time (W diag(gamma), b + W beta), so the pre-norms cost no loads; pad columns become -mean*rstd but meet zero
+// weight columns
 template <int KS>
-__device__ __forceinline__ void ln_frags(const f32x16 (&xc)[KS / 2], float mean, float rstd, const float* sg, const float* sb, int half,
-                                         bf16x8 (&xf)[KS]) {
+__device__ __forceinline__ void norm_frags(const f32x16 (&xc)[KS / 2], float mean, float rstd, bf16x8 (&xf)[KS]) {
+    const float nm = -mean * rstd;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-        uint32_t w[4];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = 32 * (s >> 1) + 8 * (2 * (s & 1) + j) + 4 * half;
-            const float4 g = *reinterpret_cast<const float4*>(sg + col), b = *reinterpret_cast<const float4*>(sb + col);
-            const int r = 8 * (s & 1) + 4 * j;
-            w[2 * j + 0] = pack_bf2((xc[s >> 1][r + 0] - mean) * rstd * g.x + b.x, (xc[s >> 1][r + 1] - mean) * rstd * g.y + b.y);
-            w[2 * j + 1] = pack_bf2((xc[s >> 1][r + 2] - mean) * rstd * g.z + b.z, (xc[s >> 1][r + 3] - mean) * rstd * g.w + b.w);
-        }
-        xf[s] = as_bf16x8(make_uint4(w[0], w[1], w[2], w[3]));
+        const int r = 8 * (s & 1);
+        xf[s] = as_bf16x8(make_uint4(pack_bf2(fmaf(xc[s >> 1][r + 0], rstd, nm), fmaf(xc[s >> 1][r + 1], rstd, nm)),
+                                     pack_bf2(fmaf(xc[s >> 1][r + 2], rstd, nm), fmaf(xc[s >> 1][r + 3], rstd, nm)),
+                                     pack_bf2(fmaf(xc[s >> 1][r + 4], rstd, nm), fmaf(xc[s >> 1][r + 5], rstd, nm)),
+                                     pack_bf2(fmaf(xc[s >> 1][r + 6], rstd, nm), fmaf(xc[s >> 1][r + 7], rstd, nm))));
     }
 }
 template <int NT>
 __device__ __forceinline__ void ln_inplace(f32x16 (&xc)[NT], float mean, float rstd, const float* sg, const float* sb, int half) {
+    int ofs = 4 * half;
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NT; ++t) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float4 g = *reinterpret_cast<const float4*>(sg + 32 * t + 8 * q + 4 * half), b = *reinterpret_cast<const float4*>(sb + 32 * t + 8 * q + 4 * half);
+            const float4 g = *reinterpret_cast<const float4*>(sg + ofs + 32 * t + 8 * q), b = *reinterpret_cast<const float4*>(sb + ofs + 32 * t + 8 * q);
             xc[t][4 * q + 0] = (xc[t][4 * q + 0] - mean) * rstd * g.x + b.x;
             xc[t][4 * q + 1] = (xc[t][4 * q + 1] - mean) * rstd * g.y + b.y;
             xc[t][4 * q + 2] = (xc[t][4 * q + 2] - mean) * rstd * g.z + b.z;
             xc[t][4 * q + 3] = (xc[t][4 * q + 3] - mean) * rstd * g.w + b.w;
         }
+        // the next tile's gamma / beta addresses depend on this tile's last result: keeps the compiler from hoisting every read
+        // of the row to the top (2 x 16 x NT live registers on top of the row itself)
+        asm volatile("" : "+v"(ofs) : "v"(xc[t][15]));
+    }
 }
 
 // ---- global <-> registers through the staging region ----------------------------------------------------------------------
@@ -249,15 +255,20 @@ __global__ __launch_bounds__(NW * 64) void chain_kernel(const ChainDev cd) {
             }
         }
     };
+    // Ring protocol.  Barrier k (the k-th call of advance()) guarantees: chunks <= k+1 have landed for everybody, and everybody
+    // is done with chunk k-1, whose buffer is refilled right after it.  Waiting one chunk AHEAD lets half of the waves run their
+    // FFN iterations one phase late (barrier between Swish and the second GEMM instead of before the first, see ffn_stage):
+    // the two waves sharing a SIMD then alternate between the MFMA pipe and the VALU instead of competing for the same one.
     int gc = 0;                                            // next chunk to consume
     auto advance = [&]() __attribute__((always_inline)) -> const char* {
-        wait_chunks<PER, NBUF - 2>(total - 1 - gc);        // chunk gc has landed (this wave's pieces)
-        wg_barrier();                                      // ... and everybody's; everybody is done with chunk gc-1
+        wait_chunks<PER, NBUF - 3>(total - 2 - gc);        // chunk gc+1 has landed (this wave's pieces)
+        wg_barrier();
         if (gc + NBUF - 1 < total) issue(gc + NBUF - 1);
         const char* buf = smem + (gc % NBUF) * BUF;
         ++gc;
         return buf;
     };
+    const bool late = (NW == 8) && wave >= NW / 2;         // waves w and w + 4 share a SIMD
 
     // ---- constants -> LDS (zero padded so that pad columns stay exactly zero through every stage)
     float* s_b0 = sf + cd.nf[0];                           // g0 bias [DP]
@@ -269,12 +280,10 @@ __global__ __launch_bounds__(NW * 64) void chain_kernel(const ChainDev cd) {
     float* s_g1b = sf + cd.nf[6];                          // g1 bias [64 * n_g1]
     float* s_uv = sf + cd.nf[7];                           // u [DP] | v [DP]
     constexpr int DP = G::DP;
-    constexpr int NLN = ISB ? 1 : 4;
     if (ISB || PRE) for (int i = tid; i < DP; i += NTHR) s_b0[i] = i < D ? p.g0.bias[i] : 0.f;
-    for (int i = tid; i < NLN * 2 * DP; i += NTHR) {
-        const int l = i / (2 * DP), j = i - l * 2 * DP, col = j < DP ? j : j - DP;
-        const bool used = ISB ? true : ((l < 2) ? PRE : POST);
-        s_ln[i] = (used && col < D) ? (j < DP ? p.ln[l].g[col] : p.ln[l].b[col]) : 0.f;
+    if (PRE) for (int i = tid; i < 2 * DP; i += NTHR) {     // block norm (the only LayerNorm whose gamma / beta are not folded into a weight)
+        const int col = i < DP ? i : i - DP;
+        s_ln[i] = col < D ? (i < DP ? p.ln[1].g[col] : p.ln[1].b[col]) : 0.f;
     }
     if (PRE) {
         for (int i = tid; i < p.f[0].Fp; i += NTHR) s_f0b1[i] = p.f[0].b1[i];
@@ -297,6 +306,12 @@ __global__ __launch_bounds__(NW * 64) void chain_kernel(const ChainDev cd) {
     bf16x8 xf[KS];
     load_x<NT, 0>(reinterpret_cast<const char*>(p.X), (size_t)p.ldx * 4, D, m_base, p.M, stg, lane, xc);
     if constexpr (ISB || PRE) load_a<KS, 0>(reinterpret_cast<const char*>(p.A), (size_t)p.lda * 2, p.lda * 2, D, m_base, p.M, stg, lane, xf);
+
+    // chunk 0 visible to everybody before anyone's first GEMM (a late wave reads a chunk before its own barrier for it)
+    if constexpr (NW == 8) {
+        if (total >= NBUF) wait_vmcnt<PER * (NBUF - 2)>(); else wait_vmcnt<0>();
+        wg_barrier();
+    }
 
     const int q0 = (half + lr) % P1;
     const int w1row = lr * (P1 * 16);
@@ -332,13 +347,13 @@ __global__ __launch_bounds__(NW * 64) void chain_kernel(const ChainDev cd) {
     }
 
     // ---- FFN stage: x += 1/2 FFN(LN(x))  (the 1/2 lives in W2 / b2)
-    auto ffn_stage = [&](const float* sg, const float* sb, const float* sb1, const float* sb2, int nchunks) __attribute__((always_inline)) {
+    auto ffn_stage = [&](const float* sb1, const float* sb2, int nchunks) __attribute__((always_inline)) {
         float mean, rstd;
         ln_stats<NT>(xc, D, mean, rstd);
-        ln_frags<KS>(xc, mean, rstd, sg, sb, half, xf);
+        norm_frags<KS>(xc, mean, rstd, xf);
         add_cvec<NT>(xc, sb2, half);
         for (int c = 0; c < nchunks; ++c) {
-            const char* buf = advance();
+            const char* buf = late ? smem + (gc % NBUF) * BUF : advance();
             const float* b1 = sb1 + c * CH + 4 * half;
             f32x16 h;
 #pragma unroll
@@ -346,7 +361,7 @@ __global__ __launch_bounds__(NW * 64) void chain_kernel(const ChainDev cd) {
                 const float4 v = *reinterpret_cast<const float4*>(b1 + 8 * q);
                 h[4 * q + 0] = v.x; h[4 * q + 1] = v.y; h[4 * q + 2] = v.z; h[4 * q + 3] = v.w;
             }
-            constexpr int FB = (KS % 8 == 0) ? 8 : ((KS % 4 == 0) ? 4 : KS);
+            constexpr int FB = (KS % 4 == 0) ? 4 : KS;
 #pragma unroll
             for (int s0 = 0; s0 < KS; s0 += FB) {
                 bf16x8 wa[FB];
@@ -359,8 +374,9 @@ __global__ __launch_bounds__(NW * 64) void chain_kernel(const ChainDev cd) {
 #pragma unroll
             for (int r = 0; r < 16; r += 2) w[r >> 1] = pack_bf2(swishf_(h[r]), swishf_(h[r + 1]));
             const bf16x8 hf0 = as_bf16x8(make_uint4(w[0], w[1], w[2], w[3])), hf1 = as_bf16x8(make_uint4(w[4], w[5], w[6], w[7]));
+            if (late) (void)advance();
             const char* w2 = buf + HALF;
-            constexpr int TB = (NT % 4 == 0) ? 4 : ((NT % 2 == 0) ? 2 : 1);
+            constexpr int TB = (NT % 2 == 0) ? 2 : 1;
 #pragma unroll
             for (int t0 = 0; t0 < NT; t0 += TB) {
                 bf16x8 wb[TB][2];
@@ -382,7 +398,7 @@ __global__ __launch_bounds__(NW * 64) void chain_kernel(const ChainDev cd) {
         // ---- conv-module pre-norm, pointwise-1 + GLU -> bf16 rows (modules.py:512-514)
         float mean, rstd;
         ln_stats<NT>(xc, D, mean, rstd);
-        ln_frags<KS>(xc, mean, rstd, s_ln, s_ln + DP, half, xf);
+        norm_frags<KS>(xc, mean, rstd, xf);
         for (int c = 0; c < n_g1; ++c) {
             const char* buf = advance();
             f32x16 acc[2];
@@ -425,16 +441,16 @@ __global__ __launch_bounds__(NW * 64) void chain_kernel(const ChainDev cd) {
         }
     } else {
         if constexpr (PRE) {
-            ffn_stage(s_ln, s_ln + DP, s_f0b1, s_f0b2, n_f0);                       // FFN2 of the previous block
+            ffn_stage(s_f0b1, s_f0b2, n_f0);                                        // FFN2 of the previous block
             float mean, rstd;
             ln_stats<NT>(xc, D, mean, rstd);
-            ln_inplace<NT>(xc, mean, rstd, s_ln + 2 * DP, s_ln + 3 * DP, half);     // block output = LayerNorm(x)  (blocks.py:135)
+            ln_inplace<NT>(xc, mean, rstd, s_ln, s_ln + DP, half);                  // block output = LayerNorm(x)  (blocks.py:135)
         }
         if constexpr (POST) {
-            ffn_stage(s_ln + 4 * DP, s_ln + 5 * DP, s_f1b1, s_f1b2, n_f1);          // FFN1 of this block
+            ffn_stage(s_f1b1, s_f1b2, n_f1);                                        // FFN1 of this block
             float mean, rstd;
             ln_stats<NT>(xc, D, mean, rstd);
-            ln_frags<KS>(xc, mean, rstd, s_ln + 6 * DP, s_ln + 7 * DP, half, xf);   // attention pre-norm
+            norm_frags<KS>(xc, mean, rstd, xf);                                     // attention pre-norm
             // x is final here (the Q/K/V projection only reads it): store it now so that its registers are free during the last stage
             store_x<NT, 0>(reinterpret_cast<char*>(p.Y), (size_t)p.ldy * 4, D, m_base, p.M, stg, lane, xc);
             // destination row offsets of the 4 rows this lane stores per window instruction: (b, t) -> (b*Tp + t)*D
@@ -511,7 +527,7 @@ inline int chain_float_layout(const ChainParams& p, int kind, int DP, int (&nf)[
     const bool isb = kind == CHAIN_B, pre = kind == CHAIN_A_FULL || kind == CHAIN_A_TAIL, post = kind == CHAIN_A_FULL || kind == CHAIN_A_HEAD;
     int o = 0;
     nf[0] = o; o += (isb || pre) ? DP : 0;
-    nf[1] = o; o += (isb ? 1 : 4) * 2 * DP;
+    nf[1] = o; o += pre ? 2 * DP : 0;
     nf[2] = o; o += pre ? p.f[0].Fp : 0;
     nf[3] = o; o += pre ? DP : 0;
     nf[4] = o; o += post ? p.f[1].Fp : 0;
@@ -555,6 +571,9 @@ int launch_chain_kind(const ChainParams& p, hipStream_t s) {
 
 // D % 8 == 0: 16-byte bf16 pieces never straddle the Q | K | V boundaries; D <= 256: the residual row fits the register file
 bool chain_supported(int D) { return D % 8 == 0 && D >= 16 && D <= 256; }
+// the FFN1 + Q/K/V half keeps more state live (Q/K/V accumulators, staging, row offsets): at KS = 16 it does not fit the register
+// file without spills, and a scratch reload inside a DMA-ring loop serialises the whole prefetch queue (shared vmcnt FIFO)
+bool chain_head_supported(int D) { return chain_supported(D) && D <= 192; }
 
 int launch_chain(const ChainParams& p, int kind, hipStream_t s) {
     if (p.M <= 0) return 0;

@@ -106,35 +106,44 @@ const HostTensor* find(EcEncoder* e, const std::string& k) {
 // [N][K] fp32 (row-major, possibly a gather of rows given by `rows`) -> padded bf16 + padded bias
 // kperm: K index permuted inside every group of 16 (packed position 8h+e holds column 4h + 8(e>>2) + (e&3)): the B fragments of
 // chain.hip are LayerNorm-ed accumulator registers in MFMA C order
+// ln_g / ln_b: a LayerNorm in front of this linear layer folded in: W diag(gamma), b + W beta (fp32, before the bf16 rounding)
 bool pack_linear(EcEncoder* e, const std::vector<const float*>& row_ptr, const std::vector<float>& bias, int K, PackedLinear* out,
-                 bool kperm = false) {
+                 bool kperm = false, const float* ln_g = nullptr, const float* ln_b = nullptr) {
     const int N = (int)row_ptr.size();
     const int Np = ec_round_up(N, 128), Kp = ec_round_up(K, 64);
     std::vector<uint16_t> w((size_t)Np * Kp, 0);
+    std::vector<float> b(Np, 0.f);
+    for (int n = 0; n < N && n < (int)bias.size(); ++n) b[n] = bias[n];
     for (int n = 0; n < N; ++n) {
         if (!row_ptr[n]) continue;
         for (int k = 0; k < Kp; ++k) {
             int src = k;
             if (kperm) { const int g = k / 16, pp = k % 16, hh = pp >> 3, ee = pp & 7; src = g * 16 + 4 * hh + 8 * (ee >> 2) + (ee & 3); }
-            if (src < K) w[(size_t)n * Kp + k] = h_f2bf(row_ptr[n][src]);
+            if (src < K) w[(size_t)n * Kp + k] = h_f2bf(row_ptr[n][src] * (ln_g ? ln_g[src] : 1.0f));
+        }
+        if (ln_b) {
+            double acc = 0.0;
+            for (int k = 0; k < K; ++k) acc += (double)row_ptr[n][k] * ln_b[k];
+            b[n] += (float)acc;
         }
     }
-    std::vector<float> b(Np, 0.f);
-    for (int n = 0; n < N && n < (int)bias.size(); ++n) b[n] = bias[n];
     out->w = upload(e, w);
     out->bias = upload(e, b);
     out->N = N; out->K = K; out->ldw = Kp;
     return out->w && out->bias;
 }
 
-bool pack_named_linear(EcEncoder* e, const std::string& prefix, int N, int K, PackedLinear* out, std::string* err, bool kperm = false) {
+bool pack_named_linear(EcEncoder* e, const std::string& prefix, int N, int K, PackedLinear* out, std::string* err, bool kperm = false,
+                       const std::string& fold_ln = "") {
     const HostTensor* w = find(e, prefix + ".weight");
     const HostTensor* b = find(e, prefix + ".bias");
     if (!w || !b) { *err = "missing tensor " + prefix + ".weight/.bias"; return false; }
     if ((int64_t)w->data.size() != (int64_t)N * K || (int)b->data.size() != N) { *err = "shape mismatch for " + prefix; return false; }
     std::vector<const float*> rows(N);
     for (int n = 0; n < N; ++n) rows[n] = w->data.data() + (size_t)n * K;
-    return pack_linear(e, rows, b->data, K, out, kperm);
+    const HostTensor *lg = fold_ln.empty() ? nullptr : find(e, fold_ln + ".weight"), *lb = fold_ln.empty() ? nullptr : find(e, fold_ln + ".bias");
+    if (!fold_ln.empty() && (!lg || !lb || (int)lg->data.size() != K || (int)lb->data.size() != K)) { *err = "missing LayerNorm " + fold_ln; return false; }
+    return pack_linear(e, rows, b->data, K, out, kperm, lg ? lg->data.data() : nullptr, lb ? lb->data.data() : nullptr);
 }
 
 // second FFN weight [D][F] with the hidden (K) index permuted inside every group of 16 so that the first GEMM's
@@ -459,9 +468,9 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
         // Q/K/V/E layout: "natural" row-major [B*Tp][D] (16-byte row stores from the GEMM, head split = pointer arithmetic in
         // the attention kernel) whenever the grouped head dim d is even (4-byte aligned head spans); head-major otherwise
         const bool nat = (d % 2) == 0;
-        const bool chain_head = e->fuse_chain && W.chain_in && nat;          // FFN1 + QKV of this block as a fused chain
+        const bool chain_head = e->fuse_chain && W.chain_in && nat && chain_head_supported(D);          // FFN1 + QKV of this block as a fused chain
         const bool chain_b = e->fuse_chain && W.chain_in;                      // out-proj + LN + pointwise-1/GLU
-        const bool chain_tail = e->fuse_chain && W.chain_out;                  // pointwise-2 + FFN2 + block norm (+ next block's head)
+        const bool chain_tail = e->fuse_chain && W.chain_out && chain_head_supported(De);                  // pointwise-2 + FFN2 + block norm (+ next block's head)
         GemmParams p{};
         p.A = a; p.lda = ld8(D); p.W = W.qkv.w; p.ldw = W.qkv.ldw; p.bias = W.qkv.bias;
         p.M = M; p.N = 3 * D; p.K = D;
@@ -558,7 +567,7 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
             bool next_head = false;
             if (!last) {
                 const EcBlock& nbk = e->blocks[k + 1];
-                next_head = e->bw[k + 1].chain_in && ((nbk.group_size * nbk.dim_model / nbk.num_heads) % 2) == 0 && nbk.dim_model == De;
+                next_head = e->bw[k + 1].chain_in && chain_head_supported(De) && ((nbk.group_size * nbk.dim_model / nbk.num_heads) % 2) == 0 && nbk.dim_model == De;
             }
             ChainParams cp{};
             cp.M = Mo; cp.D = De; cp.X = x; cp.ldx = De; cp.Y = xo; cp.ldy = De; cp.A = cbuf; cp.lda = ld8(De);
@@ -759,13 +768,14 @@ int effconf_encoder_finalize(EcEncoder* e) {
             if (!pack_linear(e, prow, pbias, D, &W.qkv_nat)) return fail("upload failed");
             W.qkv_nat.N = 3 * D;
             if (chain_supported(D)) {
-                if (!pack_linear(e, prow, pbias, D, &W.c_qkv, true)) return fail("upload failed");
+                const HostTensor *lg = find(e, m + ".norm.weight"), *lb = find(e, m + ".norm.bias");      // attention pre-norm folded in
+                if (!lg || !lb || !pack_linear(e, prow, pbias, D, &W.c_qkv, true, lg->data.data(), lb->data.data())) return fail("upload failed");
                 W.c_qkv_chunks = ec_cdiv(3 * D, 64);
             }
         }
         if (chain_supported(D)) {      // D-wide part of the block: FFN1, attention output projection (pointwise-1 below)
             const HostTensor* b2 = find(e, p + ".feed_forward_module1.layers.4.bias");
-            if (!b2 || !pack_named_linear(e, p + ".feed_forward_module1.layers.1", F1, D, &W.c_f1a, &err, true) ||
+            if (!b2 || !pack_named_linear(e, p + ".feed_forward_module1.layers.1", F1, D, &W.c_f1a, &err, true, p + ".feed_forward_module1.layers.0") ||
                 !pack_named_linear(e, m + ".mhsa.output_layer", D, D, &W.c_outp, &err, true)) return fail("chain packing failed: " + err);
             W.c_f1b = pack_ffn2_permuted(e, p + ".feed_forward_module1.layers.4", D, F1, 0.5f);
             std::vector<float> hb(b2->data); for (float& x : hb) x *= 0.5f;
@@ -775,7 +785,7 @@ int effconf_encoder_finalize(EcEncoder* e) {
         }
         if (chain_supported(De)) {     // De-wide part: pointwise-2, FFN2
             const HostTensor* b2 = find(e, p + ".feed_forward_module2.layers.4.bias");
-            if (!b2 || !pack_named_linear(e, p + ".feed_forward_module2.layers.1", F2, De, &W.c_f2a, &err, true) ||
+            if (!b2 || !pack_named_linear(e, p + ".feed_forward_module2.layers.1", F2, De, &W.c_f2a, &err, true, p + ".feed_forward_module2.layers.0") ||
                 !pack_named_linear(e, p + ".convolution_module.layers.7", De, De, &W.c_pw2, &err, true)) return fail("chain packing failed: " + err);
             W.c_f2b = pack_ffn2_permuted(e, p + ".feed_forward_module2.layers.4", De, F2, 0.5f);
             std::vector<float> hb(b2->data); for (float& x : hb) x *= 0.5f;
@@ -807,7 +817,8 @@ int effconf_encoder_finalize(EcEncoder* e) {
             }
             if (!pack_linear(e, rows, bias, D, &W.pw1)) return fail("upload failed");
             if (chain_supported(D)) {
-                if (!pack_linear(e, rows, bias, D, &W.c_pw1, true)) return fail("upload failed");
+                const HostTensor *lg = find(e, cm + ".0.weight"), *lb = find(e, cm + ".0.bias");          // conv-module pre-norm folded in
+                if (!lg || !lb || !pack_linear(e, rows, bias, D, &W.c_pw1, true, lg->data.data(), lb->data.data())) return fail("upload failed");
                 W.c_pw1_chunks = nblk;
             }
         }

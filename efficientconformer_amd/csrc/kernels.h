@@ -71,7 +71,7 @@ struct ChainParams {
     float* Y; int ldy;                  // residual stream out (may alias X)
     const bf16_t* A; int lda;           // bf16 activation feeding g0 (depthwise-conv output / attention output)
     ChainGemm g0;                       // pointwise-2 or attention output projection: x += g0(A)
-    ChainLn ln[4];                      // chain A: ffn2 pre-norm, block norm, ffn1 pre-norm, attention pre-norm; chain B: [0] = conv-module norm
+    ChainLn ln[4];                      // only ln[1] (block norm, applied in fp32) is read: the pre-norms' gamma / beta are folded into the following weights at pack time
     ChainFfn f[2];                      // chain A: ffn2, ffn1 (of the next block)
     ChainGemm g1;                       // chain A: stacked QKV (natural layout, chunk-permuted rows); chain B: pointwise-1 (a|b interleaved per 32)
     bf16_t *qu, *qv, *kh, *vt; const float *u, *v; int T, Tp;     // QKV outputs: rows (b, t) -> (b*Tp + t)*D
@@ -79,6 +79,7 @@ struct ChainParams {
 };
 enum { CHAIN_B = 0, CHAIN_A_FULL = 1, CHAIN_A_HEAD = 2, CHAIN_A_TAIL = 3 };   // HEAD: first block (no previous tail); TAIL: last block (no next head)
 bool chain_supported(int D);
+bool chain_head_supported(int D);
 int launch_chain(const ChainParams& p, int kind, hipStream_t s);
 
 // ---------------------------------------------------------------- normalisation / casts  (norm.hip)
