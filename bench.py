@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=128, help="utterances per GPU per step")
     ap.add_argument("--workload", default="libri", choices=["libri", "fixed"],
                     help="libri: lognormal LibriSpeech-shaped lengths (SURVEY.md 8d W-libri); fixed: 10 s each")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="run the batch as this many interleaved sub-batches (same padded length) on concurrent HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -156,7 +158,22 @@ def main():
     gather_buf = None
     side = torch.cuda.Stream(device=dev) if world > 1 else None
 
+    subs = None
+    if args.streams > 1:      # rows s::S keep every sub-batch length-balanced; all share the batch's padded length
+        subs = [(torch.cuda.Stream(device=dev), audio[i::args.streams].contiguous(), lens[i::args.streams].contiguous())
+                for i in range(args.streams)]
+
     def full_step():
+        if subs is not None:
+            cur = torch.cuda.current_stream(dev)
+            outs = []
+            for st, a_, l_ in subs:
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    outs.append(step(model, a_, l_))
+            for st, _, _ in subs:
+                cur.wait_stream(st)
+            return outs[0][2]
         enc, enc_len, labels, label_len = step(model, audio, lens)
         if world > 1:
             # all-gather of encoder outputs over RCCL/xGMI on a side stream, overlapped with the next step's kernels

@@ -28,6 +28,7 @@
 #include "kernels.h"
 #include "rowstat.h"
 
+#include <cstdio>
 #include <cstdlib>
 
 namespace {
@@ -45,7 +46,8 @@ struct Geo {
 struct ChainDev {
     ChainParams p;
     FastDiv32 fT, fD;
-    int nf[8];            // float offsets of the LDS constant arrays (see launch)
+    int nf[8];            // float offsets of the LDS constant arrays (see chain_const_layout)
+    int nfl_kb;           // size of the constant block in KiB (LDS-DMA pieces)
 };
 
 // ---- C-layout helpers -----------------------------------------------------------------------------------------------------
@@ -119,37 +121,37 @@ __device__ __forceinline__ void ln_inplace(f32x16 (&xc)[NT], float mean, float r
 }
 
 // ---- global <-> registers through the staging region ----------------------------------------------------------------------
-// residual rows -> xc (pairs of 64-column windows; pad columns zeroed)
+// one staged 64-column window of residual rows -> xc tiles 2W, 2W+1 (pad columns zeroed)
+template <int NT, int W, int OFF, int N>
+__device__ __forceinline__ void take_x(char* stg, int lane, int D, const u32x4 (&v)[N], f32x16 (&xc)[NT]) {
+    const int lr = lane & 31, half = lane >> 5;
+    wave_sync();
+    stage_put<OFF>(stg, lane, v);
+    wave_sync();
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const int t = 2 * W + tt;
+        if (t < NT) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int col = 32 * t + 8 * q + 4 * half;
+                float4 x4 = *reinterpret_cast<const float4*>(stg + lr * STG_ROW + (tt * 32 + q * 8 + half * 4) * 4);
+                if (col >= D) x4 = make_float4(0.f, 0.f, 0.f, 0.f);      // D % 4 == 0: a piece is valid or not as a whole
+                xc[t][4 * q + 0] = x4.x; xc[t][4 * q + 1] = x4.y; xc[t][4 * q + 2] = x4.z; xc[t][4 * q + 3] = x4.w;
+            }
+        }
+    }
+}
+// residual rows -> xc, windows W0, W0+1, ... (pairs fetched together)
 template <int NT, int W0>
 __device__ __forceinline__ void load_x(const char* xb, size_t pitch, int D, int m_base, int M, char* stg, int lane, f32x16 (&xc)[NT]) {
     constexpr int NWIN = (NT + 1) / 2;
     if constexpr (W0 < NWIN) {
-        const int lr = lane & 31, half = lane >> 5;
         u32x4 v[16] = {};
         stage_load<0>(xb, pitch, D * 4, m_base, M, 256 * W0, lane, v);
         if constexpr (W0 + 1 < NWIN) stage_load<8>(xb, pitch, D * 4, m_base, M, 256 * (W0 + 1), lane, v);
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            if (W0 + k < NWIN) {
-                wave_sync();
-                if (k == 0) stage_put<0>(stg, lane, v);
-                else stage_put<8>(stg, lane, v);
-                wave_sync();
-#pragma unroll
-                for (int tt = 0; tt < 2; ++tt) {
-                    const int t = 2 * (W0 + k) + tt;
-                    if (t < NT) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const int col = 32 * t + 8 * q + 4 * half;
-                            float4 x4 = *reinterpret_cast<const float4*>(stg + lr * STG_ROW + (tt * 32 + q * 8 + half * 4) * 4);
-                            if (col >= D) x4 = make_float4(0.f, 0.f, 0.f, 0.f);      // D % 4 == 0: a piece is valid or not as a whole
-                            xc[t][4 * q + 0] = x4.x; xc[t][4 * q + 1] = x4.y; xc[t][4 * q + 2] = x4.z; xc[t][4 * q + 3] = x4.w;
-                        }
-                    }
-                }
-            }
-        }
+        take_x<NT, W0, 0>(stg, lane, D, v, xc);
+        if constexpr (W0 + 1 < NWIN) take_x<NT, W0 + 1, 8>(stg, lane, D, v, xc);
         load_x<NT, W0 + 2>(xb, pitch, D, m_base, M, stg, lane, xc);
     }
 }
@@ -176,33 +178,42 @@ __device__ __forceinline__ void store_x(char* yb, size_t pitch, int D, int m_bas
 }
 // bf16 rows (natural column order) -> K-permuted B fragments: k-step s of half h = columns 16s + 4h + {0..3} and 16s + 8 + 4h + {0..3}
 template <int KS, int W>
+__device__ __forceinline__ void take_a(char* stg, int lane, int D, int m_base, int M, const u32x4 (&v)[8], bf16x8 (&xf)[KS]) {
+    const int lr = lane & 31, half = lane >> 5;
+    wave_sync();
+    stage_put<0>(stg, lane, v);
+    wave_sync();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int s = 8 * W + j;
+        if (s < KS) {
+            const char* src = stg + lr * STG_ROW + (16 * j + 4 * half) * 2;
+            uint2 lo = *reinterpret_cast<const uint2*>(src), hi = *reinterpret_cast<const uint2*>(src + 16);
+            const int c0 = 16 * s + 4 * half;           // D % 4 == 0: each 4-column piece is valid or not as a whole
+            if (c0 >= D || m_base + lr >= M) lo = make_uint2(0u, 0u);
+            if (c0 + 8 >= D || m_base + lr >= M) hi = make_uint2(0u, 0u);
+            xf[s] = as_bf16x8(make_uint4(lo.x, lo.y, hi.x, hi.y));
+        }
+    }
+}
+template <int KS, int W>
 __device__ __forceinline__ void load_a(const char* ab, size_t pitch, int row_bytes, int D, int m_base, int M, char* stg, int lane, bf16x8 (&xf)[KS]) {
     constexpr int NWIN = (KS + 7) / 8;                  // 128 columns per window
     if constexpr (W < NWIN) {
-        const int lr = lane & 31, half = lane >> 5;
         u32x4 v[8] = {};
         stage_load<0>(ab, pitch, row_bytes, m_base, M, 256 * W, lane, v);
-        wave_sync();
-        stage_put<0>(stg, lane, v);
-        wave_sync();
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int s = 8 * W + j;
-            if (s < KS) {
-                const char* src = stg + lr * STG_ROW + (16 * j + 4 * half) * 2;
-                uint2 lo = *reinterpret_cast<const uint2*>(src), hi = *reinterpret_cast<const uint2*>(src + 16);
-                const int c0 = 16 * s + 4 * half;           // D % 4 == 0: each 4-column piece is valid or not as a whole
-                if (c0 >= D || m_base + lr >= M) lo = make_uint2(0u, 0u);
-                if (c0 + 8 >= D || m_base + lr >= M) hi = make_uint2(0u, 0u);
-                xf[s] = as_bf16x8(make_uint4(lo.x, lo.y, hi.x, hi.y));
-            }
-        }
+        take_a<KS, W>(stg, lane, D, m_base, M, v, xf);
         load_a<KS, W + 1>(ab, pitch, row_bytes, D, m_base, M, stg, lane, xf);
     }
 }
 
-template <int KS, int NW, int NBUF, int KIND>
-__global__ __launch_bounds__(NW * 64) void chain_kernel(const ChainDev cd) {
+// PROF (tuning only, EFFCONF_CHAIN_PHASES=1, KS = 8 full chain): s_memtime per phase of the FFN stages -
+// 0 advance (DMA wait + barrier + refill), 1 GEMM1, 2 Swish, 3 GEMM2, 4 everything else, 5 waves
+template <int KS, int NW, int NBUF, int KIND, bool PROF = false>
+__global__ __launch_bounds__(NW * 64) void chain_kernel(const ChainDev cd, unsigned long long* prof = nullptr) {
+    unsigned long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0;
+    if constexpr (PROF) t0 = __builtin_readcyclecounter();
+#define CH_TICK(i) do { if constexpr (PROF) { asm volatile("" ::: "memory"); const unsigned long long t1_ = __builtin_readcyclecounter(); ph[i] += t1_ - t0; t0 = t1_; } } while (0)
     using G = Geo<KS>;
     constexpr int NT = G::NT, P1 = G::P1, HALF = G::HALF, BUF = G::BUF;
     constexpr bool ISB = KIND == CHAIN_B;
@@ -259,9 +270,16 @@ __global__ __launch_bounds__(NW * 64) void chain_kernel(const ChainDev cd) {
     // is done with chunk k-1, whose buffer is refilled right after it.  Waiting one chunk AHEAD lets half of the waves run their
     // FFN iterations one phase late (barrier between Swish and the second GEMM instead of before the first, see ffn_stage):
     // the two waves sharing a SIMD then alternate between the MFMA pipe and the VALU instead of competing for the same one.
-    int gc = 0;                                            // next chunk to consume
+    // Global stores issued between barriers (st1: since the last advance, st2: the interval before) sit in the same in-order
+    // vmcnt FIFO as the DMAs: they are younger than the chunk being waited for, so they are simply allowed to stay outstanding
+    // (waiting for them — i.e. for HBM write acknowledgements — cost ~10k cycles per Q/K/V chunk: s_memtime profile).
+    int gc = 0, st1 = 0, st2 = 0;                          // next chunk to consume; store instructions in flight
     auto advance = [&]() __attribute__((always_inline)) -> const char* {
-        wait_chunks<PER, NBUF - 3>(total - 2 - gc);        // chunk gc+1 has landed (this wave's pieces)
+        int ahead = total - 2 - gc;                        // chunks issued beyond gc+1
+        ahead = ahead < 0 ? 0 : (ahead > NBUF - 3 ? NBUF - 3 : ahead);
+        if (st1 + st2 == 0) wait_chunks<PER, NBUF - 3>(total - 2 - gc);        // chunk gc+1 has landed (this wave's pieces)
+        else wait_vmcnt_dyn(PER * ahead + st1 + (NBUF >= 4 ? st2 : 0));
+        st2 = st1; st1 = 0;
         wg_barrier();
         if (gc + NBUF - 1 < total) issue(gc + NBUF - 1);
         const char* buf = smem + (gc % NBUF) * BUF;
@@ -280,22 +298,9 @@ __global__ __launch_bounds__(NW * 64) void chain_kernel(const ChainDev cd) {
     float* s_g1b = sf + cd.nf[6];                          // g1 bias [64 * n_g1]
     float* s_uv = sf + cd.nf[7];                           // u [DP] | v [DP]
     constexpr int DP = G::DP;
-    if (ISB || PRE) for (int i = tid; i < DP; i += NTHR) s_b0[i] = i < D ? p.g0.bias[i] : 0.f;
-    if (PRE) for (int i = tid; i < 2 * DP; i += NTHR) {     // block norm (the only LayerNorm whose gamma / beta are not folded into a weight)
-        const int col = i < DP ? i : i - DP;
-        s_ln[i] = col < D ? (i < DP ? p.ln[1].g[col] : p.ln[1].b[col]) : 0.f;
-    }
-    if (PRE) {
-        for (int i = tid; i < p.f[0].Fp; i += NTHR) s_f0b1[i] = p.f[0].b1[i];
-        for (int i = tid; i < DP; i += NTHR) s_f0b2[i] = i < D ? p.f[0].b2[i] : 0.f;
-    }
-    if (POST) {
-        for (int i = tid; i < p.f[1].Fp; i += NTHR) s_f1b1[i] = p.f[1].b1[i];
-        for (int i = tid; i < DP; i += NTHR) s_f1b2[i] = i < D ? p.f[1].b2[i] : 0.f;
-        for (int i = tid; i < 2 * DP; i += NTHR) { const int col = i < DP ? i : i - DP; s_uv[i] = col < D ? (i < DP ? p.u[col] : p.v[col]) : 0.f; }
-    }
-    if (ISB || POST) for (int i = tid; i < 64 * n_g1; i += NTHR) s_g1b[i] = p.g1.bias[i];
-    __syncthreads();
+    // one contiguous, zero padded block prepared at pack time (chain_const_layout): fire-and-forget LDS-DMA, visible after the
+    // first barrier below
+    for (int i = wave; i < cd.nfl_kb; i += NW) glds16(reinterpret_cast<const char*>(p.consts) + (size_t)i * 1024 + lane * 16, reinterpret_cast<char*>(sf) + i * 1024);
 
 #pragma unroll
     for (int c = 0; c < NBUF - 1; ++c)
@@ -304,14 +309,27 @@ __global__ __launch_bounds__(NW * 64) void chain_kernel(const ChainDev cd) {
     // ---- this wave's rows
     f32x16 xc[NT];
     bf16x8 xf[KS];
-    load_x<NT, 0>(reinterpret_cast<const char*>(p.X), (size_t)p.ldx * 4, D, m_base, p.M, stg, lane, xc);
-    if constexpr (ISB || PRE) load_a<KS, 0>(reinterpret_cast<const char*>(p.A), (size_t)p.lda * 2, p.lda * 2, D, m_base, p.M, stg, lane, xf);
+    if constexpr (ISB || PRE) {
+        // first windows of x and A fetched together (one HBM latency instead of two), the rest by the generic loaders
+        const char* xb = reinterpret_cast<const char*>(p.X);
+        const char* ab = reinterpret_cast<const char*>(p.A);
+        constexpr int NWX = (NT + 1) / 2;
+        u32x4 vx[16] = {}, va[8] = {};
+        stage_load<0>(xb, (size_t)p.ldx * 4, D * 4, m_base, p.M, 0, lane, vx);
+        if constexpr (NWX > 1) stage_load<8>(xb, (size_t)p.ldx * 4, D * 4, m_base, p.M, 256, lane, vx);
+        stage_load<0>(ab, (size_t)p.lda * 2, p.lda * 2, m_base, p.M, 0, lane, va);
+        take_x<NT, 0, 0>(stg, lane, D, vx, xc);
+        if constexpr (NWX > 1) take_x<NT, 1, 8>(stg, lane, D, vx, xc);
+        take_a<KS, 0>(stg, lane, D, m_base, p.M, va, xf);
+        load_x<NT, 2>(xb, (size_t)p.ldx * 4, D, m_base, p.M, stg, lane, xc);
+        load_a<KS, 1>(ab, (size_t)p.lda * 2, p.lda * 2, D, m_base, p.M, stg, lane, xf);
+    } else {
+        load_x<NT, 0>(reinterpret_cast<const char*>(p.X), (size_t)p.ldx * 4, D, m_base, p.M, stg, lane, xc);
+    }
 
     // chunk 0 visible to everybody before anyone's first GEMM (a late wave reads a chunk before its own barrier for it)
-    if constexpr (NW == 8) {
-        if (total >= NBUF) wait_vmcnt<PER * (NBUF - 2)>(); else wait_vmcnt<0>();
-        wg_barrier();
-    }
+    if (total >= NBUF) wait_vmcnt<PER * (NBUF - 2)>(); else wait_vmcnt<0>();     // (also covers the constant block, issued first)
+    wg_barrier();
 
     const int q0 = (half + lr) % P1;
     const int w1row = lr * (P1 * 16);
@@ -323,6 +341,7 @@ __global__ __launch_bounds__(NW * 64) void chain_kernel(const ChainDev cd) {
     const int k2 = (half + (lr >> 2)) & 3;
     const int w2off0 = lr * 64 + k2 * 16, w2off1 = lr * 64 + (k2 ^ 2) * 16;
 
+    CH_TICK(5);
     // ---- stage: x += g0(A)   (alpha = 1: the accumulator starts at x + bias)
     if constexpr (ISB || PRE) {
         add_cvec<NT>(xc, s_b0, half);
@@ -346,6 +365,7 @@ __global__ __launch_bounds__(NW * 64) void chain_kernel(const ChainDev cd) {
         }
     }
 
+    CH_TICK(6);
     // ---- FFN stage: x += 1/2 FFN(LN(x))  (the 1/2 lives in W2 / b2)
     auto ffn_stage = [&](const float* sb1, const float* sb2, int nchunks) __attribute__((always_inline)) {
         float mean, rstd;
@@ -353,7 +373,9 @@ __global__ __launch_bounds__(NW * 64) void chain_kernel(const ChainDev cd) {
         norm_frags<KS>(xc, mean, rstd, xf);
         add_cvec<NT>(xc, sb2, half);
         for (int c = 0; c < nchunks; ++c) {
+            CH_TICK(4);
             const char* buf = late ? smem + (gc % NBUF) * BUF : advance();
+            CH_TICK(0);
             const float* b1 = sb1 + c * CH + 4 * half;
             f32x16 h;
 #pragma unroll
@@ -370,11 +392,16 @@ __global__ __launch_bounds__(NW * 64) void chain_kernel(const ChainDev cd) {
 #pragma unroll
                 for (int i = 0; i < FB; ++i) h = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[i], xf[s0 + i], h, 0, 0, 0);
             }
+            if constexpr (PROF) { asm volatile("s_nop 0" :: "v"(h[0]), "v"(h[15])); }
+            CH_TICK(1);
             uint32_t w[8];
 #pragma unroll
             for (int r = 0; r < 16; r += 2) w[r >> 1] = pack_bf2(swishf_(h[r]), swishf_(h[r + 1]));
             const bf16x8 hf0 = as_bf16x8(make_uint4(w[0], w[1], w[2], w[3])), hf1 = as_bf16x8(make_uint4(w[4], w[5], w[6], w[7]));
+            if constexpr (PROF) { asm volatile("s_nop 0" :: "v"(hf0), "v"(hf1)); }
+            CH_TICK(2);
             if (late) (void)advance();
+            CH_TICK(0);
             const char* w2 = buf + HALF;
             constexpr int TB = (NT % 2 == 0) ? 2 : 1;
 #pragma unroll
@@ -391,6 +418,8 @@ __global__ __launch_bounds__(NW * 64) void chain_kernel(const ChainDev cd) {
                     xc[t0 + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[i][1], hf1, xc[t0 + i], 0, 0, 0);
                 }
             }
+            if constexpr (PROF) { asm volatile("s_nop 0" :: "v"(xc[0][0]), "v"(xc[NT - 1][0])); }
+            CH_TICK(3);
         }
     };
 
@@ -438,6 +467,7 @@ __global__ __launch_bounds__(NW * 64) void chain_kernel(const ChainDev cd) {
                 const u32x4 v = *reinterpret_cast<const u32x4*>(stg + row * STG_ROW + 16 * (lane & 3));
                 if (m < p.M && col < p.Ng) *reinterpret_cast<u32x4*>(p.glu + (size_t)m * p.ldg + col) = v;
             }
+            st1 += 2;
         }
     } else {
         if constexpr (PRE) {
@@ -451,8 +481,11 @@ __global__ __launch_bounds__(NW * 64) void chain_kernel(const ChainDev cd) {
             float mean, rstd;
             ln_stats<NT>(xc, D, mean, rstd);
             norm_frags<KS>(xc, mean, rstd, xf);                                     // attention pre-norm
+            CH_TICK(4);
             // x is final here (the Q/K/V projection only reads it): store it now so that its registers are free during the last stage
             store_x<NT, 0>(reinterpret_cast<char*>(p.Y), (size_t)p.ldy * 4, D, m_base, p.M, stg, lane, xc);
+            st1 += 8 * ((NT + 1) / 2);
+            CH_TICK(7);
             // destination row offsets of the 4 rows this lane stores per window instruction: (b, t) -> (b*Tp + t)*D
             size_t qoff[4];
             bool qok[4];
@@ -514,16 +547,39 @@ __global__ __launch_bounds__(NW * 64) void chain_kernel(const ChainDev cd) {
                         const u32x4 v = *reinterpret_cast<const u32x4*>(stg + (8 * i + (lane >> 3)) * STG_ROW + 16 * (lane & 7));
                         if (colok && qok[i]) *reinterpret_cast<u32x4*>(dst + qoff[i] + nn0) = v;
                     }
+                    st1 += 4;
                 }
             }
         }
     }
     // ---- residual rows out
     if constexpr (!POST) store_x<NT, 0>(reinterpret_cast<char*>(p.Y), (size_t)p.ldy * 4, D, m_base, p.M, stg, lane, xc);
+    if constexpr (PROF) {
+        CH_TICK(8);
+        if (lane == 0) {
+            for (int i = 0; i < 9; ++i) atomicAdd(prof + i, ph[i]);
+            atomicAdd(prof + 9, 1ull);
+        }
+    }
+#undef CH_TICK
 }
 
-// LDS float-region layout shared by kernel and launcher
-inline int chain_float_layout(const ChainParams& p, int kind, int DP, int (&nf)[8]) {
+unsigned long long* g_chain_prof = nullptr;
+void chain_prof_dump() {
+    unsigned long long h[10];
+    if (!g_chain_prof || hipMemcpy(h, g_chain_prof, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess || !h[9]) return;
+    static const char* names[9] = {"ffn advance", "ffn gemm1", "ffn swish", "ffn gemm2", "norms+misc", "prologue", "g0 stage", "store_x", "qkv stage"};
+    unsigned long long tot = 0;
+    for (int i = 0; i < 9; ++i) tot += h[i];
+    fprintf(stderr, "[chain phases] KS=8 full chain: waves %llu, cycles/wave %.0f\n", h[9], (double)tot / h[9]);
+    for (int i = 0; i < 9; ++i) fprintf(stderr, "[chain phases]   %-12s %10.0f cyc/wave  %5.1f%%\n", names[i], (double)h[i] / h[9], 100.0 * h[i] / tot);
+}
+
+}  // namespace
+
+// LDS float-region layout shared by kernel, launcher and the packer (encoder.hip builds the constant block with it)
+int chain_const_layout(const ChainParams& p, int kind, int (&nf)[8]) {
+    const int DP = 32 * ((p.D + 31) / 32);
     const bool isb = kind == CHAIN_B, pre = kind == CHAIN_A_FULL || kind == CHAIN_A_TAIL, post = kind == CHAIN_A_FULL || kind == CHAIN_A_HEAD;
     int o = 0;
     nf[0] = o; o += (isb || pre) ? DP : 0;
@@ -534,8 +590,10 @@ inline int chain_float_layout(const ChainParams& p, int kind, int DP, int (&nf)[
     nf[5] = o; o += post ? DP : 0;
     nf[6] = o; o += (isb || post) ? 64 * p.g1.nchunks : 0;
     nf[7] = o; o += post ? 2 * DP : 0;
-    return o;
+    return (o + 255) / 256 * 256;          // whole KiB: copied by 1 KiB LDS-DMA pieces
 }
+
+namespace {
 
 template <int KS, int NW, int NBUF, int KIND>
 int launch_chain_t(const ChainParams& p, hipStream_t s) {
@@ -544,16 +602,30 @@ int launch_chain_t(const ChainParams& p, hipStream_t s) {
     cd.p = p;
     cd.fT = FastDiv32(p.T > 0 ? p.T : 1);
     cd.fD = FastDiv32(p.D);
-    const int nfl = chain_float_layout(p, KIND, G::DP, cd.nf);
+    const int nfl = chain_const_layout(p, KIND, cd.nf);
+    cd.nfl_kb = nfl / 256;
+    if (!p.consts) return -5;
     const int lds = NBUF * G::BUF + NW * STG_BYTES + nfl * 4;
     if (lds > 160 * 1024) return -4;
     static int attr_set = 0;
     if (attr_set < lds) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_kernel<KS, NW, NBUF, KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_kernel<KS, NW, NBUF, KIND, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = lds;
     }
     const int rows_per_wg = NW * 32;
-    hipLaunchKernelGGL((chain_kernel<KS, NW, NBUF, KIND>), dim3((p.M + rows_per_wg - 1) / rows_per_wg), dim3(NW * 64), lds, s, cd);
+    if constexpr (KS == 8 && KIND == CHAIN_A_FULL) {
+        static const bool prof = getenv("EFFCONF_CHAIN_PHASES") != nullptr;
+        if (prof) {
+            if (!g_chain_prof) {
+                if (hipMalloc(&g_chain_prof, 128) != hipSuccess || hipMemset(g_chain_prof, 0, 128) != hipSuccess) return -1;
+                atexit(chain_prof_dump);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_kernel<KS, NW, NBUF, KIND, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            }
+            hipLaunchKernelGGL((chain_kernel<KS, NW, NBUF, KIND, true>), dim3((p.M + rows_per_wg - 1) / rows_per_wg), dim3(NW * 64), lds, s, cd, g_chain_prof);
+            return hipGetLastError() == hipSuccess ? 0 : -1;
+        }
+    }
+    hipLaunchKernelGGL((chain_kernel<KS, NW, NBUF, KIND, false>), dim3((p.M + rows_per_wg - 1) / rows_per_wg), dim3(NW * 64), lds, s, cd, nullptr);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

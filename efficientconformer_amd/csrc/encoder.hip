@@ -30,7 +30,7 @@ uint16_t h_f2bf(float f) {
 
 struct HostTensor { std::vector<float> data; std::vector<int64_t> shape; };
 
-struct PackedLinear { const bf16_t* w = nullptr; const float* bias = nullptr; int N = 0, K = 0, ldw = 0; };
+struct PackedLinear { const bf16_t* w = nullptr; const float* bias = nullptr; int N = 0, K = 0, ldw = 0; std::vector<float> hbias; /* host copy of the padded bias */ };
 struct LNp { const float* g = nullptr; const float* b = nullptr; };
 
 struct BlockW {
@@ -44,6 +44,8 @@ struct BlockW {
     PackedLinear c_outp, c_pw1, c_pw2, c_qkv, c_f1a, c_f2a;
     const bf16_t *c_f1b = nullptr, *c_f2b = nullptr; const float *c_f1b2 = nullptr, *c_f2b2 = nullptr;
     int c_qkv_chunks = 0, c_pw1_chunks = 0;
+    std::vector<float> h_ln_out_g, h_ln_out_b, h_u, h_v, h_f1b2, h_f2b2;     // host copies for the chains' constant blocks
+    const float *cc_b = nullptr, *cc_head = nullptr, *cc_tail = nullptr, *cc_full = nullptr;   // constant blocks (chain_const_layout)
 };
 
 struct TraceEntry { char name[64]; int64_t offset, rows, cols, ld; int32_t dtype; };
@@ -129,6 +131,7 @@ bool pack_linear(EcEncoder* e, const std::vector<const float*>& row_ptr, const s
     }
     out->w = upload(e, w);
     out->bias = upload(e, b);
+    out->hbias = b;
     out->N = N; out->K = K; out->ldw = Kp;
     return out->w && out->bias;
 }
@@ -483,7 +486,7 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
         } else if (chain_head) {
             ChainParams cp{};
             fill_chain_head(cp, W, D, F1c(b), T, Tp, p);
-            cp.M = M; cp.X = x; cp.ldx = D; cp.Y = x; cp.ldy = D;
+            cp.M = M; cp.X = x; cp.ldx = D; cp.Y = x; cp.ldy = D; cp.consts = W.cc_head;
             PROF(PC_GEMM_FFN, 2.0 * M * (double)D * (2.0 * D * b.ff_ratio + 3.0 * D), (double)M * D * 16 + 22.0 * D * D);
             EC_TRY(launch_chain(cp, CHAIN_A_HEAD, st));
         } else {
@@ -535,7 +538,7 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
                 cp.g0 = ChainGemm{W.c_outp.w, W.c_outp.ldw, W.c_outp.bias, 0};
                 cp.ln[0] = ChainLn{W.ln_conv.g, W.ln_conv.b};
                 cp.g1 = ChainGemm{W.c_pw1.w, W.c_pw1.ldw, W.c_pw1.bias, W.c_pw1_chunks};
-                cp.glu = gbuf; cp.ldg = ld8(De); cp.Ng = De; cp.T = T; cp.Tp = Tp;
+                cp.glu = gbuf; cp.ldg = ld8(De); cp.Ng = De; cp.T = T; cp.Tp = Tp; cp.consts = W.cc_b;
                 PROF(PC_GEMM_OTHER, 2.0 * M * (double)D * (D + 2.0 * De), (double)M * D * 10 + (double)M * De * 2 + 2.0 * D * (D + 2.0 * De));
                 EC_TRY(launch_chain(cp, CHAIN_B, st));
             } else {
@@ -567,7 +570,7 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
             bool next_head = false;
             if (!last) {
                 const EcBlock& nbk = e->blocks[k + 1];
-                next_head = e->bw[k + 1].chain_in && chain_head_supported(De) && ((nbk.group_size * nbk.dim_model / nbk.num_heads) % 2) == 0 && nbk.dim_model == De;
+                next_head = W.cc_full && e->bw[k + 1].chain_in && chain_head_supported(De) && ((nbk.group_size * nbk.dim_model / nbk.num_heads) % 2) == 0 && nbk.dim_model == De;
             }
             ChainParams cp{};
             cp.M = Mo; cp.D = De; cp.X = x; cp.ldx = De; cp.Y = xo; cp.ldy = De; cp.A = cbuf; cp.lda = ld8(De);
@@ -585,6 +588,7 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
                 fill_chain_head(cp, e->bw[k + 1], De, F1c(nbk), Tn, Tpn, pn);
                 fl += 2.0 * Mo * (double)De * (2.0 * De * nbk.ff_ratio + 3.0 * De); by += (double)Mo * De * 8 + 2.0 * De * De * (3 + 2.0 * nbk.ff_ratio);
             }
+            cp.consts = next_head ? W.cc_full : W.cc_tail;
             { PROF(PC_GEMM_FFN, fl, by); EC_TRY(launch_chain(cp, next_head ? CHAIN_A_FULL : CHAIN_A_TAIL, st)); }
             head_done = next_head;
             have_a = false;
@@ -779,7 +783,7 @@ int effconf_encoder_finalize(EcEncoder* e) {
                 !pack_named_linear(e, m + ".mhsa.output_layer", D, D, &W.c_outp, &err, true)) return fail("chain packing failed: " + err);
             W.c_f1b = pack_ffn2_permuted(e, p + ".feed_forward_module1.layers.4", D, F1, 0.5f);
             std::vector<float> hb(b2->data); for (float& x : hb) x *= 0.5f;
-            W.c_f1b2 = upload(e, hb);
+            W.c_f1b2 = upload(e, hb); W.h_f1b2 = hb;
             if (!W.c_f1b || !W.c_f1b2) return fail("upload failed");
             W.chain_in = true;
         }
@@ -789,7 +793,10 @@ int effconf_encoder_finalize(EcEncoder* e) {
                 !pack_named_linear(e, p + ".convolution_module.layers.7", De, De, &W.c_pw2, &err, true)) return fail("chain packing failed: " + err);
             W.c_f2b = pack_ffn2_permuted(e, p + ".feed_forward_module2.layers.4", De, F2, 0.5f);
             std::vector<float> hb(b2->data); for (float& x : hb) x *= 0.5f;
-            W.c_f2b2 = upload(e, hb);
+            W.c_f2b2 = upload(e, hb); W.h_f2b2 = hb;
+            const HostTensor *og = find(e, p + ".norm.weight"), *ob = find(e, p + ".norm.bias");
+            if (!og || !ob) return fail("missing " + p + ".norm");
+            W.h_ln_out_g = og->data; W.h_ln_out_b = ob->data;
             if (!W.c_f2b || !W.c_f2b2) return fail("upload failed");
             W.chain_out = true;
         }
@@ -798,6 +805,7 @@ int effconf_encoder_finalize(EcEncoder* e) {
         const HostTensor *u = find(e, m + ".mhsa.u"), *v = find(e, m + ".mhsa.v");
         if (!u || !v || (int)u->data.size() != D) return fail("missing " + m + ".mhsa.u/v");
         W.u = upload(e, u->data); W.v = upload(e, v->data);
+        W.h_u = u->data; W.h_v = v->data;
         auto key = std::make_pair(b.max_pos, D);
         if (!tables.count(key)) tables[key] = build_pos_table(e, b.max_pos, D);
         W.pos_table = tables[key];
@@ -838,6 +846,50 @@ int effconf_encoder_finalize(EcEncoder* e) {
         }
         if (!pack_named_linear(e, cm + ".7", De, De, &W.pw2, &err)) return fail(err);
         if (D != De && !pack_named_linear(e, p + ".conv_res.1", De, D, &W.res, &err)) return fail(err);
+    }
+    // ---- constant blocks of the fused chains (one LDS-DMA per workgroup instead of a dozen small strided copies)
+    for (size_t k = 0; k < e->blocks.size(); ++k) {
+        BlockW& W = e->bw[k];
+        const EcBlock& b = e->blocks[k];
+        const int D = b.dim_model, De = b.dim_expand;
+        auto build = [&](int kind, int dim, const BlockW* pre, const BlockW* post, const EcBlock* pb, const EcBlock* qb) -> const float* {
+            ChainParams cp{};
+            cp.D = dim;
+            const bool isb = kind == CHAIN_B;
+            if (pre && !isb) cp.f[0].Fp = ec_round_up(pb->dim_expand * pb->ff_ratio, 32);
+            if (post) cp.f[1].Fp = ec_round_up(qb->dim_model * qb->ff_ratio, 32);
+            cp.g1.nchunks = isb ? pre->c_pw1_chunks : (post ? post->c_qkv_chunks : 0);
+            int nf[8];
+            const int nfl = chain_const_layout(cp, kind, nf);
+            const int DP = 32 * ((dim + 31) / 32);
+            std::vector<float> blk(nfl, 0.f);
+            auto put = [&](int off, const std::vector<float>& src, int n) { for (int i = 0; i < n && i < (int)src.size(); ++i) blk[off + i] = src[i]; };
+            if (isb) {
+                put(nf[0], pre->c_outp.hbias, dim);
+                put(nf[6], pre->c_pw1.hbias, 64 * cp.g1.nchunks);
+            } else {
+                if (pre) {
+                    put(nf[0], pre->c_pw2.hbias, dim);
+                    put(nf[1], pre->h_ln_out_g, dim); put(nf[1] + DP, pre->h_ln_out_b, dim);
+                    put(nf[2], pre->c_f2a.hbias, cp.f[0].Fp); put(nf[3], pre->h_f2b2, dim);
+                }
+                if (post) {
+                    put(nf[4], post->c_f1a.hbias, cp.f[1].Fp); put(nf[5], post->h_f1b2, dim);
+                    put(nf[6], post->c_qkv.hbias, 64 * cp.g1.nchunks);
+                    put(nf[7], post->h_u, dim); put(nf[7] + DP, post->h_v, dim);
+                }
+            }
+            return upload(e, blk);
+        };
+        if (W.chain_in) {
+            W.cc_b = build(CHAIN_B, D, &W, nullptr, &b, nullptr);
+            if (chain_head_supported(D)) W.cc_head = build(CHAIN_A_HEAD, D, nullptr, &W, nullptr, &b);
+        }
+        if (W.chain_out && chain_head_supported(De)) {
+            W.cc_tail = build(CHAIN_A_TAIL, De, &W, nullptr, &b, nullptr);
+            if (k + 1 < e->blocks.size() && e->bw[k + 1].chain_in && e->blocks[k + 1].dim_model == De)
+                W.cc_full = build(CHAIN_A_FULL, De, &W, &e->bw[k + 1], &b, &e->blocks[k + 1]);
+        }
     }
     e->block_stride = upload(e, strides);
     if (c.vocab_size > 0) {

@@ -76,9 +76,11 @@ struct ChainParams {
     ChainGemm g1;                       // chain A: stacked QKV (natural layout, chunk-permuted rows); chain B: pointwise-1 (a|b interleaved per 32)
     bf16_t *qu, *qv, *kh, *vt; const float *u, *v; int T, Tp;     // QKV outputs: rows (b, t) -> (b*Tp + t)*D
     bf16_t* glu; int ldg, Ng;           // GLU output [M][ldg], Ng channels
+    const float* consts;                // biases / block-norm gamma, beta / u, v as ONE zero padded block laid out by chain_const_layout
 };
 enum { CHAIN_B = 0, CHAIN_A_FULL = 1, CHAIN_A_HEAD = 2, CHAIN_A_TAIL = 3 };   // HEAD: first block (no previous tail); TAIL: last block (no next head)
 bool chain_supported(int D);
+int chain_const_layout(const ChainParams& p, int kind, int (&nf)[8]);   // float offsets of the constant block; returns its size in floats
 bool chain_head_supported(int D);
 int launch_chain(const ChainParams& p, int kind, hipStream_t s);
 

@@ -18,6 +18,17 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     static_assert(N >= 0 && N < 64, "vmcnt immediate is 6 bits");
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
+// runtime count (wave-uniform, clamped to the 6-bit immediate): used where global stores share the FIFO with the weight DMAs
+__device__ __forceinline__ void wait_vmcnt_dyn(int n) {
+    n = n < 0 ? 0 : (n > 63 ? 63 : n);
+    switch (n) {
+#define EC_VM(k) case k: wait_vmcnt<k>(); break;
+#define EC_VM8(b) EC_VM(b) EC_VM(b + 1) EC_VM(b + 2) EC_VM(b + 3) EC_VM(b + 4) EC_VM(b + 5) EC_VM(b + 6) EC_VM(b + 7)
+        EC_VM8(0) EC_VM8(8) EC_VM8(16) EC_VM8(24) EC_VM8(32) EC_VM8(40) EC_VM8(48) EC_VM8(56)
+#undef EC_VM8
+#undef EC_VM
+    }
+}
 // wait until at most `allowed` chunks (of PER DMA instructions each, issued by this wave) are still in flight
 template <int PER, int MAXC> __device__ __forceinline__ void wait_chunks(int allowed) {
     if (allowed >= MAXC) wait_vmcnt<PER * MAXC>();

@@ -174,7 +174,8 @@ class ConformerEncoder(nn.Module):
 
     # ------------------------------------------------------------------ forward
     def _workspace(self, batch: int, n: int, from_audio: bool, device) -> torch.Tensor:
-        key = (batch, n, from_audio, str(device))
+        # one workspace per (shape, stream): forwards enqueued on different streams may overlap on the GPU
+        key = (batch, n, from_audio, str(device), torch.cuda.current_stream(device).cuda_stream)
         ws = self._ws.get(key)
         if ws is None:
             nbytes = _lib.load().effconf_encoder_workspace_bytes(self._handle, batch, n, int(from_audio))
