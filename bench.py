@@ -124,9 +124,10 @@ def pmc_traffic(args, kernel_prefix):
     d = json.load(open(path))
     if (d.get("model"), d.get("batch"), d.get("workload")) != (args.model, args.batch, args.workload):
         return None
+    import re
     calls = tot = 0
     for name, k in d["kernels"].items():
-        if kernel_prefix in name:
+        if re.search(kernel_prefix, name):
             calls += k["calls"]
             tot += k["calls"] * (k["fetch_x2_bytes"] + k["write_bytes"])
     return tot / calls if calls else None
@@ -255,9 +256,10 @@ def main():
             torch.cuda.synchronize()
             per["rnnt_greedy"] = {"ms_per_step": e0.elapsed_time(e1) / nprof, "launches_per_step": 2,
                                   "tokens_per_step": int(tok_len.sum()), "encoder_frames_per_step": int(enc_len.sum())}
-        result["roofline"] = {"kernel": "ffn_fused_kernel / gemm_kernel FFN launches (LN'd x -> 4D Swish -> D + half-step residual)",
+        result["roofline"] = {"kernel": "chain_kernel A (pointwise-2 + FFN2 + block norm + next FFN1 + attention pre-norm + QKV in one pass over the rows; "
+                                        "ffn_fused_kernel / gemm_kernel where a chain is not supported)",
                               "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                              "frac": ach / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(args, "ffn_fused_kernel"),
+                              "frac": ach / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(args, r"chain_kernel<\d+, \d+, \d+, [123],|ffn_fused_kernel"),
                               "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/pmc_traffic.json)",
                               "alg_bytes_per_launch": 1e6 * dom["alg_mb_per_step"] / n_l,
                               "avg_launch_ms": avg_ms, "launches_per_step": n_l,

@@ -635,7 +635,7 @@ int launch_chain_kind(const ChainParams& p, hipStream_t s) {
     if (ks <= 2) return launch_chain_t<2, 4, 4, KIND>(p, s);
     if (ks <= 4) return launch_chain_t<4, 8, 4, KIND>(p, s);
     if (ks <= 8) return launch_chain_t<8, 8, 4, KIND>(p, s);
-    if (ks <= 12) return launch_chain_t<12, 4, 4, KIND>(p, s);
+    if (ks <= 12) return launch_chain_t<12, 8, 3, KIND>(p, s);
     return launch_chain_t<16, 4, 3, KIND>(p, s);
 }
 
