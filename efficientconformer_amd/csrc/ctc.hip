@@ -27,41 +27,49 @@ __global__ void lengths_kernel(const int64_t* __restrict__ x_len, int B, int fro
     if (out_len) out_len[b] = l;
 }
 
-constexpr int CTC_ROWS = 8;
 
+// One workgroup = CTC_ROWS frames x the whole vocabulary (thread = vocabulary column).  Every workgroup reads all of fc^T from L2, so
+// the rows per workgroup set the L2 traffic (8 rows: 3200 workgroups x 245 KB = 0.8 GB per launch, the whole 150 us of the first
+// version); the frame tile sits in LDS and is read as float4 broadcasts along k (one LDS read per 4 FMAs).
+template <int CTC_ROWS>
 __global__ __launch_bounds__(256) void ctc_argmax_kernel(const float* __restrict__ x, int M, int D,
                                                          const float* __restrict__ Wt, const float* __restrict__ bias,
                                                          int V, int* __restrict__ preds, float* __restrict__ logits) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* sx = reinterpret_cast<float*>(smem);                         // [CTC_ROWS][D]
+    float* sx = reinterpret_cast<float*>(smem);                         // [CTC_ROWS][D]   (D % 4 == 0)
     float* sbest = sx + CTC_ROWS * D;                                   // [CTC_ROWS][4]
     int* sidx = reinterpret_cast<int*>(sbest + CTC_ROWS * 4);           // [CTC_ROWS][4]
     const int m0 = blockIdx.x * CTC_ROWS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < CTC_ROWS * D; i += 256) {
-        const int r = i / D, c = i - r * D;
-        sx[i] = (m0 + r < M) ? x[(size_t)(m0 + r) * D + c] : 0.f;
+    for (int i = tid * 4; i < CTC_ROWS * D; i += 256 * 4) {
+        const int r = i / D;
+        const int mr = m0 + r < M ? m0 + r : M - 1;
+        *reinterpret_cast<float4*>(sx + i) = *reinterpret_cast<const float4*>(x + (size_t)mr * D + (i - r * D));
     }
     __syncthreads();
     float best[CTC_ROWS];
     int bidx[CTC_ROWS];
 #pragma unroll
     for (int r = 0; r < CTC_ROWS; ++r) { best[r] = -INFINITY; bidx[r] = 0x7fffffff; }
-    for (int v = tid; v < V; v += 256) {
+    for (int v0 = 0; v0 < V; v0 += 256) {
+        const int v = v0 + tid, vc = v < V ? v : V - 1;
         float acc[CTC_ROWS];
 #pragma unroll
         for (int r = 0; r < CTC_ROWS; ++r) acc[r] = 0.f;
-        for (int k = 0; k < D; ++k) {
-            const float w = Wt[(size_t)k * V + v];
+        for (int k = 0; k < D; k += 4) {
+            const float w0 = Wt[(size_t)k * V + vc], w1 = Wt[(size_t)(k + 1) * V + vc], w2 = Wt[(size_t)(k + 2) * V + vc], w3 = Wt[(size_t)(k + 3) * V + vc];
 #pragma unroll
-            for (int r = 0; r < CTC_ROWS; ++r) acc[r] = fmaf(sx[r * D + k], w, acc[r]);
+            for (int r = 0; r < CTC_ROWS; ++r) {
+                const float4 xv = *reinterpret_cast<const float4*>(sx + r * D + k);
+                acc[r] = fmaf(xv.w, w3, fmaf(xv.z, w2, fmaf(xv.y, w1, fmaf(xv.x, w0, acc[r]))));      // k ascending, as the first version
+            }
         }
-        const float bz = bias[v];
+        const float bz = bias[vc];
 #pragma unroll
         for (int r = 0; r < CTC_ROWS; ++r) {
             const float val = acc[r] + bz;
-            if (logits && m0 + r < M) logits[(size_t)(m0 + r) * V + v] = val;
-            if (val > best[r]) { best[r] = val; bidx[r] = v; }          // strictly greater: first max wins
+            if (logits && v < V && m0 + r < M) logits[(size_t)(m0 + r) * V + v] = val;
+            if (v < V && val > best[r]) { best[r] = val; bidx[r] = v; }   // strictly greater: first max wins
         }
     }
     // reduce (max value, then lowest index) across the wave, then across the 4 waves
@@ -86,20 +94,28 @@ __global__ __launch_bounds__(256) void ctc_argmax_kernel(const float* __restrict
     }
 }
 
-__global__ void ctc_collapse_kernel(const int* __restrict__ preds, const int64_t* __restrict__ lens, int B, int T,
-                                    int* __restrict__ labels, int* __restrict__ label_len) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    int n = 0, prev = 0;
+// one wave per utterance: 64 frames per step, keep = (c != 0 && c != previous frame's c), output position = running count +
+// prefix popcount of the keep ballot
+__global__ __launch_bounds__(64) void ctc_collapse_kernel(const int* __restrict__ preds, const int64_t* __restrict__ lens, int B, int T,
+                                                          int* __restrict__ labels, int* __restrict__ label_len) {
+    const int b = blockIdx.x, lane = threadIdx.x;
     long long len = lens[b];
     if (len > T) len = T;
-    for (int t = 0; t < len; ++t) {
-        const int c = preds[(size_t)b * T + t];
-        if (c != 0 && c != prev) labels[(size_t)b * T + n++] = c;
-        prev = c;
+    if (len < 0) len = 0;
+    int n = 0, carry = 0;                                      // carry = prediction of the frame before this step (0 at the start)
+    for (int t0 = 0; t0 < (int)len; t0 += 64) {
+        const int t = t0 + lane;
+        const int c = t < (int)len ? preds[(size_t)b * T + t] : 0;
+        int prev = __shfl_up(c, 1);
+        if (lane == 0) prev = carry;
+        const bool keep = t < (int)len && c != 0 && c != prev;
+        const unsigned long long m = __ballot(keep);
+        if (keep) labels[(size_t)b * T + n + __popcll(m & ((1ull << lane) - 1))] = c;
+        n += __popcll(m);
+        carry = __shfl(c, 63);
     }
-    label_len[b] = n;
-    for (int t = n; t < T; ++t) labels[(size_t)b * T + t] = 0;
+    if (lane == 0) label_len[b] = n;
+    for (int t = n + lane; t < T; t += 64) labels[(size_t)b * T + t] = 0;
 }
 
 }  // namespace
@@ -115,14 +131,20 @@ int launch_lengths(const int64_t* x_len, int B, int from_audio, int hop, int sub
 int launch_ctc_argmax(const float* x, int M, int D, const float* Wt, const float* bias, int V,
                       int* preds, float* logits_or_null, hipStream_t s) {
     if (M <= 0) return 0;
-    const size_t lds = (size_t)CTC_ROWS * D * sizeof(float) + CTC_ROWS * 4 * (sizeof(float) + sizeof(int));
-    hipLaunchKernelGGL(ctc_argmax_kernel, dim3((M + CTC_ROWS - 1) / CTC_ROWS), dim3(256), lds, s, x, M, D, Wt, bias, V,
-                       preds, logits_or_null);
+    if (D % 4) return -2;
+    // rows per workgroup: as many as keep the frame tile within the default 64 KB of dynamic LDS
+    const int rows = D <= 384 ? 32 : (D <= 768 ? 16 : 8);
+    const size_t lds = (size_t)rows * D * sizeof(float) + rows * 4 * (sizeof(float) + sizeof(int));
+    if (lds > 64 * 1024) return -2;
+    const dim3 grid((M + rows - 1) / rows);
+    if (rows == 32) hipLaunchKernelGGL(ctc_argmax_kernel<32>, grid, dim3(256), lds, s, x, M, D, Wt, bias, V, preds, logits_or_null);
+    else if (rows == 16) hipLaunchKernelGGL(ctc_argmax_kernel<16>, grid, dim3(256), lds, s, x, M, D, Wt, bias, V, preds, logits_or_null);
+    else hipLaunchKernelGGL(ctc_argmax_kernel<8>, grid, dim3(256), lds, s, x, M, D, Wt, bias, V, preds, logits_or_null);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 int launch_ctc_collapse(const int* preds, const int64_t* lens, int B, int T, int* labels, int* label_len, hipStream_t s) {
     if (B <= 0) return 0;
-    hipLaunchKernelGGL(ctc_collapse_kernel, dim3((B + 63) / 64), dim3(64), 0, s, preds, lens, B, T, labels, label_len);
+    hipLaunchKernelGGL(ctc_collapse_kernel, dim3(B), dim3(64), 0, s, preds, lens, B, T, labels, label_len);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
