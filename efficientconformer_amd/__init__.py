@@ -8,5 +8,7 @@ from .config import build_plan, load_config, named_config  # noqa: F401
 from .encoders import ConformerEncoder  # noqa: F401
 from .model_ctc import ModelCTC  # noqa: F401
 from .transducer import Transducer  # noqa: F401
+from .checkpoint import load_checkpoint, save_checkpoint  # noqa: F401
+from .batching import FrontDoor, bucket_batches, collate_fn_pad  # noqa: F401
 
-__all__ = ["ConformerEncoder", "ModelCTC", "Transducer", "build_plan", "load_config", "named_config"]
+__all__ = ["ConformerEncoder", "ModelCTC", "Transducer", "load_checkpoint", "save_checkpoint", "FrontDoor", "bucket_batches", "collate_fn_pad", "build_plan", "load_config", "named_config"]

@@ -50,6 +50,11 @@ class ModelCTC(nn.Module):
         self.encoder.repack()
         return r
 
+    def load(self, path):
+        """Reference ``Model.load`` (model.py:361-384): a ``.ckpt`` path or dict; restores weights and the pickled tokenizer."""
+        from .checkpoint import load_checkpoint
+        return load_checkpoint(self, path)
+
     # ---- reference ModelCTC.forward (model_ctc.py:57-68): batch = (x, y, x_len, y_len)
     def forward(self, batch):
         x, _, x_len, _ = batch

@@ -93,6 +93,11 @@ class Transducer(nn.Module):
         self._rnnt_packed = False
         return r
 
+    def load(self, path):
+        """Reference ``Model.load`` (model.py:361-384): a ``.ckpt`` path or dict; restores weights and the pickled tokenizer."""
+        from .checkpoint import load_checkpoint
+        return load_checkpoint(self, path)
+
     def forward(self, batch):
         raise NotImplementedError("Transducer.forward builds the (B, T, U+1, V) training lattice (transducer.py:88-107): "
                                   "training is out of scope of the native inference path; use greedy_tokens / gready_search_decoding")

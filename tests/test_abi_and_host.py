@@ -124,3 +124,47 @@ def test_transducer_state_dict_surface_and_config_checks():
     lib = _lib.load()
     bad = _lib.EcRnntConfig(360, 640, 640, 1000, 2, 5, 0, 0)
     assert not lib.effconf_rnnt_create(ctypes.byref(bad)) and b"num_layers" in lib.effconf_last_error()
+
+
+def test_checkpoint_roundtrip_reference_layout(tmp_path):
+    """Reference checkpoint dict layout (model.py:345-384): DDP '.module.' infix stripped when is_distributed, tokenizer restored,
+    optimizer / step ignored."""
+    from efficientconformer_amd import load_checkpoint, save_checkpoint
+    cfg = named_config("Tiny")
+    m = ModelCTC.from_config(cfg)
+    sd = synth.make_state_dict(m.encoder.plan, 3, cfg["tokenizer_params"]["vocab_size"], prefix="encoder.")
+    ddp = {k.replace("encoder.", "encoder.module.", 1).replace("fc.", "fc.module.", 1): torch.from_numpy(v) for k, v in sd.items()}
+    path = str(tmp_path / "ref.ckpt")
+    torch.save({"model_state_dict": ddp, "optimizer_state_dict": {"state": {}}, "model_step": 1234, "tokenizer": {"fake": "tokenizer"},
+                "is_distributed": True}, path)
+    m.load(path)
+    assert m.tokenizer == {"fake": "tokenizer"}
+    assert torch.equal(m.fc.weight, torch.from_numpy(sd["fc.weight"]))
+    assert torch.equal(m.encoder.blocks[2].norm.weight, torch.from_numpy(sd["encoder.blocks.2.norm.weight"]))
+    out = str(tmp_path / "native.ckpt")
+    save_checkpoint(m, out)
+    m2 = ModelCTC.from_config(cfg)
+    load_checkpoint(m2, out)
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
+
+
+def test_collate_and_bucketing():
+    """collate_fn_pad as the reference (utils/preprocessing.py:27-45); bucket plan deterministic, bounded, covering."""
+    from efficientconformer_amd import bucket_batches, collate_fn_pad
+    g = torch.Generator().manual_seed(0)
+    lens = [5, 9, 3, 9, 7]
+    batch = [[torch.randn(1, n, generator=g), torch.arange(1, 1 + n // 3)] for n in lens]
+    data, target, dl, tl = collate_fn_pad(batch)
+    assert dl.tolist() == [9, 9, 7, 5, 3] and data.shape == (5, 9) and tl.tolist() == [3, 3, 2, 1, 1]
+    assert torch.equal(data[0, :9], batch[1][0].reshape(-1)) and torch.equal(data[1], batch[3][0].reshape(-1))   # stable for ties
+    assert float(data[4, 3:].abs().sum()) == 0.0 and target.shape == (5, 3)
+    d2, t2, dl2, tl2 = collate_fn_pad([b[0] for b in batch])
+    assert t2 is None and tl2 is None and torch.equal(d2, data)
+    lengths = synth.libri_lengths(300, seed=5).tolist()
+    plan = bucket_batches(lengths, max_batch=64, max_padded_samples=64 * 160000)
+    flat = [i for b in plan for i in b]
+    assert sorted(flat) == list(range(300))
+    for b in plan:
+        assert len(b) <= 64 and len(b) * lengths[b[0]] <= 64 * 160000
+        assert all(lengths[b[j]] >= lengths[b[j + 1]] for j in range(len(b) - 1))
+    assert plan == bucket_batches(lengths, max_batch=64, max_padded_samples=64 * 160000)

@@ -261,3 +261,26 @@ def test_rnnt_full_pipeline_matches_oracle_on_own_encoder_output():
     assert full == RT.greedy_decode(tsd, f.cpu(), [f.shape[1]] * f.shape[0], 5)
     ids = m.greedy_tokens(torch.from_numpy(mel).cuda(), torch.from_numpy(ln).cuda(), from_mel=True)
     assert ids[:4] == got[:4]
+
+
+def test_front_door_matches_direct_calls():
+    """FrontDoor (pinned staging + H2D on a side stream, length-bucketed batches) returns, in the caller's order, exactly what the
+    model returns when the same batches are built by hand."""
+    from efficientconformer_amd import FrontDoor, bucket_batches
+    m, _ = _model("Tiny", 7)
+    lens = synth.libri_lengths(11, seed=3) // 8           # short utterances
+    audio = synth.make_audio(lens, seed=3)
+    order = np.random.Generator(np.random.PCG64(1)).permutation(len(lens))
+    waves = [torch.from_numpy(audio[i, :lens[i]].copy()) for i in order]
+    door = FrontDoor(m.greedy_labels, "cuda", max_batch=4)
+    got = door.run(waves)
+    plan = bucket_batches([w.numel() for w in waves], 4)
+    assert len(plan) == 3
+    for idx in plan:
+        n = [waves[i].numel() for i in idx]
+        x = torch.zeros(len(idx), max(n))
+        for r, i in enumerate(idx):
+            x[r, :n[r]] = waves[i]
+        want = m.greedy_labels(x.cuda(), torch.tensor(n).cuda())
+        for r, i in enumerate(idx):
+            assert got[i] == want[r]
