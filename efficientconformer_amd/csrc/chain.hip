@@ -643,8 +643,9 @@ int launch_chain_kind(const ChainParams& p, hipStream_t s) {
 
 // D % 8 == 0: 16-byte bf16 pieces never straddle the Q | K | V boundaries; D <= 256: the residual row fits the register file
 bool chain_supported(int D) { return D % 8 == 0 && D >= 16 && D <= 256; }
-// the FFN1 + Q/K/V half keeps more state live (Q/K/V accumulators, staging, row offsets): at KS = 16 it does not fit the register
-// file without spills, and a scratch reload inside a DMA-ring loop serialises the whole prefetch queue (shared vmcnt FIFO)
+// The FFN-carrying chain A at KS = 16 (D = 240 / 256) runs at one wave per SIMD with its LayerNorm / load phases spilling (the
+// chunk loops stay spill-free); measured it only ties the per-GEMM kernels there (5.60 vs 5.54 ms per step), so it is used up to
+// D = 192.  A 16-row-per-wave variant (v_mfma_f32_16x16x32_bf16, half the registers per lane) is the planned fix.
 bool chain_head_supported(int D) { return chain_supported(D) && D <= 192; }
 
 int launch_chain(const ChainParams& p, int kind, hipStream_t s) {
