@@ -77,7 +77,16 @@ __global__ __launch_bounds__(NWV * 64) void relpos_attention_kernel(const AttnPa
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, g = lane >> 4;
     const int qtiles = (p.Tg + BI - 1) / BI;
+    // XCD-aware order: hardware places block i on XCD i % 8.  All heads and query tiles of one utterance re-read the same K / V
+    // rows, so they should share an L2: utterance b goes to XCD b % 8 (utterances are sorted by length, so dealing them round-robin
+    // also keeps the XCDs balanced; a contiguous range per XCD was 16 % slower).  Un-remapped, K / V / E were fetched from HBM
+    // ~3x (profiles/r1_10_pmc_hbm_traffic.txt).
     int id = blockIdx.x;
+    if ((p.B & 7) == 0) {
+        const int per_b = p.H * qtiles, xcd = id & 7, slot = id >> 3;
+        const int j = slot / per_b;
+        id = (xcd + 8 * j) * per_b + (slot - j * per_b);
+    }
     const int qt = id % qtiles; id /= qtiles;
     const int h = id % p.H; const int b = id / p.H;
     const int i0 = qt * BI, iw0 = i0 + wave * 16;
