@@ -51,6 +51,7 @@ SIGNATURES = {
     "effconf_rnnt_finalize": (C.c_int, [_P]),
     "effconf_rnnt_workspace_bytes": (_SZ, [_P, _I32, _I32]),
     "effconf_rnnt_max_tokens": (_I32, [_P, _I32]),
+    "effconf_rnnt_set_option": (C.c_int, [_P, C.c_char_p, _I32]),
     "effconf_rnnt_greedy": (C.c_int, [_P, _F32P, _I64P, _I32, _I32, _P, _P, _I32, _P, _SZ, _P]),
     "effconf_encoder_set_option": (C.c_int, [_P, C.c_char_p, _I32]),
     "effconf_profile_enable": (C.c_int, [_P, _I32]),

@@ -23,6 +23,9 @@
 #include "../../include/effconf.h"
 
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <map>
 #include <string>
 #include <vector>
@@ -245,6 +248,283 @@ __global__ __launch_bounds__(NT) void rnnt_greedy_kernel(RnntDev w, const float*
     for (int i = ntok + tid; i < max_tok; i += NT) tokens[(size_t)b * max_tok + i] = 0;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Cluster decode: CW workgroups share CU utterances and run them in lockstep rounds.  Every workgroup owns 1/CW of the
+// LSTM's hidden units (their 4 gate columns and cell state), of the decoder projection's columns and of the vocabulary, so the
+// weights a round streams from L2 are read ONCE per cluster instead of once per utterance, and the per-step latency of an
+// utterance drops from "10.7 MB through one CU" to "1.3 MB through each of CW CUs" plus three cluster barriers
+// (counter in global memory: agent-scope release / acquire, bounded spin).  State machines (token, frame, counters) are
+// replicated: every workgroup takes the same decisions from the same exchanged argmax candidates.  The arithmetic (k order
+// of every dot product, libm tanhf / expf) is that of rnnt_greedy_kernel, so both produce identical tokens.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int CW = 8;          // workgroups per cluster
+constexpr int CU = 8;          // utterances per cluster
+constexpr int CKF = 2;         // encoder frames per joint pass
+constexpr int CNT = 512;
+constexpr int CLB = 8;         // weight loads kept in flight per thread (H/4 and J/4 must be multiples)
+
+struct ClusterArgs {
+    RnntDev w;
+    const float* fe; const int64_t* lens; int T, B;
+    int* tokens; int* counts; int max_tok;
+    float* xh; float* xgd; float* xav; int* xai; unsigned* cnt; int* status;     // exchange buffers (per cluster), barrier counters
+    int ncl;
+};
+
+// Exchange data and the barrier counter are accessed with relaxed agent-scope atomics (sc1 loads / stores served at the coherent
+// level) instead of plain accesses bracketed by agent-scope release / acquire fences: the fences cost a full L2 write-back +
+// invalidate per workgroup per barrier (~40 us each here; three barriers per round made the cluster no faster than one workgroup per
+// utterance).  Ordering: every wave drains its stores (s_waitcnt vmcnt(0) in __syncthreads) before thread 0 bumps the counter; the
+// consumers read only after thread 0 has seen the counter and a second __syncthreads.
+__device__ __forceinline__ void xstore(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void xstorei(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float xload(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int xloadi(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ bool cluster_sync(unsigned* cnt, unsigned& epoch, int* status) {
+    __syncthreads();
+    epoch += CW;
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        long spins = 0;
+        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1l << 26)) { __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }   // never hang the GPU
+        }
+    }
+    __syncthreads();
+    return __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+}
+
+__global__ __launch_bounds__(CNT) void rnnt_cluster_kernel(const ClusterArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const RnntDev& w = a.w;
+    const int H = w.H, J = w.J, V = w.V;
+    const int HU = H / CW, JU = J / CW, VU = (V + CW - 1) / CW;
+    float* sh = lds;                         // [CU][H]   h of every utterance
+    float* sgd = sh + CU * H;                // [CU][J]
+    float* sz = sgd + CU * J;                // [CU*CKF][J]
+    float* sc = sz + CU * CKF * J;           // [CU][HU]  cell state of this workgroup's units
+    float* sg = sc + CU * HU;                // [CU][4*HU] gate pre-activations
+    float* sred = sg + CU * 4 * HU;          // [CU*CKF][8] partial argmax values, then indices
+    int* sredi = reinterpret_cast<int*>(sred + CU * CKF * 8);
+    __shared__ int s_y[CU], s_step[CU], s_consec[CU], s_ntok[CU], s_need[CU], s_T[CU], s_pred[CU * CKF];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cl = blockIdx.x % a.ncl, wg = blockIdx.x / a.ncl;      // cluster members are a.ncl apart: same XCD when ncl % 8 == 0
+    const int u0 = cl * CU;
+    float* xh = a.xh + (size_t)cl * CU * H;
+    float* xgd = a.xgd + (size_t)cl * CU * J;
+    float* xav = a.xav + (size_t)cl * CW * CU * CKF;
+    int* xai = a.xai + (size_t)cl * CW * CU * CKF;
+    unsigned* cnt = a.cnt + cl * 64;          // one counter per 256-byte line
+    unsigned epoch = 0;
+
+    for (int i = tid; i < CU * H; i += CNT) sh[i] = 0.f;             // hidden = None -> zeros
+    for (int i = tid; i < CU * J; i += CNT) sgd[i] = 0.f;
+    for (int i = tid; i < CU * HU; i += CNT) sc[i] = 0.f;
+    if (tid < CU) {
+        const int b = u0 + tid;
+        int Tb = b < a.B ? (int)a.lens[b] : 0;
+        Tb = Tb < 0 ? 0 : (Tb > a.T ? a.T : Tb);
+        s_T[tid] = Tb; s_y[tid] = 0; s_step[tid] = 0; s_consec[tid] = 0; s_ntok[tid] = 0; s_need[tid] = Tb > 0;
+    }
+    __syncthreads();
+
+    bool ok = true;
+    while (ok) {
+        bool active = false, dec = false;
+#pragma unroll
+        for (int u = 0; u < CU; ++u) { const bool act = s_step[u] < s_T[u]; active |= act; dec |= act && s_need[u]; }
+        if (!active) break;
+        if (dec) {
+            // ---- phase 1: gates of this workgroup's units, cell update, h slice out
+            if (tid < 4 * HU) {
+                const int gate = tid / HU, unit = tid - gate * HU;
+                const int n = gate * H + wg * HU + unit;
+                float acc[CU];
+#pragma unroll
+                for (int u = 0; u < CU; ++u) acc[u] = 0.f;
+                const float4* __restrict__ wp = w.whh4 + n;
+                float4 wn[CLB];
+#pragma unroll
+                for (int i = 0; i < CLB; ++i) wn[i] = wp[(size_t)i * 4 * H];
+                for (int k0 = 0; k0 < H / 4; k0 += CLB) {                  // next batch of weight loads in flight under this batch's FMAs
+                    float4 wv[CLB];
+#pragma unroll
+                    for (int i = 0; i < CLB; ++i) wv[i] = wn[i];
+                    const int kn = k0 + CLB < H / 4 ? k0 + CLB : k0;       // last iteration: harmless re-load
+#pragma unroll
+                    for (int i = 0; i < CLB; ++i) wn[i] = wp[(size_t)(kn + i) * 4 * H];
+#pragma unroll
+                    for (int i = 0; i < CLB; ++i)
+#pragma unroll
+                        for (int u = 0; u < CU; ++u) {
+                            const float4 xv = *reinterpret_cast<const float4*>(sh + u * H + 4 * (k0 + i));
+                            acc[u] = fmaf(wv[i].w, xv.w, fmaf(wv[i].z, xv.z, fmaf(wv[i].y, xv.y, fmaf(wv[i].x, xv.x, acc[u]))));
+                        }
+                }
+#pragma unroll
+                for (int u = 0; u < CU; ++u) sg[u * 4 * HU + tid] = acc[u] + w.gin[(size_t)s_y[u] * 4 * H + n];
+            }
+            __syncthreads();
+            for (int i = tid; i < CU * HU; i += CNT) {
+                const int u = i / HU, unit = i - u * HU;
+                float hv = sh[u * H + wg * HU + unit];
+                if (s_need[u] && s_step[u] < s_T[u]) {
+                    const float* g = sg + u * 4 * HU + unit;
+                    const float ig = sigmoid_precise(g[0]), fg = sigmoid_precise(g[HU]), gg = tanhf(g[2 * HU]), og = sigmoid_precise(g[3 * HU]);
+                    const float c = fg * sc[i] + ig * gg;
+                    sc[i] = c;
+                    hv = og * tanhf(c);
+                }
+                xstore(xh + u * H + wg * HU + unit, hv);
+            }
+            ok = cluster_sync(cnt, epoch, a.status);
+            for (int i = tid; i < CU * H; i += CNT) sh[i] = xload(xh + i);
+            __syncthreads();
+            // ---- phase 2: this workgroup's columns of linear_decoder(h)
+            if (tid < JU * 4) {
+                const int lc = tid % JU, ug = tid / JU;                   // 4 groups of CU/4 utterances
+                const int n = wg * JU + lc;
+                float acc[CU / 4];
+#pragma unroll
+                for (int q = 0; q < CU / 4; ++q) acc[q] = 0.f;
+                const float4* __restrict__ wp = w.wd4 + n;
+                float4 wn[CLB];
+#pragma unroll
+                for (int i = 0; i < CLB; ++i) wn[i] = wp[(size_t)i * J];
+                for (int k0 = 0; k0 < H / 4; k0 += CLB) {
+                    float4 wv[CLB];
+#pragma unroll
+                    for (int i = 0; i < CLB; ++i) wv[i] = wn[i];
+                    const int kn = k0 + CLB < H / 4 ? k0 + CLB : k0;
+#pragma unroll
+                    for (int i = 0; i < CLB; ++i) wn[i] = wp[(size_t)(kn + i) * J];
+#pragma unroll
+                    for (int i = 0; i < CLB; ++i)
+#pragma unroll
+                        for (int q = 0; q < CU / 4; ++q) {
+                            const float4 xv = *reinterpret_cast<const float4*>(sh + (ug * (CU / 4) + q) * H + 4 * (k0 + i));
+                            acc[q] = fmaf(wv[i].w, xv.w, fmaf(wv[i].z, xv.z, fmaf(wv[i].y, xv.y, fmaf(wv[i].x, xv.x, acc[q]))));
+                        }
+                }
+#pragma unroll
+                for (int q = 0; q < CU / 4; ++q) {
+                    const int u = ug * (CU / 4) + q;
+                    const bool upd = s_need[u] && s_step[u] < s_T[u];
+                    xstore(xgd + u * J + n, upd ? acc[q] + w.bd[n] : sgd[u * J + n]);
+                }
+            }
+            ok = cluster_sync(cnt, epoch, a.status) && ok;
+            for (int i = tid; i < CU * J; i += CNT) sgd[i] = xload(xgd + i);
+            __syncthreads();
+        }
+        // ---- phase 3: joint on CKF frames per utterance, this workgroup's slice of the vocabulary
+        for (int i = tid; i < CU * CKF * J; i += CNT) {
+            const int row = i / J, j = i - row * J, u = row / CKF, kf = row - u * CKF;
+            const int b = u0 + u < a.B ? u0 + u : a.B - 1;
+            int t = s_step[u] + kf;
+            t = t < s_T[u] ? t : (s_T[u] > 0 ? s_T[u] - 1 : 0);
+            sz[i] = tanhf(a.fe[((size_t)b * a.T + t) * J + j] + sgd[u * J + j]);
+        }
+        __syncthreads();
+        {
+            constexpr int RG = CNT / 128, RPG = CU * CKF / RG;          // 4 row groups of 4 rows
+            const int lc = tid & 127, rg = tid >> 7;
+            const int n = wg * VU + lc;
+            const bool colok = lc < VU && n < V;
+            const int nc = colok ? n : V - 1;
+            float acc[RPG];
+#pragma unroll
+            for (int q = 0; q < RPG; ++q) acc[q] = 0.f;
+            const float4* __restrict__ wp = w.wj4 + nc;
+            float4 wn[CLB];
+#pragma unroll
+            for (int i = 0; i < CLB; ++i) wn[i] = wp[(size_t)i * V];
+            for (int k0 = 0; k0 < J / 4; k0 += CLB) {
+                float4 wv[CLB];
+#pragma unroll
+                for (int i = 0; i < CLB; ++i) wv[i] = wn[i];
+                const int kn = k0 + CLB < J / 4 ? k0 + CLB : k0;
+#pragma unroll
+                for (int i = 0; i < CLB; ++i) wn[i] = wp[(size_t)(kn + i) * V];
+#pragma unroll
+                for (int i = 0; i < CLB; ++i)
+#pragma unroll
+                    for (int q = 0; q < RPG; ++q) {
+                        const float4 xv = *reinterpret_cast<const float4*>(sz + (rg * RPG + q) * J + 4 * (k0 + i));
+                        acc[q] = fmaf(wv[i].w, xv.w, fmaf(wv[i].z, xv.z, fmaf(wv[i].y, xv.y, fmaf(wv[i].x, xv.x, acc[q]))));
+                    }
+            }
+            const float bz = w.bj[nc];
+#pragma unroll
+            for (int q = 0; q < RPG; ++q) {
+                float bv = colok ? acc[q] + bz : -INFINITY; int bi = colok ? n : 0x7fffffff;
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) {
+                    const float ov = __shfl_xor(bv, o); const int oi = __shfl_xor(bi, o);
+                    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+                }
+                if (lane == 0) { sred[(rg * RPG + q) * 8 + (wave & 1)] = bv; sredi[(rg * RPG + q) * 8 + (wave & 1)] = bi; }
+            }
+        }
+        __syncthreads();
+        if (tid < CU * CKF) {
+            float bv = sred[tid * 8]; int bi = sredi[tid * 8];
+            const float ov = sred[tid * 8 + 1]; const int oi = sredi[tid * 8 + 1];
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            xstore(xav + wg * CU * CKF + tid, bv); xstorei(xai + wg * CU * CKF + tid, bi);
+        }
+        ok = cluster_sync(cnt, epoch, a.status) && ok;
+        if (tid < CU * CKF) {
+            float bv = xload(xav + tid); int bi = xloadi(xai + tid);
+            for (int q = 1; q < CW; ++q) {
+                const float ov = xload(xav + q * CU * CKF + tid); const int oi = xloadi(xai + q * CU * CKF + tid);
+                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            }
+            s_pred[tid] = bi;
+        }
+        __syncthreads();
+        // ---- decisions (transducer.py:158-176), identical in every workgroup
+        if (tid < CU) {
+            const int u = tid, b = u0 + u;
+            int step = s_step[u], consec = s_consec[u], ntok = s_ntok[u], need = 0;
+            for (int kf = 0; kf < CKF && step < s_T[u]; ++kf) {
+                const int pred = s_pred[u * CKF + kf];
+                if (pred == 0 || consec == w.max_consec) { consec = 0; ++step; }
+                else {
+                    ++consec;
+                    if (wg == 0 && b < a.B && ntok < a.max_tok) a.tokens[(size_t)b * a.max_tok + ntok] = pred;
+                    ++ntok;
+                    s_y[u] = pred;
+                    need = 1;
+                    break;
+                }
+            }
+            s_step[u] = step; s_consec[u] = consec; s_ntok[u] = ntok; s_need[u] = need;
+        }
+        __syncthreads();
+    }
+    if (wg == 0) {
+        for (int u = 0; u < CU; ++u) {
+            const int b = u0 + u;
+            if (b >= a.B) continue;
+            const int ntok = s_ntok[u] < a.max_tok ? s_ntok[u] : a.max_tok;
+            if (tid == 0) a.counts[b] = ntok;
+            for (int i = ntok + tid; i < a.max_tok; i += CNT) a.tokens[(size_t)b * a.max_tok + i] = 0;
+        }
+    }
+}
+
+inline size_t cluster_exchange_bytes(int ncl, int H, int J) {
+    return (size_t)ncl * ((size_t)CU * H * 4 + (size_t)CU * J * 4 + (size_t)CW * CU * CKF * 8 + 256) + 256;
+}
+inline bool cluster_supported(const EcRnntConfig& c) {
+    return c.dim_decoder % (4 * CW) == 0 && c.dim_joint % (4 * CW) == 0 && (c.dim_decoder / 4) % CLB == 0 && (c.dim_joint / 4) % CLB == 0 && 4 * (c.dim_decoder / CW) <= CNT && 4 * (c.dim_joint / CW) <= CNT &&
+           (c.vocab_size + CW - 1) / CW <= 128;
+}
+
 struct HostT { std::vector<int64_t> shape; std::vector<float> data; };
 
 }  // namespace
@@ -257,6 +537,7 @@ struct EcRnnt {
     float* we = nullptr;     // linear_encoder.weight [J][De]
     float* be = nullptr;
     bool finalized = false;
+    int cluster_mode = -1;   // -1 auto (cluster decode for batches >= 2*CU), 0 per-utterance kernel, 1 force cluster
 };
 
 namespace {
@@ -362,7 +643,14 @@ int effconf_rnnt_finalize(EcRnnt* r) {
 
 size_t effconf_rnnt_workspace_bytes(const EcRnnt* r, int32_t batch, int32_t t_out) {
     if (!r || batch < 0 || t_out < 0) return 0;
-    return (size_t)batch * t_out * r->cfg.dim_joint * 4 + 256;
+    const int ncl = (batch + CU - 1) / CU;
+    return (size_t)batch * t_out * r->cfg.dim_joint * 4 + 256 + cluster_exchange_bytes(ncl, r->cfg.dim_decoder, r->cfg.dim_joint);
+}
+
+int effconf_rnnt_set_option(EcRnnt* r, const char* name, int32_t value) {
+    if (!r || !name) return ec_fail("null argument");
+    if (!strcmp(name, "cluster_decode")) { r->cluster_mode = value; return 0; }
+    return ec_fail("unknown option");
 }
 
 int32_t effconf_rnnt_max_tokens(const EcRnnt* r, int32_t t_out) {
@@ -383,6 +671,29 @@ int effconf_rnnt_greedy(EcRnnt* r, const float* enc_out, const int64_t* out_len,
     float* fe = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
     // linear_encoder(f) for every frame of the batch, once (joint_networks.py:82 recomputes it per decision)
     if (launch_sgemm_nt(enc_out, De, r->we, De, r->be, fe, J, batch * t_out, J, De, s) != 0) return ec_fail("linear_encoder GEMM launch failed");
+    const bool cluster = cluster_supported(r->cfg) && (r->cluster_mode == 1 || (r->cluster_mode < 0 && batch >= 2 * CU));
+    if (cluster) {
+        const int ncl = (batch + CU - 1) / CU;
+        if (ncl * CW > 256) return ec_fail("cluster decode needs every workgroup resident: batch <= 256");
+        char* ex = reinterpret_cast<char*>(fe) + (size_t)batch * t_out * J * 4;
+        ex = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(ex) + 255) & ~(uintptr_t)255);
+        ClusterArgs a{};
+        a.w = r->dev; a.fe = fe; a.lens = out_len; a.T = t_out; a.B = batch; a.tokens = tokens; a.counts = token_len; a.max_tok = max_tokens;
+        a.ncl = ncl;
+        a.cnt = reinterpret_cast<unsigned*>(ex); a.status = reinterpret_cast<int*>(ex + (size_t)ncl * 256);
+        char* p = ex + (size_t)ncl * 256 + 256;
+        a.xh = reinterpret_cast<float*>(p); p += (size_t)ncl * CU * H * 4;
+        a.xgd = reinterpret_cast<float*>(p); p += (size_t)ncl * CU * J * 4;
+        a.xav = reinterpret_cast<float*>(p); p += (size_t)ncl * CW * CU * CKF * 4;
+        a.xai = reinterpret_cast<int*>(p);
+        if (hipMemsetAsync(ex, 0, (size_t)ncl * 256 + 256, s) != hipSuccess) return ec_fail("memset failed");
+        const int HU = H / CW;
+        const size_t lds = (size_t)(CU * H + CU * J + CU * CKF * J + CU * HU + CU * 4 * HU + CU * CKF * 16) * 4;
+        static size_t attr = 0;
+        if (attr < lds) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rnnt_cluster_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = lds; }
+        hipLaunchKernelGGL(rnnt_cluster_kernel, dim3(ncl * CW), dim3(CNT), lds, s, a);
+        return hipGetLastError() == hipSuccess ? 0 : ec_fail("rnnt cluster launch failed");
+    }
     const size_t lds = (size_t)(2 * H + 4 * H + J + KF * J + 2 * KF * (NT / 64)) * 4;
     hipLaunchKernelGGL(rnnt_greedy_kernel, dim3(batch), dim3(NT), lds, s, r->dev, fe, out_len, t_out, tokens, token_len, max_tokens);
     return hipGetLastError() == hipSuccess ? 0 : ec_fail("rnnt_greedy launch failed");

@@ -133,6 +133,11 @@ class Transducer(nn.Module):
         except Exception:
             pass
 
+    def set_decode_option(self, name: str, value: int):
+        """Forward an option to the native decoder (effconf_rnnt_set_option), e.g. ``cluster_decode`` = -1 auto / 0 / 1."""
+        self._ensure_rnnt()
+        _lib.check(_lib.load().effconf_rnnt_set_option(self._rnnt, name.encode(), int(value)), "rnnt_set_option(%s)" % name)
+
     # ------------------------------------------------------------------ decoding
     def decode_encoded(self, f: torch.Tensor, f_len: Optional[torch.Tensor]):
         """Greedy RNN-T decode of encoder outputs f (B, T, Denc) fp32 on the GPU -> (tokens (B, max_tok) i32, token_len (B) i32)."""

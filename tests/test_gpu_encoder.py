@@ -284,3 +284,29 @@ def test_front_door_matches_direct_calls():
         want = m.greedy_labels(x.cuda(), torch.tensor(n).cuda())
         for r, i in enumerate(idx):
             assert got[i] == want[r]
+
+
+@pytest.mark.parametrize("name,tag,nb", [("TinyTransducer", "rand", 19), ("TinyTransducer", "blank", 16), ("EfficientConformerTransducerMedium", "blank", 24),
+                                         ("EfficientConformerTransducerMedium", "rand", 16)])
+def test_rnnt_cluster_decode_equals_per_utterance_decode(golden_dir, name, tag, nb):
+    """Batches of >= 16 utterances decode in clusters of 8 workgroups x 8 utterances (shared weight streams, lockstep rounds,
+    cross-workgroup barriers); tokens must equal the one-workgroup-per-utterance kernel's and, for the golden rows, the reference's."""
+    g = np.load(os.path.join(golden_dir, "rnnt_%s.npz" % name))
+    m, _ = _transducer(name, int(g["weight_seed"]), float(g["blank_bias_" + tag]))
+    f0, l0 = torch.from_numpy(g["f"]), torch.from_numpy(g["f_len"])
+    rows = [i % f0.shape[0] for i in range(nb)]
+    f = f0[rows].clone()
+    lens = torch.tensor([max(0, int(l0[r]) - 3 * (i // f0.shape[0])) for i, r in enumerate(rows)])   # ragged, incl. repeated golden rows
+    f, lens = f.cuda(), lens.cuda()
+    m.set_decode_option("cluster_decode", 0)
+    ref_t, ref_n = m.decode_encoded(f, lens)
+    m.set_decode_option("cluster_decode", 1)
+    got_t, got_n = m.decode_encoded(f, lens)
+    assert torch.equal(got_n, ref_n) and torch.equal(got_t, ref_t)
+    offs = g["offsets_" + tag]
+    for b in range(f0.shape[0]):                      # the first copies keep the golden lengths
+        want = g["tokens_" + tag][offs[b]:offs[b + 1]].tolist()
+        assert got_t[b, :int(got_n[b])].tolist() == want
+    m.set_decode_option("cluster_decode", -1)
+    auto_t, auto_n = m.decode_encoded(f, lens)
+    assert torch.equal(auto_t, ref_t) and torch.equal(auto_n, ref_n)
