@@ -210,7 +210,7 @@ __device__ __forceinline__ void load_a(const char* ab, size_t pitch, int row_byt
 // PROF (tuning only, EFFCONF_CHAIN_PHASES=1, KS = 8 full chain): s_memtime per phase of the FFN stages -
 // 0 advance (DMA wait + barrier + refill), 1 GEMM1, 2 Swish, 3 GEMM2, 4 everything else, 5 waves
 template <int KS, int NW, int NBUF, int KIND, bool PROF = false>
-__global__ __launch_bounds__(NW * 64) void chain_kernel(const ChainDev cd, unsigned long long* prof = nullptr) {
+__global__ __launch_bounds__(NW * 64, (NW == 4 && KS <= 8) ? 2 : 1) void chain_kernel(const ChainDev cd, unsigned long long* prof = nullptr) {
     unsigned long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0;
     if constexpr (PROF) t0 = __builtin_readcyclecounter();
 #define CH_TICK(i) do { if constexpr (PROF) { asm volatile("" ::: "memory"); const unsigned long long t1_ = __builtin_readcyclecounter(); ph[i] += t1_ - t0; t0 = t1_; } } while (0)
@@ -274,11 +274,17 @@ __global__ __launch_bounds__(NW * 64) void chain_kernel(const ChainDev cd, unsig
     // vmcnt FIFO as the DMAs: they are younger than the chunk being waited for, so they are simply allowed to stay outstanding
     // (waiting for them — i.e. for HBM write acknowledgements — cost ~10k cycles per Q/K/V chunk: s_memtime profile).
     int gc = 0, st1 = 0, st2 = 0;                          // next chunk to consume; store instructions in flight
+    // 8-wave workgroups wait one chunk AHEAD (late waves, see above; needs a ring of >= 3); 4-wave workgroups use the plain rule
+    // (barrier k: chunk k has landed) which works with a ring of 2 and leaves LDS for a second workgroup per CU
+    constexpr bool AHEAD = (NW == 8);
+    static_assert(!AHEAD || NBUF >= 3, "wait-ahead protocol needs three ring buffers");
     auto advance = [&]() __attribute__((always_inline)) -> const char* {
-        int ahead = total - 2 - gc;                        // chunks issued beyond gc+1
-        ahead = ahead < 0 ? 0 : (ahead > NBUF - 3 ? NBUF - 3 : ahead);
-        if (st1 + st2 == 0) wait_chunks<PER, NBUF - 3>(total - 2 - gc);        // chunk gc+1 has landed (this wave's pieces)
-        else wait_vmcnt_dyn(PER * ahead + st1 + (NBUF >= 4 ? st2 : 0));
+        constexpr int MAXC = AHEAD ? NBUF - 3 : NBUF - 2;
+        int ahead = (AHEAD ? total - 2 : total - 1) - gc;  // chunks issued beyond the one being waited for
+        const int rem = ahead;
+        ahead = ahead < 0 ? 0 : (ahead > MAXC ? MAXC : ahead);
+        if (st1 + st2 == 0) wait_chunks<PER, MAXC>(rem);
+        else wait_vmcnt_dyn(PER * ahead + st1 + ((AHEAD ? NBUF >= 4 : NBUF >= 3) ? st2 : 0));
         st2 = st1; st1 = 0;
         wg_barrier();
         if (gc + NBUF - 1 < total) issue(gc + NBUF - 1);
@@ -634,19 +640,22 @@ int launch_chain_kind(const ChainParams& p, hipStream_t s) {
     const int ks = 2 * ((p.D + 31) / 32);
     if (ks <= 2) return launch_chain_t<2, 4, 4, KIND>(p, s);
     if (ks <= 4) return launch_chain_t<4, 8, 4, KIND>(p, s);
-    if (ks <= 8) return launch_chain_t<8, 8, 4, KIND>(p, s);
+    static const int var = getenv("EFFCONF_CHAIN_VARIANT") ? atoi(getenv("EFFCONF_CHAIN_VARIANT")) : 0;
+    if (ks <= 8) return var == 1 ? launch_chain_t<8, 4, 2, KIND>(p, s) : launch_chain_t<8, 8, 4, KIND>(p, s);
     if (ks <= 12) return launch_chain_t<12, 8, 3, KIND>(p, s);
     return launch_chain_t<16, 4, 3, KIND>(p, s);
 }
 
 }  // namespace
 
-// D % 8 == 0: 16-byte bf16 pieces never straddle the Q | K | V boundaries; D <= 256: the residual row fits the register file
-bool chain_supported(int D) { return D % 8 == 0 && D >= 16 && D <= 256; }
+// D <= 256: the residual row fits the register file.  The Q/K/V-emitting half additionally needs D % 8 == 0 (16-byte bf16 pieces
+// never straddle the Q | K | V boundaries) — Medium's D = 180 stage runs chain B and the tail chain only.
+bool chain_supported(int D) { return D % 4 == 0 && D >= 16 && D <= 256; }
 // The FFN-carrying chain A at KS = 16 (D = 240 / 256) runs at one wave per SIMD with its LayerNorm / load phases spilling (the
 // chunk loops stay spill-free); measured it only ties the per-GEMM kernels there (5.60 vs 5.54 ms per step), so it is used up to
 // D = 192.  A 16-row-per-wave variant (v_mfma_f32_16x16x32_bf16, half the registers per lane) is the planned fix.
-bool chain_head_supported(int D) { return chain_supported(D) && D <= 192; }
+bool chain_head_supported(int D) { return chain_supported(D) && D % 8 == 0 && D <= 192; }
+bool chain_tail_supported(int D) { return chain_supported(D) && D <= 192; }
 
 int launch_chain(const ChainParams& p, int kind, hipStream_t s) {
     if (p.M <= 0) return 0;

@@ -473,7 +473,7 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
         const bool nat = (d % 2) == 0;
         const bool chain_head = e->fuse_chain && W.chain_in && nat && chain_head_supported(D);          // FFN1 + QKV of this block as a fused chain
         const bool chain_b = e->fuse_chain && W.chain_in;                      // out-proj + LN + pointwise-1/GLU
-        const bool chain_tail = e->fuse_chain && W.chain_out && chain_head_supported(De);                  // pointwise-2 + FFN2 + block norm (+ next block's head)
+        const bool chain_tail = e->fuse_chain && W.chain_out && chain_tail_supported(De);                  // pointwise-2 + FFN2 + block norm (+ next block's head)
         GemmParams p{};
         p.A = a; p.lda = ld8(D); p.W = W.qkv.w; p.ldw = W.qkv.ldw; p.bias = W.qkv.bias;
         p.M = M; p.N = 3 * D; p.K = D;
@@ -885,9 +885,9 @@ int effconf_encoder_finalize(EcEncoder* e) {
             W.cc_b = build(CHAIN_B, D, &W, nullptr, &b, nullptr);
             if (chain_head_supported(D)) W.cc_head = build(CHAIN_A_HEAD, D, nullptr, &W, nullptr, &b);
         }
-        if (W.chain_out && chain_head_supported(De)) {
+        if (W.chain_out && chain_tail_supported(De)) {
             W.cc_tail = build(CHAIN_A_TAIL, De, &W, nullptr, &b, nullptr);
-            if (k + 1 < e->blocks.size() && e->bw[k + 1].chain_in && e->blocks[k + 1].dim_model == De)
+            if (chain_head_supported(De) && k + 1 < e->blocks.size() && e->bw[k + 1].chain_in && e->blocks[k + 1].dim_model == De)
                 W.cc_full = build(CHAIN_A_FULL, De, &W, &e->bw[k + 1], &b, &e->blocks[k + 1]);
         }
     }

@@ -81,7 +81,8 @@ struct ChainParams {
 enum { CHAIN_B = 0, CHAIN_A_FULL = 1, CHAIN_A_HEAD = 2, CHAIN_A_TAIL = 3 };   // HEAD: first block (no previous tail); TAIL: last block (no next head)
 bool chain_supported(int D);
 int chain_const_layout(const ChainParams& p, int kind, int (&nf)[8]);   // float offsets of the constant block; returns its size in floats
-bool chain_head_supported(int D);
+bool chain_head_supported(int D);   // FFN1 + Q/K/V half (chain A head / full)
+bool chain_tail_supported(int D);   // pointwise-2 + FFN2 + block norm half
 int launch_chain(const ChainParams& p, int kind, hipStream_t s);
 
 // ---------------------------------------------------------------- normalisation / casts  (norm.hip)
