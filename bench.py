@@ -7,7 +7,10 @@
 
 A "step" is one pass of the hot path (ConformerEncoder.forward: mel frontend -> conv subsampling -> 15
 Conformer blocks, then fc + argmax + CTC collapse) over one synthetic LibriSpeech-shaped batch that is
-already resident in HBM.  One process per GPU; utterances shard across ranks with no data-path
+already resident in HBM.  By default the batch (256 utterances per GPU) runs as two interleaved
+sub-batches with the batch's common padded length on two HIP streams: the row-local chain kernels alternate
+HBM-bound load/store bursts with compute, and a second stream fills one's bursts with the other's compute
+(--streams 1 --batch 128 reproduces the single-stream numbers of profiles/r1_0x).  One process per GPU; utterances shard across ranks with no data-path
 collective inside the timed loop except the all-gather of encoder outputs (RCCL), as north_star asks.
 Rank 0 prints ONE JSON line.  `value` counts VALID (un-padded) mel frames of all ranks per second.
 """
@@ -39,10 +42,10 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--model", default="EfficientConformerCTCSmall")
-    ap.add_argument("--batch", type=int, default=128, help="utterances per GPU per step")
+    ap.add_argument("--batch", type=int, default=256, help="utterances per GPU per step")
     ap.add_argument("--workload", default="libri", choices=["libri", "fixed"],
                     help="libri: lognormal LibriSpeech-shaped lengths (SURVEY.md 8d W-libri); fixed: 10 s each")
-    ap.add_argument("--streams", type=int, default=1,
+    ap.add_argument("--streams", type=int, default=2,
                     help="run the batch as this many interleaved sub-batches (same padded length) on concurrent HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -164,26 +167,35 @@ def main():
         subs = [(torch.cuda.Stream(device=dev), audio[i::args.streams].contiguous(), lens[i::args.streams].contiguous())
                 for i in range(args.streams)]
 
+    def gather(idx, enc, producer):
+        # all-gather of encoder outputs over RCCL/xGMI on a side stream, overlapped with the following kernels
+        nonlocal gather_buf
+        if gather_buf is None:
+            gather_buf = {}
+        if idx not in gather_buf:
+            gather_buf[idx] = torch.empty((world,) + tuple(enc.shape), dtype=torch.bfloat16, device=dev)
+        side.wait_stream(producer)
+        with torch.cuda.stream(side):
+            e16 = enc.to(torch.bfloat16)
+            enc.record_stream(side)
+            dist.all_gather_into_tensor(gather_buf[idx], e16)
+
     def full_step():
+        cur = torch.cuda.current_stream(dev)
         if subs is not None:
-            cur = torch.cuda.current_stream(dev)
             outs = []
-            for st, a_, l_ in subs:
+            for i, (st, a_, l_) in enumerate(subs):
                 st.wait_stream(cur)
                 with torch.cuda.stream(st):
                     outs.append(step(model, a_, l_))
+                if world > 1:
+                    gather(i, outs[-1][0], st)
             for st, _, _ in subs:
                 cur.wait_stream(st)
             return outs[0][2]
         enc, enc_len, labels, label_len = step(model, audio, lens)
         if world > 1:
-            # all-gather of encoder outputs over RCCL/xGMI on a side stream, overlapped with the next step's kernels
-            nonlocal gather_buf
-            if gather_buf is None:
-                gather_buf = torch.empty((world,) + tuple(enc.shape), dtype=torch.bfloat16, device=dev)
-            side.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(side):
-                dist.all_gather_into_tensor(gather_buf, enc.to(torch.bfloat16))
+            gather(0, enc, cur)
         return labels
 
     for _ in range(args.warmup):
@@ -222,7 +234,7 @@ def main():
                                       "lognormal 1.5-16 s (LibriSpeech-shaped), sorted desc, zero-padded to the batch max"
                                       if args.workload == "libri" else "10 s",
                                       "RNN-T token ids (synthetic blank bias %.1f)" % RNNT_BLANK_BIAS if isinstance(model, Transducer) else "CTC labels"),
-                       "global_batch": args.batch * world, "padded_frames_per_s": all_padded * args.steps / elapsed,
+                       "global_batch": args.batch * world, "streams_per_gpu": args.streams, "padded_frames_per_s": all_padded * args.steps / elapsed,
                        "parallelism": "dp%d (utterance shards, all-gather of encoder outputs)" % world},
         }
 
@@ -232,8 +244,12 @@ def main():
         h = model.encoder._handle
         _lib.check(lib.effconf_profile_enable(h, 1), "profile_enable")
         nprof = min(args.steps, 5)
-        for _ in range(nprof):
-            step(model, audio, lens)
+        for _ in range(nprof):      # same launch shapes as the timed region (sub-batches), one after the other on one stream
+            if subs is not None:
+                for _, a_, l_ in subs:
+                    step(model, a_, l_)
+            else:
+                step(model, audio, lens)
         torch.cuda.synchronize()
         per = {}
         for ci, cname in enumerate(PROF_CLASSES):
@@ -265,7 +281,8 @@ def main():
                               "avg_launch_ms": avg_ms, "launches_per_step": n_l,
                               "alg_gflop_per_launch": dom["gflop_per_step"] / n_l,
                               "alg_hbm_gbs": dom["alg_mb_per_step"] / max(dom["ms_per_step"], 1e-9),
-                              "note": "HIP events around every launch of the class on the launch stream, %d extra steps after the timed region" % nprof}
+                              "note": "HIP events around every launch of the class on the launch stream, %d extra steps after the timed region "
+                                      "(the step's %d sub-batches one after the other, so launches do not overlap)" % (nprof, max(args.streams, 1))}
         result["kernel_classes"] = per
 
     if rank == 0 and not args.no_cpu_baseline:
