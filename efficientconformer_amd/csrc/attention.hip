@@ -20,6 +20,7 @@
 //   * group-reshape / head split are index arithmetic (inputs are head-major, output is (B*T, D)).
 // All MFMA are v_mfma_f32_16x16x32_bf16, fp32 accumulation.
 #include "kernels.h"
+#include <cstdio>
 #include <cstdlib>
 
 namespace {
@@ -59,8 +60,11 @@ struct AttnSmem {
 // (BI + 63 rows per key block, shifting by 64 rows per block) lives in a ring indexed by the absolute E row, so only the
 // 64 NEW rows are staged per key block.  Staging is software pipelined through registers (loads of block j+1 are in
 // flight during block j's MFMA / softmax work) and all loads are unconditional at clamped addresses.
-template <int DP, int NWV>
-__global__ __launch_bounds__(NWV * 64) void relpos_attention_kernel(const AttnParams p) {
+template <int DP, int NWV, bool PROF = false>
+__global__ __launch_bounds__(NWV * 64) void relpos_attention_kernel(const AttnParams p, unsigned long long* prof = nullptr) {
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0;
+    if constexpr (PROF) t0 = __builtin_readcyclecounter();
+#define AT_TICK(i) do { if constexpr (PROF) { asm volatile("" ::: "memory"); const unsigned long long t1_ = __builtin_readcyclecounter(); ph[i] += t1_ - t0; t0 = t1_; } } while (0)
     using SM = AttnSmem<DP, NWV>;
     constexpr int KS = DP / 32;     // k-steps over the head dim
     constexpr int DT = DP / 16;     // 16-wide output column tiles
@@ -124,12 +128,25 @@ __global__ __launch_bounds__(NWV * 64) void relpos_attention_kernel(const AttnPa
     }
     // ---- first positional band: rows R0 .. R0 + BI + 62 (absolute E rows), staged directly
     const int R0 = p.Tg - 1 - i0 - (BI - 1);           // E row of band row 0 for key block 0
-    for (int q = tid; q < (BI + 63) * CPR; q += NTHR) {
-        const int rr = q / CPR, x = (q - rr * CPR) * 8;
-        const int r = R0 + rr;
-        const int rc = r < 0 ? 0 : (r >= erows ? erows - 1 : r);
-        const uint4 v = ld16(Eh + (size_t)rc * ERS + x);
-        *reinterpret_cast<uint4*>(sE + ((r + 8192) & (ERING - 1)) * SM::KROW + x * 2) = mask_chunk(v, (r >= 0 && r < erows) ? p.d - x : 0);
+    {   // all loads first (one latency), then the LDS writes
+        constexpr int NB = ((BI + 63) * CPR + NTHR - 1) / NTHR;
+        uint4 fb[NB];
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+            const int q = tid + NTHR * n;
+            const int rr = q / CPR, x = (q - rr * CPR) * 8;
+            const int r = R0 + (rr < BI + 63 ? rr : BI + 62);
+            const int rc = r < 0 ? 0 : (r >= erows ? erows - 1 : r);
+            fb[n] = ld16(Eh + (size_t)rc * ERS + x);
+        }
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+            const int q = tid + NTHR * n;
+            const int rr = q / CPR, x = (q - rr * CPR) * 8;
+            const int r = R0 + rr;
+            if (q < (BI + 63) * CPR)
+                *reinterpret_cast<uint4*>(sE + ((r + 8192) & (ERING - 1)) * SM::KROW + x * 2) = mask_chunk(fb[n], (r >= 0 && r < erows) ? p.d - x : 0);
+        }
     }
 
     f32x4 acc[DT];
@@ -139,78 +156,91 @@ __global__ __launch_bounds__(NWV * 64) void relpos_attention_kernel(const AttnPa
     float* skew = sS + wave * 16 * SKEW_LD + c * SKEW_LD;
     const int woff = BI - 16 - 16 * wave;             // first band row of this wave inside the workgroup band
 
-    // ---- K / V / new-E staging registers (zero-initialised: conditionally written arrays end up in scratch otherwise)
+    // ---- K / V / new-E staging registers, TWO sets: the loads of key block n+2 are issued when block n is published, so they
+    // have a whole block's publish + compute time to arrive.  (With one set the s_memtime phase profile showed the MFMA / softmax
+    // phases at 9 % of a wave's life and 46 % waiting for the next block's loads at the publish point: EFFCONF_ATTN_PHASES.)
     constexpr int NK = (BJ * CPR + NTHR - 1) / NTHR, NV = ((BJ / 2) * CPR + NTHR - 1) / NTHR, NE = (64 * CPR + NTHR - 1) / NTHR;
-    uint4 lk[NK], lv0[NV], lv1[NV], le[NE];
+    struct Stage { uint4 lk[NK], lv0[NV], lv1[NV], le[NE]; };
+    Stage sa, sb;
 #pragma unroll
-    for (int n = 0; n < NK; ++n) lk[n] = make_uint4(0, 0, 0, 0);
+    for (int n = 0; n < NK; ++n) { sa.lk[n] = make_uint4(0, 0, 0, 0); sb.lk[n] = sa.lk[n]; }
 #pragma unroll
-    for (int n = 0; n < NV; ++n) { lv0[n] = make_uint4(0, 0, 0, 0); lv1[n] = lv0[n]; }
+    for (int n = 0; n < NV; ++n) { sa.lv0[n] = make_uint4(0, 0, 0, 0); sa.lv1[n] = sa.lv0[n]; sb.lv0[n] = sa.lv0[n]; sb.lv1[n] = sa.lv0[n]; }
 #pragma unroll
-    for (int n = 0; n < NE; ++n) le[n] = make_uint4(0, 0, 0, 0);
+    for (int n = 0; n < NE; ++n) { sa.le[n] = make_uint4(0, 0, 0, 0); sb.le[n] = sa.le[n]; }
 
-    for (int j0 = -BJ; j0 < nkeys; j0 += BJ) {        // iteration -BJ is the prologue (loads of block 0 only)
-        const int jn = j0 + BJ;                       // block whose loads are issued in this iteration
-        if (j0 >= 0) {
-            __syncthreads();                          // previous block's LDS reads are done
-            // ---- publish block j0: K rows, transposed V, and (for j0 > 0) the 64 new band rows
+    auto issue_loads = [&](Stage& st_, int jn) __attribute__((always_inline)) {
 #pragma unroll
-            for (int n = 0; n < NK; ++n) {
-                const int q = tid + NTHR * n, r = q / CPR, x = (q - r * CPR) * 8;
-                if (q < BJ * CPR) *reinterpret_cast<uint4*>(sK + r * SM::KROW + x * 2) = mask_chunk(lk[n], (j0 + r < p.Tg) ? p.d - x : 0);
-            }
-#pragma unroll
-            for (int n = 0; n < NV; ++n) {
-                const int q = tid + NTHR * n, pr = q & (BJ / 2 - 1), x = (q / (BJ / 2)) * 8;
-                const int j = j0 + 2 * pr;
-                if (q < (BJ / 2) * CPR) {
-                    const uint4 v0 = mask_chunk(lv0[n], (j < p.Tg) ? 8 : 0), v1 = mask_chunk(lv1[n], (j + 1 < p.Tg) ? 8 : 0);
-                    const uint32_t a[4] = {v0.x, v0.y, v0.z, v0.w}, bq[4] = {v1.x, v1.y, v1.z, v1.w};
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const uint32_t lo = (a[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu, hi = (bq[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu;
-                        *reinterpret_cast<uint32_t*>(sV + (x + e) * SM::VROW + pr * 4) = lo | (hi << 16);
-                    }
-                }
-            }
-            if (j0 > 0) {
-                const int rnew = R0 + j0 + BI - 1;    // first new absolute E row of this block
-#pragma unroll
-                for (int n = 0; n < NE; ++n) {
-                    const int q = tid + NTHR * n, rr = q / CPR, x = (q - rr * CPR) * 8;
-                    const int r = rnew + rr;
-                    if (q < 64 * CPR)
-                        *reinterpret_cast<uint4*>(sE + ((r + 8192) & (ERING - 1)) * SM::KROW + x * 2) = mask_chunk(le[n], (r >= 0 && r < erows) ? p.d - x : 0);
-                }
-            }
-            __syncthreads();
+        for (int n = 0; n < NK; ++n) {
+            const int q = tid + NTHR * n, r = q / CPR, x = (q - r * CPR) * 8;
+            const int j = jn + r;
+            st_.lk[n] = ld16(Kh + (size_t)(j < p.Tg ? j : p.Tg - 1) * RS + (x < DP ? x : 0));
         }
-        if (jn < nkeys) {                             // loads of the next block: in flight during this block's compute
 #pragma unroll
-            for (int n = 0; n < NK; ++n) {
-                const int q = tid + NTHR * n, r = q / CPR, x = (q - r * CPR) * 8;
-                const int j = jn + r;
-                lk[n] = ld16(Kh + (size_t)(j < p.Tg ? j : p.Tg - 1) * RS + (x < DP ? x : 0));
+        for (int n = 0; n < NV; ++n) {
+            const int q = tid + NTHR * n, pr = q & (BJ / 2 - 1), x = (q / (BJ / 2)) * 8;
+            const int j = jn + 2 * pr, xc = x < DP ? x : 0;
+            st_.lv0[n] = ld16(Vh + (size_t)(j < p.Tg ? j : p.Tg - 1) * RS + xc);
+            st_.lv1[n] = ld16(Vh + (size_t)(j + 1 < p.Tg ? j + 1 : p.Tg - 1) * RS + xc);
+        }
+        if (jn > 0) {
+            const int rnew = R0 + jn + BI - 1;
+#pragma unroll
+            for (int n = 0; n < NE; ++n) {
+                const int q = tid + NTHR * n, rr = q / CPR, x = (q - rr * CPR) * 8;
+                int r = rnew + rr;
+                r = r < 0 ? 0 : (r >= erows ? erows - 1 : r);
+                st_.le[n] = ld16(Eh + (size_t)r * ERS + (x < DP ? x : 0));
             }
+        }
+    };
+    auto publish = [&](const Stage& st_, int j0) __attribute__((always_inline)) {
+        __syncthreads();                          // previous block's LDS reads are done
+        // ---- publish block j0: K rows, transposed V, and (for j0 > 0) the 64 new band rows
 #pragma unroll
-            for (int n = 0; n < NV; ++n) {
-                const int q = tid + NTHR * n, pr = q & (BJ / 2 - 1), x = (q / (BJ / 2)) * 8;
-                const int j = jn + 2 * pr, xc = x < DP ? x : 0;
-                lv0[n] = ld16(Vh + (size_t)(j < p.Tg ? j : p.Tg - 1) * RS + xc);
-                lv1[n] = ld16(Vh + (size_t)(j + 1 < p.Tg ? j + 1 : p.Tg - 1) * RS + xc);
-            }
-            if (jn > 0) {
-                const int rnew = R0 + jn + BI - 1;
+        for (int n = 0; n < NK; ++n) {
+            const int q = tid + NTHR * n, r = q / CPR, x = (q - r * CPR) * 8;
+            if (q < BJ * CPR) *reinterpret_cast<uint4*>(sK + r * SM::KROW + x * 2) = mask_chunk(st_.lk[n], (j0 + r < p.Tg) ? p.d - x : 0);
+        }
 #pragma unroll
-                for (int n = 0; n < NE; ++n) {
-                    const int q = tid + NTHR * n, rr = q / CPR, x = (q - rr * CPR) * 8;
-                    int r = rnew + rr;
-                    r = r < 0 ? 0 : (r >= erows ? erows - 1 : r);
-                    le[n] = ld16(Eh + (size_t)r * ERS + (x < DP ? x : 0));
+        for (int n = 0; n < NV; ++n) {
+            const int q = tid + NTHR * n, pr = q & (BJ / 2 - 1), x = (q / (BJ / 2)) * 8;
+            const int j = j0 + 2 * pr;
+            if (q < (BJ / 2) * CPR) {
+                const uint4 v0 = mask_chunk(st_.lv0[n], (j < p.Tg) ? 8 : 0), v1 = mask_chunk(st_.lv1[n], (j + 1 < p.Tg) ? 8 : 0);
+                const uint32_t a[4] = {v0.x, v0.y, v0.z, v0.w}, bq[4] = {v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const uint32_t lo = (a[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu, hi = (bq[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu;
+                    *reinterpret_cast<uint32_t*>(sV + (x + e) * SM::VROW + pr * 4) = lo | (hi << 16);
                 }
             }
         }
-        if (j0 < 0) continue;
+        if (j0 > 0) {
+            const int rnew = R0 + j0 + BI - 1;    // first new absolute E row of this block
+#pragma unroll
+            for (int n = 0; n < NE; ++n) {
+                const int q = tid + NTHR * n, rr = q / CPR, x = (q - rr * CPR) * 8;
+                const int r = rnew + rr;
+                if (q < 64 * CPR)
+                    *reinterpret_cast<uint4*>(sE + ((r + 8192) & (ERING - 1)) * SM::KROW + x * 2) = mask_chunk(st_.le[n], (r >= 0 && r < erows) ? p.d - x : 0);
+            }
+        }
+        __syncthreads();
+    };
+
+    issue_loads(sa, 0);
+    if (BJ < nkeys) issue_loads(sb, BJ);
+    AT_TICK(0);
+    for (int jb = 0; jb < nkeys; jb += 2 * BJ)
+#pragma unroll
+    for (int half2 = 0; half2 < 2; ++half2) {
+        const int j0 = jb + half2 * BJ;
+        if (j0 >= nkeys) break;
+        if (half2 == 0) publish(sa, j0); else publish(sb, j0);
+        AT_TICK(1);
+        if (j0 + 2 * BJ < nkeys) { if (half2 == 0) issue_loads(sa, j0 + 2 * BJ); else issue_loads(sb, j0 + 2 * BJ); }
+        AT_TICK(2);
 
         // ---- S^T tiles: rows = keys (g*4+reg within tile jt), cols = queries (c)
         f32x4 st[4];
@@ -223,6 +253,8 @@ __global__ __launch_bounds__(NWV * 64) void relpos_attention_kernel(const AttnPa
                 st[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qu[ks], st[jt], 0, 0, 0);
             }
         }
+        if constexpr (PROF) { asm volatile("s_nop 0" :: "v"(st[0]), "v"(st[3])); }
+        AT_TICK(3);
         // ---- positional band: PE^T[r'][i] = E[rw0 + r'] . Qv[i], r' in [0, 80); rw0 = absolute E row of this wave's band row 0
         const int rw0 = R0 + j0 + woff + 8192;
 #pragma unroll
@@ -237,6 +269,7 @@ __global__ __launch_bounds__(NWV * 64) void relpos_attention_kernel(const AttnPa
             *reinterpret_cast<f32x4*>(skew + rt * 16 + g * 4) = pe;
         }
         wave_sync();                                  // skew buffer is per wave: LDS ops of one wave execute in order
+        AT_TICK(4);
 
         // ---- realign (r' = j_local - i_local + 15), scale, mask, online softmax
         float mloc = -INFINITY;
@@ -269,6 +302,8 @@ __global__ __launch_bounds__(NWV * 64) void relpos_attention_kernel(const AttnPa
         for (int dt = 0; dt < DT; ++dt) {
             acc[dt][0] *= alpha; acc[dt][1] *= alpha; acc[dt][2] *= alpha; acc[dt][3] *= alpha;
         }
+        if constexpr (PROF) { asm volatile("s_nop 0" :: "v"(st[0]), "v"(acc[0])); }
+        AT_TICK(5);
         // ---- O^T += V^T P^T ; contraction slot (g, e) <-> key (2*c2 + (e>>2))*16 + g*4 + (e&3) on both operands
 #pragma unroll
         for (int c2 = 0; c2 < 2; ++c2) {
@@ -289,6 +324,8 @@ __global__ __launch_bounds__(NWV * 64) void relpos_attention_kernel(const AttnPa
         }
     }
 
+    if constexpr (PROF) { asm volatile("s_nop 0" :: "v"(acc[0]), "v"(acc[DT - 1])); }
+    AT_TICK(6);
     // ---- normalise and scatter back to the un-grouped (B*T, D) layout: 4 consecutive head columns per store when they
     // stay inside one original frame (8-byte stores), element-wise otherwise
     float l_tot = l_run + __shfl_xor(l_run, 16);
@@ -323,6 +360,29 @@ __global__ __launch_bounds__(NWV * 64) void relpos_attention_kernel(const AttnPa
                 }
             }
         }
+    }
+    if constexpr (PROF) {
+        AT_TICK(7);
+        if ((threadIdx.x & 63) == 0) {
+            for (int i = 0; i < 8; ++i) atomicAdd(prof + i, ph[i]);
+            atomicAdd(prof + 8, 1ull);
+        }
+    }
+#undef AT_TICK
+}
+
+unsigned long long* g_attn_prof = nullptr;
+void attn_prof_dump() {
+    unsigned long long all[4 * 16];
+    if (!g_attn_prof || hipMemcpy(all, g_attn_prof, sizeof(all), hipMemcpyDeviceToHost) != hipSuccess) return;
+    static const char* names[8] = {"prologue", "publish+barriers", "issue loads", "S = K Q^T", "PE band + skew", "softmax", "PV", "epilogue"};
+    for (int c = 0; c < 4; ++c) {
+        const unsigned long long* h = all + 16 * c;
+        if (!h[8]) continue;
+        unsigned long long tot = 0;
+        for (int i = 0; i < 8; ++i) tot += h[i];
+        fprintf(stderr, "[attn phases] DP=%d: waves %llu, cycles/wave %.0f\n", 32 * (c + 1), h[8], (double)tot / h[8]);
+        for (int i = 0; i < 8; ++i) fprintf(stderr, "[attn phases]   %-17s %10.0f cyc/wave  %5.1f%%\n", names[i], (double)h[i] / h[8], 100.0 * h[i] / tot);
     }
 }
 
@@ -362,23 +422,37 @@ int launch_dp_w(const AttnParams& p, hipStream_t s) {
     using SM = AttnSmem<DP, NWV>;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&relpos_attention_kernel<DP, NWV>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&relpos_attention_kernel<DP, NWV, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, SM::TOTAL);
         attr_set = true;
     }
     const int qtiles = (p.Tg + NWV * 16 - 1) / (NWV * 16);
-    hipLaunchKernelGGL((relpos_attention_kernel<DP, NWV>), dim3(p.B * p.H * qtiles), dim3(NWV * 64), SM::TOTAL, s, p);
+    if constexpr (NWV == 4 && DP <= 128) {
+        static const bool prof = getenv("EFFCONF_ATTN_PHASES") != nullptr;
+        if (prof) {
+            if (!g_attn_prof) {
+                if (hipMalloc(&g_attn_prof, 512) != hipSuccess || hipMemset(g_attn_prof, 0, 512) != hipSuccess) return -1;
+                atexit(attn_prof_dump);
+            }
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&relpos_attention_kernel<DP, NWV, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SM::TOTAL);
+            hipLaunchKernelGGL((relpos_attention_kernel<DP, NWV, true>), dim3(p.B * p.H * qtiles), dim3(NWV * 64), SM::TOTAL, s, p, g_attn_prof + 16 * (DP / 32 - 1));
+            return hipGetLastError() == hipSuccess ? 0 : -1;
+        }
+    }
+    hipLaunchKernelGGL((relpos_attention_kernel<DP, NWV, false>), dim3(p.B * p.H * qtiles), dim3(NWV * 64), SM::TOTAL, s, p, nullptr);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 template <int DP>
 int launch_dp(const AttnParams& p, hipStream_t s) {
-    // 128-query workgroups halve the K / V staging per query; short sequences keep 64-query workgroups
+    // 64-query (4-wave) workgroups, two per CU: the kernel is latency-bound on its K / V / E loads (phase profile above), and two
+    // independent workgroups per CU hide more of it than one 128-query workgroup that stages K / V half as often (1.31 -> 1.23 ms
+    // per step once the loads run two key blocks ahead).  EFFCONF_ATTN_WAVES=8 selects the 128-query variant.
     static const char* ev = getenv("EFFCONF_ATTN_WAVES");
     const int force = ev ? atoi(ev) : 0;
     constexpr bool fits8 = AttnSmem<DP, 8>::TOTAL <= 160 * 1024;
     if constexpr (fits8)
-        if ((p.Tg > 96 && force != 4) || force == 8) return launch_dp_w<DP, 8>(p, s);
+        if (force == 8) return launch_dp_w<DP, 8>(p, s);
     return launch_dp_w<DP, 4>(p, s);
 }
 
