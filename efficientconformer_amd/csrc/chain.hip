@@ -654,8 +654,8 @@ bool chain_supported(int D) { return D % 4 == 0 && D >= 16 && D <= 256; }
 // The FFN-carrying chain A at KS = 16 (D = 240 / 256) runs at one wave per SIMD with its LayerNorm / load phases spilling (the
 // chunk loops stay spill-free); measured it only ties the per-GEMM kernels there (5.60 vs 5.54 ms per step), so it is used up to
 // D = 192.  A 16-row-per-wave variant (v_mfma_f32_16x16x32_bf16, half the registers per lane) is the planned fix.
-bool chain_head_supported(int D) { return chain_supported(D) && D % 8 == 0 && D <= 192; }
-bool chain_tail_supported(int D) { return chain_supported(D) && D <= 192; }
+bool chain_head_supported(int D) { return chain_supported(D) && D % 8 == 0 && D <= (getenv("EFFCONF_CHAIN_WIDE") ? 256 : 192); }
+bool chain_tail_supported(int D) { return chain_supported(D) && D <= (getenv("EFFCONF_CHAIN_WIDE") ? 256 : 192); }
 
 int launch_chain(const ChainParams& p, int kind, hipStream_t s) {
     if (p.M <= 0) return 0;
