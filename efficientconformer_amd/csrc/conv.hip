@@ -85,12 +85,24 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const bf16_t* __restrict__ 
     constexpr int HALF = (KSZ - 1) / 2;
     const int tin0 = to0 * STRIDE - HALF;
     const int tid = threadIdx.x;
-    for (int i = tid; i < ROWS * (DW_CC / 8); i += 256) {
-        const int r = i >> 3, ch = (i & 7) * 8;
-        const int t = tin0 + r, c = c0 + ch;
-        const int tc = t < 0 ? 0 : (t < T ? t : T - 1), cc = c < ld - 8 ? c : ld - 8;      // clamped, unconditional load
-        const uint4 v = *reinterpret_cast<const uint4*>(g + ((size_t)b * T + tc) * ld + cc);
-        *reinterpret_cast<uint4*>(sg + r * DW_PITCH + ch * 2) = mask_chunk(v, (t >= 0 && t < T && c < ld) ? C - c : 0);
+    {   // all loads of the tile first (one memory latency instead of one per pass), then the LDS writes
+        constexpr int NL = (ROWS * (DW_CC / 8) + 255) / 256;
+        uint4 v[NL];
+#pragma unroll
+        for (int n = 0; n < NL; ++n) {
+            const int i = tid + 256 * n;
+            const int r = i >> 3, ch = (i & 7) * 8;
+            const int t = tin0 + (r < ROWS ? r : ROWS - 1), c = c0 + ch;
+            const int tc = t < 0 ? 0 : (t < T ? t : T - 1), cc = c < ld - 8 ? c : ld - 8;      // clamped, unconditional load
+            v[n] = *reinterpret_cast<const uint4*>(g + ((size_t)b * T + tc) * ld + cc);
+        }
+#pragma unroll
+        for (int n = 0; n < NL; ++n) {
+            const int i = tid + 256 * n;
+            const int r = i >> 3, ch = (i & 7) * 8;
+            const int t = tin0 + r, c = c0 + ch;
+            if (r < ROWS) *reinterpret_cast<uint4*>(sg + r * DW_PITCH + ch * 2) = mask_chunk(v[n], (t >= 0 && t < T && c < ld) ? C - c : 0);
+        }
     }
     for (int i = tid; i < (KSZ + 1) * DW_CC; i += 256) {
         const int j = i / DW_CC, ch = i - j * DW_CC, c = c0 + ch;

@@ -250,6 +250,7 @@ bool build_mel_tables(EcEncoder* e, std::string* err) {
     e->mel.fb_start = upload(e, start);
     e->mel.fb_count = upload(e, count);
     e->mel.fb_offset = upload(e, offs);
+    e->mel.fb_nnz = (int)wts.size();
     e->mel.fb_weight = upload(e, wts);
     return e->mel.window && e->mel.twiddle && e->mel.fb_weight;
 }

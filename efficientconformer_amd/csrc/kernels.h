@@ -139,6 +139,7 @@ struct MelTables {                 // device tables built once per encoder
     const int* fb_count;           // [n_mels]
     const int* fb_offset;          // [n_mels] offset into fb_weight
     const float* fb_weight;        // packed non-zero triangular weights
+    int fb_nnz;                    // number of packed weights
 };
 int launch_mel(const float* audio, int B, int L, const MelTables& t, int n_fft, int hop, int n_mels, int Tm,
                int normalize, float mean, float std, float* mel, hipStream_t s);

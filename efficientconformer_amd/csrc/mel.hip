@@ -24,6 +24,7 @@ constexpr int FRAMES_PER_BLOCK = 32;     // 4 waves x 4 iterations x 2 frames
 constexpr int MAX_MELS = 128;
 constexpr int P1 = 72;                   // float2 pitch of the step-1 exchange buffer [k1][n2*8+n3]
 constexpr int P2 = 68;                   // float2 pitch of the step-2 exchange buffer [n3][k1+8*k2]
+constexpr int MAX_FBW = 768;             // filterbank weights kept in LDS (every bin belongs to <= 2 triangles: ~2 * 257)
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
@@ -64,6 +65,8 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ audi
     __shared__ float2 stw[NFFT];                                 // W512^m
     __shared__ float swin[NFFT];
     __shared__ float sout[MAX_MELS][FRAMES_PER_BLOCK + 1];
+    __shared__ float sfw[MAX_FBW];                               // packed triangular weights (a global load per tap made the
+                                                                 // rolled per-mel loop one L1 round trip per bin)
     const int tiles = (Tm + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK;
     const int b = blockIdx.x / tiles, t0 = (blockIdx.x % tiles) * FRAMES_PER_BLOCK;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -72,6 +75,8 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ audi
         stw[i] = i < 256 ? w : make_float2(-w.x, -w.y);
         swin[i] = tb.window[i];
     }
+    const bool fw_lds = tb.fb_nnz <= MAX_FBW;
+    if (fw_lds) for (int i = tid; i < tb.fb_nnz; i += 256) sfw[i] = tb.fb_weight[i];
     __syncthreads();
     float2* A = sbuf[wave][0];
     float2* B = sbuf[wave][1];
@@ -135,9 +140,24 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ audi
         // ---- sparse triangular filterbank + log for both frames
         for (int m = lane; m < n_mels; m += 64) {
             const int s0 = tb.fb_start[m], cnt = tb.fb_count[m];
-            const float* w = tb.fb_weight + tb.fb_offset[m];
+            const int off = tb.fb_offset[m];
             float ya = 0.f, yb = 0.f;
-            for (int j = 0; j < cnt; ++j) { const float wj = w[j]; ya = fmaf(Pa[s0 + j], wj, ya); yb = fmaf(Pb[s0 + j], wj, yb); }
+            if (fw_lds) {
+                for (int j0 = 0; j0 < cnt; j0 += 4) {             // 4 taps per trip, same summation order; taps >= cnt weigh 0
+                    float wj[4], pa[4], pb[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int j = j0 + e, jc = j < cnt ? j : cnt - 1;
+                        wj[e] = j < cnt ? sfw[off + jc] : 0.f;
+                        pa[e] = Pa[s0 + jc]; pb[e] = Pb[s0 + jc];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { ya = fmaf(pa[e], wj[e], ya); yb = fmaf(pb[e], wj[e], yb); }
+                }
+            } else {
+                const float* w = tb.fb_weight + off;
+                for (int j = 0; j < cnt; ++j) { const float wj = w[j]; ya = fmaf(Pa[s0 + j], wj, ya); yb = fmaf(Pb[s0 + j], wj, yb); }
+            }
             ya = logf(ya + 1e-9f); yb = logf(yb + 1e-9f);
             if (normalize) { ya = (ya - mean) * inv_std; yb = (yb - mean) * inv_std; }
             sout[m][fl] = ya;
