@@ -47,7 +47,13 @@ __device__ __forceinline__ void wave_sync() {
 template <int DP, int NWV>
 struct AttnSmem {
     static constexpr int ERING = NWV * 32;           // rows of the rolling relative-position ring (power of two >= BI + BJ - 1)
-    static constexpr int KROW = DP * 2 + 16;         // bytes per K / E row
+    // DP == 64: unpadded 128-byte rows with the 16-byte chunk index XOR-ed by 2*((row>>1)&3).  gfx950 services ds_read_b128 in the
+    // lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ...: under them every padded-pitch layout has 2-way conflicts on the
+    // K / E fragment reads (brute-forced; 43 % of the LDS-active cycles in profiles/r1_10_sq_counters.txt), this one has none for
+    // any ring offset.  Other head widths keep the padded rows.
+    static constexpr bool SWZ = (DP == 64);
+    static constexpr int KROW = SWZ ? DP * 2 : DP * 2 + 16;         // bytes per K / E row
+    static __device__ __forceinline__ int koff(int row, int chunk) { return row * KROW + ((SWZ ? (chunk ^ (2 * ((row >> 1) & 3))) : chunk) << 4); }
     static constexpr int VROW = BJ * 2 + 16;         // bytes per V^T row
     static constexpr int K_BYTES = BJ * KROW;
     static constexpr int V_BYTES = DP * VROW;
@@ -145,7 +151,7 @@ __global__ __launch_bounds__(NWV * 64) void relpos_attention_kernel(const AttnPa
             const int rr = q / CPR, x = (q - rr * CPR) * 8;
             const int r = R0 + rr;
             if (q < (BI + 63) * CPR)
-                *reinterpret_cast<uint4*>(sE + ((r + 8192) & (ERING - 1)) * SM::KROW + x * 2) = mask_chunk(fb[n], (r >= 0 && r < erows) ? p.d - x : 0);
+                *reinterpret_cast<uint4*>(sE + SM::koff((r + 8192) & (ERING - 1), x >> 3)) = mask_chunk(fb[n], (r >= 0 && r < erows) ? p.d - x : 0);
         }
     }
 
@@ -200,7 +206,7 @@ __global__ __launch_bounds__(NWV * 64) void relpos_attention_kernel(const AttnPa
 #pragma unroll
         for (int n = 0; n < NK; ++n) {
             const int q = tid + NTHR * n, r = q / CPR, x = (q - r * CPR) * 8;
-            if (q < BJ * CPR) *reinterpret_cast<uint4*>(sK + r * SM::KROW + x * 2) = mask_chunk(st_.lk[n], (j0 + r < p.Tg) ? p.d - x : 0);
+            if (q < BJ * CPR) *reinterpret_cast<uint4*>(sK + SM::koff(r, x >> 3)) = mask_chunk(st_.lk[n], (j0 + r < p.Tg) ? p.d - x : 0);
         }
 #pragma unroll
         for (int n = 0; n < NV; ++n) {
@@ -223,7 +229,7 @@ __global__ __launch_bounds__(NWV * 64) void relpos_attention_kernel(const AttnPa
                 const int q = tid + NTHR * n, rr = q / CPR, x = (q - rr * CPR) * 8;
                 const int r = rnew + rr;
                 if (q < 64 * CPR)
-                    *reinterpret_cast<uint4*>(sE + ((r + 8192) & (ERING - 1)) * SM::KROW + x * 2) = mask_chunk(st_.le[n], (r >= 0 && r < erows) ? p.d - x : 0);
+                    *reinterpret_cast<uint4*>(sE + SM::koff((r + 8192) & (ERING - 1), x >> 3)) = mask_chunk(st_.le[n], (r >= 0 && r < erows) ? p.d - x : 0);
             }
         }
         __syncthreads();
@@ -249,7 +255,7 @@ __global__ __launch_bounds__(NWV * 64) void relpos_attention_kernel(const AttnPa
             st[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(sK + (jt * 16 + c) * SM::KROW + (ks * 32 + g * 8) * 2);
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(sK + SM::koff(jt * 16 + c, ks * 4 + g));
                 st[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qu[ks], st[jt], 0, 0, 0);
             }
         }
@@ -260,10 +266,10 @@ __global__ __launch_bounds__(NWV * 64) void relpos_attention_kernel(const AttnPa
 #pragma unroll
         for (int rt = 0; rt < 5; ++rt) {
             f32x4 pe = f32x4{0.f, 0.f, 0.f, 0.f};
-            const char* erow = sE + ((rw0 + rt * 16 + c) & (ERING - 1)) * SM::KROW + g * 16;
+            const int er = (rw0 + rt * 16 + c) & (ERING - 1);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(erow + ks * 64);
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(sE + SM::koff(er, ks * 4 + g));
                 pe = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qv[ks], pe, 0, 0, 0);
             }
             *reinterpret_cast<f32x4*>(skew + rt * 16 + g * 4) = pe;

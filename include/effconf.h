@@ -139,7 +139,9 @@ int effconf_rnnt_greedy(EcRnnt* r, const float* enc_out, const int64_t* out_len,
 /* Options.  "cache_pos_embeddings" = 1: the positional projections E = pos_layer(R) (reference attentions.py:588, 678)
  * are input independent; they live in the workspace and are recomputed only when the workspace pointer or the number
  * of frames changes.  Enable ONLY if the caller passes the same workspace and leaves it untouched between forwards.
- * "fuse_subsample" (default 1): 0 selects the unfused conv-subsampling + Linear kernels (kept for tests / odd shapes). */
+ * "fuse_subsample" (default 1): 0 selects the unfused conv-subsampling + Linear kernels (kept for tests / odd shapes).
+ * "fuse_chain" (default 1): 0 runs every GEMM of a block as its own kernel instead of the fused row-local chains (chain.hip);
+ *   with the debug trace this exposes the intermediate residual-stream states that otherwise only exist in registers. */
 int effconf_encoder_set_option(EcEncoder* enc, const char* name, int32_t value);
 
 /* ---- per-launch event profiler (bench / tuning only) --------------------------------------- */
