@@ -33,7 +33,7 @@ struct GemmDev {
 };
 
 template <int BN, int EPI>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmDev gd) {
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmDev gd) {
     const GemmParams& p = gd.p;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sA = smem;                       // [2][BM][LROW]
@@ -77,53 +77,67 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDev gd) {
 
     const int nk = (p.K + BK - 1) / BK;
     const int frag_off = (lane & 31) * LROW + (lane >> 5) * 16;
-    // one staging site (iteration -1 is the prologue): global loads of tile kt+1, MFMA on tile kt, then publish tile kt+1.
-    // (staging arrays written inside lambdas end up in scratch memory; keep this inline)
-    for (int kt = -1; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        const bool more = kt + 1 < nk;
-        uint4 ra[4], rb[NB];
+    // Two register staging sets: the global loads of k-tile kt+2 are issued at the top of iteration kt and published (written to
+    // LDS) at the bottom of iteration kt+1, so they have a whole iteration to arrive.  (One set - issue at the top, publish at the
+    // bottom of the SAME iteration - left only one 16-MFMA compute phase to cover the L2 / HBM latency.)
+    struct Stage { uint4 ra[4], rb[NB]; };
+    Stage s0, s1;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ra[i] = make_uint4(0, 0, 0, 0);
+    for (int i = 0; i < 4; ++i) { s0.ra[i] = make_uint4(0, 0, 0, 0); s1.ra[i] = s0.ra[i]; }
 #pragma unroll
-        for (int i = 0; i < NB; ++i) rb[i] = make_uint4(0, 0, 0, 0);
-        if (more) {
-            const int k = (kt + 1) * BK + kc * 8;
-            const int valid = p.K - k;
-            const int kcl = k < p.lda - 8 ? k : p.lda - 8;      // unconditional, clamped (in-bounds) loads; masked below
+    for (int i = 0; i < NB; ++i) { s0.rb[i] = make_uint4(0, 0, 0, 0); s1.rb[i] = s0.rb[i]; }
+    auto load_tile = [&](Stage& st, int t) __attribute__((always_inline)) {
+        const int k = t * BK + kc * 8;
+        const int valid = p.K - k;
+        const int kcl = k < p.lda - 8 ? k : p.lda - 8;          // unconditional, clamped (in-bounds) loads; masked below
+        const int tb = t < nk ? t : nk - 1;                     // weight tiles past the end: harmless re-read, never published
 #pragma unroll
-            for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const uint4*>(a_ptr[i] + kcl);
+        for (int i = 0; i < 4; ++i) st.ra[i] = *reinterpret_cast<const uint4*>(a_ptr[i] + (kcl < 0 ? 0 : kcl));
 #pragma unroll
-            for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const uint4*>(b_ptr[i] + (kt + 1) * BK);
+        for (int i = 0; i < NB; ++i) st.rb[i] = *reinterpret_cast<const uint4*>(b_ptr[i] + tb * BK);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) ra[i] = mask_chunk(ra[i], valid);
+        for (int i = 0; i < 4; ++i) st.ra[i] = mask_chunk(st.ra[i], valid);
+    };
+    auto publish = [&](const Stage& st, int buf) __attribute__((always_inline)) {
+        char* a = sA + buf * BM * LROW;
+        char* b = sB + buf * BN * LROW;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(a + (srow + 32 * i) * LROW + kc * 16) = st.ra[i];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) *reinterpret_cast<uint4*>(b + (srow + 32 * i) * LROW + kc * 16) = st.rb[i];
+    };
+    auto compute = [&](int buf) __attribute__((always_inline)) {
+        const char* a = sA + buf * BM * LROW + (wm * 64) * LROW + frag_off;
+        const char* b = sB + buf * BN * LROW + (wn * (BN / 2)) * LROW + frag_off;
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            bf16x8 af[2], bf[NF];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) af[mi] = *reinterpret_cast<const bf16x8*>(a + mi * 32 * LROW + kk * 32);
+#pragma unroll
+            for (int ni = 0; ni < NF; ++ni) bf[ni] = *reinterpret_cast<const bf16x8*>(b + ni * 32 * LROW + kk * 32);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NF; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
         }
-        if (kt >= 0) {
-            const char* a = sA + buf * BM * LROW + (wm * 64) * LROW + frag_off;
-            const char* b = sB + buf * BN * LROW + (wn * (BN / 2)) * LROW + frag_off;
+    };
+    load_tile(s0, 0);
+    if (nk > 1) load_tile(s1, 1);
+    publish(s0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
 #pragma unroll
-            for (int kk = 0; kk < BK / 16; ++kk) {
-                bf16x8 af[2], bf[NF];
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi) af[mi] = *reinterpret_cast<const bf16x8*>(a + mi * 32 * LROW + kk * 32);
-#pragma unroll
-                for (int ni = 0; ni < NF; ++ni) bf[ni] = *reinterpret_cast<const bf16x8*>(b + ni * 32 * LROW + kk * 32);
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < NF; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+        for (int h = 0; h < 2; ++h) {            // h = 0: tile kt in buffer 0, tile kt+1 waiting in s1, tile kt+2 -> s0;  h = 1: roles swapped
+            const int t = kt + h;
+            if (t < nk) {
+                if (t + 2 < nk) { if (h == 0) load_tile(s0, t + 2); else load_tile(s1, t + 2); }
+                compute(h);
+                if (t + 1 < nk) { if (h == 0) publish(s1, 1); else publish(s0, 0); }
+                __syncthreads();
             }
         }
-        if (more) {
-            char* a = sA + (buf ^ 1) * BM * LROW;
-            char* b = sB + (buf ^ 1) * BN * LROW;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(a + (srow + 32 * i) * LROW + kc * 16) = ra[i];
-#pragma unroll
-            for (int i = 0; i < NB; ++i) *reinterpret_cast<uint4*>(b + (srow + 32 * i) * LROW + kc * 16) = rb[i];
-        }
-        __syncthreads();
     }
 
     // ---- epilogue.  C layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
