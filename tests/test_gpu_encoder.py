@@ -173,6 +173,24 @@ def test_batch_rows_are_independent_given_the_padded_length():
         assert torch.equal(one[0], full[b]) and int(one_len[0]) == int(full_len[b])
 
 
+def test_batch_of_16_matches_rows_and_oracle_small_model():
+    """B = 16 (a multiple of 8: the attention kernel's utterance-per-XCD block mapping, many workgroups per chain launch,
+    ragged lengths) on the real Small model: every row equals its single-utterance run bit for bit and stays within the
+    stated tolerance of the oracle."""
+    m, sd = _model("EfficientConformerCTCSmall", 0)
+    lens = np.sort(synth.libri_lengths(16, seed=11) // 4)[::-1].copy()
+    audio = torch.from_numpy(synth.make_audio(lens, seed=11)).cuda()
+    ln = torch.from_numpy(lens).cuda()
+    full, full_len, _ = m.encoder(audio, ln)
+    for b in (0, 7, 15):
+        one, one_len, _ = m.encoder(audio[b:b + 1].contiguous(), ln[b:b + 1].contiguous())
+        assert torch.equal(one[0], full[b]) and int(one_len[0]) == int(full_len[b])
+    with torch.no_grad():
+        ref, ref_len = R.encoder(audio[:2].cpu(), ln[:2].cpu(), sd, m.encoder.plan)
+    mx, mean = _err(full[:2].cpu(), ref)
+    assert ref_len.tolist() == full_len[:2].cpu().tolist() and mx < OUT_MAX and mean < OUT_MEAN, (mx, mean)
+
+
 def test_single_short_utterance():
     m, sd = _model("Tiny", 7)
     lens = np.array([3000], dtype=np.int64)            # 19 mel frames -> 10 -> 5 -> 3 encoder frames
