@@ -163,6 +163,8 @@ def main():
     side = torch.cuda.Stream(device=dev) if world > 1 else None
 
     subs = None
+    if isinstance(model, Transducer) and args.batch // max(args.streams, 1) > 128:
+        args.streams = max(args.streams, (args.batch + 127) // 128)       # keep every sub-batch within the cluster decode's auto range
     if args.streams > 1:      # rows s::S keep every sub-batch length-balanced; all share the batch's padded length
         subs = [(torch.cuda.Stream(device=dev), audio[i::args.streams].contiguous(), lens[i::args.streams].contiguous())
                 for i in range(args.streams)]

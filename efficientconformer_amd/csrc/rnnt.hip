@@ -671,7 +671,9 @@ int effconf_rnnt_greedy(EcRnnt* r, const float* enc_out, const int64_t* out_len,
     float* fe = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
     // linear_encoder(f) for every frame of the batch, once (joint_networks.py:82 recomputes it per decision)
     if (launch_sgemm_nt(enc_out, De, r->we, De, r->be, fe, J, batch * t_out, J, De, s) != 0) return ec_fail("linear_encoder GEMM launch failed");
-    const bool cluster = cluster_supported(r->cfg) && (r->cluster_mode == 1 || (r->cluster_mode < 0 && batch >= 2 * CU));
+    // auto: clusters only while they need at most half of the CUs (two decodes on two streams must not starve each other's
+    // cluster-mates: a spinning workgroup keeps its CU)
+    const bool cluster = cluster_supported(r->cfg) && (r->cluster_mode == 1 || (r->cluster_mode < 0 && batch >= 2 * CU && ((batch + CU - 1) / CU) * CW <= 128));
     if (cluster) {
         const int ncl = (batch + CU - 1) / CU;
         if (ncl * CW > 256) return ec_fail("cluster decode needs every workgroup resident: batch <= 256");

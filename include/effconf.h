@@ -128,9 +128,10 @@ int32_t effconf_rnnt_max_tokens(const EcRnnt* r, int32_t t_out);
 /* enc_out dev f32 (batch, T_out, dim_encoder), out_len dev i64 (batch) -> tokens dev i32 (batch, max_tokens), zero-filled
  * tails (the leading start token of the reference's `y` is not included: transducer.py:179 decodes y[:, 1:]),
  * token_len dev i32 (batch). */
-/* "cluster_decode": -1 auto (default: batches of >= 16 utterances decode in clusters of 8 workgroups x 8 utterances that share the
- * weight streams; needs all workgroups co-resident, i.e. batch <= 256 and an otherwise idle device), 0 one workgroup per utterance,
- * 1 force.  Both paths produce identical tokens. */
+/* "cluster_decode": -1 auto (default: batches of 16..128 utterances decode in clusters of 8 workgroups x 8 utterances that share the
+ * weight streams), 0 one workgroup per utterance, 1 force (batch <= 256).  A cluster's workgroups synchronise through global memory
+ * and must be co-resident: do not run two forced cluster decodes that together need more than the device's 256 CUs concurrently
+ * (the spin is bounded: a starved cluster gives up with undefined tokens instead of hanging).  Both paths produce identical tokens. */
 int effconf_rnnt_set_option(EcRnnt* r, const char* name, int32_t value);
 int effconf_rnnt_greedy(EcRnnt* r, const float* enc_out, const int64_t* out_len, int32_t batch, int32_t t_out,
                         int32_t* tokens, int32_t* token_len, int32_t max_tokens, void* workspace, size_t workspace_bytes,
