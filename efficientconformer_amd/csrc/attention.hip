@@ -108,6 +108,9 @@ __global__ __launch_bounds__(NWV * 64) void relpos_attention_kernel(const AttnPa
     const bf16_t* Eh = p.eh + (size_t)h * p.e_hstride;
     const int RS = p.q_rowstride, ERS = p.e_rowstride; // row strides (elements); rows may be only 4-byte aligned (natural layout)
     const int erows = 2 * p.Tg - 1;
+    // 16-byte chunks entirely beyond the head width d (DP pads d up to a multiple of 32) are masked to zero anyway: point their
+    // loads at chunk 0 of the same row (same cache line as a neighbouring lane's request) instead of fetching the next head's data
+    const int dceil = (p.d + 7) & ~7;
 
     int nkeys = (p.lens[b] + p.G - 1) / p.G;          // unmasked key groups: G*j < lens[b]
     nkeys = nkeys < p.Tg ? nkeys : p.Tg;
@@ -121,9 +124,9 @@ __global__ __launch_bounds__(NWV * 64) void relpos_attention_kernel(const AttnPa
         uint4 ra[KS], rb[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const int x = ks * 32 + g * 8;
-            ra[ks] = ld16(Qu + (size_t)ic * RS + x);
-            rb[ks] = ld16(Qv + (size_t)ic * RS + x);
+            const int x = ks * 32 + g * 8, xq = x < dceil ? x : 0;
+            ra[ks] = ld16(Qu + (size_t)ic * RS + xq);
+            rb[ks] = ld16(Qv + (size_t)ic * RS + xq);
         }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(NWV * 64) void relpos_attention_kernel(const AttnPa
             const int rr = q / CPR, x = (q - rr * CPR) * 8;
             const int r = R0 + (rr < BI + 63 ? rr : BI + 62);
             const int rc = r < 0 ? 0 : (r >= erows ? erows - 1 : r);
-            fb[n] = ld16(Eh + (size_t)rc * ERS + x);
+            fb[n] = ld16(Eh + (size_t)rc * ERS + (x < dceil ? x : 0));
         }
 #pragma unroll
         for (int n = 0; n < NB; ++n) {
@@ -180,12 +183,12 @@ __global__ __launch_bounds__(NWV * 64) void relpos_attention_kernel(const AttnPa
         for (int n = 0; n < NK; ++n) {
             const int q = tid + NTHR * n, r = q / CPR, x = (q - r * CPR) * 8;
             const int j = jn + r;
-            st_.lk[n] = ld16(Kh + (size_t)(j < p.Tg ? j : p.Tg - 1) * RS + (x < DP ? x : 0));
+            st_.lk[n] = ld16(Kh + (size_t)(j < p.Tg ? j : p.Tg - 1) * RS + (x < dceil ? x : 0));
         }
 #pragma unroll
         for (int n = 0; n < NV; ++n) {
             const int q = tid + NTHR * n, pr = q & (BJ / 2 - 1), x = (q / (BJ / 2)) * 8;
-            const int j = jn + 2 * pr, xc = x < DP ? x : 0;
+            const int j = jn + 2 * pr, xc = x < dceil ? x : 0;
             st_.lv0[n] = ld16(Vh + (size_t)(j < p.Tg ? j : p.Tg - 1) * RS + xc);
             st_.lv1[n] = ld16(Vh + (size_t)(j + 1 < p.Tg ? j + 1 : p.Tg - 1) * RS + xc);
         }
@@ -196,7 +199,7 @@ __global__ __launch_bounds__(NWV * 64) void relpos_attention_kernel(const AttnPa
                 const int q = tid + NTHR * n, rr = q / CPR, x = (q - rr * CPR) * 8;
                 int r = rnew + rr;
                 r = r < 0 ? 0 : (r >= erows ? erows - 1 : r);
-                st_.le[n] = ld16(Eh + (size_t)r * ERS + (x < DP ? x : 0));
+                st_.le[n] = ld16(Eh + (size_t)r * ERS + (x < dceil ? x : 0));
             }
         }
     };
