@@ -192,6 +192,8 @@ _NAMED = {
     "ConformerCTCLarge": ("CTC", _plain(512, 8, 18), 256),
     # not a shipped model: small dims for unit tests (exercises grouping, T % G != 0, both transitions)
     "Tiny": ("CTC", dict(_eff([24, 32, 48], 4, 6, [1, 3], 24), max_pos_encoding=2000), 32),
+    # not a shipped model: the Small topology with widths whose per-head spans are 16-byte aligned (alignment experiments)
+    "SmallAligned": ("CTC", _eff([128, 192, 256], 4, 15, [4, 9], 128), 256),
     "TinyTransducer": ("Transducer", dict(_eff([24, 32, 48], 4, 6, [1, 3], 24), max_pos_encoding=2000), 40),
 }
 
