@@ -328,3 +328,27 @@ def test_rnnt_cluster_decode_equals_per_utterance_decode(golden_dir, name, tag, 
     m.set_decode_option("cluster_decode", -1)
     auto_t, auto_n = m.decode_encoded(f, lens)
     assert torch.equal(auto_t, ref_t) and torch.equal(auto_n, ref_n)
+
+
+def test_very_short_utterance_inside_a_long_batch():
+    """A 25 ms utterance (3 mel frames, 2 encoder frames at stage 0, 1 at the end) next to a 2 s one: masks, length bookkeeping and the
+    pad-frame semantics must match the oracle for both rows."""
+    m, sd = _model("Tiny", 7)
+    lens = np.array([32000, 400], dtype=np.int64)
+    audio = synth.make_audio(lens, seed=5)
+    out, out_len, _ = m.encoder(torch.from_numpy(audio).cuda(), torch.from_numpy(lens).cuda())
+    with torch.no_grad():
+        ref, ref_len = R.encoder(torch.from_numpy(audio), torch.from_numpy(lens), sd, m.encoder.plan)
+    assert out_len.cpu().tolist() == ref_len.tolist() and int(out_len[1]) == 1
+    mx, mean = _err(out.cpu(), ref)
+    assert mx < OUT_MAX and mean < OUT_MEAN, (mx, mean)
+
+
+def test_sequence_longer_than_max_pos_encoding_is_an_error():
+    """The relative-position table has max_pos_encoding rows per direction (attentions.py:1209-1226): a longer sequence cannot be
+    encoded and must be reported, not silently truncated."""
+    from efficientconformer_amd._lib import EffconfError
+    m, _ = _model("Tiny", 7)                                   # max_pos_encoding 2000 -> 2000 frames after the stride-2 subsampling
+    mel = torch.zeros(1, 80, 2 * 2000 + 40).cuda()
+    with pytest.raises(EffconfError, match="max_pos"):
+        m.encoder.forward_mel(mel, torch.tensor([mel.shape[2]]).cuda())
