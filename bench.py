@@ -69,12 +69,19 @@ def build_model(name):
     return cfg, model, sd
 
 
-def make_batch(args, rank):
+def make_batch(args, rank, world=1):
     if args.workload == "fixed":
         lens = np.full(args.batch, 160000, dtype=np.int64)
+        lmax = 160000
     else:
         lens = synth.libri_lengths(args.batch, seed=1234 + rank)
-    return synth.make_audio(lens, seed=1234 + rank), lens
+        # every rank pads to the longest utterance of the GLOBAL batch (seeds are known, so no exchange is needed): the
+        # all-gather of encoder outputs needs one shape on all ranks, exactly as a data-parallel collate would give it
+        lmax = max(int(synth.libri_lengths(args.batch, seed=1234 + r).max()) for r in range(world))
+    audio = synth.make_audio(lens, seed=1234 + rank)
+    if audio.shape[1] < lmax:
+        audio = np.pad(audio, ((0, 0), (0, lmax - audio.shape[1])))
+    return audio, lens
 
 
 def step(model, audio, lens):
@@ -154,7 +161,7 @@ def main():
     cfg, model, sd = build_model(args.model)
     model = model.to(dev)
     plan = model.encoder.plan
-    audio_np, lens_np = make_batch(args, rank)
+    audio_np, lens_np = make_batch(args, rank, world)
     audio, lens = torch.from_numpy(audio_np).to(dev), torch.from_numpy(lens_np).to(dev)
     valid_frames = int((lens_np // plan.hop_length + 1).sum())
     padded_frames = int(args.batch * (audio_np.shape[1] // plan.hop_length + 1))

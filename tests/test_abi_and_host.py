@@ -168,3 +168,17 @@ def test_collate_and_bucketing():
         assert len(b) <= 64 and len(b) * lengths[b[0]] <= 64 * 160000
         assert all(lengths[b[j]] >= lengths[b[j + 1]] for j in range(len(b) - 1))
     assert plan == bucket_batches(lengths, max_batch=64, max_padded_samples=64 * 160000)
+
+
+def test_bench_batches_share_one_padded_length_across_ranks():
+    """bench.py: the all-gather of encoder outputs needs one (B, T) shape on every rank."""
+    import importlib.util
+    import types
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    args = types.SimpleNamespace(workload="libri", batch=3)       # tiny batches: per-rank maxima differ
+    shapes = {bench.make_batch(args, r, 4)[0].shape for r in range(4)}
+    assert len(shapes) == 1
+    own = [int(synth.libri_lengths(3, seed=1234 + r).max()) for r in range(4)]
+    assert len(set(own)) > 1 and max(own) == next(iter(shapes))[1]
