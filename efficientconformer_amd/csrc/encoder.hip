@@ -79,8 +79,23 @@ struct EcEncoder {
     std::vector<TraceEntry> trace;
     // positional-embedding cache: E = pos_layer(R) depends only on (block, T); when the caller keeps the SAME workspace
     // untouched between forwards (opt-in), the 15-18 small E projections are skipped for an unchanged T
+    // One tag per workspace: callers that alternate workspaces (one per stream) keep every one of them warm.
     bool e_cache_on = false;
-    const void* e_cache_ws = nullptr; int e_cache_tm = -1;
+    struct ECacheTag { const void* ws; int batch, tm; };
+    std::vector<ECacheTag> e_cache;          // most recently used last; at most E_CACHE_MAX entries
+    static constexpr size_t E_CACHE_MAX = 16;
+    bool e_cache_hit(const void* ws, int batch, int tm) const {   // the workspace layout depends on (batch, tm)
+        for (const ECacheTag& t : e_cache) if (t.ws == ws) return t.batch == batch && t.tm == tm;
+        return false;
+    }
+    void e_cache_put(const void* ws, int batch, int tm) {
+        e_cache_drop(ws);
+        if (e_cache.size() >= E_CACHE_MAX) e_cache.erase(e_cache.begin());
+        e_cache.push_back({ws, batch, tm});
+    }
+    void e_cache_drop(const void* ws) {
+        for (size_t i = 0; i < e_cache.size(); ++i) if (e_cache[i].ws == ws) { e_cache.erase(e_cache.begin() + i); break; }
+    }
     // per-launch event profiler (bench / tuning only; off by default)
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev;          // pairs
@@ -459,7 +474,8 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
     bf16_t* xs = reinterpret_cast<bf16_t*>(ws + w.xs);
     bool have_a = false, head_done = false;
     char nm[64];
-    const bool e_cached = e->e_cache_on && e->e_cache_ws == ws && e->e_cache_tm == s.Tm;
+    const bool e_cached = e->e_cache_on && e->e_cache_hit(ws, B, s.Tm);
+    if (!e_cached) e->e_cache_drop(ws);       // re-tagged only after every projection of this forward was enqueued
 
     for (int k = 0; k < nb; ++k) {
         const EcBlock& b = e->blocks[k];
@@ -613,7 +629,7 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
         have_a = !last;
         snprintf(nm, sizeof(nm), "blocks.%d.out", k); trace_add(e, st, nm, xo, Mo, De, De, 0);
     }
-    e->e_cache_ws = ws; e->e_cache_tm = s.Tm;
+    e->e_cache_put(ws, B, s.Tm);
     return 0;
 }
 
@@ -907,7 +923,7 @@ int effconf_encoder_finalize(EcEncoder* e) {
     for (void* p : e->allocs) if (!p) return fail("device allocation failed");
     if (hipDeviceSynchronize() != hipSuccess) return fail("upload failed");
     e->host.clear();
-    e->e_cache_ws = nullptr; e->e_cache_tm = -1;
+    e->e_cache.clear();
     e->finalized = true;
     return 0;
 }
@@ -975,7 +991,7 @@ int effconf_encoder_set_option(EcEncoder* e, const char* name, int32_t value) {
     if (!e || !name) return fail("null argument");
     if (!strcmp(name, "fuse_subsample")) { e->fuse_subsample = value != 0; return 0; }
     if (!strcmp(name, "fuse_chain")) { e->fuse_chain = value != 0; return 0; }
-    if (!strcmp(name, "cache_pos_embeddings")) { e->e_cache_on = value != 0; e->e_cache_ws = nullptr; e->e_cache_tm = -1; return 0; }
+    if (!strcmp(name, "cache_pos_embeddings")) { e->e_cache_on = value != 0; e->e_cache.clear(); return 0; }
     return fail(std::string("unknown option ") + name);
 }
 

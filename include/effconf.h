@@ -138,8 +138,11 @@ int effconf_rnnt_greedy(EcRnnt* r, const float* enc_out, const int64_t* out_len,
                         void* stream);
 
 /* Options.  "cache_pos_embeddings" = 1: the positional projections E = pos_layer(R) (reference attentions.py:588, 678)
- * are input independent; they live in the workspace and are recomputed only when the workspace pointer or the number
- * of frames changes.  Enable ONLY if the caller passes the same workspace and leaves it untouched between forwards.
+ * are input independent; they live in the workspace and are recomputed only when that workspace last held a forward of
+ * another batch size or number of frames.  The library remembers one tag per workspace pointer (the 16 most recently used),
+ * so a caller that alternates workspaces (one per stream) keeps all of them warm.  Enable ONLY if the caller leaves the
+ * workspaces untouched between forwards; setting the option again (to any value) forgets every tag — do that when a
+ * workspace is freed and its address may be reused.  Host calls on one handle must not run concurrently (they only enqueue).
  * "fuse_subsample" (default 1): 0 selects the unfused conv-subsampling + Linear kernels (kept for tests / odd shapes).
  * "fuse_chain" (default 1): 0 runs every GEMM of a block as its own kernel instead of the fused row-local chains (chain.hip);
  *   with the debug trace this exposes the intermediate residual-stream states that otherwise only exist in registers. */

@@ -352,3 +352,22 @@ def test_sequence_longer_than_max_pos_encoding_is_an_error():
     mel = torch.zeros(1, 80, 2 * 2000 + 40).cuda()
     with pytest.raises(EffconfError, match="max_pos"):
         m.encoder.forward_mel(mel, torch.tensor([mel.shape[2]]).cuda())
+
+
+def test_positional_cache_stays_valid_when_streams_alternate_workspaces():
+    """The wrapper keeps one workspace per stream and the library one positional-projection tag per workspace: forwards that
+    alternate between two streams (bench.py's sub-batches) and between two lengths must reproduce the cold results bit for bit."""
+    m, _ = _model("Tiny", 7)
+    lens_a, lens_b = np.array([30000, 22000], dtype=np.int64), np.array([18000, 9000], dtype=np.int64)
+    aud = [torch.from_numpy(synth.make_audio(l, seed=5 + i)).cuda() for i, l in enumerate((lens_a, lens_b))]
+    ln = [torch.from_numpy(l).cuda() for l in (lens_a, lens_b)]
+    cold = [m.encoder(aud[i], ln[i])[0].clone() for i in range(2)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    for rep in range(3):
+        for si, st in enumerate(streams):
+            for i in ((0, 1) if rep != 1 else (1, 0)):       # same stream, other length: the tag of that workspace must miss
+                with torch.cuda.stream(st):
+                    got = m.encoder(aud[i], ln[i])[0]
+                st.synchronize()
+                assert torch.equal(got, cold[i]), (rep, si, i)
