@@ -68,7 +68,7 @@ struct AttnSmem {
 // flight during block j's MFMA / softmax work) and all loads are unconditional at clamped addresses.
 template <int DP, int NWV, bool PROF = false>
 __global__ __launch_bounds__(NWV * 64) void relpos_attention_kernel(const AttnParams p, unsigned long long* prof = nullptr) {
-    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0;
+    unsigned long long ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0;
     if constexpr (PROF) t0 = __builtin_readcyclecounter();
 #define AT_TICK(i) do { if constexpr (PROF) { asm volatile("" ::: "memory"); const unsigned long long t1_ = __builtin_readcyclecounter(); ph[i] += t1_ - t0; t0 = t1_; } } while (0)
     using SM = AttnSmem<DP, NWV>;
@@ -115,6 +115,8 @@ __global__ __launch_bounds__(NWV * 64) void relpos_attention_kernel(const AttnPa
     int nkeys = (p.lens[b] + p.G - 1) / p.G;          // unmasked key groups: G*j < lens[b]
     nkeys = nkeys < p.Tg ? nkeys : p.Tg;
     nkeys = nkeys < 1 ? 1 : nkeys;
+    if constexpr (PROF) { asm volatile("s_nop 0" :: "s"(nkeys)); }
+    AT_TICK(8);                                        // prologue a: arguments, tile indices, utterance length
 
     // ---- this lane's query (column c of the wave's 16): B operands of S^T = K Q^T, kept in registers
     bf16x8 qu[KS], qv[KS];
@@ -135,6 +137,8 @@ __global__ __launch_bounds__(NWV * 64) void relpos_attention_kernel(const AttnPa
             qv[ks] = as_bf16x8(mask_chunk(rb[ks], valid));
         }
     }
+    if constexpr (PROF) { asm volatile("s_nop 0" :: "v"(qu[0]), "v"(qv[KS - 1])); }
+    AT_TICK(9);                                        // prologue b: query loads
     // ---- first positional band: rows R0 .. R0 + BI + 62 (absolute E rows), staged directly
     const int R0 = p.Tg - 1 - i0 - (BI - 1);           // E row of band row 0 for key block 0
     {   // all loads first (one latency), then the LDS writes
@@ -158,6 +162,7 @@ __global__ __launch_bounds__(NWV * 64) void relpos_attention_kernel(const AttnPa
         }
     }
 
+    AT_TICK(10);                                       // prologue c: first positional band -> LDS
     f32x4 acc[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -372,9 +377,10 @@ __global__ __launch_bounds__(NWV * 64) void relpos_attention_kernel(const AttnPa
     }
     if constexpr (PROF) {
         AT_TICK(7);
-        if ((threadIdx.x & 63) == 0) {
-            for (int i = 0; i < 8; ++i) atomicAdd(prof + i, ph[i]);
-            atomicAdd(prof + 8, 1ull);
+        // a 1/32 sample of the workgroups reports: same-address atomics from every wave congest the memory system the phases measure
+        if ((threadIdx.x & 63) == 0 && (blockIdx.x & 31) == 0) {
+            for (int i = 0; i < 11; ++i) atomicAdd(prof + i, ph[i]);
+            atomicAdd(prof + 15, 1ull);
         }
     }
 #undef AT_TICK
@@ -384,14 +390,15 @@ unsigned long long* g_attn_prof = nullptr;
 void attn_prof_dump() {
     unsigned long long all[4 * 16];
     if (!g_attn_prof || hipMemcpy(all, g_attn_prof, sizeof(all), hipMemcpyDeviceToHost) != hipSuccess) return;
-    static const char* names[8] = {"prologue", "publish+barriers", "issue loads", "S = K Q^T", "PE band + skew", "softmax", "PV", "epilogue"};
+    static const char* names[11] = {"prologue d (issue)", "publish+barriers", "issue loads", "S = K Q^T", "PE band + skew", "softmax", "PV", "epilogue",
+                                    "prologue a (args)", "prologue b (Q)", "prologue c (band)"};
     for (int c = 0; c < 4; ++c) {
         const unsigned long long* h = all + 16 * c;
-        if (!h[8]) continue;
+        if (!h[15]) continue;
         unsigned long long tot = 0;
-        for (int i = 0; i < 8; ++i) tot += h[i];
-        fprintf(stderr, "[attn phases] DP=%d: waves %llu, cycles/wave %.0f\n", 32 * (c + 1), h[8], (double)tot / h[8]);
-        for (int i = 0; i < 8; ++i) fprintf(stderr, "[attn phases]   %-17s %10.0f cyc/wave  %5.1f%%\n", names[i], (double)h[i] / h[8], 100.0 * h[i] / tot);
+        for (int i = 0; i < 11; ++i) tot += h[i];
+        fprintf(stderr, "[attn phases] DP=%d: waves %llu, cycles/wave %.0f\n", 32 * (c + 1), h[15], (double)tot / h[15]);
+        for (int i = 0; i < 11; ++i) fprintf(stderr, "[attn phases]   %-20s %10.0f cyc/wave  %5.1f%%\n", names[i], (double)h[i] / h[15], 100.0 * h[i] / tot);
     }
 }
 

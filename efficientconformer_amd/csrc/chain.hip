@@ -48,6 +48,7 @@ struct ChainDev {
     FastDiv32 fT, fD;
     int nf[8];            // float offsets of the LDS constant arrays (see chain_const_layout)
     int nfl_kb;           // size of the constant block in KiB (LDS-DMA pieces)
+    int ldr, ld2;         // row pitch (elements) shared by every row-shaped weight of the chain / by the FFN second weights
 };
 
 // ---- C-layout helpers -----------------------------------------------------------------------------------------------------
@@ -240,29 +241,41 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && KS <= 8) ? 2 : 1) void chain_k
     const int n_g1 = (ISB || POST) ? p.g1.nchunks : 0;
     const int e0 = n_g0, e1 = e0 + n_f0, e2 = e1 + n_f1, total = e2 + n_g1;
 
+    // Per-lane byte offsets of this wave's PER DMA instructions, computed ONCE and kept in registers: every weight matrix of a chain
+    // has the same row pitch (K = D for all of them; launch_chain checks), so one set serves the row-shaped chunks (off_r) and one
+    // the FFN chunks (off_f: W1 rows, then W2 pieces).  The DMA address is (wave-uniform chunk base) + offset; with per-issue
+    // temporaries the compiler has to drain the DMA queue (s_waitcnt vmcnt(0)) before it may reuse an address register, which
+    // it did a few instructions after every issue.
+    uint32_t off_r[PER], off_f[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int i = wave + NW * k;
+        off_r[k] = i < KS ? dma_rows32_off<P1>(cd.ldr, i, lane) : dma_rows32_off<P1>(cd.ldr, i - KS, lane) + (uint32_t)(32 * cd.ldr) * 2u;
+        off_f[k] = i < KS ? off_r[k] : dma_w2_off(cd.ld2, i - KS, lane);
+    }
     auto issue = [&](int c) __attribute__((always_inline)) {
         char* buf = smem + (c % NBUF) * BUF;
         const bool ffn = c >= e0 && c < e2;
         if (ffn) {
             const ChainFfn& f = p.f[(c >= e1) ? 1 : 0];
             const int cc = c - ((c >= e1) ? e1 : e0);
-            const bf16_t* w1 = f.w1 + (size_t)cc * CH * f.ldw1;
-            const bf16_t* w2 = f.w2 + cc * CH;
+            const char* w1 = reinterpret_cast<const char*>(f.w1 + (size_t)cc * CH * cd.ldr);
+            const char* w2 = reinterpret_cast<const char*>(f.w2 + cc * CH);
 #pragma unroll
             for (int k = 0; k < PER; ++k) {
                 const int i = wave + NW * k;
-                if (i < KS) dma_rows32<P1>(w1, f.ldw1, buf, i, lane);
-                else dma_w2(w2, f.ldw2, buf + HALF, i - KS, lane);
+                if (i < KS) glds16(w1, off_f[k], buf + 64 * i * 16);
+                else glds16(w2, off_f[k], buf + HALF + 64 * (i - KS) * 16);
             }
         } else {
             const ChainGemm& g = (c < e0) ? p.g0 : p.g1;
             const int cc = (c < e0) ? c : c - e2;
-            const bf16_t* w = g.w + (size_t)cc * 64 * g.ldw;
+            const char* w = reinterpret_cast<const char*>(g.w + (size_t)cc * 64 * cd.ldr);
 #pragma unroll
             for (int k = 0; k < PER; ++k) {
                 const int i = wave + NW * k;
-                if (i < KS) dma_rows32<P1>(w, g.ldw, buf, i, lane);
-                else dma_rows32<P1>(w + (size_t)32 * g.ldw, g.ldw, buf + HALF, i - KS, lane);
+                if (i < KS) glds16(w, off_r[k], buf + 64 * i * 16);
+                else glds16(w, off_r[k], buf + HALF + 64 * (i - KS) * 16);
             }
         }
     };
@@ -562,7 +575,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && KS <= 8) ? 2 : 1) void chain_k
     if constexpr (!POST) store_x<NT, 0>(reinterpret_cast<char*>(p.Y), (size_t)p.ldy * 4, D, m_base, p.M, stg, lane, xc);
     if constexpr (PROF) {
         CH_TICK(8);
-        if (lane == 0) {
+        if (lane == 0 && (blockIdx.x & 7) == 0) {      // a 1/8 sample of the workgroups reports (keeps the atomics out of the measurement)
             for (int i = 0; i < 9; ++i) atomicAdd(prof + i, ph[i]);
             atomicAdd(prof + 9, 1ull);
         }
@@ -608,6 +621,19 @@ int launch_chain_t(const ChainParams& p, hipStream_t s) {
     cd.p = p;
     cd.fT = FastDiv32(p.T > 0 ? p.T : 1);
     cd.fD = FastDiv32(p.D);
+    {   // one row pitch for g0 / g1 / W1 (all have K = D), one for the W2 matrices: the kernel keeps its DMA offsets in registers
+        constexpr bool isb = KIND == CHAIN_B, pre = KIND == CHAIN_A_FULL || KIND == CHAIN_A_TAIL, post = KIND == CHAIN_A_FULL || KIND == CHAIN_A_HEAD;
+        int ldr = 0, ld2 = 0;
+        bool ok = true;
+        auto row = [&](int ld) { if (!ldr) ldr = ld; else ok = ok && ld == ldr; };
+        auto w2 = [&](int ld) { if (!ld2) ld2 = ld; else ok = ok && ld == ld2; };
+        if (isb || pre) row(p.g0.ldw);
+        if (isb || post) row(p.g1.ldw);
+        if (pre) { row(p.f[0].ldw1); w2(p.f[0].ldw2); }
+        if (post) { row(p.f[1].ldw1); w2(p.f[1].ldw2); }
+        if (!ok || ldr <= 0) return -6;
+        cd.ldr = ldr; cd.ld2 = ld2;
+    }
     const int nfl = chain_const_layout(p, KIND, cd.nf);
     cd.nfl_kb = nfl / 256;
     if (!p.consts) return -5;

@@ -61,21 +61,27 @@ __global__ __launch_bounds__(256) void subsample_conv_kernel(const float* __rest
     }
 }
 
-// ---- depthwise conv: block = 128 output frames x 64 channels; thread = 8 channels (one 16-byte vector) x 4 consecutive
-// output frames with a sliding window over the input rows, so every input row is read once from LDS (as one ds_read_b128)
-// and every tap weight once per 4 outputs; global loads and stores are 16 bytes per lane, 128 contiguous bytes per row.
-constexpr int DW_NT = 4;                       // outputs per thread
-constexpr int DW_TT = 32 * DW_NT;              // output frames per workgroup
+// ---- depthwise conv: block = 128 output frames x 64 channels; thread = one channel PAIR (one dword of a bf16 row) x 16
+// consecutive output frames.  The pair's KSZ x 2 folded tap weights live in registers and the input rows stream through once:
+// row r is read from LDS as one dword, unpacked once, and feeds every output whose window contains it (static tap indices, the
+// whole nest unrolled: 16*KSZ packed FMAs, (15*STRIDE + KSZ) LDS dwords and as many unpacks per thread).  An earlier version
+// (8 channels x 4 outputs per thread, tap loop rolled) re-read and re-unpacked every row once per (tap, output) and fetched the
+// tap weights from LDS per tap: ~2x the VALU work and 12x the LDS bytes, and it was the VALU / LDS pipes, not HBM, that bounded
+// it (profiles/r1_12_kernel_stats.txt: 22 us for 36 MB).
+constexpr int DW_NT = 16;                      // outputs per thread
+constexpr int DW_TT = 8 * DW_NT;               // output frames per workgroup
 constexpr int DW_CC = 64;                      // channels per workgroup
-constexpr int DW_PITCH = DW_CC * 2 + 16;       // bytes per LDS row (144: 4-row-strided b128 reads spread over all 16 slots)
+constexpr int DW_PITCH = DW_CC * 2 + 16;       // bytes per LDS row
+
+typedef float dwf2 __attribute__((ext_vector_type(2)));
 
 template <int KSZ, int STRIDE>
 __global__ __launch_bounds__(256) void dwconv_kernel(const bf16_t* __restrict__ g, int T, int To, int C, int ld,
                                                      const float* __restrict__ w_kc, const float* __restrict__ bias, bf16_t* out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ROWS = (DW_TT - 1) * STRIDE + KSZ;
+    constexpr int TROWS = (DW_NT - 1) * STRIDE + KSZ;                       // input rows one thread consumes
     char* sg = smem;                                                        // [ROWS][DW_PITCH] bf16 rows
-    float* sw = reinterpret_cast<float*>(smem + ROWS * DW_PITCH);           // [KSZ][64] folded weights, then [64] bias
     const int ctiles = (C + DW_CC - 1) / DW_CC;
     const int ttiles = (To + DW_TT - 1) / DW_TT;
     int id = blockIdx.x;
@@ -85,63 +91,61 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const bf16_t* __restrict__ 
     constexpr int HALF = (KSZ - 1) / 2;
     const int tin0 = to0 * STRIDE - HALF;
     const int tid = threadIdx.x;
+    const int cp = tid & 31, tg = tid >> 5;
+    const int c = c0 + 2 * cp;                                              // this thread's channel pair
+    // the pair's folded taps + bias: clamped unconditional loads (tiny, L2-resident), issued with the tile loads
+    dwf2 w[KSZ], bz;
+    {
+        const unsigned ca = c < C ? c : C - 1, cb = c + 1 < C ? c + 1 : C - 1;     // unsigned 32-bit offsets: base + offset addressing
+#pragma unroll
+        for (int j = 0; j < KSZ; ++j) {
+            const float wa = w_kc[(unsigned)(j * C) + ca], wb = w_kc[(unsigned)(j * C) + cb];
+            w[j] = dwf2{c < C ? wa : 0.f, c + 1 < C ? wb : 0.f};
+        }
+        const float ba = bias[ca], bb = bias[cb];
+        bz = dwf2{c < C ? ba : 0.f, c + 1 < C ? bb : 0.f};
+    }
     {   // all loads of the tile first (one memory latency instead of one per pass), then the LDS writes
         constexpr int NL = (ROWS * (DW_CC / 8) + 255) / 256;
+        const bf16_t* gb = g + (size_t)b * T * ld;                          // uniform base; one utterance is < 2^31 elements
         uint4 v[NL];
 #pragma unroll
         for (int n = 0; n < NL; ++n) {
             const int i = tid + 256 * n;
             const int r = i >> 3, ch = (i & 7) * 8;
-            const int t = tin0 + (r < ROWS ? r : ROWS - 1), c = c0 + ch;
-            const int tc = t < 0 ? 0 : (t < T ? t : T - 1), cc = c < ld - 8 ? c : ld - 8;      // clamped, unconditional load
-            v[n] = *reinterpret_cast<const uint4*>(g + ((size_t)b * T + tc) * ld + cc);
+            const int t = tin0 + (r < ROWS ? r : ROWS - 1), cq = c0 + ch;
+            const int tc = t < 0 ? 0 : (t < T ? t : T - 1), cc = cq < ld - 8 ? cq : ld - 8;    // clamped, unconditional load
+            v[n] = *reinterpret_cast<const uint4*>(gb + (unsigned)(tc * ld + cc));
         }
 #pragma unroll
         for (int n = 0; n < NL; ++n) {
             const int i = tid + 256 * n;
             const int r = i >> 3, ch = (i & 7) * 8;
-            const int t = tin0 + r, c = c0 + ch;
-            if (r < ROWS) *reinterpret_cast<uint4*>(sg + r * DW_PITCH + ch * 2) = mask_chunk(v[n], (t >= 0 && t < T && c < ld) ? C - c : 0);
+            const int t = tin0 + r, cq = c0 + ch;
+            if (r < ROWS) *reinterpret_cast<uint4*>(sg + r * DW_PITCH + ch * 2) = mask_chunk(v[n], (t >= 0 && t < T && cq < ld) ? C - cq : 0);
         }
-    }
-    for (int i = tid; i < (KSZ + 1) * DW_CC; i += 256) {
-        const int j = i / DW_CC, ch = i - j * DW_CC, c = c0 + ch;
-        sw[i] = c < C ? (j < KSZ ? w_kc[j * C + c] : bias[c]) : 0.f;
     }
     __syncthreads();
-    const int cc = tid & 7, tg = tid >> 3;
-    float acc[DW_NT][8];
+    dwf2 acc[DW_NT];
 #pragma unroll
-    for (int o = 0; o < DW_NT; ++o) {
-        const float4 b0 = *reinterpret_cast<const float4*>(sw + KSZ * DW_CC + cc * 8), b1 = *reinterpret_cast<const float4*>(sw + KSZ * DW_CC + cc * 8 + 4);
-        acc[o][0] = b0.x; acc[o][1] = b0.y; acc[o][2] = b0.z; acc[o][3] = b0.w;
-        acc[o][4] = b1.x; acc[o][5] = b1.y; acc[o][6] = b1.z; acc[o][7] = b1.w;
-    }
-    const char* base = sg + (tg * DW_NT * STRIDE) * DW_PITCH + cc * 16;
-    // tap loop kept rolled: fully unrolled the compiler keeps every window row / tap weight live (> 256 VGPRs)
-#pragma unroll 1
-    for (int tap = 0; tap < KSZ; ++tap) {
-        const float4 w0 = *reinterpret_cast<const float4*>(sw + tap * DW_CC + cc * 8), w1 = *reinterpret_cast<const float4*>(sw + tap * DW_CC + cc * 8 + 4);
+    for (int o = 0; o < DW_NT; ++o) acc[o] = bz;
+    const char* base = sg + (tg * DW_NT * STRIDE) * DW_PITCH + cp * 4;
+#pragma unroll
+    for (int r = 0; r < TROWS; ++r) {
+        const uint32_t raw = *reinterpret_cast<const uint32_t*>(base + r * DW_PITCH);
+        const dwf2 x = dwf2{__uint_as_float(raw << 16), __uint_as_float(raw & 0xFFFF0000u)};
 #pragma unroll
         for (int o = 0; o < DW_NT; ++o) {
-            const uint4 raw = *reinterpret_cast<const uint4*>(base + (tap + o * STRIDE) * DW_PITCH);
-            acc[o][0] = fmaf(w0.x, __uint_as_float(raw.x << 16), acc[o][0]); acc[o][1] = fmaf(w0.y, __uint_as_float(raw.x & 0xFFFF0000u), acc[o][1]);
-            acc[o][2] = fmaf(w0.z, __uint_as_float(raw.y << 16), acc[o][2]); acc[o][3] = fmaf(w0.w, __uint_as_float(raw.y & 0xFFFF0000u), acc[o][3]);
-            acc[o][4] = fmaf(w1.x, __uint_as_float(raw.z << 16), acc[o][4]); acc[o][5] = fmaf(w1.y, __uint_as_float(raw.z & 0xFFFF0000u), acc[o][5]);
-            acc[o][6] = fmaf(w1.z, __uint_as_float(raw.w << 16), acc[o][6]); acc[o][7] = fmaf(w1.w, __uint_as_float(raw.w & 0xFFFF0000u), acc[o][7]);
+            const int tap = r - o * STRIDE;                                 // static after unrolling
+            if (tap >= 0 && tap < KSZ) acc[o] = __builtin_elementwise_fma(w[tap], x, acc[o]);
         }
     }
-    const int c = c0 + cc * 8;
-    if (c < ld) {
+    if (c < ld) {   // ld is even, so the pair is inside the row; channels >= C have zero taps and bias: swish(0) = 0 keeps the pad columns zero
+        bf16_t* ob = out + (size_t)b * To * ld;
 #pragma unroll
         for (int o = 0; o < DW_NT; ++o) {
             const int to = to0 + tg * DW_NT + o;
-            if (to < To) {
-                uint4 w;                                   // channels >= C have zero weights and bias: swish(0) = 0 keeps the pad columns zero
-                w.x = pack_bf2(swishf_(acc[o][0]), swishf_(acc[o][1])); w.y = pack_bf2(swishf_(acc[o][2]), swishf_(acc[o][3]));
-                w.z = pack_bf2(swishf_(acc[o][4]), swishf_(acc[o][5])); w.w = pack_bf2(swishf_(acc[o][6]), swishf_(acc[o][7]));
-                *reinterpret_cast<uint4*>(out + ((size_t)b * To + to) * ld + c) = w;
-            }
+            if (to < To) *reinterpret_cast<uint32_t*>(ob + (unsigned)(to * ld + c)) = pack_bf2(swishf_(acc[o].x), swishf_(acc[o].y));
         }
     }
 }
@@ -150,7 +154,7 @@ template <int KSZ, int STRIDE>
 int launch_dw_t(const bf16_t* g, int B, int T, int To, int C, int ld, const float* w_kc, const float* bias, bf16_t* out, hipStream_t s) {
     const int ctiles = (C + DW_CC - 1) / DW_CC, ttiles = (To + DW_TT - 1) / DW_TT;
     constexpr int ROWS = (DW_TT - 1) * STRIDE + KSZ;
-    const size_t lds = (size_t)ROWS * DW_PITCH + (size_t)(KSZ + 1) * DW_CC * sizeof(float);
+    const size_t lds = (size_t)ROWS * DW_PITCH;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv_kernel<KSZ, STRIDE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -10,9 +10,20 @@ constexpr int CH = 32;   // weight rows per LDS chunk (== hidden units per FFN s
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 
-// one wave-wide LDS-DMA: lane i's 16 bytes at g land at lds_wave_base + 16*i
+// One wave-wide LDS-DMA: lane i's 16 bytes at g land at lds_wave_base + 16*i (lds_wave_base wave-uniform).
+// Written as inline assembly on purpose.  Through __builtin_amdgcn_global_load_lds the compiler knows the instruction writes LDS
+// and, unable to prove which bytes, makes the next LDS read it considers aliasing wait for vmcnt(0) - i.e. for the prefetch that
+// was just issued, three chunks ahead of its use (found in the ISA of every chain kernel: a drained DMA queue per chunk).  The
+// ring protocol already orders every DMA against its readers with counted s_waitcnt vmcnt(N) + s_barrier (wait_chunks /
+// wg_barrier), so the instruction is made opaque; "memory" keeps the compiler from moving LDS or global accesses across it.
 __device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((gbl_void_t*)g, (lds_void_t*)lds_wave_base, 16, 0, 0);
+    const uint32_t l = (uint32_t)(uintptr_t)(lds_void_t*)lds_wave_base;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(l), "v"(g) : "memory", "m0");
+}
+// same with a wave-uniform base and a per-lane 32-bit byte offset (saddr form: the offset register can live for the whole kernel)
+__device__ __forceinline__ void glds16(const char* base, uint32_t off, char* lds_wave_base) {
+    const uint32_t l = (uint32_t)(uintptr_t)(lds_void_t*)lds_wave_base;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(l), "v"(off), "s"(base) : "memory", "m0");
 }
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
     static_assert(N >= 0 && N < 64, "vmcnt immediate is 6 bits");
@@ -47,6 +58,22 @@ template <int P> __device__ __forceinline__ void dma_rows32(const bf16_t* src, i
     int pc = q - (r % P);
     pc += pc < 0 ? P : 0;
     glds16(src + (size_t)r * ld + pc * 8, img + 64 * i * 16);
+}
+// Per-lane BYTE offsets of the same two DMA shapes, for callers that keep them in registers for the whole kernel and pass
+// glds16 a wave-uniform base plus this offset (see chain.hip: the address registers of an LDS-DMA must not be rewritten while
+// it is in flight, so temporaries cost a vmcnt(0) at their next reuse).
+template <int P> __device__ __forceinline__ uint32_t dma_rows32_off(int ld, int i, int lane) {
+    const int L = 64 * i + lane;
+    const int r = L / P, q = L - r * P;
+    int pc = q - (r % P);
+    pc += pc < 0 ? P : 0;
+    return (uint32_t)(r * ld + pc * 8) * 2u;
+}
+__device__ __forceinline__ uint32_t dma_w2_off(int ld, int j, int lane) {
+    const int L = 64 * j + lane;
+    const int n = L >> 2, q = L & 3;
+    const int pc = (q - (n >> 2)) & 3;
+    return (uint32_t)(n * ld + pc * 8) * 2u;
 }
 // FFN second weight chunk: [R rows][4 pieces] (32 hidden units), piece pc of row n at slot n*4 + ((pc + (n>>2)) & 3)
 __device__ __forceinline__ void dma_w2(const bf16_t* src, int ld, char* img, int j, int lane) {

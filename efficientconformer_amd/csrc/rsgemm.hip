@@ -66,8 +66,10 @@ __device__ __forceinline__ void layernorm_regs(float4 (&ra)[KS], float4 (&rb)[KS
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
         const int c0 = s * 16 + half * 8;
-        if (c0 < D) { const float a = ra[s].x - mean, b = ra[s].y - mean, c = ra[s].z - mean, d = ra[s].w - mean; var += (a * a + b * b) + (c * c + d * d); }
-        if (c0 + 4 < D) { const float a = rb[s].x - mean, b = rb[s].y - mean, c = rb[s].z - mean, d = rb[s].w - mean; var += (a * a + b * b) + (c * c + d * d); }
+        // branch-free: a padded chunk holds zeros and subtracts 0 instead of the mean (one select per chunk, no exec-masked blocks)
+        const float ma = c0 < D ? mean : 0.f, mb = c0 + 4 < D ? mean : 0.f;
+        { const float a = ra[s].x - ma, b = ra[s].y - ma, c = ra[s].z - ma, d = ra[s].w - ma; var += (a * a + b * b) + (c * c + d * d); }
+        { const float a = rb[s].x - mb, b = rb[s].y - mb, c = rb[s].z - mb, d = rb[s].w - mb; var += (a * a + b * b) + (c * c + d * d); }
     }
     const float rstd = rsqrtf((var + __shfl_xor(var, 32)) / (float)D + 1e-6f);
 #pragma unroll
@@ -75,13 +77,16 @@ __device__ __forceinline__ void layernorm_regs(float4 (&ra)[KS], float4 (&rb)[KS
         const int c0 = s * 16 + half * 8;               // gamma / beta live in LDS, zero padded to KS*16 columns
         const float4 g0 = *reinterpret_cast<const float4*>(sg + c0), g1 = *reinterpret_cast<const float4*>(sg + c0 + 4);
         const float4 b0 = *reinterpret_cast<const float4*>(sb + c0), b1 = *reinterpret_cast<const float4*>(sb + c0 + 4);
-        const bool va = live && c0 < D, vb = live && c0 + 4 < D;
+        // No column / row guards: columns >= D have x = 0 (zeroed above) and gamma = beta = 0, so they come out as 0; rows >= M
+        // were fetched from a clamped (valid) row and are never stored.  With per-element selects the compiler sinks the LDS
+        // reads of gamma / beta under 2*KS exec-masked branches, each waiting for its own LDS round trip.
         uint4 w;
-        w.x = va ? pack_bf2((ra[s].x - mean) * rstd * g0.x + b0.x, (ra[s].y - mean) * rstd * g0.y + b0.y) : 0u;
-        w.y = va ? pack_bf2((ra[s].z - mean) * rstd * g0.z + b0.z, (ra[s].w - mean) * rstd * g0.w + b0.w) : 0u;
-        w.z = vb ? pack_bf2((rb[s].x - mean) * rstd * g1.x + b1.x, (rb[s].y - mean) * rstd * g1.y + b1.y) : 0u;
-        w.w = vb ? pack_bf2((rb[s].z - mean) * rstd * g1.z + b1.z, (rb[s].w - mean) * rstd * g1.w + b1.w) : 0u;
+        w.x = pack_bf2((ra[s].x - mean) * rstd * g0.x + b0.x, (ra[s].y - mean) * rstd * g0.y + b0.y);
+        w.y = pack_bf2((ra[s].z - mean) * rstd * g0.z + b0.z, (ra[s].w - mean) * rstd * g0.w + b0.w);
+        w.z = pack_bf2((rb[s].x - mean) * rstd * g1.x + b1.x, (rb[s].y - mean) * rstd * g1.y + b1.y);
+        w.w = pack_bf2((rb[s].z - mean) * rstd * g1.z + b1.z, (rb[s].w - mean) * rstd * g1.w + b1.w);
         xf[s] = as_bf16x8(w);
+        (void)live;
     }
 }
 
@@ -316,7 +321,7 @@ __global__ __launch_bounds__(NW * 64) void ffn_fused_kernel(const FfnParams p, u
     if constexpr (PROF) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         FFN_TICK(6);
-        if (lane == 0) {
+        if (lane == 0 && (blockIdx.x & 7) == 0) {      // a 1/8 sample of the workgroups reports (keeps the atomics out of the measurement)
             for (int i = 0; i < 7; ++i) atomicAdd(prof + i, ph[i]);
             atomicAdd(prof + 7, 1ull);
         }
@@ -419,6 +424,12 @@ void rs_gemm_kernel(const RsDev gd) {
     for (int i = tid; i < nchunks * CH; i += NTHR) sbias[i] = p.bias[i];
     float* sgam = sbias + nchunks * CH;                       // LayerNorm gamma | beta (KS*16 each, zero padded)
     float* sbet = sgam + KS * 16;
+    // QKV epilogues: the rel-pos biases u, v (D floats each) also live in LDS.  Read from global inside the flush (under the
+    // `which == 0` branch) every Q tile exposed one L2 round trip before its stores: ~16 of them per workgroup.
+    float* su = sbet + KS * 16;
+    float* sv = su + ((p.D + 3) & ~3);
+    if constexpr (EPI == RS_QKV || EPI == RS_QKV_NAT)
+        for (int i = tid; i < p.D; i += NTHR) { su[i] = p.u[i]; sv[i] = p.v[i]; }       // visible after the first wg_barrier
     const bool fuse_ln = p.X != nullptr;
     if (fuse_ln) {
         for (int i = tid; i < KS * 16; i += NTHR) { sgam[i] = i < p.K ? p.ln_g[i] : 0.f; sbet[i] = i < p.K ? p.ln_b[i] : 0.f; }
@@ -551,10 +562,10 @@ void rs_gemm_kernel(const RsDev gd) {
                                 const size_t idx = qrow[rt] + nn0;
                                 if (which == 0) {
                                     float uu[8], vv[8];
-                                    *reinterpret_cast<float4*>(uu) = *reinterpret_cast<const float4*>(p.u + nn0);
-                                    *reinterpret_cast<float4*>(uu + 4) = *reinterpret_cast<const float4*>(p.u + nn0 + 4);
-                                    *reinterpret_cast<float4*>(vv) = *reinterpret_cast<const float4*>(p.v + nn0);
-                                    *reinterpret_cast<float4*>(vv + 4) = *reinterpret_cast<const float4*>(p.v + nn0 + 4);
+                                    *reinterpret_cast<float4*>(uu) = *reinterpret_cast<const float4*>(su + nn0);
+                                    *reinterpret_cast<float4*>(uu + 4) = *reinterpret_cast<const float4*>(su + nn0 + 4);
+                                    *reinterpret_cast<float4*>(vv) = *reinterpret_cast<const float4*>(sv + nn0);
+                                    *reinterpret_cast<float4*>(vv + 4) = *reinterpret_cast<const float4*>(sv + nn0 + 4);
                                     *reinterpret_cast<uint4*>(p.qu + idx) = make_uint4(pack_bf2(v[0] + uu[0], v[1] + uu[1]), pack_bf2(v[2] + uu[2], v[3] + uu[3]),
                                                                                      pack_bf2(v[4] + uu[4], v[5] + uu[5]), pack_bf2(v[6] + uu[6], v[7] + uu[7]));
                                     *reinterpret_cast<uint4*>(p.qv + idx) = make_uint4(pack_bf2(v[0] + vv[0], v[1] + vv[1]), pack_bf2(v[2] + vv[2], v[3] + vv[3]),
@@ -576,7 +587,7 @@ void rs_gemm_kernel(const RsDev gd) {
                                 for (int i = 0; i < 4; ++i) v[i] = acc[rt][g][r0 + i] + bias[(i) + 8 * (r0 >> 2) + 4 * half];
                                 const size_t idx = qrow[rt] + nn0;
                                 if (which == 0) {
-                                    const float4 u4 = *reinterpret_cast<const float4*>(p.u + nn0), v4 = *reinterpret_cast<const float4*>(p.v + nn0);
+                                    const float4 u4 = *reinterpret_cast<const float4*>(su + nn0), v4 = *reinterpret_cast<const float4*>(sv + nn0);
                                     *reinterpret_cast<uint2*>(p.qu + idx) = make_uint2(pack_bf2(v[0] + u4.x, v[1] + u4.y), pack_bf2(v[2] + u4.z, v[3] + u4.w));
                                     *reinterpret_cast<uint2*>(p.qv + idx) = make_uint2(pack_bf2(v[0] + v4.x, v[1] + v4.y), pack_bf2(v[2] + v4.z, v[3] + v4.w));
                                 } else {
@@ -602,7 +613,7 @@ void rs_gemm_kernel(const RsDev gd) {
                             const size_t idx = ((size_t)(qb[rt] * p.H + h) * p.Tg + qtq[rt]) * p.dpad + x;
                             if ((p.d & 1) == 0) {
                                 if (which == 0) {
-                                    const float u0 = p.u[nn0 + i2], u1 = p.u[nn0 + i2 + 1], w0 = p.v[nn0 + i2], w1 = p.v[nn0 + i2 + 1];
+                                    const float u0 = su[nn0 + i2], u1 = su[nn0 + i2 + 1], w0 = sv[nn0 + i2], w1 = sv[nn0 + i2 + 1];
                                     *reinterpret_cast<uint32_t*>(p.qu + idx) = pack_bf2(v0 + u0, v1 + u1);
                                     *reinterpret_cast<uint32_t*>(p.qv + idx) = pack_bf2(v0 + w0, v1 + w1);
                                 } else {
@@ -613,8 +624,8 @@ void rs_gemm_kernel(const RsDev gd) {
                                 const int h1 = gd.fd.div(flat1), x1 = flat1 - h1 * p.d;
                                 const size_t idx1 = ((size_t)(qb[rt] * p.H + h1) * p.Tg + qtq[rt]) * p.dpad + x1;
                                 if (which == 0) {
-                                    p.qu[idx] = f2bf(v0 + p.u[nn0 + i2]); p.qv[idx] = f2bf(v0 + p.v[nn0 + i2]);
-                                    p.qu[idx1] = f2bf(v1 + p.u[nn0 + i2 + 1]); p.qv[idx1] = f2bf(v1 + p.v[nn0 + i2 + 1]);
+                                    p.qu[idx] = f2bf(v0 + su[nn0 + i2]); p.qv[idx] = f2bf(v0 + sv[nn0 + i2]);
+                                    p.qu[idx1] = f2bf(v1 + su[nn0 + i2 + 1]); p.qv[idx1] = f2bf(v1 + sv[nn0 + i2 + 1]);
                                 } else { dst[idx] = f2bf(v0); dst[idx1] = f2bf(v1); }
                             }
                         }
@@ -666,7 +677,7 @@ void rs_gemm_kernel(const RsDev gd) {
 
 template <int KS, int G, int RT, int NW, int NBUF, int EPI>
 int launch_rs_t(const RsDev& gd, hipStream_t s) {
-    const int lds = NBUF * CH * KS * 32 + gd.nchunks * CH * 4 + KS * 32 * 4;
+    const int lds = NBUF * CH * KS * 32 + gd.nchunks * CH * 4 + KS * 32 * 4 + ((EPI == RS_QKV || EPI == RS_QKV_NAT) ? 2 * ((gd.p.D + 3) & ~3) * 4 : 0);
     if (lds > 160 * 1024) return -4;
     if ((EPI == RS_RESID || EPI == RS_F32) && gd.nchunks > G) return -5;
     static int attr_set = 0;

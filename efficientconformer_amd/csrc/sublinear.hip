@@ -43,6 +43,9 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void sublinear_kernel(const f
     float patch[17][3];
     int cur_fc = -1;
     auto load_patch = [&](int fc) __attribute__((always_inline)) {
+        // clamped, unconditional loads, ALL issued before the first select: the empty asm pins each loaded value, otherwise the
+        // compiler sinks every load under its select's condition (exec-masked branches) and waits for each row's three loads
+        // before the next row's - 17 serialized memory latencies per patch instead of one
 #pragma unroll
         for (int i = 0; i < 17; ++i) {
             const int fr = 16 * fc - 1 + i;
@@ -50,8 +53,20 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void sublinear_kernel(const f
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const int tc = 2 * pt - 1 + j;
-                const float v = melb[(size_t)frc * Tm + (tc < 0 ? 0 : (tc < Tm ? tc : Tm - 1))];   // clamped, unconditional
-                patch[i][j] = (fr >= 0 && fr < F && tc >= 0 && tc < Tm) ? v : 0.f;
+                patch[i][j] = melb[(unsigned)(frc * Tm + (tc < 0 ? 0 : (tc < Tm ? tc : Tm - 1)))];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 17; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) asm volatile("" : "+v"(patch[i][j]));
+#pragma unroll
+        for (int i = 0; i < 17; ++i) {
+            const int fr = 16 * fc - 1 + i;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int tc = 2 * pt - 1 + j;
+                patch[i][j] = (fr >= 0 && fr < F && tc >= 0 && tc < Tm) ? patch[i][j] : 0.f;
             }
         }
     };
