@@ -50,18 +50,11 @@ __device__ __forceinline__ void wg_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// Issue the DMA for a [32 rows][P pieces of 16 B] weight chunk (row r at src + r*ld elements).  LDS image: piece pc of row r
-// sits at slot r*P + (pc + r) % P.  Wave-instruction i (32*P/64 per chunk) covers slots [64i, 64i+64).
-template <int P> __device__ __forceinline__ void dma_rows32(const bf16_t* src, int ld, char* img, int i, int lane) {
-    const int L = 64 * i + lane;
-    const int r = L / P, q = L - r * P;
-    int pc = q - (r % P);
-    pc += pc < 0 ? P : 0;
-    glds16(src + (size_t)r * ld + pc * 8, img + 64 * i * 16);
-}
-// Per-lane BYTE offsets of the same two DMA shapes, for callers that keep them in registers for the whole kernel and pass
-// glds16 a wave-uniform base plus this offset (see chain.hip: the address registers of an LDS-DMA must not be rewritten while
-// it is in flight, so temporaries cost a vmcnt(0) at their next reuse).
+// DMA shapes of the weight ring.  A kernel computes the per-lane BYTE offsets of its wave's DMA instructions once, keeps them in
+// registers, and per chunk only moves the wave-uniform base it hands to glds16 (a division, a modulo and a 64-bit multiply-add
+// per instruction and chunk otherwise: ~80 cycles per DMA in the EFFCONF_FFN_PHASES profile).
+//  * [32 rows][P pieces of 16 B] weight chunk (row r at base + r*ld elements).  LDS image: piece pc of row r sits at slot
+//    r*P + (pc + r) % P.  Wave-instruction i (32*P/64 per chunk) covers slots [64i, 64i+64) -> LDS bytes [1024 i, 1024 i + 1024).
 template <int P> __device__ __forceinline__ uint32_t dma_rows32_off(int ld, int i, int lane) {
     const int L = 64 * i + lane;
     const int r = L / P, q = L - r * P;
@@ -69,18 +62,12 @@ template <int P> __device__ __forceinline__ uint32_t dma_rows32_off(int ld, int 
     pc += pc < 0 ? P : 0;
     return (uint32_t)(r * ld + pc * 8) * 2u;
 }
+//  * FFN second weight chunk: [R rows][4 pieces] (32 hidden units), piece pc of row n at slot n*4 + ((pc + (n>>2)) & 3)
 __device__ __forceinline__ uint32_t dma_w2_off(int ld, int j, int lane) {
     const int L = 64 * j + lane;
     const int n = L >> 2, q = L & 3;
     const int pc = (q - (n >> 2)) & 3;
     return (uint32_t)(n * ld + pc * 8) * 2u;
-}
-// FFN second weight chunk: [R rows][4 pieces] (32 hidden units), piece pc of row n at slot n*4 + ((pc + (n>>2)) & 3)
-__device__ __forceinline__ void dma_w2(const bf16_t* src, int ld, char* img, int j, int lane) {
-    const int L = 64 * j + lane;
-    const int n = L >> 2, q = L & 3;
-    const int pc = (q - (n >> 2)) & 3;
-    glds16(src + (size_t)n * ld + pc * 8, img + 64 * j * 16);
 }
 
 

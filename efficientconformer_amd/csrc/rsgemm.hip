@@ -184,15 +184,24 @@ __global__ __launch_bounds__(NW * 64) void ffn_fused_kernel(const FfnParams p, u
     static_assert(RT == 1, "one 32-row tile per wave");
     char* stg = (ST::ALIAS ? smem + (NBUF - 1) * SM::BUF : reinterpret_cast<char*>(sbet + KS * 16)) + wave * STG_BYTES;
 
+    // per-lane byte offsets of this wave's PER DMA instructions, computed once (the address arithmetic - a division, a modulo and
+    // a 64-bit multiply-add per instruction - was ~80 cycles per DMA: the "dma_issue" phase of EFFCONF_FFN_PHASES); per chunk only
+    // the wave-uniform base moves
+    uint32_t doff[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int i = wave + NW * k;
+        doff[k] = i < KS ? dma_rows32_off<P1>(p.ldw1, i, lane) : dma_w2_off(p.ldw2, i - KS, lane);
+    }
     auto issue = [&](int c) {
         char* buf = smem + (c % NBUF) * SM::BUF;
-        const bf16_t* w1 = p.W1 + (size_t)c * CH * p.ldw1;
-        const bf16_t* w2 = p.W2 + c * CH;
+        const char* w1 = reinterpret_cast<const char*>(p.W1 + (size_t)c * CH * p.ldw1);
+        const char* w2 = reinterpret_cast<const char*>(p.W2 + c * CH);
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int i = wave + NW * k;
-            if (i < KS) dma_rows32<P1>(w1, p.ldw1, buf, i, lane);
-            else dma_w2(w2, p.ldw2, buf + SM::W1_BYTES, i - KS, lane);
+            if (i < KS) glds16(w1, doff[k], buf + 64 * i * 16);
+            else glds16(w2, doff[k], buf + SM::W1_BYTES + 64 * (i - KS) * 16);
         }
     };
 
@@ -240,7 +249,10 @@ __global__ __launch_bounds__(NW * 64) void ffn_fused_kernel(const FfnParams p, u
         wait_chunks<PER, NBUF - 2>(nchunks - 1 - c);       // chunk c has landed (this wave's pieces)
         wg_barrier();                                      // ... and everybody's; everybody is done with chunk c-1
         FFN_TICK(1);
-        if (c + NBUF - 1 < nchunks) issue(c + NBUF - 1);   // refill the buffer chunk c-1 used
+        if (c + NBUF - 1 < nchunks) issue(c + NBUF - 1);   // refill the buffer chunk c-1 used.  (Spreading these DMA instructions over
+                                                           // GEMM1 was slower: a wave's MFMAs queue behind a DMA that waits for the
+                                                           // CU's 64 B/clk address path, which the four waves' 32 KB per chunk keep busy
+                                                           // for ~512 cycles either way.)
         FFN_TICK(2);
         const char* buf = smem + (c % NBUF) * SM::BUF;
         const char* w1 = buf + lr * (P1 * 16);
@@ -414,11 +426,14 @@ void rs_gemm_kernel(const RsDev gd) {
     const int m_base = (blockIdx.x * NW + wave) * (RT * 32);
     const int nchunks = gd.nchunks;
 
+    uint32_t doff[PER];                                        // per-lane DMA byte offsets, computed once (see ffn_fused_kernel)
+#pragma unroll
+    for (int k = 0; k < PER; ++k) doff[k] = dma_rows32_off<P1>(p.ldw, wave + NW * k, lane);
     auto issue = [&](int c) {
         char* buf = smem + (c % NBUF) * BUF;
-        const bf16_t* w = p.W + (size_t)c * CH * p.ldw;
+        const char* w = reinterpret_cast<const char*>(p.W + (size_t)c * CH * p.ldw);
 #pragma unroll
-        for (int k = 0; k < PER; ++k) dma_rows32<P1>(w, p.ldw, buf, wave + NW * k, lane);
+        for (int k = 0; k < PER; ++k) glds16(w, doff[k], buf + 64 * (wave + NW * k) * 16);
     };
 
     for (int i = tid; i < nchunks * CH; i += NTHR) sbias[i] = p.bias[i];
