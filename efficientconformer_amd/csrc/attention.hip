@@ -67,7 +67,9 @@ struct AttnSmem {
 // 64 NEW rows are staged per key block.  Staging is software pipelined through registers (loads of block j+1 are in
 // flight during block j's MFMA / softmax work) and all loads are unconditional at clamped addresses.
 template <int DP, int NWV, bool PROF = false>
-__global__ __launch_bounds__(NWV * 64) void relpos_attention_kernel(const AttnParams p, unsigned long long* prof = nullptr) {
+// second launch bound: two 4-wave workgroups per CU share each SIMD's 512 registers, so VGPRs + AGPRs must stay <= 256 - without it
+// a 272-register DP = 96 build silently ran one workgroup per CU (+46 %)
+__global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void relpos_attention_kernel(const AttnParams p, unsigned long long* prof = nullptr) {
     unsigned long long ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0;
     if constexpr (PROF) t0 = __builtin_readcyclecounter();
 #define AT_TICK(i) do { if constexpr (PROF) { asm volatile("" ::: "memory"); const unsigned long long t1_ = __builtin_readcyclecounter(); ph[i] += t1_ - t0; t0 = t1_; } } while (0)
@@ -167,6 +169,7 @@ __global__ __launch_bounds__(NWV * 64) void relpos_attention_kernel(const AttnPa
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_run = 0.f;
+    const float scale2 = p.scale * 1.44269504088896340736f;
     float* skew = sS + wave * 16 * SKEW_LD + c * SKEW_LD;
     const int woff = BI - 16 - 16 * wave;             // first band row of this wave inside the workgroup band
 
@@ -286,36 +289,49 @@ __global__ __launch_bounds__(NWV * 64) void relpos_attention_kernel(const AttnPa
         AT_TICK(4);
 
         // ---- realign (r' = j_local - i_local + 15), scale, mask, online softmax
+        // scores are kept in log2 units (scale2 = scale * log2 e), so every exponential is one v_exp_f32; the key mask is only
+        // applied in an utterance's last block and the running sums are only rescaled when some row's maximum moved (both
+        // wave-uniform branches): the softmax was 18 % of a wave's life, all of it VALU
         float mloc = -INFINITY;
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int jl = jt * 16 + g * 4 + r;
-                float sc = (st[jt][r] + skew[jl + 15 - c]) * p.scale;
-                sc = (j0 + jl < nkeys) ? sc : -INFINITY;
-                st[jt][r] = sc;
-                mloc = fmaxf(mloc, sc);
+                st[jt][r] = (st[jt][r] + skew[jl + 15 - c]) * scale2;
             }
+        if (j0 + BJ > nkeys) {
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) st[jt][r] = (j0 + jt * 16 + g * 4 + r < nkeys) ? st[jt][r] : -INFINITY;
+        }
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mloc = fmaxf(mloc, st[jt][r]);
         mloc = fmaxf(mloc, __shfl_xor(mloc, 16));
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
         const float m_new = fmaxf(m_run, mloc);       // finite: key j0 of every visited block is unmasked
-        const float alpha = __expf(m_run - m_new);
-        m_run = m_new;
+        {
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            l_run *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                acc[dt][0] *= alpha; acc[dt][1] *= alpha; acc[dt][2] *= alpha; acc[dt][3] *= alpha;
+            }
+            m_run = m_new;
+        }
         float lsum = 0.f;
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float e = __expf(st[jt][r] - m_new);
+                const float e = __builtin_amdgcn_exp2f(st[jt][r] - m_run);
                 st[jt][r] = e;
                 lsum += e;
             }
-        l_run = l_run * alpha + lsum;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            acc[dt][0] *= alpha; acc[dt][1] *= alpha; acc[dt][2] *= alpha; acc[dt][3] *= alpha;
-        }
+        l_run += lsum;
         if constexpr (PROF) { asm volatile("s_nop 0" :: "v"(st[0]), "v"(acc[0])); }
         AT_TICK(5);
         // ---- O^T += V^T P^T ; contraction slot (g, e) <-> key (2*c2 + (e>>2))*16 + g*4 + (e&3) on both operands
