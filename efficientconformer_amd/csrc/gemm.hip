@@ -80,12 +80,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmDev gd) {
     // Two register staging sets: the global loads of k-tile kt+2 are issued at the top of iteration kt and published (written to
     // LDS) at the bottom of iteration kt+1, so they have a whole iteration to arrive.  (One set - issue at the top, publish at the
     // bottom of the SAME iteration - left only one 16-MFMA compute phase to cover the L2 / HBM latency.)
-    struct Stage { uint4 ra[4], rb[NB]; };
+    struct Stage { uint4 ra[4], rb[NB]; int valid; };
     Stage s0, s1;
 #pragma unroll
     for (int i = 0; i < 4; ++i) { s0.ra[i] = make_uint4(0, 0, 0, 0); s1.ra[i] = s0.ra[i]; }
 #pragma unroll
     for (int i = 0; i < NB; ++i) { s0.rb[i] = make_uint4(0, 0, 0, 0); s1.rb[i] = s0.rb[i]; }
+    s0.valid = s1.valid = 0;
     auto load_tile = [&](Stage& st, int t) __attribute__((always_inline)) {
         const int k = t * BK + kc * 8;
         const int valid = p.K - k;
@@ -95,14 +96,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmDev gd) {
         for (int i = 0; i < 4; ++i) st.ra[i] = *reinterpret_cast<const uint4*>(a_ptr[i] + (kcl < 0 ? 0 : kcl));
 #pragma unroll
         for (int i = 0; i < NB; ++i) st.rb[i] = *reinterpret_cast<const uint4*>(b_ptr[i] + tb * BK);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) st.ra[i] = mask_chunk(st.ra[i], valid);
+        st.valid = valid;          // the K tail is masked at PUBLISH time: masking here made every iteration wait for the loads it had
+                                   // just issued (s_waitcnt vmcnt right after them: one L2 round trip per k-tile, 20 % of MFMA peak)
     };
     auto publish = [&](const Stage& st, int buf) __attribute__((always_inline)) {
         char* a = sA + buf * BM * LROW;
         char* b = sB + buf * BN * LROW;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(a + (srow + 32 * i) * LROW + kc * 16) = st.ra[i];
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(a + (srow + 32 * i) * LROW + kc * 16) = mask_chunk(st.ra[i], st.valid);
 #pragma unroll
         for (int i = 0; i < NB; ++i) *reinterpret_cast<uint4*>(b + (srow + 32 * i) * LROW + kc * 16) = st.rb[i];
     };
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmDev gd) {
         }
     };
     load_tile(s0, 0);
-    if (nk > 1) load_tile(s1, 1);
+    load_tile(s1, 1);
     publish(s0, 0);
     __syncthreads();
     for (int kt = 0; kt < nk; kt += 2) {
@@ -132,7 +133,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmDev gd) {
         for (int h = 0; h < 2; ++h) {            // h = 0: tile kt in buffer 0, tile kt+1 waiting in s1, tile kt+2 -> s0;  h = 1: roles swapped
             const int t = kt + h;
             if (t < nk) {
-                if (t + 2 < nk) { if (h == 0) load_tile(s0, t + 2); else load_tile(s1, t + 2); }
+                // UNCONDITIONAL (tiles past the end re-read a clamped tile and are never published): with `if (t + 2 < nk)` the
+                // compiler has to cover the path without these 8 younger loads and waits vmcnt(7..0) at the publish below instead
+                // of vmcnt(15..8) - i.e. for the loads just issued, which removes the second stage of the prefetch
+                if (h == 0) load_tile(s0, t + 2); else load_tile(s1, t + 2);
                 compute(h);
                 if (t + 1 < nk) { if (h == 0) publish(s1, 1); else publish(s0, 0); }
                 __syncthreads();
