@@ -211,36 +211,53 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void relpos_attention_k
             }
         }
     };
+    // Column masks of this thread's K / E chunks (elements >= d of the padded head width), loop invariant: the per-block
+    // mask_chunk (two compares + two selects per dword, six chunks per thread and key block) was a fifth of the loop's VALU work.
+    // Row validity only matters in an utterance's last key block / the band's tail: wave-uniform branches.
+    uint4 cm[NK];
+    static_assert(NE == NK, "K and E chunks share the column mapping");
+#pragma unroll
+    for (int n = 0; n < NK; ++n) {
+        const int q = tid + NTHR * n, r = q / CPR, x = (q - r * CPR) * 8;
+        cm[n] = mask_chunk(make_uint4(~0u, ~0u, ~0u, ~0u), p.d - x);
+    }
+    auto and4 = [](uint4 a, uint4 m) { return make_uint4(a.x & m.x, a.y & m.y, a.z & m.z, a.w & m.w); };
     auto publish = [&](const Stage& st_, int j0) __attribute__((always_inline)) {
         __syncthreads();                          // previous block's LDS reads are done
         // ---- publish block j0: K rows, transposed V, and (for j0 > 0) the 64 new band rows
+        const bool rows_ok = j0 + BJ <= p.Tg;     // every key row of the block exists
 #pragma unroll
         for (int n = 0; n < NK; ++n) {
             const int q = tid + NTHR * n, r = q / CPR, x = (q - r * CPR) * 8;
-            if (q < BJ * CPR) *reinterpret_cast<uint4*>(sK + SM::koff(r, x >> 3)) = mask_chunk(st_.lk[n], (j0 + r < p.Tg) ? p.d - x : 0);
+            uint4 v = and4(st_.lk[n], cm[n]);
+            if (!rows_ok) v = (j0 + r < p.Tg) ? v : make_uint4(0, 0, 0, 0);
+            if (q < BJ * CPR) *reinterpret_cast<uint4*>(sK + SM::koff(r, x >> 3)) = v;
         }
 #pragma unroll
         for (int n = 0; n < NV; ++n) {
             const int q = tid + NTHR * n, pr = q & (BJ / 2 - 1), x = (q / (BJ / 2)) * 8;
             const int j = j0 + 2 * pr;
             if (q < (BJ / 2) * CPR) {
-                const uint4 v0 = mask_chunk(st_.lv0[n], (j < p.Tg) ? 8 : 0), v1 = mask_chunk(st_.lv1[n], (j + 1 < p.Tg) ? 8 : 0);
+                uint4 v0 = st_.lv0[n], v1 = st_.lv1[n];
+                if (!rows_ok) { v0 = mask_chunk(v0, (j < p.Tg) ? 8 : 0); v1 = mask_chunk(v1, (j + 1 < p.Tg) ? 8 : 0); }
                 const uint32_t a[4] = {v0.x, v0.y, v0.z, v0.w}, bq[4] = {v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const uint32_t lo = (a[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu, hi = (bq[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu;
-                    *reinterpret_cast<uint32_t*>(sV + (x + e) * SM::VROW + pr * 4) = lo | (hi << 16);
-                }
+                for (int e = 0; e < 8; ++e)            // element e of both keys as one dword: a byte permute (v_perm_b32)
+                    *reinterpret_cast<uint32_t*>(sV + (x + e) * SM::VROW + pr * 4) =
+                        __builtin_amdgcn_perm(bq[e >> 1], a[e >> 1], (e & 1) ? 0x07060302u : 0x05040100u);
             }
         }
         if (j0 > 0) {
             const int rnew = R0 + j0 + BI - 1;    // first new absolute E row of this block
+            const bool band_ok = rnew >= 0 && rnew + 63 < erows;
 #pragma unroll
             for (int n = 0; n < NE; ++n) {
                 const int q = tid + NTHR * n, rr = q / CPR, x = (q - rr * CPR) * 8;
                 const int r = rnew + rr;
+                uint4 v = and4(st_.le[n], cm[n]);
+                if (!band_ok) v = (r >= 0 && r < erows) ? v : make_uint4(0, 0, 0, 0);
                 if (q < 64 * CPR)
-                    *reinterpret_cast<uint4*>(sE + SM::koff((r + 8192) & (ERING - 1), x >> 3)) = mask_chunk(st_.le[n], (r >= 0 && r < erows) ? p.d - x : 0);
+                    *reinterpret_cast<uint4*>(sE + SM::koff((r + 8192) & (ERING - 1), x >> 3)) = v;
             }
         }
         __syncthreads();
