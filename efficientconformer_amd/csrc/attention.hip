@@ -104,7 +104,6 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void relpos_attention_k
     const int i0 = qt * BI, iw0 = i0 + wave * 16;
     const size_t qoff = (size_t)b * p.q_bstride + (size_t)h * p.q_hstride;
     const bf16_t* Qu = p.qu + qoff;
-    const bf16_t* Qv = p.qv + qoff;
     const bf16_t* Kh = p.kh + qoff;
     const bf16_t* Vh = p.vt + qoff;                    // V, same layout as K (transposed at LDS fill)
     const bf16_t* Eh = p.eh + (size_t)h * p.e_hstride;
@@ -121,22 +120,32 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void relpos_attention_k
     AT_TICK(8);                                        // prologue a: arguments, tile indices, utterance length
 
     // ---- this lane's query (column c of the wave's 16): B operands of S^T = K Q^T, kept in registers
+    // Only Q + u is stored (attentions.py:674): Q + v = (Q + u) + (v - u), with (v - u) per head column from a small fp32 table
+    // (zero beyond d).  One query tensor less to write (the producers' Q/K/V write-out is HBM-write bound) and to read.
     bf16x8 qu[KS], qv[KS];
     {
         const int i = iw0 + c;
         const int ic = i < p.Tg ? i : p.Tg - 1;
-        uint4 ra[KS], rb[KS];
+        uint4 ra[KS];
+        float4 da[KS], db[KS];
+        const float* dv = p.dvu + (size_t)h * p.dvu_ld;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int x = ks * 32 + g * 8, xq = x < dceil ? x : 0;
             ra[ks] = ld16(Qu + (size_t)ic * RS + xq);
-            rb[ks] = ld16(Qv + (size_t)ic * RS + xq);
+            da[ks] = *reinterpret_cast<const float4*>(dv + x);
+            db[ks] = *reinterpret_cast<const float4*>(dv + x + 4);
         }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int valid = i < p.Tg ? p.d - (ks * 32 + g * 8) : 0;
-            qu[ks] = as_bf16x8(mask_chunk(ra[ks], valid));
-            qv[ks] = as_bf16x8(mask_chunk(rb[ks], valid));
+            const uint4 m = mask_chunk(ra[ks], valid);
+            qu[ks] = as_bf16x8(m);
+            const uint4 w = make_uint4(pack_bf2(__uint_as_float(m.x << 16) + da[ks].x, __uint_as_float(m.x & 0xFFFF0000u) + da[ks].y),
+                                       pack_bf2(__uint_as_float(m.y << 16) + da[ks].z, __uint_as_float(m.y & 0xFFFF0000u) + da[ks].w),
+                                       pack_bf2(__uint_as_float(m.z << 16) + db[ks].x, __uint_as_float(m.z & 0xFFFF0000u) + db[ks].y),
+                                       pack_bf2(__uint_as_float(m.w << 16) + db[ks].z, __uint_as_float(m.w & 0xFFFF0000u) + db[ks].w));
+            qv[ks] = as_bf16x8(mask_chunk(w, valid));
         }
     }
     if constexpr (PROF) { asm volatile("s_nop 0" :: "v"(qu[0]), "v"(qv[KS - 1])); }
@@ -436,7 +445,7 @@ void attn_prof_dump() {
 }
 
 __global__ void attn_pad_rows_kernel(GemmParams p, int B) {
-    // rows t in [T, Tp): Q = 0 -> Qu = u, Qv = v;  K = V = 0
+    // rows t in [T, Tp): Q = 0 -> Qu = u (and Qv = u + (v - u) = v in the attention kernel);  K = V = 0
     const int Tp = p.Tg * p.G;
     const int npad = Tp - p.T;
     const int total = B * npad * p.D;
@@ -449,7 +458,6 @@ __global__ void attn_pad_rows_kernel(GemmParams p, int B) {
         const int h = flat / p.d, x = flat - h * p.d;
         const size_t i1 = ((size_t)(b * p.H + h) * p.Tg + tq) * p.dpad + x;
         p.qu[i1] = f2bf(p.u[nn]);
-        p.qv[i1] = f2bf(p.v[nn]);
         p.kh[i1] = 0;
         p.vt[i1] = 0;
     }
@@ -462,7 +470,7 @@ __global__ void attn_pad_rows_nat_kernel(GemmParams p, int B) {
         const int nn = idx % p.D, rest = idx / p.D;
         const int t = p.T + rest % npad, b = rest / npad;
         const size_t i1 = ((size_t)b * Tp + t) * p.D + nn;
-        p.qu[i1] = f2bf(p.u[nn]); p.qv[i1] = f2bf(p.v[nn]); p.kh[i1] = 0; p.vt[i1] = 0;
+        p.qu[i1] = f2bf(p.u[nn]); p.kh[i1] = 0; p.vt[i1] = 0;
     }
 }
 

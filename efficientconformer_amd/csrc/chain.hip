@@ -540,10 +540,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && KS <= 8) ? 2 : 1) void chain_k
                     }
                 }
                 // registers r = 8g .. 8g+7 of tile j are the columns 64c + 32j + 16g + 8*half + (0..7) of the stacked [Q | K | V]
-                // (row permutation of pack_linear_chunkperm).  Variant 0: Q + u | K | V, variant 1: Q + v (only Q columns stored).
-                const int nvar = (64 * c < D) ? 2 : 1;
-                for (int var = 0; var < nvar; ++var) {
-                    const float* su = s_uv + var * DP;
+                // (row permutation of pack_linear_chunkperm).  Q columns get + u; Q + v is derived in the attention kernel, so it is
+                // never written (the Q/K/V write-out is HBM-write bound: one tensor less is a quarter of its bytes).
+                {
+                    const float* su = s_uv;
                     wave_sync();
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
@@ -559,8 +559,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && KS <= 8) ? 2 : 1) void chain_k
                     wave_sync();
                     const int n0 = 64 * c + pc8;
                     const int which = cd.fD.div(n0), nn0 = n0 - which * D;
-                    bf16_t* dst = which == 0 ? (var == 0 ? p.qu : p.qv) : (which == 1 ? p.kh : p.vt);
-                    const bool colok = n0 < 3 * D && (var == 0 || which == 0);
+                    bf16_t* dst = which == 0 ? p.qu : (which == 1 ? p.kh : p.vt);
+                    const bool colok = n0 < 3 * D;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const u32x4 v = *reinterpret_cast<const u32x4*>(stg + (8 * i + (lane >> 3)) * STG_ROW + 16 * (lane & 7));

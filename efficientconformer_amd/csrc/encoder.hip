@@ -38,6 +38,7 @@ struct BlockW {
     PackedLinear ffn1_a, ffn1_b, qkv, qkv_nat, pos, outp, pw1, pw2, res, ffn2_a, ffn2_b;
     const bf16_t *ffn1_bp = nullptr, *ffn2_bp = nullptr;   // W2 with the hidden index permuted per 16 (rsgemm.hip)
     const float *u = nullptr, *v = nullptr, *dw_w = nullptr, *dw_b = nullptr;
+    const float* dvu = nullptr; int dvu_ld = 0;   // (v - u) per head column [H][dvu_ld], zero beyond d (attention derives Q + v from Q + u)
     const bf16_t* pos_table = nullptr;   // [2*max_pos-1][ld8(D)], row r <-> position max_pos-1-r
     // fused row-local chains (chain.hip): every weight with its K index permuted per 16; FFN second weight / bias pre-scaled by 1/2
     bool chain_in = false, chain_out = false;          // chain-packed weights exist for the D-wide / De-wide parts of the block
@@ -291,7 +292,7 @@ Shapes make_shapes(const EcEncoder* e, int B, int Tm) {
 
 struct Workspace {
     size_t total = 0;
-    size_t mel, sub, sub1, x0, x1, a, hbuf, qu, qv, kh, vt, eh, o, gbuf, cbuf, xs, lens, preds;
+    size_t mel, sub, sub1, x0, x1, a, hbuf, qu, kh, vt, eh, o, gbuf, cbuf, xs, lens, preds;
     std::vector<size_t> eh_blk;   // per-block E (kept across forwards for the cache)
 };
 
@@ -329,7 +330,7 @@ Workspace make_workspace(const EcEncoder* e, const Shapes& s, bool from_audio) {
     }
     w.x0 = take(mx); w.x1 = take(mx);
     w.a = take(ma); w.hbuf = take(mh);
-    w.qu = take(mq); w.qv = take(mq); w.kh = take(mq); w.vt = take(mvt); w.eh = take(me);
+    w.qu = take(mq); w.kh = take(mq); w.vt = take(mvt); w.eh = take(me);
     w.o = take(ma); w.gbuf = take(mg); w.cbuf = take(mc); w.xs = take(ma);
     w.lens = take((e->blocks.size() + 1) * B * 4);
     for (size_t k = 0; k < esz.size(); ++k) w.eh_blk.push_back(take(esz[k]));
@@ -396,7 +397,7 @@ void fill_chain_head(ChainParams& cp, const BlockW& W, int D, int Fp, int T, int
     cp.ln[3] = ChainLn{W.ln_att.g, W.ln_att.b};
     cp.f[1] = ChainFfn{W.c_f1a.w, W.c_f1a.ldw, W.c_f1a.bias, W.c_f1b, W.ffn1_b.ldw, W.c_f1b2, Fp};
     cp.g1 = ChainGemm{W.c_qkv.w, W.c_qkv.ldw, W.c_qkv.bias, W.c_qkv_chunks};
-    cp.qu = q.qu; cp.qv = q.qv; cp.kh = q.kh; cp.vt = q.vt; cp.u = W.u; cp.v = W.v; cp.T = T; cp.Tp = Tp;
+    cp.qu = q.qu; cp.kh = q.kh; cp.vt = q.vt; cp.u = W.u; cp.v = W.v; cp.T = T; cp.Tp = Tp;
 }
 
 int run_ffn(EcEncoder* e, hipStream_t st, const bf16_t* a, int M, int D, const PackedLinear& L1, const PackedLinear& L2,
@@ -495,7 +496,7 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
         p.A = a; p.lda = ld8(D); p.W = W.qkv.w; p.ldw = W.qkv.ldw; p.bias = W.qkv.bias;
         p.M = M; p.N = 3 * D; p.K = D;
         p.T = T; p.G = G; p.H = H; p.D = D; p.d = d; p.dpad = dpad; p.Tg = Tg; p.Tgp = Tgp;
-        p.qu = reinterpret_cast<bf16_t*>(ws + w.qu); p.qv = reinterpret_cast<bf16_t*>(ws + w.qv);
+        p.qu = reinterpret_cast<bf16_t*>(ws + w.qu);
         p.kh = reinterpret_cast<bf16_t*>(ws + w.kh); p.vt = reinterpret_cast<bf16_t*>(ws + w.vt);
         p.u = W.u; p.v = W.v;
         if (head_done) {
@@ -540,7 +541,8 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
             if (!e_cached) { PROF(PC_GEMM_OTHER, 2.0 * erows * (double)D * D, (double)erows * D * 4 + (double)D * D * 2);
                              EC_TRY(launch_gemm(pe, nat ? EPI_BF16 : EPI_HEADS, st)); }
             AttnParams ap{};
-            ap.qu = p.qu; ap.qv = p.qv; ap.kh = p.kh; ap.vt = p.vt; ap.eh = pe.kh;
+            ap.qu = p.qu; ap.kh = p.kh; ap.vt = p.vt; ap.eh = pe.kh;
+            ap.dvu = W.dvu; ap.dvu_ld = W.dvu_ld;
             ap.lens = lens + (size_t)k * B;
             ap.B = B; ap.H = H; ap.T = T; ap.G = G; ap.D = D; ap.d = d; ap.dpad = dpad; ap.Tg = Tg; ap.Tgp = Tgp;
             if (nat) { ap.q_bstride = (long long)Tp * D; ap.q_hstride = d; ap.q_rowstride = G * D; ap.e_hstride = d; ap.e_rowstride = G * D; }
@@ -600,7 +602,7 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
                 const EcBlock& nbk = e->blocks[k + 1];
                 const int Tn = s.Tin[k + 1], Gn = nbk.group_size, Tpn = ec_round_up(Tn, Gn);
                 GemmParams pn{};
-                pn.qu = reinterpret_cast<bf16_t*>(ws + w.qu); pn.qv = reinterpret_cast<bf16_t*>(ws + w.qv);
+                pn.qu = reinterpret_cast<bf16_t*>(ws + w.qu);
                 pn.kh = reinterpret_cast<bf16_t*>(ws + w.kh); pn.vt = reinterpret_cast<bf16_t*>(ws + w.vt);
                 fill_chain_head(cp, e->bw[k + 1], De, F1c(nbk), Tn, Tpn, pn);
                 fl += 2.0 * Mo * (double)De * (2.0 * De * nbk.ff_ratio + 3.0 * De); by += (double)Mo * De * 8 + 2.0 * De * De * (3 + 2.0 * nbk.ff_ratio);
@@ -823,6 +825,14 @@ int effconf_encoder_finalize(EcEncoder* e) {
         if (!u || !v || (int)u->data.size() != D) return fail("missing " + m + ".mhsa.u/v");
         W.u = upload(e, u->data); W.v = upload(e, v->data);
         W.h_u = u->data; W.h_v = v->data;
+        {   // head column x of head h is feature (h*d + x) % D of the un-grouped row (group = view, attentions.py:677-686)
+            const int H = b.num_heads, d = b.group_size * D / H;
+            W.dvu_ld = ec_round_up(d, 32);
+            std::vector<float> t((size_t)H * W.dvu_ld, 0.f);
+            for (int h = 0; h < H; ++h)
+                for (int x = 0; x < d; ++x) { const int n = (h * d + x) % D; t[(size_t)h * W.dvu_ld + x] = v->data[n] - u->data[n]; }
+            W.dvu = upload(e, t);
+        }
         auto key = std::make_pair(b.max_pos, D);
         if (!tables.count(key)) tables[key] = build_pos_table(e, b.max_pos, D);
         W.pos_table = tables[key];

@@ -171,8 +171,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmDev gd) {
             int which = 1, nn = n;
             if (EPI == EPI_QKV) { which = gd.fD.div(n); nn = n - which * p.D; }
             const float bias = p.bias[n];
-            float bu = 0.f, bv = 0.f;
-            if (EPI == EPI_QKV && which == 0) { bu = p.u[nn]; bv = p.v[nn]; }
+            float bu = 0.f;
+            if (EPI == EPI_QKV && which == 0) bu = p.u[nn];
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmDev gd) {
                     const int h = gd.fd.div(flat), x = flat - h * p.d;
                     const float val = acc[mi][ni][r] + bias;
                     const size_t idx = ((size_t)(b * p.H + h) * p.Tg + tq) * p.dpad + x;
-                    if (which == 0) { p.qu[idx] = f2bf(val + bu); p.qv[idx] = f2bf(val + bv); }
+                    if (which == 0) p.qu[idx] = f2bf(val + bu);
                     else if (which == 1) p.kh[idx] = f2bf(val);
                     else p.vt[idx] = f2bf(val);
                 }
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmDev gd) {
             if (n >= p.N) continue;
             const int which = gd.fD.div(n), nn = n - which * p.D;
             const float bias = p.bias[n];
-            const float bu = which == 0 ? p.u[nn] : 0.f, bv = which == 0 ? p.v[nn] : 0.f;
+            const float bu = which == 0 ? p.u[nn] : 0.f;
             bf16_t* dst = which == 1 ? p.kh : (which == 2 ? p.vt : p.qu);
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmDev gd) {
                     while (t >= p.T) { t -= p.T; ++b; }
                     const size_t idx = ((size_t)b * Tp + t) * p.D + nn;
                     const float val = acc[mi][ni][r] + bias;
-                    if (which == 0) { p.qu[idx] = f2bf(val + bu); p.qv[idx] = f2bf(val + bv); }
+                    if (which == 0) p.qu[idx] = f2bf(val + bu);
                     else dst[idx] = f2bf(val);
                 }
         }

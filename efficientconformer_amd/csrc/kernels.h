@@ -27,7 +27,7 @@ struct GemmParams {
     const float* R; int ldr; float alpha;
     // EPI_QKV / EPI_HEADS: rows m = (b, t) with t < T; grouped attention view
     int T, G, H, D, d, dpad, Tg, Tgp;
-    bf16_t *qu, *qv, *kh, *vt;         // [B][H][Tg][dpad] x3, [B][H][dpad][Tgp]
+    bf16_t *qu, *kh, *vt;              // Q + u, K, V: [B][H][Tg][dpad] (head major) or rows (b*Tp + t)*D (natural); Q + v is derived in the attention kernel
     const float *u, *v;                // [D] content / position bias (attentions.py:474-475)
     // row-stationary kernels only: if X != null the A operand is LayerNorm(X[m][0..K)) (eps 1e-6, fp32 two-pass statistics)
     // computed in the prologue from the fp32 residual stream instead of being read from A
@@ -74,7 +74,7 @@ struct ChainParams {
     ChainLn ln[4];                      // only ln[1] (block norm, applied in fp32) is read: the pre-norms' gamma / beta are folded into the following weights at pack time
     ChainFfn f[2];                      // chain A: ffn2, ffn1 (of the next block)
     ChainGemm g1;                       // chain A: stacked QKV (natural layout, chunk-permuted rows); chain B: pointwise-1 (a|b interleaved per 32)
-    bf16_t *qu, *qv, *kh, *vt; const float *u, *v; int T, Tp;     // QKV outputs: rows (b, t) -> (b*Tp + t)*D
+    bf16_t *qu, *kh, *vt; const float *u, *v; int T, Tp;          // QKV outputs (Q + u, K, V): rows (b, t) -> (b*Tp + t)*D
     bf16_t* glu; int ldg, Ng;           // GLU output [M][ldg], Ng channels
     const float* consts;                // biases / block-norm gamma, beta / u, v as ONE zero padded block laid out by chain_const_layout
 };
@@ -99,7 +99,8 @@ int launch_cast_rows(const float* x, int D, int rows_per_batch, int stride, int 
 
 // ---------------------------------------------------------------- attention  (attention.hip)
 struct AttnParams {
-    const bf16_t *qu, *qv, *kh, *vt, *eh;   // see GemmParams; eh [H][2Tg-1][dpad]
+    const bf16_t *qu, *kh, *vt, *eh;        // see GemmParams; eh [H][2Tg-1][dpad]
+    const float* dvu; int dvu_ld;           // (v - u) per head column [H][dvu_ld] (zero beyond d): Q + v = (Q + u) + (v - u)
     // element strides: row (b, h, tq) of Q/K/V starts at b*q_bstride + h*q_hstride + tq*q_rowstride; E row r of head h at
     // h*e_hstride + r*e_rowstride.  head-major: (H*Tg*dpad, Tg*dpad, dpad) / ((2Tg-1)*dpad, dpad);
     // natural [B*Tp][D]: (Tp*D, d, G*D) / (d, G*D) — a grouped row is G consecutive rows, head h is the span [h*d, (h+1)*d)

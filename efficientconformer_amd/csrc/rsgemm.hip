@@ -439,12 +439,11 @@ void rs_gemm_kernel(const RsDev gd) {
     for (int i = tid; i < nchunks * CH; i += NTHR) sbias[i] = p.bias[i];
     float* sgam = sbias + nchunks * CH;                       // LayerNorm gamma | beta (KS*16 each, zero padded)
     float* sbet = sgam + KS * 16;
-    // QKV epilogues: the rel-pos biases u, v (D floats each) also live in LDS.  Read from global inside the flush (under the
+    // QKV epilogues: the rel-pos bias u (D floats; Q + v is derived from Q + u in the attention kernel) also lives in LDS.  Read from global inside the flush (under the
     // `which == 0` branch) every Q tile exposed one L2 round trip before its stores: ~16 of them per workgroup.
     float* su = sbet + KS * 16;
-    float* sv = su + ((p.D + 3) & ~3);
     if constexpr (EPI == RS_QKV || EPI == RS_QKV_NAT)
-        for (int i = tid; i < p.D; i += NTHR) { su[i] = p.u[i]; sv[i] = p.v[i]; }       // visible after the first wg_barrier
+        for (int i = tid; i < p.D; i += NTHR) su[i] = p.u[i];                            // visible after the first wg_barrier
     const bool fuse_ln = p.X != nullptr;
     if (fuse_ln) {
         for (int i = tid; i < KS * 16; i += NTHR) { sgam[i] = i < p.K ? p.ln_g[i] : 0.f; sbet[i] = i < p.K ? p.ln_b[i] : 0.f; }
@@ -576,15 +575,11 @@ void rs_gemm_kernel(const RsDev gd) {
                                 for (int i = 0; i < 8; ++i) v[i] = acc[rt][g][r0 + i] + bias[(i & 3) + 8 * ((r0 + i) >> 2) + 4 * half];
                                 const size_t idx = qrow[rt] + nn0;
                                 if (which == 0) {
-                                    float uu[8], vv[8];
+                                    float uu[8];
                                     *reinterpret_cast<float4*>(uu) = *reinterpret_cast<const float4*>(su + nn0);
                                     *reinterpret_cast<float4*>(uu + 4) = *reinterpret_cast<const float4*>(su + nn0 + 4);
-                                    *reinterpret_cast<float4*>(vv) = *reinterpret_cast<const float4*>(sv + nn0);
-                                    *reinterpret_cast<float4*>(vv + 4) = *reinterpret_cast<const float4*>(sv + nn0 + 4);
                                     *reinterpret_cast<uint4*>(p.qu + idx) = make_uint4(pack_bf2(v[0] + uu[0], v[1] + uu[1]), pack_bf2(v[2] + uu[2], v[3] + uu[3]),
                                                                                      pack_bf2(v[4] + uu[4], v[5] + uu[5]), pack_bf2(v[6] + uu[6], v[7] + uu[7]));
-                                    *reinterpret_cast<uint4*>(p.qv + idx) = make_uint4(pack_bf2(v[0] + vv[0], v[1] + vv[1]), pack_bf2(v[2] + vv[2], v[3] + vv[3]),
-                                                                                     pack_bf2(v[4] + vv[4], v[5] + vv[5]), pack_bf2(v[6] + vv[6], v[7] + vv[7]));
                                 } else {
                                     bf16_t* dst = which == 1 ? p.kh : p.vt;
                                     *reinterpret_cast<uint4*>(dst + idx) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
@@ -602,9 +597,8 @@ void rs_gemm_kernel(const RsDev gd) {
                                 for (int i = 0; i < 4; ++i) v[i] = acc[rt][g][r0 + i] + bias[(i) + 8 * (r0 >> 2) + 4 * half];
                                 const size_t idx = qrow[rt] + nn0;
                                 if (which == 0) {
-                                    const float4 u4 = *reinterpret_cast<const float4*>(su + nn0), v4 = *reinterpret_cast<const float4*>(sv + nn0);
+                                    const float4 u4 = *reinterpret_cast<const float4*>(su + nn0);
                                     *reinterpret_cast<uint2*>(p.qu + idx) = make_uint2(pack_bf2(v[0] + u4.x, v[1] + u4.y), pack_bf2(v[2] + u4.z, v[3] + u4.w));
-                                    *reinterpret_cast<uint2*>(p.qv + idx) = make_uint2(pack_bf2(v[0] + v4.x, v[1] + v4.y), pack_bf2(v[2] + v4.z, v[3] + v4.w));
                                 } else {
                                     bf16_t* dst = which == 1 ? p.kh : p.vt;
                                     *reinterpret_cast<uint2*>(dst + idx) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
@@ -628,9 +622,8 @@ void rs_gemm_kernel(const RsDev gd) {
                             const size_t idx = ((size_t)(qb[rt] * p.H + h) * p.Tg + qtq[rt]) * p.dpad + x;
                             if ((p.d & 1) == 0) {
                                 if (which == 0) {
-                                    const float u0 = su[nn0 + i2], u1 = su[nn0 + i2 + 1], w0 = sv[nn0 + i2], w1 = sv[nn0 + i2 + 1];
+                                    const float u0 = su[nn0 + i2], u1 = su[nn0 + i2 + 1];
                                     *reinterpret_cast<uint32_t*>(p.qu + idx) = pack_bf2(v0 + u0, v1 + u1);
-                                    *reinterpret_cast<uint32_t*>(p.qv + idx) = pack_bf2(v0 + w0, v1 + w1);
                                 } else {
                                     *reinterpret_cast<uint32_t*>(dst + idx) = pack_bf2(v0, v1);
                                 }
@@ -639,8 +632,8 @@ void rs_gemm_kernel(const RsDev gd) {
                                 const int h1 = gd.fd.div(flat1), x1 = flat1 - h1 * p.d;
                                 const size_t idx1 = ((size_t)(qb[rt] * p.H + h1) * p.Tg + qtq[rt]) * p.dpad + x1;
                                 if (which == 0) {
-                                    p.qu[idx] = f2bf(v0 + su[nn0 + i2]); p.qv[idx] = f2bf(v0 + sv[nn0 + i2]);
-                                    p.qu[idx1] = f2bf(v1 + su[nn0 + i2 + 1]); p.qv[idx1] = f2bf(v1 + sv[nn0 + i2 + 1]);
+                                    p.qu[idx] = f2bf(v0 + su[nn0 + i2]);
+                                    p.qu[idx1] = f2bf(v1 + su[nn0 + i2 + 1]);
                                 } else { dst[idx] = f2bf(v0); dst[idx1] = f2bf(v1); }
                             }
                         }
@@ -692,7 +685,7 @@ void rs_gemm_kernel(const RsDev gd) {
 
 template <int KS, int G, int RT, int NW, int NBUF, int EPI>
 int launch_rs_t(const RsDev& gd, hipStream_t s) {
-    const int lds = NBUF * CH * KS * 32 + gd.nchunks * CH * 4 + KS * 32 * 4 + ((EPI == RS_QKV || EPI == RS_QKV_NAT) ? 2 * ((gd.p.D + 3) & ~3) * 4 : 0);
+    const int lds = NBUF * CH * KS * 32 + gd.nchunks * CH * 4 + KS * 32 * 4 + ((EPI == RS_QKV || EPI == RS_QKV_NAT) ? ((gd.p.D + 3) & ~3) * 4 : 0);
     if (lds > 160 * 1024) return -4;
     if ((EPI == RS_RESID || EPI == RS_F32) && gd.nchunks > G) return -5;
     static int attr_set = 0;
