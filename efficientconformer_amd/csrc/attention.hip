@@ -68,8 +68,9 @@ struct AttnSmem {
 // flight during block j's MFMA / softmax work) and all loads are unconditional at clamped addresses.
 template <int DP, int NWV, bool PROF = false>
 // second launch bound: two 4-wave workgroups per CU share each SIMD's 512 registers, so VGPRs + AGPRs must stay <= 256 - without it
-// a 272-register DP = 96 build silently ran one workgroup per CU (+46 %)
-__global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void relpos_attention_kernel(const AttnParams p, unsigned long long* prof = nullptr) {
+// a 272-register DP = 96 build silently ran one workgroup per CU (+46 %).  Head widths above 96 only fit one workgroup per CU in LDS
+// anyway and keep the full register file (bounded to 256 they spill ~200 registers)
+__global__ __launch_bounds__(NWV * 64, (NWV == 4 && DP <= 96) ? 2 : 1) void relpos_attention_kernel(const AttnParams p, unsigned long long* prof = nullptr) {
     unsigned long long ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0;
     if constexpr (PROF) t0 = __builtin_readcyclecounter();
 #define AT_TICK(i) do { if constexpr (PROF) { asm volatile("" ::: "memory"); const unsigned long long t1_ = __builtin_readcyclecounter(); ph[i] += t1_ - t0; t0 = t1_; } } while (0)
