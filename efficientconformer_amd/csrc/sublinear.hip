@@ -18,6 +18,7 @@
 namespace {
 
 constexpr int BM = 128, BK = 64, LROW = BK * 2 + 16;
+typedef float slf2 __attribute__((ext_vector_type(2)));
 
 template <int NT>   // NT = number of 128-wide output tiles (D0 <= 128*NT)
 __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void sublinear_kernel(const float* __restrict__ mel, int F, int Tm, int T1, int M,
@@ -107,13 +108,17 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void sublinear_kernel(const f
                 const float wt[9] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x};
                 float r[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float a = w2.y;                     // folded bias
+                for (int e = 0; e < 8; e += 2) {        // two outputs at a time: the Swish's plain multiplies / add go out as packed f32 ops
+                    slf2 a = slf2{w2.y, w2.y};          // folded bias
 #pragma unroll
                     for (int ii = 0; ii < 3; ++ii)
 #pragma unroll
-                        for (int jj = 0; jj < 3; ++jj) a = fmaf(wt[ii * 3 + jj], patch[2 * e + ii][jj], a);
-                    r[e] = swishf_(a);
+                        for (int jj = 0; jj < 3; ++jj)
+                            a = __builtin_elementwise_fma(slf2{wt[ii * 3 + jj], wt[ii * 3 + jj]}, slf2{patch[2 * e + ii][jj], patch[2 * e + 2 + ii][jj]}, a);
+                    const slf2 t = a * slf2{-1.44269504088896f, -1.44269504088896f};
+                    const slf2 d = slf2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + slf2{1.0f, 1.0f};
+                    const slf2 y = a * slf2{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+                    r[e] = y.x; r[e + 1] = y.y;
                 }
                 pa[i] = make_uint4(pack_bf2(r[0], r[1]), pack_bf2(r[2], r[3]), pack_bf2(r[4], r[5]), pack_bf2(r[6], r[7]));
             }
