@@ -70,13 +70,29 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ audi
     const int tiles = (Tm + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK;
     const int b = blockIdx.x / tiles, t0 = (blockIdx.x % tiles) * FRAMES_PER_BLOCK;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < NFFT; i += 256) {
-        const float2 w = tb.twiddle[i & 255];                    // table holds W512^k for k < 256; W^(k+256) = -W^k
-        stw[i] = i < 256 ? w : make_float2(-w.x, -w.y);
-        swin[i] = tb.window[i];
-    }
     const bool fw_lds = tb.fb_nnz <= MAX_FBW;
-    if (fw_lds) for (int i = tid; i < tb.fb_nnz; i += 256) sfw[i] = tb.fb_weight[i];
+    {   // tables -> LDS: every global load of the set-up is issued before the first wait (the rolled copy loops paid one memory
+        // round trip per iteration, ~7 per workgroup of 32 frames)
+        static_assert(NFFT == 512 && MAX_FBW == 768, "two / three passes of 256 threads");
+        const float2 w = tb.twiddle[tid];                        // table holds W512^k for k < 256; W^(k+256) = -W^k
+        const float wn0 = tb.window[tid], wn1 = tb.window[tid + 256];
+        float f[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { const int i = tid + 256 * j; f[j] = tb.fb_weight[i < tb.fb_nnz ? i : (tb.fb_nnz > 0 ? tb.fb_nnz - 1 : 0)]; }
+        stw[tid] = w; stw[tid + 256] = make_float2(-w.x, -w.y);
+        swin[tid] = wn0; swin[tid + 256] = wn1;
+        if (fw_lds) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) if (tid + 256 * j < tb.fb_nnz) sfw[tid + 256 * j] = f[j];
+        }
+    }
+    // this lane's mel bins (m = lane, lane + 64): filter descriptors fetched once, not once per frame pair inside the loop
+    int fs0[2], fcnt[2], foff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int m = (threadIdx.x & 63) + 64 * j, mc = m < n_mels ? m : n_mels - 1;
+        fs0[j] = tb.fb_start[mc]; fcnt[j] = m < n_mels ? tb.fb_count[mc] : 0; foff[j] = tb.fb_offset[mc];
+    }
     __syncthreads();
     float2* A = sbuf[wave][0];
     float2* B = sbuf[wave][1];
@@ -138,9 +154,11 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ audi
         }
         wave_sync();
         // ---- sparse triangular filterbank + log for both frames
-        for (int m = lane; m < n_mels; m += 64) {
-            const int s0 = tb.fb_start[m], cnt = tb.fb_count[m];
-            const int off = tb.fb_offset[m];
+#pragma unroll
+        for (int mj = 0; mj < 2; ++mj) {
+            const int m = lane + 64 * mj;
+            if (m >= n_mels) break;
+            const int s0 = fs0[mj], cnt = fcnt[mj], off = foff[mj];
             float ya = 0.f, yb = 0.f;
             if (fw_lds) {
                 for (int j0 = 0; j0 < cnt; j0 += 4) {             // 4 taps per trip, same summation order; taps >= cnt weigh 0
