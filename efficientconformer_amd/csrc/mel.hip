@@ -98,21 +98,30 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ audi
     float2* B = sbuf[wave][1];
     const float* a = audio + (size_t)b * L;
 
-    for (int it = 0; it < FRAMES_PER_BLOCK / 8; ++it) {
-        const int fl = wave * (FRAMES_PER_BLOCK / 4) + 2 * it;   // local index of the first frame of the pair
-        const int ta = t0 + fl, tbb = ta + 1;
-        // ---- gather both frames (reflect at the ends of the padded waveform, torch.stft center=True) and window them
-        float2 v[8];
+    // gather of one frame pair (reflect at the ends of the padded waveform, torch.stft center=True): unconditional clamped loads
+    auto gather = [&](int ta, float (&xa)[8], float (&xb)[8]) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int n = lane + 64 * j;
-            const float w = swin[n];
             int sa = ta * hop - NFFT / 2 + n, sb = sa + hop;
             sa = sa < 0 ? -sa : sa; sa = sa >= L ? 2 * (L - 1) - sa : sa; sa = sa < 0 ? 0 : (sa >= L ? L - 1 : sa);
             sb = sb < 0 ? -sb : sb; sb = sb >= L ? 2 * (L - 1) - sb : sb; sb = sb < 0 ? 0 : (sb >= L ? L - 1 : sb);
-            const float xa = a[sa], xb = a[sb];                  // unconditional clamped loads
-            v[j] = make_float2(ta < Tm ? xa * w : 0.f, tbb < Tm ? xb * w : 0.f);
+            xa[j] = a[sa]; xb[j] = a[sb];
         }
+    };
+    float nxa[8], nxb[8];                                        // the NEXT pair's samples are in flight during this pair's transform
+    gather(t0 + wave * (FRAMES_PER_BLOCK / 4), nxa, nxb);
+    for (int it = 0; it < FRAMES_PER_BLOCK / 8; ++it) {
+        const int fl = wave * (FRAMES_PER_BLOCK / 4) + 2 * it;   // local index of the first frame of the pair
+        const int ta = t0 + fl, tbb = ta + 1;
+        // ---- window both frames
+        float2 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float w = swin[lane + 64 * j];
+            v[j] = make_float2(ta < Tm ? nxa[j] * w : 0.f, tbb < Tm ? nxb[j] * w : 0.f);
+        }
+        if (it + 1 < FRAMES_PER_BLOCK / 8) gather(ta + 2, nxa, nxb);
         // ---- step 1: lane = 8*n2 + n3 holds x[64*n1 + lane]; DFT over n1, twiddle W64^{n2 k1}
         {
             const int n2 = lane >> 3;
