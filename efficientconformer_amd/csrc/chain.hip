@@ -243,9 +243,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && KS <= 8) ? 2 : 1) void chain_k
 
     // Per-lane byte offsets of this wave's PER DMA instructions, computed ONCE and kept in registers: every weight matrix of a chain
     // has the same row pitch (K = D for all of them; launch_chain checks), so one set serves the row-shaped chunks (off_r) and one
-    // the FFN chunks (off_f: W1 rows, then W2 pieces).  The DMA address is (wave-uniform chunk base) + offset; with per-issue
-    // temporaries the compiler has to drain the DMA queue (s_waitcnt vmcnt(0)) before it may reuse an address register, which
-    // it did a few instructions after every issue.
+    // the FFN chunks (off_f: W1 rows, then W2 pieces).  The DMA address is (wave-uniform chunk base) + offset (saddr form), so an
+    // issue costs no per-lane address arithmetic (a division, a modulo and a 64-bit multiply-add per instruction otherwise).
     uint32_t off_r[PER], off_f[PER];
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
