@@ -676,11 +676,13 @@ int launch_chain_kind(const ChainParams& p, hipStream_t s) {
 // D <= 256: the residual row fits the register file.  The Q/K/V-emitting half additionally needs D % 8 == 0 (16-byte bf16 pieces
 // never straddle the Q | K | V boundaries) — Medium's D = 180 stage runs chain B and the tail chain only.
 bool chain_supported(int D) { return D % 4 == 0 && D >= 16 && D <= 256; }
-// The FFN-carrying chain A at KS = 16 (D = 240 / 256) runs at one wave per SIMD with its LayerNorm / load phases spilling (the
-// chunk loops stay spill-free); measured it only ties the per-GEMM kernels there (5.60 vs 5.54 ms per step), so it is used up to
-// D = 192.  A 16-row-per-wave variant (v_mfma_f32_16x16x32_bf16, half the registers per lane) is the planned fix.
-bool chain_head_supported(int D) { return chain_supported(D) && D % 8 == 0 && D <= (getenv("EFFCONF_CHAIN_WIDE") ? 256 : 192); }
-bool chain_tail_supported(int D) { return chain_supported(D) && D <= (getenv("EFFCONF_CHAIN_WIDE") ? 256 : 192); }
+// At KS = 16 (D = 240 / 256) the chains run at one wave per SIMD; the tail and the head each fit the register file (AGPRs as the
+// overflow, no scratch), the combined tail + head kernel does not (see chain_full_supported).
+bool chain_head_supported(int D) { return chain_supported(D) && D % 8 == 0; }
+bool chain_tail_supported(int D) { return chain_supported(D); }
+// tail + next head in ONE kernel: up to D = 192 the whole state fits the register file; at D = 240 (KS = 16) the combined kernel spills
+// (199 us per block against 181 us for the five per-GEMM kernels) while the tail and the head as TWO chain launches do not
+bool chain_full_supported(int D) { return chain_head_supported(D) && D <= (getenv("EFFCONF_CHAIN_WIDE") ? 256 : 192); }
 
 int launch_chain(const ChainParams& p, int kind, hipStream_t s) {
     if (p.M <= 0) return 0;

@@ -589,7 +589,7 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
             bool next_head = false;
             if (!last) {
                 const EcBlock& nbk = e->blocks[k + 1];
-                next_head = W.cc_full && e->bw[k + 1].chain_in && chain_head_supported(De) && ((nbk.group_size * nbk.dim_model / nbk.num_heads) % 2) == 0 && nbk.dim_model == De;
+                next_head = W.cc_full && e->bw[k + 1].chain_in && chain_full_supported(De) && ((nbk.group_size * nbk.dim_model / nbk.num_heads) % 2) == 0 && nbk.dim_model == De;
             }
             ChainParams cp{};
             cp.M = Mo; cp.D = De; cp.X = x; cp.ldx = De; cp.Y = xo; cp.ldy = De; cp.A = cbuf; cp.lda = ld8(De);
@@ -914,7 +914,7 @@ int effconf_encoder_finalize(EcEncoder* e) {
         }
         if (W.chain_out && chain_tail_supported(De)) {
             W.cc_tail = build(CHAIN_A_TAIL, De, &W, nullptr, &b, nullptr);
-            if (chain_head_supported(De) && k + 1 < e->blocks.size() && e->bw[k + 1].chain_in && e->blocks[k + 1].dim_model == De)
+            if (chain_full_supported(De) && k + 1 < e->blocks.size() && e->bw[k + 1].chain_in && e->blocks[k + 1].dim_model == De)
                 W.cc_full = build(CHAIN_A_FULL, De, &W, &e->bw[k + 1], &b, &e->blocks[k + 1]);
         }
     }

@@ -83,6 +83,7 @@ bool chain_supported(int D);
 int chain_const_layout(const ChainParams& p, int kind, int (&nf)[8]);   // float offsets of the constant block; returns its size in floats
 bool chain_head_supported(int D);   // FFN1 + Q/K/V half (chain A head / full)
 bool chain_tail_supported(int D);   // pointwise-2 + FFN2 + block norm half
+bool chain_full_supported(int D);   // tail + next block's head in one kernel
 int launch_chain(const ChainParams& p, int kind, hipStream_t s);
 
 // ---------------------------------------------------------------- normalisation / casts  (norm.hip)
