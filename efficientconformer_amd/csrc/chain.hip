@@ -682,7 +682,10 @@ bool chain_head_supported(int D) { return chain_supported(D) && D % 8 == 0; }
 bool chain_tail_supported(int D) { return chain_supported(D); }
 // tail + next head in ONE kernel: up to D = 192 the whole state fits the register file; at D = 240 (KS = 16) the combined kernel spills
 // (199 us per block against 181 us for the five per-GEMM kernels) while the tail and the head as TWO chain launches do not
-bool chain_full_supported(int D) { return chain_head_supported(D) && D <= (getenv("EFFCONF_CHAIN_WIDE") ? 256 : 192); }
+bool chain_full_supported(int D) {
+    static const int dmax = [] { const char* e = getenv("EFFCONF_CHAIN_FULL_MAX"); return e ? atoi(e) : 192; }();   // tuning knob
+    return chain_head_supported(D) && D <= dmax;
+}
 
 int launch_chain(const ChainParams& p, int kind, hipStream_t s) {
     if (p.M <= 0) return 0;
