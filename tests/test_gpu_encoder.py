@@ -371,3 +371,24 @@ def test_positional_cache_stays_valid_when_streams_alternate_workspaces():
                     got = m.encoder(aud[i], ln[i])[0]
                 st.synchronize()
                 assert torch.equal(got, cold[i]), (rep, si, i)
+
+
+def test_sub_batch_streams_are_bit_identical_to_one_stream():
+    """ConformerEncoder.forward splits large batches into contiguous row ranges on concurrent streams (encoders.py); rows are
+    independent given the padded length, so any split must reproduce the single-stream result bit for bit."""
+    m, _ = _model("Tiny", 7)
+    lens = np.array([30000, 27000, 22000, 15000, 9000, 4000, 2500], dtype=np.int64)
+    audio = torch.from_numpy(synth.make_audio(lens, seed=33)).cuda()
+    ln = torch.from_numpy(lens).cuda()
+    m.encoder.sub_batches = 1
+    ref, ref_len, _ = m.encoder(audio, ln)
+    for nsub in (2, 3, 7):
+        m.encoder.sub_batches = nsub
+        for _ in range(2):                                   # second pass: warm workspaces / positional caches on every stream
+            got, got_len, _ = m.encoder(audio, ln)
+            torch.cuda.synchronize()
+            assert torch.equal(got, ref) and torch.equal(got_len, ref_len), nsub
+    m.encoder.sub_batches = None
+    m.encoder.sub_batch_min = 4                              # automatic split (2 ranges) from 4 utterances on
+    got, got_len, _ = m.encoder(audio, ln)
+    assert torch.equal(got, ref) and torch.equal(got_len, ref_len)
