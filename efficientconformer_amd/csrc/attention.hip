@@ -478,12 +478,8 @@ __global__ void attn_pad_rows_nat_kernel(GemmParams p, int B) {
 template <int DP, int NWV>
 int launch_dp_w(const AttnParams& p, hipStream_t s) {
     using SM = AttnSmem<DP, NWV>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&relpos_attention_kernel<DP, NWV, false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, SM::TOTAL);
-        attr_set = true;
-    }
+    static LdsAttr attr;
+    ensure_dynamic_lds(reinterpret_cast<const void*>(&relpos_attention_kernel<DP, NWV, false>), SM::TOTAL, attr);
     const int qtiles = (p.Tg + NWV * 16 - 1) / (NWV * 16);
     if constexpr (NWV == 4 && DP <= 128) {
         static const bool prof = getenv("EFFCONF_ATTN_PHASES") != nullptr;

@@ -638,11 +638,8 @@ int launch_chain_t(const ChainParams& p, hipStream_t s) {
     if (!p.consts) return -5;
     const int lds = NBUF * G::BUF + NW * STG_BYTES + nfl * 4;
     if (lds > 160 * 1024) return -4;
-    static int attr_set = 0;
-    if (attr_set < lds) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_kernel<KS, NW, NBUF, KIND, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = lds;
-    }
+    static LdsAttr attr;
+    ensure_dynamic_lds(reinterpret_cast<const void*>(&chain_kernel<KS, NW, NBUF, KIND, false>), lds, attr);
     const int rows_per_wg = NW * 32;
     if constexpr (KS == 8 && KIND == CHAIN_A_FULL) {
         static const bool prof = getenv("EFFCONF_CHAIN_PHASES") != nullptr;

@@ -40,6 +40,19 @@ __device__ __forceinline__ bf16x8 as_bf16x8(uint4 v) {
     return c.b;
 }
 
+// Raise a kernel's dynamic-LDS limit when a launch needs more than any earlier launch of that instantiation ON THAT DEVICE (the
+// attribute is per device; one process may hold handles on several).  One static LdsAttr per launch site.
+struct LdsAttr { int bytes[16] = {}; };
+inline void ensure_dynamic_lds(const void* fn, int bytes, LdsAttr& st) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev &= 15;
+    if (st.bytes[dev] < bytes) {
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        st.bytes[dev] = bytes;
+    }
+}
+
 // XCD-aware, bijective remap of a linear workgroup id: hardware places block b on XCD b % 8
 // (speed only, never correctness); give every XCD a contiguous chunk of the logical tile space so
 // neighbouring tiles (which share operand panels) hit the same private L2.

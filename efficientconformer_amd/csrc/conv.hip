@@ -155,11 +155,8 @@ int launch_dw_t(const bf16_t* g, int B, int T, int To, int C, int ld, const floa
     const int ctiles = (C + DW_CC - 1) / DW_CC, ttiles = (To + DW_TT - 1) / DW_TT;
     constexpr int ROWS = (DW_TT - 1) * STRIDE + KSZ;
     const size_t lds = (size_t)ROWS * DW_PITCH;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv_kernel<KSZ, STRIDE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    static LdsAttr attr;
+    ensure_dynamic_lds(reinterpret_cast<const void*>(&dwconv_kernel<KSZ, STRIDE>), (int)lds, attr);
     hipLaunchKernelGGL((dwconv_kernel<KSZ, STRIDE>), dim3(B * ttiles * ctiles), dim3(256), lds, s, g, T, To, C, ld, w_kc, bias, out);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

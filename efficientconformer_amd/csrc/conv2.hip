@@ -189,11 +189,8 @@ int launch_conv2_igemm(const bf16_t* act1, int B, int F1, int T1, int Cp, const 
     if (Cp % 64 || ldw != 9 * Cp) return -2;
     const int M = B * F2 * T2;
     const size_t lds = 2 * (BM + BN) * LROW;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2_igemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    static LdsAttr attr;
+    ensure_dynamic_lds(reinterpret_cast<const void*>(&conv2_igemm_kernel), (int)lds, attr);
     const int n_tiles = (N + BN - 1) / BN, m_tiles = (M + BM - 1) / BM;
     hipLaunchKernelGGL(conv2_igemm_kernel, dim3(m_tiles * n_tiles), dim3(256), lds, s, act1, F1, T1, Cp, W, ldw, bias, F2, T2, M, N, out);
     return hipGetLastError() == hipSuccess ? 0 : -1;

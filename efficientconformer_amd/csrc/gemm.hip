@@ -251,11 +251,8 @@ int launch_t(const GemmDev& gd, hipStream_t s) {
     const GemmParams& p = gd.p;
     const int n_tiles = (p.N + BN - 1) / BN, m_tiles = (p.M + BM - 1) / BM;
     const size_t lds = 2 * (BM + BN) * LROW;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BN, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    static LdsAttr attr;
+    ensure_dynamic_lds(reinterpret_cast<const void*>(&gemm_kernel<BN, EPI>), (int)lds, attr);
     hipLaunchKernelGGL((gemm_kernel<BN, EPI>), dim3(m_tiles * n_tiles), dim3(256), lds, s, gd);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -691,8 +691,8 @@ int effconf_rnnt_greedy(EcRnnt* r, const float* enc_out, const int64_t* out_len,
         if (hipMemsetAsync(ex, 0, (size_t)ncl * 256 + 256, s) != hipSuccess) return ec_fail("memset failed");
         const int HU = H / CW;
         const size_t lds = (size_t)(CU * H + CU * J + CU * CKF * J + CU * HU + CU * 4 * HU + CU * CKF * 16) * 4;
-        static size_t attr = 0;
-        if (attr < lds) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rnnt_cluster_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = lds; }
+        static LdsAttr attr;
+        ensure_dynamic_lds(reinterpret_cast<const void*>(&rnnt_cluster_kernel), (int)lds, attr);
         hipLaunchKernelGGL(rnnt_cluster_kernel, dim3(ncl * CW), dim3(CNT), lds, s, a);
         return hipGetLastError() == hipSuccess ? 0 : ec_fail("rnnt cluster launch failed");
     }

@@ -362,14 +362,9 @@ int launch_ffn_t(const FfnParams& p, hipStream_t s) {
     using ST = FfnStage<KS, NT2, NW, NBUF>;
     const int lds = SM::RING + p.Fp * 4 + NT2 * 32 * 4 + KS * 32 * 4 + (ST::ALIAS ? 0 : ST::BYTES);
     if (lds > 160 * 1024) return -4;
-    static int attr_set = 0;
-    if (attr_set < lds) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_fused_kernel<KS, NT2, RT, NW, NBUF, false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_fused_kernel<KS, NT2, RT, NW, NBUF, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = lds;
-    }
+    static LdsAttr attr, attr_prof;
+    ensure_dynamic_lds(reinterpret_cast<const void*>(&ffn_fused_kernel<KS, NT2, RT, NW, NBUF, false>), lds, attr);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(&ffn_fused_kernel<KS, NT2, RT, NW, NBUF, true>), lds, attr_prof);
     const int rows_per_wg = NW * RT * 32;
     static const bool prof = getenv("EFFCONF_FFN_PHASES") != nullptr;
     if (prof) {
@@ -688,12 +683,8 @@ int launch_rs_t(const RsDev& gd, hipStream_t s) {
     const int lds = NBUF * CH * KS * 32 + gd.nchunks * CH * 4 + KS * 32 * 4 + ((EPI == RS_QKV || EPI == RS_QKV_NAT) ? ((gd.p.D + 3) & ~3) * 4 : 0);
     if (lds > 160 * 1024) return -4;
     if ((EPI == RS_RESID || EPI == RS_F32) && gd.nchunks > G) return -5;
-    static int attr_set = 0;
-    if (attr_set < lds) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rs_gemm_kernel<KS, G, RT, NW, NBUF, EPI>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = lds;
-    }
+    static LdsAttr attr;
+    ensure_dynamic_lds(reinterpret_cast<const void*>(&rs_gemm_kernel<KS, G, RT, NW, NBUF, EPI>), lds, attr);
     const int rows_per_wg = NW * RT * 32;
     hipLaunchKernelGGL((rs_gemm_kernel<KS, G, RT, NW, NBUF, EPI>), dim3((gd.p.M + rows_per_wg - 1) / rows_per_wg), dim3(NW * 64), lds, s, gd);
     return hipGetLastError() == hipSuccess ? 0 : -1;

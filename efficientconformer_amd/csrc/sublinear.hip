@@ -176,11 +176,8 @@ int launch_t(const float* mel, int B, int F, int Tm, int T1, const float* w9, co
              const bf16_t* W, int ldw, const float* bias, int N, float* out, int ldc, hipStream_t s) {
     const int M = B * T1;
     const size_t lds = 2 * (BM + NT * 128) * LROW + (size_t)Cp * 12 * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sublinear_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    static LdsAttr attr;
+    ensure_dynamic_lds(reinterpret_cast<const void*>(&sublinear_kernel<NT>), (int)lds, attr);
     hipLaunchKernelGGL((sublinear_kernel<NT>), dim3((M + BM - 1) / BM), dim3(256), lds, s, mel, F, Tm, T1, M, w9, cbias, C, Cp,
                        W, ldw, bias, N, out, ldc);
     return hipGetLastError() == hipSuccess ? 0 : -1;
