@@ -225,6 +225,28 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmDev gd) {
             const int nlim = f32out ? p.N : p.ldc;   // bf16 outputs also write their (zero) pad columns
             if (n >= nlim) continue;
             const float bias = p.bias[n];
+            if constexpr (EPI == EPI_RESID_F32) {
+                // residual epilogue: all 32 residual loads of this column tile first (unconditional, clamped rows), then the stores.
+                // As one guarded load -> add -> store per element the loads were waited for one by one: 47 % of a wave's life
+                // (s_memtime phases) for K = 2048.
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+                    float rv[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + lrow;
+                        rv[r] = p.R[(size_t)(m < p.M ? m : p.M - 1) * p.ldr + n];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(rv[r]));
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + lrow;
+                        if (m < p.M) reinterpret_cast<float*>(p.C)[(size_t)m * p.ldc + n] = rv[r] + p.alpha * (acc[mi][ni][r] + bias);
+                    }
+                }
+                continue;
+            }
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
