@@ -30,6 +30,7 @@ struct FastDiv {   // exact for n * d < 2^32
 struct GemmDev {
     GemmParams p;
     FastDiv fG, fD, fd;
+    bool staged;          // bf16 row outputs leave through the LDS-staged 16-byte-piece epilogue (alignment checked by launch_gemm)
 };
 
 template <int BN, int EPI>
@@ -146,6 +147,54 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmDev gd) {
 
     // ---- epilogue.  C layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     const int lcol = lane & 31, lrow = 4 * (lane >> 5);
+    if ((EPI == EPI_BF16 || EPI == EPI_SWISH_BF16 || EPI == EPI_QKV_NAT) && gd.staged) {
+        // bf16 row outputs: the wave's 64 x BN/2 tile goes through LDS (the operand buffers are free now) and leaves as 16-byte
+        // pieces, 64-128 contiguous bytes per row and 8-16 rows per store instruction.  One 2-byte global store per element (64
+        // store instructions per wave, each touching two 64-byte row fragments) was half of the kernel (s_memtime phases: 51 %).
+        constexpr int WCOLS = BN / 2, PITCH = WCOLS * 2 + 16, PPR = WCOLS / 8, RPI = 64 / PPR;
+        __syncthreads();                                   // every wave is done with the last k-tile
+        char* wbuf = smem + wave * 64 * PITCH;
+        static_assert(4 * 64 * PITCH <= 2 * (BM + BN) * LROW, "staging fits the operand buffers");
+#pragma unroll
+        for (int ni = 0; ni < NF; ++ni) {
+            const int n = n0 + wn * WCOLS + ni * 32 + lcol;
+            const int nc = n < p.N ? n : p.N - 1;
+            float add = p.bias[nc];
+            if constexpr (EPI == EPI_QKV_NAT) { const int which = gd.fD.div(nc); if (which == 0) add += p.u[nc]; }
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float val = acc[mi][ni][r] + add;
+                    if constexpr (EPI == EPI_SWISH_BF16) val = swishf_(val);
+                    if (n >= p.N) val = 0.f;               // pad columns of the row buffers stay zero
+                    const int row = mi * 32 + (r & 3) + 8 * (r >> 2) + lrow;
+                    *reinterpret_cast<bf16_t*>(wbuf + row * PITCH + (ni * 32 + lcol) * 2) = f2bf(val);
+                }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int piece = lane % PPR, prow = lane / PPR;
+        const int nb = n0 + wn * WCOLS + piece * 8;       // first column of this lane's 8-column piece
+        const int Tp = p.Tg * p.G;
+#pragma unroll
+        for (int it = 0; it < 64 / RPI; ++it) {
+            const int row = it * RPI + prow, m = m0 + wm * 64 + row;
+            const uint4 v = *reinterpret_cast<const uint4*>(wbuf + row * PITCH + piece * 16);
+            if (m >= p.M) continue;
+            if constexpr (EPI == EPI_QKV_NAT) {
+                if (nb >= p.N) continue;                   // D % 8 == 0 (checked by the launcher): a piece never straddles Q | K | V
+                const int which = gd.fD.div(nb), nn = nb - which * p.D;
+                const int b = m / p.T, t = m - b * p.T;
+                bf16_t* dst = which == 1 ? p.kh : (which == 2 ? p.vt : p.qu);
+                *reinterpret_cast<uint4*>(dst + ((size_t)b * Tp + t) * p.D + nn) = v;
+            } else {
+                if (nb < p.ldc) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + nb) = v;
+            }
+        }
+        return;
+    }
     if constexpr (EPI == EPI_GLU_BF16) {
         static_assert(BN == 128, "GLU needs both halves in one wave");
         const int j = (n0 + wn * 64) / 2 + lcol;           // output channel
@@ -296,6 +345,12 @@ int launch_gemm(const GemmParams& p, int epi, hipStream_t s) {
     if (p.lda % 8 || p.ldw % 64) return -2;
     GemmDev gd;
     gd.p = p;
+    {
+        auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+        gd.staged = false;
+        if (epi == EPI_BF16 || epi == EPI_SWISH_BF16) gd.staged = p.ldc % 8 == 0 && al16(p.C);
+        if (epi == EPI_QKV_NAT) gd.staged = p.D % 8 == 0 && al16(p.qu) && al16(p.kh) && al16(p.vt);
+    }
     if (epi == EPI_QKV || epi == EPI_HEADS || epi == EPI_QKV_NAT) {
         gd.fG = FastDiv(p.G); gd.fD = FastDiv(p.D); gd.fd = FastDiv(p.d);
     }
