@@ -195,6 +195,72 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmDev gd) {
         }
         return;
     }
+    if (EPI == EPI_GLU_BF16 && gd.staged) {
+        // a wave's 64 columns are (a | b) of 32 output channels: stage 64 rows x 32 channels of bf16, leave as 16-byte pieces
+        constexpr int PITCH = 32 * 2 + 16, PPR = 4, RPI = 16;
+        __syncthreads();
+        char* wbuf = smem + wave * 64 * PITCH;
+        const int jc = (n0 + wn * 64) / 2;                 // first output channel of this wave
+        const float ba = p.bias[n0 + wn * 64 + lcol], bb = p.bias[n0 + wn * 64 + 32 + lcol];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mi * 32 + (r & 3) + 8 * (r >> 2) + lrow;
+                *reinterpret_cast<bf16_t*>(wbuf + row * PITCH + lcol * 2) = f2bf((acc[mi][0][r] + ba) * sigmoidf_(acc[mi][NF - 1][r] + bb));
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int piece = lane % PPR, prow = lane / PPR, jb = jc + piece * 8;
+#pragma unroll
+        for (int it = 0; it < 64 / RPI; ++it) {
+            const int row = it * RPI + prow, m = m0 + wm * 64 + row;
+            const uint4 v = *reinterpret_cast<const uint4*>(wbuf + row * PITCH + piece * 16);
+            if (m < p.M && jb < p.ldc) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + jb) = v;
+        }
+        return;
+    }
+    if (EPI == EPI_RESID_F32 && gd.staged) {
+        // fp32 residual rows: stage the wave's 64 x BN/2 tile of (acc + bias), then per 16-byte piece: residual in, sum out
+        constexpr int WCOLS = BN / 2, PITCH = WCOLS * 4 + 16, PPR = WCOLS / 4, RPI = 64 / PPR, NIT = 64 / RPI;
+        static_assert(4 * 64 * PITCH <= 2 * (BM + BN) * LROW, "staging fits the operand buffers");
+        __syncthreads();
+        char* wbuf = smem + wave * 64 * PITCH;
+#pragma unroll
+        for (int ni = 0; ni < NF; ++ni) {
+            const int n = n0 + wn * WCOLS + ni * 32 + lcol;
+            const float bias = p.bias[n < p.N ? n : p.N - 1];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = mi * 32 + (r & 3) + 8 * (r >> 2) + lrow;
+                    *reinterpret_cast<float*>(wbuf + row * PITCH + (ni * 32 + lcol) * 4) = p.alpha * (acc[mi][ni][r] + bias);
+                }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int piece = lane % PPR, prow = lane / PPR, nb = n0 + wn * WCOLS + piece * 4;
+        const int nbc = nb < p.N - 4 ? nb : p.N - 4;
+        float4 rv[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {                 // all residual pieces first (unconditional, clamped)
+            const int m = m0 + wm * 64 + it * RPI + prow;
+            rv[it] = *reinterpret_cast<const float4*>(p.R + (size_t)(m < p.M ? m : p.M - 1) * p.ldr + nbc);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) asm volatile("" : "+v"(rv[it].x), "+v"(rv[it].y), "+v"(rv[it].z), "+v"(rv[it].w));
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int row = it * RPI + prow, m = m0 + wm * 64 + row;
+            const float4 a = *reinterpret_cast<const float4*>(wbuf + row * PITCH + piece * 16);
+            if (m < p.M && nb < p.N)
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + nb) = make_float4(rv[it].x + a.x, rv[it].y + a.y, rv[it].z + a.z, rv[it].w + a.w);
+        }
+        return;
+    }
     if constexpr (EPI == EPI_GLU_BF16) {
         static_assert(BN == 128, "GLU needs both halves in one wave");
         const int j = (n0 + wn * 64) / 2 + lcol;           // output channel
@@ -350,6 +416,8 @@ int launch_gemm(const GemmParams& p, int epi, hipStream_t s) {
         gd.staged = false;
         if (epi == EPI_BF16 || epi == EPI_SWISH_BF16) gd.staged = p.ldc % 8 == 0 && al16(p.C);
         if (epi == EPI_QKV_NAT) gd.staged = p.D % 8 == 0 && al16(p.qu) && al16(p.kh) && al16(p.vt);
+        if (epi == EPI_GLU_BF16) gd.staged = p.ldc % 8 == 0 && al16(p.C);
+        if (epi == EPI_RESID_F32) gd.staged = p.N % 4 == 0 && p.N >= 4 && p.ldc % 4 == 0 && p.ldr % 4 == 0 && al16(p.C) && al16(p.R);
     }
     if (epi == EPI_QKV || epi == EPI_HEADS || epi == EPI_QKV_NAT) {
         gd.fG = FastDiv(p.G); gd.fD = FastDiv(p.D); gd.fd = FastDiv(p.d);
