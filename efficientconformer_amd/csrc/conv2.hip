@@ -150,23 +150,42 @@ __global__ __launch_bounds__(256) void conv2_igemm_kernel(const bf16_t* __restri
         }
         __syncthreads();
     }
-    // ---- epilogue: out2[(b, t2)][f2*N + n] = swish(acc + bias)
+    // ---- epilogue: out2[(b, t2)][f2*N + n] = swish(acc + bias).  The wave's 64 x 64 tile is staged through LDS (the operand buffers
+    // are free after the loop's last barrier) and leaves as 16-byte pieces, 128 contiguous bytes per row - not one 2-byte store and
+    // two integer divisions per element.
     const int lcol = lane & 31, lrow = 4 * (lane >> 5);
+    constexpr int PITCH = 64 * 2 + 16;
+    char* wbuf = smem + wave * 64 * PITCH;
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
         const int n = n0 + wn * 64 + ni * 32 + lcol;
-        if (n >= N) continue;
-        const float bz = bias[n];
+        const float bz = bias[n < N ? n : N - 1];
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + lrow;
-                if (m >= M) continue;
-                const int t2 = m % T2, rest = m / T2;
-                const int f2 = rest % F2, b = rest / F2;
-                out[((size_t)b * T2 + t2) * ((size_t)F2 * N) + (size_t)f2 * N + n] = f2bf(swishf_(acc[mi][ni][r] + bz));
+                const int row = mi * 32 + (r & 3) + 8 * (r >> 2) + lrow;
+                *reinterpret_cast<bf16_t*>(wbuf + row * PITCH + (ni * 32 + lcol) * 2) = f2bf(swishf_(acc[mi][ni][r] + bz));
             }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int piece = lane & 7, prow = lane >> 3, nb = n0 + wn * 64 + piece * 8;
+    const bool piece_ok = (N % 8) == 0 && nb < N;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int row = it * 8 + prow, m = m0 + wm * 64 + row;
+        if (m >= M) continue;
+        const int t2 = m % T2, rest = m / T2;
+        const int f2 = rest % F2, b = rest / F2;
+        bf16_t* dst = out + ((size_t)b * T2 + t2) * ((size_t)F2 * N) + (size_t)f2 * N + nb;
+        if (piece_ok) {
+            *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(wbuf + row * PITCH + piece * 16);
+        } else {
+            for (int e = 0; e < 8; ++e)
+                if (nb + e < N) dst[e] = *reinterpret_cast<const bf16_t*>(wbuf + row * PITCH + piece * 16 + e * 2);
+        }
     }
 }
 
