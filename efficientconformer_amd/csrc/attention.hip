@@ -29,9 +29,10 @@ constexpr int BI = 64;          // queries per workgroup (16 per wave)
 constexpr int BJ = 64;          // keys per block
 constexpr int SKEW_LD = 84;     // floats per query row of the skew buffer (>= 80, multiple of 4)
 
-// 16-byte global load from a (possibly only) 4-byte aligned address (natural layout: head h starts at element h*d)
+// 16-byte global load from a (possibly only) 2-byte aligned address (natural layout: head h starts at element h*d, d may be odd);
+// still one global_load_dwordx4 - global memory accesses are alignment-free on gfx950
 __device__ __forceinline__ uint4 ld16(const bf16_t* p) {
-    typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+    typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(2)));
     const u32x4_a4 v = *reinterpret_cast<const u32x4_a4*>(p);
     return make_uint4(v[0], v[1], v[2], v[3]);
 }

@@ -487,8 +487,11 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
         const int Tp = ec_round_up(T, G), Tg = Tp / G, Tgp = ec_round_up(Tg, 8);
         const int d = G * D / H, dpad = ec_round_up(d, 32);
         // Q/K/V/E layout: "natural" row-major [B*Tp][D] (16-byte row stores from the GEMM, head split = pointer arithmetic in
-        // the attention kernel) whenever the grouped head dim d is even (4-byte aligned head spans); head-major otherwise
-        const bool nat = (d % 2) == 0;
+        // the attention kernel).  An odd grouped head width (d = 135: Medium / Large stage 0) makes the head spans only 2-byte
+        // aligned; gfx950 global loads are alignment-free, so the attention kernel reads them as they are - the head-major
+        // fallback (a scatter epilogue of 2-byte stores, 9 % of Medium's step) is kept behind EFFCONF_HEAD_MAJOR_ODD=1 for tests.
+        static const bool head_major_odd = getenv("EFFCONF_HEAD_MAJOR_ODD") != nullptr;
+        const bool nat = (d % 2) == 0 || !head_major_odd;
         const bool chain_head = e->fuse_chain && W.chain_in && nat && chain_head_supported(D);          // FFN1 + QKV of this block as a fused chain
         const bool chain_b = e->fuse_chain && W.chain_in;                      // out-proj + LN + pointwise-1/GLU
         const bool chain_tail = e->fuse_chain && W.chain_out && chain_tail_supported(De);                  // pointwise-2 + FFN2 + block norm (+ next block's head)
@@ -589,7 +592,7 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
             bool next_head = false;
             if (!last) {
                 const EcBlock& nbk = e->blocks[k + 1];
-                next_head = W.cc_full && e->bw[k + 1].chain_in && chain_full_supported(De) && ((nbk.group_size * nbk.dim_model / nbk.num_heads) % 2) == 0 && nbk.dim_model == De;
+                next_head = W.cc_full && e->bw[k + 1].chain_in && chain_full_supported(De) && (((nbk.group_size * nbk.dim_model / nbk.num_heads) % 2) == 0 || !getenv("EFFCONF_HEAD_MAJOR_ODD")) && nbk.dim_model == De;
             }
             ChainParams cp{};
             cp.M = Mo; cp.D = De; cp.X = x; cp.ldx = De; cp.Y = xo; cp.ldy = De; cp.A = cbuf; cp.lda = ld8(De);
