@@ -557,15 +557,31 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && KS <= 8) ? 2 : 1) void chain_k
                         }
                     wave_sync();
                     const int n0 = 64 * c + pc8;
-                    const int which = cd.fD.div(n0), nn0 = n0 - which * D;
-                    bf16_t* dst = which == 0 ? p.qu : (which == 1 ? p.kh : p.vt);
-                    const bool colok = n0 < 3 * D;
+                    if ((D & 7) == 0) {                    // a 16-byte piece never straddles the Q | K | V boundaries
+                        const int which = cd.fD.div(n0), nn0 = n0 - which * D;
+                        bf16_t* dst = which == 0 ? p.qu : (which == 1 ? p.kh : p.vt);
+                        const bool colok = n0 < 3 * D;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const u32x4 v = *reinterpret_cast<const u32x4*>(stg + (8 * i + (lane >> 3)) * STG_ROW + 16 * (lane & 7));
-                        if (colok && qok[i]) *reinterpret_cast<u32x4*>(dst + qoff[i] + nn0) = v;
+                        for (int i = 0; i < 4; ++i) {
+                            const u32x4 v = *reinterpret_cast<const u32x4*>(stg + (8 * i + (lane >> 3)) * STG_ROW + 16 * (lane & 7));
+                            if (colok && qok[i]) *reinterpret_cast<u32x4*>(dst + qoff[i] + nn0) = v;
+                        }
+                        st1 += 4;
+                    } else {                               // D % 8 == 4 (Medium's D = 180): two 8-byte halves, each inside one tensor
+                        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                        const int wa = cd.fD.div(n0), wb = cd.fD.div(n0 + 4);
+                        const int na = n0 - wa * D, nb = n0 + 4 - wb * D;
+                        bf16_t* da = wa == 0 ? p.qu : (wa == 1 ? p.kh : p.vt);
+                        bf16_t* db = wb == 0 ? p.qu : (wb == 1 ? p.kh : p.vt);
+                        const bool oka = n0 < 3 * D, okb = n0 + 4 < 3 * D;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const u32x4 v = *reinterpret_cast<const u32x4*>(stg + (8 * i + (lane >> 3)) * STG_ROW + 16 * (lane & 7));
+                            if (oka && qok[i]) *reinterpret_cast<u32x2*>(da + qoff[i] + na) = u32x2{v[0], v[1]};
+                            if (okb && qok[i]) *reinterpret_cast<u32x2*>(db + qoff[i] + nb) = u32x2{v[2], v[3]};
+                        }
+                        st1 += 8;
                     }
-                    st1 += 4;
                 }
             }
         }
@@ -670,12 +686,12 @@ int launch_chain_kind(const ChainParams& p, hipStream_t s) {
 
 }  // namespace
 
-// D <= 256: the residual row fits the register file.  The Q/K/V-emitting half additionally needs D % 8 == 0 (16-byte bf16 pieces
-// never straddle the Q | K | V boundaries) — Medium's D = 180 stage runs chain B and the tail chain only.
+// D <= 256: the residual row fits the register file.  The Q/K/V-emitting half stores 16-byte pieces when D % 8 == 0 (they never
+// straddle the Q | K | V boundaries) and 8-byte halves otherwise (Medium's D = 180).
 bool chain_supported(int D) { return D % 4 == 0 && D >= 16 && D <= 256; }
 // At KS = 16 (D = 240 / 256) the chains run at one wave per SIMD; the tail and the head each fit the register file (AGPRs as the
 // overflow, no scratch), the combined tail + head kernel does not (see chain_full_supported).
-bool chain_head_supported(int D) { return chain_supported(D) && D % 8 == 0; }
+bool chain_head_supported(int D) { return chain_supported(D); }      // D % 4 == 0: the Q/K/V rows leave as 16- or 8-byte pieces
 bool chain_tail_supported(int D) { return chain_supported(D); }
 // tail + next head in ONE kernel: up to D = 192 the whole state fits the register file; at D = 240 (KS = 16) the combined kernel spills
 // (199 us per block against 181 us for the five per-GEMM kernels) while the tail and the head as TWO chain launches do not
