@@ -81,13 +81,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmDev gd) {
     // Two register staging sets: the global loads of k-tile kt+2 are issued at the top of iteration kt and published (written to
     // LDS) at the bottom of iteration kt+1, so they have a whole iteration to arrive.  (One set - issue at the top, publish at the
     // bottom of the SAME iteration - left only one 16-MFMA compute phase to cover the L2 / HBM latency.)
-    struct Stage { uint4 ra[4], rb[NB]; int valid; };
+    struct Stage { uint4 ra[4], rb[NB]; int valid, tail; };
     Stage s0, s1;
 #pragma unroll
     for (int i = 0; i < 4; ++i) { s0.ra[i] = make_uint4(0, 0, 0, 0); s1.ra[i] = s0.ra[i]; }
 #pragma unroll
     for (int i = 0; i < NB; ++i) { s0.rb[i] = make_uint4(0, 0, 0, 0); s1.rb[i] = s0.rb[i]; }
     s0.valid = s1.valid = 0;
+    s0.tail = s1.tail = 1;
     auto load_tile = [&](Stage& st, int t) __attribute__((always_inline)) {
         const int k = t * BK + kc * 8;
         const int valid = p.K - k;
@@ -97,14 +98,21 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmDev gd) {
         for (int i = 0; i < 4; ++i) st.ra[i] = *reinterpret_cast<const uint4*>(a_ptr[i] + (kcl < 0 ? 0 : kcl));
 #pragma unroll
         for (int i = 0; i < NB; ++i) st.rb[i] = *reinterpret_cast<const uint4*>(b_ptr[i] + tb * BK);
+        st.tail = t >= nk - 1;
         st.valid = valid;          // the K tail is masked at PUBLISH time: masking here made every iteration wait for the loads it had
                                    // just issued (s_waitcnt vmcnt right after them: one L2 round trip per k-tile, 20 % of MFMA peak)
     };
     auto publish = [&](const Stage& st, int buf) __attribute__((always_inline)) {
         char* a = sA + buf * BM * LROW;
         char* b = sB + buf * BN * LROW;
+        // only the last k-tile can hold columns >= K: wave-uniform branch (the 64 mask instructions were ~15 % of a k-tile's issue slots)
+        if (__builtin_amdgcn_readfirstlane(st.tail)) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(a + (srow + 32 * i) * LROW + kc * 16) = mask_chunk(st.ra[i], st.valid);
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(a + (srow + 32 * i) * LROW + kc * 16) = mask_chunk(st.ra[i], st.valid);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(a + (srow + 32 * i) * LROW + kc * 16) = st.ra[i];
+        }
 #pragma unroll
         for (int i = 0; i < NB; ++i) *reinterpret_cast<uint4*>(b + (srow + 32 * i) * LROW + kc * 16) = st.rb[i];
     };
