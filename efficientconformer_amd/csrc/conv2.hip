@@ -111,6 +111,7 @@ __global__ __launch_bounds__(256) void conv2_igemm_kernel(const bf16_t* __restri
         const int buf = kt & 1;
         const bool more = kt + 1 < nk;
         uint4 ra[4], rb[4];
+        bool ok[4] = {false, false, false, false};
 #pragma unroll
         for (int i = 0; i < 4; ++i) { ra[i] = make_uint4(0, 0, 0, 0); rb[i] = ra[i]; }
         if (more) {
@@ -125,9 +126,9 @@ __global__ __launch_bounds__(256) void conv2_igemm_kernel(const bf16_t* __restri
 #pragma unroll
             for (int i = 0; i < 4; ++i) rb[i] = *reinterpret_cast<const uint4*>(b_ptr[i] + (kt + 1) * BK);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int f1 = 2 * rf2[i] + ti - 1, t1 = 2 * rt2[i] + tj - 1;
-                ra[i] = mask_chunk(ra[i], (f1 >= 0 && f1 < F1 && t1 >= 0 && t1 < T1) ? 8 : 0);
+            for (int i = 0; i < 4; ++i) {                     // validity now, the zeroing at publish time: masking here made the
+                const int f1 = 2 * rf2[i] + ti - 1, t1 = 2 * rt2[i] + tj - 1;     // wave wait for the loads it had just issued
+                ok[i] = f1 >= 0 && f1 < F1 && t1 >= 0 && t1 < T1;
             }
         }
         if (kt >= 0) {
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(256) void conv2_igemm_kernel(const bf16_t* __restri
             char* a = sA + (buf ^ 1) * BM * LROW;
             char* b = sB + (buf ^ 1) * BN * LROW;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(a + (srow + 32 * i) * LROW + kc * 16) = ra[i];
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(a + (srow + 32 * i) * LROW + kc * 16) = ok[i] ? ra[i] : make_uint4(0, 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(b + (srow + 32 * i) * LROW + kc * 16) = rb[i];
         }
