@@ -7,12 +7,12 @@
 
 A "step" is one pass of the hot path (ConformerEncoder.forward: mel frontend -> conv subsampling -> 15
 Conformer blocks, then fc + argmax + CTC collapse) over one synthetic LibriSpeech-shaped batch that is
-already resident in HBM.  By default the batch (256 utterances per GPU) runs as two contiguous row ranges on two HIP
-streams inside ConformerEncoder.forward (`sub_batches`, efficientconformer_amd/encoders.py): every kernel of the path is a
-one-round launch that alternates HBM-bound load/store bursts with compute, and a second stream fills one's bursts with the
-other's compute (--streams 1 --batch 128 reproduces the single-stream numbers).  One process per GPU; utterances shard across
-ranks with no data-path collective inside the timed loop except the all-gather of encoder outputs (RCCL) on a side stream,
-overlapped with the CTC head, as north_star asks.
+already resident in HBM (default: 256 utterances per GPU on one stream).  `--streams 2` runs the batch as two contiguous row
+ranges on two HIP streams inside ConformerEncoder.forward (`sub_batches`, efficientconformer_amd/encoders.py): every kernel of the
+path is a one-round launch that alternates HBM-bound load/store bursts with compute, and a second stream fills one's bursts with the
+other's compute (+12 %) - opt-in, because two concurrent forwards are not bit-reproducible yet (open issue).  One process
+per GPU; utterances shard across ranks with no data-path collective inside the timed loop except the all-gather of encoder outputs
+(RCCL) on a side stream, overlapped with the CTC head, as north_star asks.
 Rank 0 prints ONE JSON line.  `value` counts VALID (un-padded) mel frames of all ranks per second.
 """
 from __future__ import annotations
@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=256, help="utterances per GPU per step")
     ap.add_argument("--workload", default="libri", choices=["libri", "fixed"],
                     help="libri: lognormal LibriSpeech-shaped lengths (SURVEY.md 8d W-libri); fixed: 10 s each")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=1,
                     help="ConformerEncoder.sub_batches: contiguous row ranges of the batch on concurrent HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")

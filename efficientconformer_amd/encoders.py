@@ -90,11 +90,13 @@ class ConformerEncoder(nn.Module):
         self._packed = False
         object.__setattr__(self, "_head", None)   # not a sub-module: keeps state_dict keys equal to the reference's
         self._ws: Dict[tuple, torch.Tensor] = {}
-        # Sub-batch streams: a forward over >= `sub_batch_min` utterances runs as `sub_batches` contiguous row ranges on
-        # concurrent HIP streams (None = automatic: 2).  Every kernel of the path is a one-round launch that alternates HBM-bound
-        # load / store bursts with compute; a second stream fills the first one's bursts (+15 % frames/s).
-        # Rows are independent given the padded length, so the results are bit-identical to the single-stream run.
-        self.sub_batches: Optional[int] = None
+        # Sub-batch streams (opt-in): `sub_batches = S > 1` runs a forward as S contiguous row ranges on concurrent HIP streams
+        # (None = automatic: 2 from `sub_batch_min` utterances on).  Every kernel of the path is a one-round launch that alternates
+        # HBM-bound load / store bursts with compute; a second stream fills the first one's bursts (+12 % frames/s).  NOT the
+        # default: with two forwards in flight the fused chain-A kernels (chain.hip) show an unresolved sensitivity - a few
+        # utterances of the later range come out perturbed by <= 0.02 (inside the parity tolerance, but not bit-reproducible;
+        # DESIGN.md "Open issue").  One stream is bit-reproducible.
+        self.sub_batches: Optional[int] = 1
         self.sub_batch_min = 64
         self._sub_streams: Dict[tuple, torch.cuda.Stream] = {}
         self.eval()

@@ -374,8 +374,10 @@ def test_positional_cache_stays_valid_when_streams_alternate_workspaces():
 
 
 def test_sub_batch_streams_are_bit_identical_to_one_stream():
-    """ConformerEncoder.forward splits large batches into contiguous row ranges on concurrent streams (encoders.py); rows are
-    independent given the padded length, so any split must reproduce the single-stream result bit for bit."""
+    """ConformerEncoder.forward can split a batch into contiguous row ranges on concurrent streams (encoders.py, opt-in); rows are
+    independent given the padded length, so any split must reproduce the single-stream result bit for bit.  (Holds here, on a
+    model whose launches are short; with LibriSpeech-sized batches two concurrent forwards are not bit-reproducible yet -
+    DESIGN.md "Open issue" - which is why one stream is the default.)"""
     m, _ = _model("Tiny", 7)
     lens = np.array([30000, 27000, 22000, 15000, 9000, 4000, 2500], dtype=np.int64)
     audio = torch.from_numpy(synth.make_audio(lens, seed=33)).cuda()

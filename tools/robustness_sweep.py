@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Odd batch sizes / one very short utterance / sub-batch splits: every split must reproduce the one-stream result bit for bit.
+At the end of round 1 this FAILS for the larger batches of the Small model when sub_batches > 1 (two forwards in flight are not
+bit-reproducible: DESIGN.md, section 5, open issue) and passes with one stream, which is therefore the default."""
+import sys, torch, numpy as np
+sys.path.insert(0, ".")
+import bench
+from efficientconformer_amd import synth
+ok = True
+for name in ("EfficientConformerCTCSmall", "EfficientConformerCTCMedium"):
+    cfg, model, sd = bench.build_model(name)
+    model = model.cuda()
+    for B in (1, 7, 65, 129):
+        lens = synth.libri_lengths(B, seed=100 + B)[:B]
+        lens[-1] = 2000            # one very short utterance
+        audio = torch.from_numpy(synth.make_audio(lens, seed=B)).cuda(); ln = torch.from_numpy(lens).cuda()
+        model.encoder.sub_batches = 1
+        ref, rl, _ = model.encoder(audio, ln); lab_ref = model._head(ref, rl)[1]
+        for ns in (None, 2, 3):
+            model.encoder.sub_batches = ns; model.encoder.sub_batch_min = 2
+            got, gl, _ = model.encoder(audio, ln); lab = model._head(got, gl)[1]
+            torch.cuda.synchronize()
+            e = torch.equal(got, ref) and torch.equal(gl, rl) and torch.equal(lab, lab_ref) and bool(torch.isfinite(got).all())
+            ok &= e
+            print(name, "B=%d" % B, "sub_batches", ns, "equal" if e else "MISMATCH")
+print("ALL OK" if ok else "FAILED")
