@@ -10,7 +10,8 @@ Conformer blocks, then fc + argmax + CTC collapse) over one synthetic LibriSpeec
 already resident in HBM (default: 256 utterances per GPU on one stream).  `--streams 2` runs the batch as two contiguous row
 ranges on two HIP streams inside ConformerEncoder.forward (`sub_batches`, efficientconformer_amd/encoders.py): every kernel of the
 path is a one-round launch that alternates HBM-bound load/store bursts with compute, and a second stream fills one's bursts with the
-other's compute (+12 %) - opt-in, because two concurrent forwards are not bit-reproducible yet (open issue).  One process
+other's compute (+10 %, bit-identical to one stream; the mel frontend stays one launch: DESIGN.md section 5) - opt-in this round,
+the committed profiles are the one-stream ones.  One process
 per GPU; utterances shard across ranks with no data-path collective inside the timed loop except the all-gather of encoder outputs
 (RCCL) on a side stream, overlapped with the CTC head, as north_star asks.
 Rank 0 prints ONE JSON line.  `value` counts VALID (un-padded) mel frames of all ranks per second.

@@ -92,10 +92,12 @@ class ConformerEncoder(nn.Module):
         self._ws: Dict[tuple, torch.Tensor] = {}
         # Sub-batch streams (opt-in): `sub_batches = S > 1` runs a forward as S contiguous row ranges on concurrent HIP streams
         # (None = automatic: 2 from `sub_batch_min` utterances on).  Every kernel of the path is a one-round launch that alternates
-        # HBM-bound load / store bursts with compute; a second stream fills the first one's bursts (+12 % frames/s).  NOT the
-        # default: with two forwards in flight the fused chain-A kernels (chain.hip) show an unresolved sensitivity - a few
-        # utterances of the later range come out perturbed by <= 0.02 (inside the parity tolerance, but not bit-reproducible;
-        # DESIGN.md "Open issue").  One stream is bit-reproducible.
+        # HBM-bound load / store bursts with compute; a second stream fills the first one's bursts (+12 % frames/s).
+        # The mel frontend is NOT split: it runs once for the whole batch on the caller's stream and the streams fork at the mel
+        # boundary.  Measured on the MI355X ("mel kernel next to another kernel's workgroups"): mel_kernel
+        # workgroups that share a CU with workgroups of the subsampling kernels of ANOTHER stream return perturbed spectra for
+        # some frame pairs - the one sensitivity the stream sweep found; everything from the mel boundary on is bit-identical
+        # with any number of streams in flight.  One stream stays the default.
         self.sub_batches: Optional[int] = 1
         self.sub_batch_min = 64
         self._sub_streams: Dict[tuple, torch.cuda.Stream] = {}
@@ -222,6 +224,14 @@ class ConformerEncoder(nn.Module):
         if nsub == 1:
             launch(0, batch)
         else:
+            if from_audio:
+                # the whole batch's mel on the caller's stream (see __init__), then forward_mel per row range
+                tm = n // self.plan.hop_length + 1
+                mel = torch.empty(batch, self.plan.n_mels, tm, dtype=torch.float32, device=x.device)
+                _lib.check(lib.effconf_mel_frontend(self._handle, x.data_ptr(), batch, n, mel.data_ptr(),
+                                                    torch.cuda.current_stream(x.device).cuda_stream), "mel_frontend")
+                x, n, from_audio, fn = mel, tm, False, lib.effconf_encoder_forward_mel
+                lens = torch.div(lens, self.plan.hop_length, rounding_mode="floor") + 1
             cur = torch.cuda.current_stream(x.device)
             streams = []
             for i in range(nsub):
@@ -232,6 +242,7 @@ class ConformerEncoder(nn.Module):
                 st.wait_stream(cur)                      # inputs (and anything queued before this forward) are ready
                 with torch.cuda.stream(st):
                     launch(batch * i // nsub, batch * (i + 1) // nsub)
+                    x.record_stream(st); lens.record_stream(st)
                 streams.append(st)
             for st in streams:
                 cur.wait_stream(st)                      # joined: the caller continues on its own stream

@@ -375,9 +375,7 @@ def test_positional_cache_stays_valid_when_streams_alternate_workspaces():
 
 def test_sub_batch_streams_are_bit_identical_to_one_stream():
     """ConformerEncoder.forward can split a batch into contiguous row ranges on concurrent streams (encoders.py, opt-in); rows are
-    independent given the padded length, so any split must reproduce the single-stream result bit for bit.  (Holds here, on a
-    model whose launches are short; with LibriSpeech-sized batches two concurrent forwards are not bit-reproducible yet -
-    DESIGN.md "Open issue" - which is why one stream is the default.)"""
+    independent given the padded length, so any split must reproduce the single-stream result bit for bit."""
     m, _ = _model("Tiny", 7)
     lens = np.array([30000, 27000, 22000, 15000, 9000, 4000, 2500], dtype=np.int64)
     audio = torch.from_numpy(synth.make_audio(lens, seed=33)).cuda()
@@ -394,3 +392,27 @@ def test_sub_batch_streams_are_bit_identical_to_one_stream():
     m.encoder.sub_batch_min = 4                              # automatic split (2 ranges) from 4 utterances on
     got, got_len, _ = m.encoder(audio, ln)
     assert torch.equal(got, ref) and torch.equal(got_len, ref_len)
+
+
+def test_sub_batch_streams_are_bit_identical_at_librispeech_batch_sizes():
+    """The case the robustness sweep (tools/robustness_sweep.py) used to fail: EfficientConformerCTCSmall, an odd LibriSpeech-sized
+    batch with one very short utterance, 2 and 3 row ranges in flight.  The mel frontend runs once for the whole batch and the
+    streams fork at the mel boundary (encoders.py; DESIGN.md section 5: mel_kernel workgroups next to another stream's subsampling
+    workgroups were the one sensitivity), so every split is bit-identical to one stream - outputs, lengths and labels."""
+    m, _ = _model("EfficientConformerCTCSmall", 3)
+    B = 65
+    lens = synth.libri_lengths(B, seed=100 + B)[:B]
+    lens[-1] = 2000
+    audio = torch.from_numpy(synth.make_audio(lens, seed=B)).cuda()
+    ln = torch.from_numpy(lens).cuda()
+    m.encoder.sub_batches = 1
+    ref, ref_len, _ = m.encoder(audio, ln)
+    lab_ref = m._head(ref, ref_len)[1]
+    for nsub in (2, 3):
+        m.encoder.sub_batches = nsub
+        for _ in range(3):                                   # repeated: the old failure needed warm allocations to overlap
+            got, got_len, _ = m.encoder(audio, ln)
+            lab = m._head(got, got_len)[1]
+            torch.cuda.synchronize()
+            assert torch.equal(got, ref) and torch.equal(got_len, ref_len) and torch.equal(lab, lab_ref), nsub
+            assert bool(torch.isfinite(got).all())

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Odd batch sizes / one very short utterance / sub-batch splits: every split must reproduce the one-stream result bit for bit.
-At the end of round 1 this FAILS for the larger batches of the Small model when sub_batches > 1 (two forwards in flight are not
-bit-reproducible: DESIGN.md, section 5, open issue) and passes with one stream, which is therefore the default."""
+This failed for the larger batches while the mel frontend was split across the streams (DESIGN.md section 5,
+profiles/r1_16_stream_sensitivity.txt) and passes since ConformerEncoder forks its streams at the mel boundary."""
 import sys, torch, numpy as np
 sys.path.insert(0, ".")
 import bench
