@@ -7,11 +7,10 @@
 
 A "step" is one pass of the hot path (ConformerEncoder.forward: mel frontend -> conv subsampling -> 15
 Conformer blocks, then fc + argmax + CTC collapse) over one synthetic LibriSpeech-shaped batch that is
-already resident in HBM (default: 256 utterances per GPU on one stream).  `--streams 2` runs the batch as two contiguous row
+already resident in HBM (default: 256 utterances per GPU, `--streams 2`).  `--streams 2` runs the batch as two contiguous row
 ranges on two HIP streams inside ConformerEncoder.forward (`sub_batches`, efficientconformer_amd/encoders.py): every kernel of the
 path is a one-round launch that alternates HBM-bound load/store bursts with compute, and a second stream fills one's bursts with the
-other's compute (+10 %, bit-identical to one stream; the mel frontend stays one launch: DESIGN.md section 5) - opt-in this round,
-the committed profiles are the one-stream ones.  One process
+other's compute (+10-13 %, bit-identical to `--streams 1`; the mel frontend stays one launch: DESIGN.md section 5).  One process
 per GPU; utterances shard across ranks with no data-path collective inside the timed loop except the all-gather of encoder outputs
 (RCCL) on a side stream, overlapped with the CTC head, as north_star asks.
 Rank 0 prints ONE JSON line.  `value` counts VALID (un-padded) mel frames of all ranks per second.
@@ -47,7 +46,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=256, help="utterances per GPU per step")
     ap.add_argument("--workload", default="libri", choices=["libri", "fixed"],
                     help="libri: lognormal LibriSpeech-shaped lengths (SURVEY.md 8d W-libri); fixed: 10 s each")
-    ap.add_argument("--streams", type=int, default=1,
+    ap.add_argument("--streams", type=int, default=2,
                     help="ConformerEncoder.sub_batches: contiguous row ranges of the batch on concurrent HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -141,7 +140,7 @@ def pmc_traffic(args, kernel_prefix):
     if not os.path.exists(path):
         return None
     d = json.load(open(path))
-    if (d.get("model"), d.get("batch"), d.get("workload")) != (args.model, args.batch, args.workload):
+    if (d.get("model"), d.get("batch"), d.get("workload"), d.get("streams", 1)) != (args.model, args.batch, args.workload, max(args.streams, 1)):
         return None
     import re
     calls = tot = 0
@@ -247,18 +246,32 @@ def main():
         _lib.check(lib.effconf_profile_enable(h, 1), "profile_enable")
         nprof = min(args.steps, 5)
         nsub = max(args.streams, 1)
+
+        def read_classes():
+            torch.cuda.synchronize()
+            out = {}
+            for ci, cname in enumerate(PROF_CLASSES):
+                ms, n, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+                _lib.check(lib.effconf_profile_read(h, ci, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)), "profile_read")
+                out[cname] = {"ms_per_step": ms.value / nprof, "launches_per_step": n.value / nprof,
+                              "gflop_per_step": fl.value / nprof / 1e9, "alg_mb_per_step": by.value / nprof / 1e6}
+            return out
+        # Launch durations are taken with the step's row ranges one after the other on ONE stream: same launch shapes as the timed
+        # region, no neighbour kernel on the chip.  (With S streams in flight an event pair on one stream also brackets the time
+        # its kernel queues behind the other stream's: that figure is reported as `in_flight`, it is not a kernel duration.)
         model.encoder.sub_batches = 1
-        for _ in range(nprof):      # same launch shapes as the timed region (the sub-batches' row ranges), one after the other on one stream
+        for _ in range(nprof):
             for i in range(nsub):
                 lo, hi = args.batch * i // nsub, args.batch * (i + 1) // nsub
                 step(model, audio[lo:hi], lens[lo:hi])
-        torch.cuda.synchronize()
-        per = {}
-        for ci, cname in enumerate(PROF_CLASSES):
-            ms, n, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
-            _lib.check(lib.effconf_profile_read(h, ci, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)), "profile_read")
-            per[cname] = {"ms_per_step": ms.value / nprof, "launches_per_step": n.value / nprof,
-                          "gflop_per_step": fl.value / nprof / 1e9, "alg_mb_per_step": by.value / nprof / 1e6}
+        per = read_classes()
+        model.encoder.sub_batches = nsub
+        flight = None
+        if nsub > 1:
+            _lib.check(lib.effconf_profile_enable(h, 1), "profile_enable")
+            for _ in range(nprof):
+                step(model, audio, lens)
+            flight = read_classes()["gemm_ffn"]
         _lib.check(lib.effconf_profile_enable(h, 0), "profile_enable")
         dom = per["gemm_ffn"]
         n_l = max(dom["launches_per_step"], 1)
@@ -284,7 +297,11 @@ def main():
                               "alg_gflop_per_launch": dom["gflop_per_step"] / n_l,
                               "alg_hbm_gbs": dom["alg_mb_per_step"] / max(dom["ms_per_step"], 1e-9),
                               "note": "HIP events around every launch of the class on the launch stream, %d extra steps after the timed region "
-                                      "(the step's %d sub-batches one after the other, so launches do not overlap)" % (nprof, max(args.streams, 1))}
+                                      "(the step's %d row ranges one after the other on one stream, so launches do not overlap)" % (nprof, nsub)}
+        if flight:
+            result["roofline"]["in_flight"] = {"event_bracket_ms": flight["ms_per_step"] / max(flight["launches_per_step"], 1),
+                                               "note": "event pairs around the same launches with the %d row ranges in flight on %d streams, as in the timed "
+                                                       "region: includes the time a kernel queues behind the other stream's kernel" % (nsub, nsub)}
         result["kernel_classes"] = per
 
     if rank == 0 and not args.no_cpu_baseline:

@@ -28,11 +28,22 @@ def main():
             n, kb = fetch[name]
             wn, wkb = write.get(name, [1, 0.0])
             f.write("%-100s %7d %12.2f %12.2f %12.2f\n" % (name[:100], n, kb / n / 1024, 2 * kb / n / 1024, wkb / max(wn, 1) / 1024))
+        # the --pmc passes serialise dispatches: their kernel trace gives every launch's duration WITHOUT a neighbour kernel
+        try:
+            c = sqlite3.connect(sys.argv[1])
+            rows = c.execute("select name, count(*), sum(end - start) / 1000.0 from kernels group by name order by 3 desc").fetchall()
+            f.write("#\n# kernel durations in the FETCH_SIZE pass (dispatches serialised by the counter collection), microseconds\n")
+            f.write("%-100s %7s %12s %12s\n" % ("kernel", "calls", "total_us", "avg_us"))
+            for name, n, tot in rows[:24]:
+                f.write("%-100s %7d %12.1f %12.3f\n" % (name[:100], n, tot, tot / n))
+        except Exception as e:        # older rocpd schemas: no `kernels` view
+            f.write("# (no kernel durations in this database: %s)\n" % e)
     print(open(out).read())
-    if len(sys.argv) > 5:          # machine-readable copy for bench.py's roofline.traffic: argv[5] = json path, argv[6..8] = model batch workload
+    if len(sys.argv) > 5:          # machine-readable copy for bench.py's roofline.traffic: argv[5] = json path, argv[6..8] = model batch workload, [9] = streams
         kern = {name: {"calls": fetch[name][0], "fetch_x2_bytes": 2 * 1024 * fetch[name][1] / fetch[name][0],
                        "write_bytes": 1024 * write.get(name, [1, 0.0])[1] / max(write.get(name, [1, 0.0])[0], 1)} for name in fetch}
         json.dump({"source": out, "model": sys.argv[6], "batch": int(sys.argv[7]), "workload": sys.argv[8],
+                   "streams": int(sys.argv[9]) if len(sys.argv) > 9 else 1,
                    "correction": "FETCH_SIZE x2 (gfx950: 128-B read requests tallied as 64 B), WRITE_SIZE as reported; KB -> bytes",
                    "kernels": kern}, open(sys.argv[5], "w"), indent=1)
 
