@@ -90,7 +90,7 @@ class ConformerEncoder(nn.Module):
         self._packed = False
         object.__setattr__(self, "_head", None)   # not a sub-module: keeps state_dict keys equal to the reference's
         self._ws: Dict[tuple, torch.Tensor] = {}
-        # Sub-batch streams (opt-in): `sub_batches = S > 1` runs a forward as S contiguous row ranges on concurrent HIP streams
+        # Sub-batch streams (opt-in here; bench.py runs with 2): `sub_batches = S > 1` runs a forward as S contiguous row ranges on concurrent HIP streams
         # (None = automatic: 2 from `sub_batch_min` utterances on).  Every kernel of the path is a one-round launch that alternates
         # HBM-bound load / store bursts with compute; a second stream fills the first one's bursts (+12 % frames/s).
         # The mel frontend is NOT split: it runs once for the whole batch on the caller's stream and the streams fork at the mel
