@@ -182,3 +182,47 @@ def test_bench_batches_share_one_padded_length_across_ranks():
     assert len(shapes) == 1
     own = [int(synth.libri_lengths(3, seed=1234 + r).max()) for r in range(4)]
     assert len(set(own)) > 1 and max(own) == next(iter(shapes))[1]
+
+
+def test_pmc_summary_feeds_bench_traffic_only_for_the_profiled_command(tmp_path, monkeypatch):
+    """tools/pmc_summary.py turns two rocprofv3 --pmc databases into the text summary + profiles/pmc_traffic.json; bench.py's
+    roofline.traffic must come from it ONLY when model, batch, workload AND --streams equal the profiled command's (launch shapes
+    differ with the number of row ranges), with FETCH_SIZE doubled (gfx950 correction, MI355X_MICROARCH.md)."""
+    import json
+    import sqlite3
+    import subprocess
+    import sys
+    import types
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    name = "void (anonymous namespace)::chain_kernel<8, 8, 4, 1, false>((anonymous namespace)::ChainDev, unsigned long long*)"
+    dbs = []
+    for counter, vals in (("FETCH_SIZE", [1000.0, 3000.0]), ("WRITE_SIZE", [500.0, 700.0])):
+        p = tmp_path / (counter + ".db")
+        c = sqlite3.connect(p)
+        c.execute("create table pmc_events (name text, counter_name text, counter_value real)")
+        c.execute("create table kernels (name text, start integer, end integer)")
+        for i, v in enumerate(vals):
+            c.execute("insert into pmc_events values (?, ?, ?)", (name, counter, v))
+            c.execute("insert into kernels values (?, ?, ?)", (name, 1000 * i, 1000 * i + 90000 + 4000 * i))
+        c.commit(); c.close()
+        dbs.append(str(p))
+    txt, js = tmp_path / "pmc.txt", tmp_path / "pmc.json"
+    subprocess.run([sys.executable, os.path.join(root, "tools", "pmc_summary.py"), dbs[0], dbs[1], str(txt), "python bench.py", str(js),
+                    "EfficientConformerCTCSmall", "256", "libri", "2"], check=True, capture_output=True)
+    d = json.load(open(js))
+    assert d["streams"] == 2 and d["batch"] == 256
+    k = d["kernels"][name]
+    assert k["calls"] == 2 and k["fetch_x2_bytes"] == 2 * 1024 * 2000.0 and k["write_bytes"] == 1024 * 600.0
+    body = open(txt).read()
+    assert "kernel durations" in body and "92.000" in body          # (90 + 94) / 2 us with dispatches serialised
+
+    import bench
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    os.makedirs(tmp_path / "profiles")
+    os.replace(js, tmp_path / "profiles" / "pmc_traffic.json")
+    args = types.SimpleNamespace(model="EfficientConformerCTCSmall", batch=256, workload="libri", streams=2)
+    pat = r"chain_kernel<\d+, \d+, \d+, [123],"
+    assert bench.pmc_traffic(args, pat) == k["fetch_x2_bytes"] + k["write_bytes"]
+    for other in (dict(streams=1), dict(batch=128), dict(model="EfficientConformerCTCMedium")):
+        a2 = types.SimpleNamespace(**{**vars(args), **other})
+        assert bench.pmc_traffic(a2, pat) is None
