@@ -193,6 +193,10 @@ def main():
 
     def full_step():
         cur = torch.cuda.current_stream(dev)
+        if world > 1:
+            # the previous step's all-gather (normally long finished under the head) is complete before this step's mel kernel starts:
+            # mel launches are kept away from kernels of other streams they were not swept against
+            cur.wait_stream(side)
         enc, enc_len, _ = model.encoder(audio, lens)
         if world > 1:
             gather(enc, cur)

@@ -61,6 +61,10 @@ class ShardedEncoder:
     def __call__(self, x: torch.Tensor, x_len: torch.Tensor):
         rank, world = dist.get_rank(self.group), dist.get_world_size(self.group)
         xs, ls = shard_batch(x, x_len, rank, world)
+        if xs.is_cuda and self._side is not None:
+            # the previous call's all-gather is complete before this call's mel kernel starts (normally it finished long ago under
+            # the caller's head): mel launches are kept away from other streams' kernels they were not swept against
+            torch.cuda.current_stream(xs.device).wait_stream(self._side)
         out, out_len = self.encoder(xs, ls)[:2]
         if out.is_cuda:
             if self._side is None:
