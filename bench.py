@@ -308,7 +308,7 @@ def main():
                                                        "region: includes the time a kernel queues behind the other stream's kernel" % (nsub, nsub)}
         result["kernel_classes"] = per
 
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:      # reported at N = 1 only (task contract)
         result["cpu_baseline"] = cpu_baseline(sd, plan, audio_np, lens_np)
 
     if rank == 0:
