@@ -10,9 +10,15 @@ Conformer blocks, then fc + argmax + CTC collapse) over one synthetic LibriSpeec
 already resident in HBM (default: 256 utterances per GPU, `--streams 2`).  `--streams 2` runs the batch as two contiguous row
 ranges on two HIP streams inside ConformerEncoder.forward (`sub_batches`, efficientconformer_amd/encoders.py): every kernel of the
 path is a one-round launch that alternates HBM-bound load/store bursts with compute, and a second stream fills one's bursts with the
-other's compute (+10-13 %, bit-identical to `--streams 1`; the mel frontend stays one launch: DESIGN.md section 5).  One process
-per GPU; utterances shard across ranks with no data-path collective inside the timed loop except the all-gather of encoder outputs
-(RCCL) on a side stream, overlapped with the CTC head, as north_star asks.
+other's compute (+10-13 %, bit-identical to `--streams 1`; the mel frontend stays one launch: DESIGN.md section 5).
+
+Multi-GPU: one process per GPU.  `--gpus N` without a torchrun environment re-executes this script under
+`python -m torch.distributed.run --nproc-per-node N` (the reference spawns one process per GPU the same way: main.py:217-220);
+under torchrun (the driver's launch line) WORLD_SIZE must equal --gpus.  Utterances shard across ranks (weak scaling: B utterances
+per GPU); the only data-path collective is the RCCL all-gather of encoder outputs, issued PER ROW RANGE on a comm stream as soon
+as that range's last kernel is enqueued (efficientconformer_amd/dist.py), so range 0 is on the wire during range 1's last stage
+and range 1's collective overlaps the head of range 0 and the next step's encoder.  The CTC head consumes the gathered chunks
+(every rank ends up with the labels of the GLOBAL batch) on a head stream; `--gather labels` gathers label ids instead.
 Rank 0 prints ONE JSON line.  `value` counts VALID (un-padded) mel frames of all ranks per second.
 """
 from __future__ import annotations
@@ -21,6 +27,8 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -50,7 +58,23 @@ def parse():
                     help="ConformerEncoder.sub_batches: contiguous row ranges of the batch on concurrent HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--gather", default="outputs", choices=["outputs", "labels"],
+                    help="N > 1: all-gather the encoder outputs before the CTC head (north_star) or the label ids after it")
+    ap.add_argument("--wire", default="fp32", choices=["fp32", "bf16"], help="dtype of the gathered encoder outputs on xGMI")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU work: build the batch plan, join the process group (gloo) and print the JSON skeleton (CPU tests)")
     return ap.parse_args()
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` outside torchrun: re-execute under torch.distributed.run with N local ranks (one per GPU)."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this driver (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    return subprocess.call(cmd, env=env)
 
 
 RNNT_BLANK_BIAS = 1.2         # synthetic joint bias of the blank: ~1 token per 3 encoder frames (synth.make_transducer_state_dict)
@@ -101,35 +125,81 @@ def step(model, audio, lens):
     return enc, enc_len, labels, label_len
 
 
-def cpu_baseline(sd, plan, audio_np, lens_np, budget_s=12.0):
-    """The oracle (CPU port of the reference path, oracle/ref_encoder.py) on the host cores, bounded sample."""
+def host_cpu():
+    """(model string, physical cores, logical cpus) of the host the baseline runs on."""
+    model, cores = "unknown", set()
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                phys = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    cores.add((phys, core))
+                phys = core = None
+    except OSError:
+        pass
+    logical = os.cpu_count() or 1
+    return model, (len(cores) or logical), logical
+
+
+def cpu_baseline(sd, plan, budget_s=24.0):
+    """The oracle (CPU port of the reference path, oracle/ref_encoder.py) on the host cores, BASELINE.md section 3: same timed
+    region (audio -> encoder -> fc -> greedy labels), W-fixed B = 4 (10 s utterances) for torch.set_num_threads in {1, 8, 16, 32,
+    all physical cores}, then a W-libri B = 4 sample and W-fixed B = 32 at the best thread count.  The headline `value` is the
+    best W-fixed B = 4 rate; every measurement is listed.  Bounded to about `budget_s` seconds."""
     from oracle import ref_encoder as R
     osd = {k[len("encoder."):] if k.startswith("encoder.") else k: torch.from_numpy(v) for k, v in sd.items()}
-    idx = np.linspace(0, len(lens_np) - 1, 4).round().astype(int)      # 4 utterances spread over the sorted batch
-    lens = torch.from_numpy(lens_np[idx].copy())
-    audio = torch.from_numpy(audio_np[idx][:, :int(lens.max())].copy())
-    frames = int((lens // plan.hop_length + 1).sum())
-    threads = torch.get_num_threads()
-
+    model, phys, logical = host_cpu()
     rnnt = "decoder.embedding.weight" in sd
     if rnnt:
         from oracle import ref_transducer as RT
 
-    def run():
-        with torch.no_grad():
-            x, l = R.encoder(audio, lens, osd, plan)
-            if rnnt:
-                return RT.greedy_decode(osd, x, l, 5)
-            return R.ctc_greedy(R.ctc_logits(x, osd), l)
-    run()
-    t0, n = time.perf_counter(), 0
-    while time.perf_counter() - t0 < budget_s or n < 2:
+    def measure(lens_np, seed, threads, seconds):
+        torch.set_num_threads(threads)
+        lens = torch.from_numpy(lens_np)
+        audio = torch.from_numpy(synth.make_audio(lens_np, seed=seed))
+        frames = int((lens // plan.hop_length + 1).sum())
+
+        def run():
+            with torch.no_grad():
+                x, l = R.encoder(audio, lens, osd, plan)
+                if rnnt:
+                    return RT.greedy_decode(osd, x, l, 5)
+                return R.ctc_greedy(R.ctc_logits(x, osd), l)
         run()
-        n += 1
-    dt = time.perf_counter() - t0
-    return {"value": frames * n / dt, "unit": "mel-frames/s", "cores": threads, "kind": "port",
-            "sample": "4 of the %d utterances of rank 0's batch (evenly spaced over the length-sorted batch), %d forward passes "
-                      "of the fp32 torch oracle in %.1f s" % (len(lens_np), n, dt)}
+        times = []
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < seconds or len(times) < 2:
+            t1 = time.perf_counter()
+            run()
+            times.append(time.perf_counter() - t1)
+        return frames / float(np.median(times)), len(times)
+
+    prev = torch.get_num_threads()
+    runs = []
+    fixed4 = np.full(4, 160000, dtype=np.int64)
+    cand = sorted({t for t in (1, 8, 16, 32, phys) if t <= logical})
+    per = budget_s * 0.6 / len(cand)
+    for t in cand:
+        v, n = measure(fixed4, 1234, t, per)
+        runs.append({"workload": "W-fixed B=4 (10 s)", "threads": t, "value": v, "iters": n})
+    best = max(runs, key=lambda r: r["value"])
+    v, n = measure(np.sort(synth.libri_lengths(4, seed=1234))[::-1].copy(), 1234, best["threads"], budget_s * 0.15)
+    runs.append({"workload": "W-libri B=4", "threads": best["threads"], "value": v, "iters": n})
+    v, n = measure(np.full(32, 160000, dtype=np.int64), 1234, best["threads"], budget_s * 0.25)
+    runs.append({"workload": "W-fixed B=32 (10 s)", "threads": best["threads"], "value": v, "iters": n})
+    torch.set_num_threads(prev)
+    one = [r for r in runs if r["threads"] == 1][0]
+    return {"value": best["value"], "unit": "mel-frames/s", "cores": best["threads"], "kind": "port",
+            "cpu_model": model, "physical_cores": phys, "logical_cpus": logical, "single_thread_value": one["value"],
+            "sample": "fp32 torch oracle (oracle/ref_encoder.py: audio -> mel -> encoder -> fc -> greedy labels), W-fixed B = 4 x 10 s "
+                      "utterances, median of %d passes on %d threads (best of threads %s); all runs listed" % (best["iters"], best["threads"], cand),
+            "runs": runs}
 
 
 def pmc_traffic(args, kernel_prefix):
@@ -137,7 +207,7 @@ def pmc_traffic(args, kernel_prefix):
     by tools/pmc_summary.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command).  Counters
     cannot be read from inside the timed process, so this is only filled when the run matches the profiled configuration."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if not os.path.exists(path):
+    if not os.path.exists(path) or kernel_prefix is None:
         return None
     d = json.load(open(path))
     if (d.get("model"), d.get("batch"), d.get("workload"), d.get("streams", 1)) != (args.model, args.batch, args.workload, max(args.streams, 1)):
@@ -151,20 +221,75 @@ def pmc_traffic(args, kernel_prefix):
     return tot / calls if calls else None
 
 
+# kernel class -> (what it is, bounding roofline, rocprof kernel-name pattern for the PMC traffic)
+CLASS_INFO = {
+    "mel": ("mel_kernel (log-mel frontend)", "hbm", r"mel_kernel"),
+    "subsample_conv": ("conv subsampling (sublinear_kernel: fused 3x3 conv + Linear; subsample_conv_* for two layers)", "mfma", r"sublinear_kernel|subsample_conv"),
+    "gemm_ffn": ("FFN-carrying kernels: chain_kernel A (pointwise-2 + FFN2 + block norm + next FFN1 + attention pre-norm + QKV in one pass over "
+                 "the rows); ffn_fused_kernel / gemm_kernel where a chain is not supported", "mfma", r"chain_kernel<\d+, \d+, \d+, [123],|ffn_fused_kernel"),
+    "gemm_other": ("chain_kernel B (attention output projection + conv-module LayerNorm + pointwise-1 + GLU), rs_gemm / gemm_kernel projections", "mfma",
+                   r"chain_kernel<\d+, \d+, \d+, 0,|rs_gemm_kernel|gemm_kernel"),
+    "layernorm": ("layernorm_kernel", "hbm", r"layernorm_kernel"),
+    "attention": ("relpos_attention_kernel (grouped relative-position MHSA, QK^T + QE^T + softmax + PV)", "mfma", r"relpos_attention_kernel"),
+    "dwconv": ("dwconv_kernel (depthwise conv + BN + Swish)", "hbm", r"dwconv_kernel"),
+    "misc": ("lengths / pad rows / casts", "hbm", None),
+}
+
+
+def result_skeleton(args, world, value, ms_per_step, gb, extra_cfg):
+    label = args.model.replace("EfficientConformer", "EffConformer").replace("CTCSmall", "CTC-Small")
+    return {
+        "metric": "audio-frames/sec through encoder, %s, 1/2/4/8 GPU" % label,
+        "value": value, "unit": "mel-frames/s (valid, 10 ms hop)",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": dict({"workload": "%s: %s, B=%d utterances/GPU, %s lengths, audio in HBM -> encoder out + greedy labels"
+                                    % (args.model, "bf16 operands / fp32 accumulate", args.batch,
+                                       "lognormal 1.5-16 s (LibriSpeech-shaped), sorted desc, zero-padded to the batch max"
+                                       if args.workload == "libri" else "10 s"),
+                        "global_batch": gb, "streams_per_gpu": args.streams}, **extra_cfg),
+    }
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch N ranks with `python bench.py --gpus N` or with "
+                         "torch.distributed.run --nproc-per-node N ... bench.py --gpus N" % (args.gpus, world))
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    if args.dry_run:           # CPU-only plumbing check (tests): same launcher, same batch plan, gloo instead of RCCL
+        if world > 1:
+            dist.init_process_group("gloo")
+        audio_np, lens_np = make_batch(args, rank, world)
+        t = torch.tensor([float(audio_np.shape[1]), float((lens_np // 160 + 1).sum())], dtype=torch.float64)
+        lo = t.clone()
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        if rank == 0:
+            r = result_skeleton(args, world, 0.0, 0.0, args.batch * world, {"parallelism": "dp%d" % world})
+            r.update({"dry_run": True, "padded_samples_equal_on_all_ranks": bool(t[0] == lo[0] * world), "valid_frames_per_step": float(t[1])})
+            print(json.dumps(r))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
     assert torch.cuda.is_available(), "bench.py needs a GPU (HIP path only)"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
 
     cfg, model, sd = build_model(args.model)
     model = model.to(dev)
@@ -177,43 +302,55 @@ def main():
     # Sub-batch streams live in the library's host layer (ConformerEncoder.sub_batches): the batch runs as `--streams` contiguous
     # row ranges on concurrent HIP streams and is joined before forward() returns.
     model.encoder.sub_batches = max(args.streams, 1)
-    gather_buf = None
-    side = torch.cuda.Stream(device=dev) if world > 1 else None
-
-    def gather(enc, producer):
-        # all-gather of the encoder outputs over RCCL/xGMI on a side stream, overlapped with the head that follows
-        nonlocal gather_buf
-        if gather_buf is None:
-            gather_buf = torch.empty((world,) + tuple(enc.shape), dtype=torch.bfloat16, device=dev)
-        side.wait_stream(producer)
-        with torch.cuda.stream(side):
-            e16 = enc.to(torch.bfloat16)
-            enc.record_stream(side)
-            dist.all_gather_into_tensor(gather_buf, e16)
+    sharded = head_stream = None
+    if world > 1:
+        from efficientconformer_amd.dist import ShardedEncoder
+        sharded = ShardedEncoder(model.encoder, wire_dtype=torch.bfloat16 if args.wire == "bf16" else None)
+        head_stream = torch.cuda.Stream(device=dev)
+    last = {}
 
     def full_step():
+        if world == 1:
+            enc, enc_len, _ = model.encoder(audio, lens)
+            last["labels"] = head(model, enc, enc_len)
+            return
         cur = torch.cuda.current_stream(dev)
-        if world > 1:
-            # the previous step's all-gather (normally long finished under the head) is complete before this step's mel kernel starts:
-            # mel launches are kept away from kernels of other streams they were not swept against
-            cur.wait_stream(side)
-        enc, enc_len, _ = model.encoder(audio, lens)
-        if world > 1:
-            gather(enc, cur)
-        labels, _ = head(model, enc, enc_len)
-        return labels
+        if args.gather == "outputs":
+            # encoder on this rank's utterances; per-row-range all-gather on the comm stream (dist.py); the head consumes the
+            # gathered chunks on its own stream, so the next step's encoder is not queued behind the collectives
+            g = sharded.encode_shard(audio, lens, args.batch * world)
+            head_stream.wait_stream(cur)
+            with torch.cuda.stream(head_stream):
+                res = []
+                for ch in g.chunks:
+                    ch.wait(head_stream)
+                    res.append(head(model, ch.out if ch.out.dtype == torch.float32 else ch.out.float(), ch.out_len))
+            last["labels"] = res
+        else:
+            enc, enc_len, _ = model.encoder(audio, lens)
+            labels, label_len = head(model, enc, enc_len)
+            head_stream.wait_stream(cur)
+            with torch.cuda.stream(head_stream):
+                gl = labels.new_empty((world,) + tuple(labels.shape)); gn = label_len.new_empty((world,) + tuple(label_len.shape))
+                labels.record_stream(head_stream); label_len.record_stream(head_stream)
+                dist.all_gather_into_tensor(gl, labels)
+                dist.all_gather_into_tensor(gn, label_len)
+            last["labels"] = (gl, gn)
+
+    def drain():
+        if head_stream is not None:
+            torch.cuda.current_stream(dev).wait_stream(head_stream)
 
     for _ in range(args.warmup):
         full_step()
+    drain()
     if world > 1:
-        torch.cuda.current_stream(dev).wait_stream(side)
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         full_step()
-    if world > 1:
-        torch.cuda.current_stream(dev).wait_stream(side)
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -228,20 +365,13 @@ def main():
 
     result = None
     if rank == 0:
-        result = {
-            "metric": "audio-frames/sec through encoder, EffConformerCTC-Small, 1/2/4/8 GPU",
-            "value": all_valid * args.steps / elapsed, "unit": "mel-frames/s (valid, 10 ms hop)",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "%s: %s, B=%d utterances/GPU, %s lengths, audio in HBM -> encoder out + greedy %s"
-                                   % (args.model, "bf16 operands / fp32 accumulate", args.batch,
-                                      "lognormal 1.5-16 s (LibriSpeech-shaped), sorted desc, zero-padded to the batch max"
-                                      if args.workload == "libri" else "10 s",
-                                      "RNN-T token ids (synthetic blank bias %.1f)" % RNNT_BLANK_BIAS if isinstance(model, Transducer) else "CTC labels"),
-                       "global_batch": args.batch * world, "streams_per_gpu": args.streams, "padded_frames_per_s": all_padded * args.steps / elapsed,
-                       "parallelism": "dp%d (utterance shards, all-gather of encoder outputs)" % world},
-        }
+        par = "dp%d (utterance shards" % world
+        if world > 1:
+            par += ", RCCL all-gather of %s per row range on a comm stream, wire %s" % ("encoder outputs" if args.gather == "outputs" else "label ids", args.wire)
+        result = result_skeleton(args, world, all_valid * args.steps / elapsed, 1000.0 * elapsed / args.steps, args.batch * world,
+                                 {"padded_frames_per_s": all_padded * args.steps / elapsed, "parallelism": par + ")"})
+        if isinstance(model, Transducer):
+            result["config"]["workload"] += " (RNN-T greedy token ids, synthetic blank bias %.1f)" % RNNT_BLANK_BIAS
 
     # ---- roofline leg: the same steps again with every launch bracketed by HIP events on the launch stream
     if rank == 0 and not args.no_roofline:
@@ -270,17 +400,23 @@ def main():
                 step(model, audio[lo:hi], lens[lo:hi])
         per = read_classes()
         model.encoder.sub_batches = nsub
+        # the dominant class is the one that takes the most time in THIS model's step (gemm_ffn for Small; Large's tiled GEMMs too)
+        dom_name = max(PROF_CLASSES, key=lambda c: per[c]["ms_per_step"])
         flight = None
         if nsub > 1:
             _lib.check(lib.effconf_profile_enable(h, 1), "profile_enable")
             for _ in range(nprof):
                 step(model, audio, lens)
-            flight = read_classes()["gemm_ffn"]
+            flight = read_classes()[dom_name]
         _lib.check(lib.effconf_profile_enable(h, 0), "profile_enable")
-        dom = per["gemm_ffn"]
+        for cname, c in per.items():      # every class against its own bound
+            bound = CLASS_INFO[cname][1]
+            ms = max(c["ms_per_step"], 1e-9)
+            c["bound"] = bound
+            c["achieved"] = c["gflop_per_step"] / ms if bound == "mfma" else c["alg_mb_per_step"] / ms       # TFLOP/s | GB/s
+            c["frac"] = c["achieved"] / (PEAK_BF16_TFLOPS if bound == "mfma" else PEAK_HBM_GBS) if c["launches_per_step"] else 0.0
+        dom = per[dom_name]
         n_l = max(dom["launches_per_step"], 1)
-        avg_ms = dom["ms_per_step"] / n_l
-        ach = dom["gflop_per_step"] / max(dom["ms_per_step"], 1e-9)          # GFLOP/ms == TFLOP/s
         if isinstance(model, Transducer):      # decode leg on its own (torch events: it is launched on torch's current stream)
             enc, enc_len, _ = model.encoder(audio, lens)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -291,17 +427,23 @@ def main():
             torch.cuda.synchronize()
             per["rnnt_greedy"] = {"ms_per_step": e0.elapsed_time(e1) / nprof, "launches_per_step": 2,
                                   "tokens_per_step": int(tok_len.sum()), "encoder_frames_per_step": int(enc_len.sum())}
-        result["roofline"] = {"kernel": "chain_kernel A (pointwise-2 + FFN2 + block norm + next FFN1 + attention pre-norm + QKV in one pass over the rows; "
-                                        "ffn_fused_kernel / gemm_kernel where a chain is not supported)",
-                              "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                              "frac": ach / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(args, r"chain_kernel<\d+, \d+, \d+, [123],|ffn_fused_kernel"),
+        tot_ms = sum(c["ms_per_step"] for k, c in per.items() if k in PROF_CLASSES)
+        tot_gf = sum(c["gflop_per_step"] for k, c in per.items() if k in PROF_CLASSES)
+        result["roofline"] = {"kernel": "%s: %s" % (dom_name, CLASS_INFO[dom_name][0]),
+                              "bound": dom["bound"], "achieved": dom["achieved"],
+                              "peak": PEAK_BF16_TFLOPS if dom["bound"] == "mfma" else PEAK_HBM_GBS,
+                              "unit": "TFLOP/s" if dom["bound"] == "mfma" else "GB/s",
+                              "frac": dom["frac"], "traffic": pmc_traffic(args, CLASS_INFO[dom_name][2]),
                               "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/pmc_traffic.json)",
                               "alg_bytes_per_launch": 1e6 * dom["alg_mb_per_step"] / n_l,
-                              "avg_launch_ms": avg_ms, "launches_per_step": n_l,
+                              "avg_launch_ms": dom["ms_per_step"] / n_l, "launches_per_step": n_l,
                               "alg_gflop_per_launch": dom["gflop_per_step"] / n_l,
                               "alg_hbm_gbs": dom["alg_mb_per_step"] / max(dom["ms_per_step"], 1e-9),
-                              "note": "HIP events around every launch of the class on the launch stream, %d extra steps after the timed region "
-                                      "(the step's %d row ranges one after the other on one stream, so launches do not overlap)" % (nprof, nsub)}
+                              "share_of_step": dom["ms_per_step"] / max(tot_ms, 1e-9),
+                              "whole_step": {"sum_kernel_ms": tot_ms, "alg_gflop": tot_gf, "mfma_frac": tot_gf / max(tot_ms, 1e-9) / PEAK_BF16_TFLOPS},
+                              "note": "dominant class = most time per step; HIP events around every launch of the class on the launch stream, %d extra "
+                                      "steps after the timed region (the step's %d row ranges one after the other on one stream, so launches do not "
+                                      "overlap); kernel_classes lists every class against its own bound" % (nprof, nsub)}
         if flight:
             result["roofline"]["in_flight"] = {"event_bracket_ms": flight["ms_per_step"] / max(flight["launches_per_step"], 1),
                                                "note": "event pairs around the same launches with the %d row ranges in flight on %d streams, as in the timed "
@@ -309,7 +451,7 @@ def main():
         result["kernel_classes"] = per
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:      # reported at N = 1 only (task contract)
-        result["cpu_baseline"] = cpu_baseline(sd, plan, audio_np, lens_np)
+        result["cpu_baseline"] = cpu_baseline(sd, plan)
 
     if rank == 0:
         print(json.dumps(result))

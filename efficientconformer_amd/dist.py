@@ -1,19 +1,27 @@
 """Multi-GPU: utterances shard data-parallel, one process per GPU, RCCL all-gather of encoder outputs.
 
-The reference's only parallelism is data parallelism (DDP + DistributedSampler, reference main.py:33-35,
+The reference's only parallelism is data parallelism (DDP + DistributedSampler, reference main.py:33-35, 217-220,
 model_ctc.py:70-75, functions.py:167-170); in eval mode its encoder performs no collective at all and only
 decoded strings are gathered (model.py:463-466).  The path shards naturally along the batch: utterance b's
 output depends only on its own row and on the padded length (pad frames are live), so
 
   * rank r takes rows r::world of the length-sorted global batch (round-robin keeps shards length-balanced);
   * every shard keeps the GLOBAL padded length, so results are bit-equal to the unsharded run;
-  * one all-gather per forward of the (B_loc, T_out, D) outputs (+ lengths) — `backend="nccl"` is RCCL over
-    xGMI on ROCm — issued on a side stream so it overlaps the next batch's encoder kernels;
+  * every shard has ceil(B / world) rows (a short shard is filled with a copy of its last row), so all ranks
+    launch identical shapes and every collective is one fixed-size all_gather_into_tensor (the RCCL fast path);
+  * the encoder outputs are all-gathered PER SUB-BATCH ROW RANGE (`backend="nccl"` is RCCL over xGMI on ROCm):
+    `ConformerEncoder.forward(..., range_hook=...)` calls back as soon as a row range's last kernel is enqueued,
+    the collective of that range waits for an event on the range's stream and runs on a side ("comm") stream —
+    range 0 (higher stream priority) is on the wire while the later ranges are still in their last stage, and the
+    last range's collective overlaps the consumer's work on the earlier chunks;
+  * consumers (CTC head, RNN-T decode) work chunk by chunk on the gathered tensors (`Gathered.chunks`), or call
+    `Gathered.assemble()` for one (B, T, D) tensor in global order;
   * weights are replicated (<= 251 MB bf16), there is no other data-path collective.
 """
 from __future__ import annotations
 
-from typing import Callable, Optional, Tuple
+import inspect
+from typing import Callable, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -23,55 +31,128 @@ def shard_rows(batch: int, rank: int, world: int) -> torch.Tensor:
     return torch.arange(rank, batch, world) if rank < batch else torch.empty(0, dtype=torch.int64)
 
 
-def shard_batch(x: torch.Tensor, x_len: torch.Tensor, rank: int, world: int) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Rows rank::world of a (B, L) batch; L (the global pad length) is preserved on purpose."""
-    idx = shard_rows(x.shape[0], rank, world).to(x.device)
+def shard_size(batch: int, world: int) -> int:
+    return (batch + world - 1) // world
+
+
+def shard_batch(x: torch.Tensor, x_len: torch.Tensor, rank: int, world: int, uniform: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Rows rank::world of a (B, L) batch; L (the global pad length) is preserved on purpose.
+    uniform=True: ceil(B / world) rows on every rank (a short shard repeats its last row; the copy is dropped after the gather)."""
+    idx = shard_rows(x.shape[0], rank, world)
+    if uniform:
+        per = shard_size(x.shape[0], world)
+        fill = idx[-1:] if len(idx) else torch.zeros(1, dtype=torch.int64)
+        idx = torch.cat([idx] + [fill] * (per - len(idx)))
+    idx = idx.to(x.device)
     return x.index_select(0, idx).contiguous(), x_len.index_select(0, idx).contiguous()
 
 
-def all_gather_outputs(out: torch.Tensor, out_len: torch.Tensor, global_batch: int, group=None,
-                       wire_dtype: Optional[torch.dtype] = None) -> Tuple[torch.Tensor, torch.Tensor]:
-    """All-gather (B_loc, T, D) shard outputs into the global (B, T, D) order of ``shard_rows``.
+class GatheredChunk:
+    """Local rows [lo, hi) of every rank: `out` is (world * (hi - lo), T, D) in wire dtype, row r * (hi - lo) + j  <->  global row
+    (lo + j) * world + r (`rows`, entries >= global_batch are shard fill and are dropped by `keep`)."""
 
-    Shards may differ by one row when world does not divide B; they are padded to ceil(B/world) rows for the
-    collective (a single fixed-size all_gather_into_tensor — the RCCL fast path) and trimmed afterwards."""
-    world = dist.get_world_size(group)
-    per = (global_batch + world - 1) // world
-    wire = out if wire_dtype is None else out.to(wire_dtype)
-    pad = per - wire.shape[0]
-    if pad:
-        wire = torch.cat([wire, wire.new_zeros((pad,) + tuple(wire.shape[1:]))], 0)
-        out_len = torch.cat([out_len, out_len.new_zeros(pad)], 0)
-    gathered = wire.new_empty((world * per,) + tuple(wire.shape[1:]))
-    glen = out_len.new_empty(world * per)
-    dist.all_gather_into_tensor(gathered, wire.contiguous(), group=group)
-    dist.all_gather_into_tensor(glen, out_len.contiguous(), group=group)
-    # gathered row (r*per + i) is global row i*world + r
-    order = torch.arange(world * per, device=out.device).view(world, per).t().reshape(-1)[:global_batch]
-    return gathered.index_select(0, order), glen.index_select(0, order)
+    def __init__(self, lo, hi, out, out_len, rows, keep, event, comm):
+        self.lo, self.hi, self.out, self.out_len, self.rows, self.keep = lo, hi, out, out_len, rows, keep
+        self._event, self._comm = event, comm
+
+    def wait(self, stream: Optional["torch.cuda.Stream"] = None):
+        """Make `stream` (default: the current stream) wait for this chunk's collective; keeps the buffers alive for it."""
+        if self._event is None:
+            return self
+        stream = stream or torch.cuda.current_stream(self.out.device)
+        stream.wait_event(self._event)
+        self.out.record_stream(stream)
+        self.out_len.record_stream(stream)
+        return self
+
+
+class Gathered:
+    def __init__(self, chunks: List[GatheredChunk], global_batch: int):
+        self.chunks, self.global_batch = chunks, global_batch
+
+    def wait(self, stream=None):
+        for c in self.chunks:
+            c.wait(stream)
+        return self
+
+    def assemble(self, dtype: Optional[torch.dtype] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """One (B, T, D) tensor + (B,) lengths in global row order (waits for every chunk on the current stream)."""
+        self.wait()
+        c0 = self.chunks[0]
+        out = c0.out.new_empty((self.global_batch,) + tuple(c0.out.shape[1:]), dtype=dtype or c0.out.dtype)
+        out_len = c0.out_len.new_empty(self.global_batch)
+        for c in self.chunks:
+            out[c.rows[c.keep]] = c.out[c.keep].to(out.dtype)
+            out_len[c.rows[c.keep]] = c.out_len[c.keep]
+        return out, out_len
 
 
 class ShardedEncoder:
-    """encoder(x, x_len) on this rank's shard + all-gather on a side stream (when CUDA), global order restored."""
+    """encoder(x, x_len) on this rank's shard + per-row-range all-gather on a comm stream (CUDA), global order restored.
+
+    `encoder` is a `ConformerEncoder` (its `forward` accepts `range_hook`) or any callable `(x, x_len) -> (out, out_len, ...)`
+    (one range; CPU / gloo tests wrap the oracle this way).  `wire_dtype=None` sends the encoder's fp32 outputs unchanged, so
+    what a consumer computes from a gathered chunk is bit-identical to what the producing rank would compute locally;
+    `torch.bfloat16` halves the xGMI bytes."""
 
     def __init__(self, encoder: Callable, group=None, wire_dtype: Optional[torch.dtype] = None):
         self.encoder, self.group, self.wire_dtype = encoder, group, wire_dtype
-        self._side = None
+        self._comm: Optional["torch.cuda.Stream"] = None
+        fwd = getattr(encoder, "forward", encoder)
+        try:
+            self._hooked = "range_hook" in inspect.signature(fwd).parameters
+        except (TypeError, ValueError):
+            self._hooked = False
+        if self._hooked and hasattr(encoder, "stagger_ranges"):
+            encoder.stagger_ranges = True
 
-    def __call__(self, x: torch.Tensor, x_len: torch.Tensor):
-        rank, world = dist.get_rank(self.group), dist.get_world_size(self.group)
-        xs, ls = shard_batch(x, x_len, rank, world)
-        if xs.is_cuda and self._side is not None:
-            # the previous call's all-gather is complete before this call's mel kernel starts (normally it finished long ago under
-            # the caller's head): mel launches are kept away from other streams' kernels they were not swept against (DESIGN.md section 5)
-            torch.cuda.current_stream(xs.device).wait_stream(self._side)
-        out, out_len = self.encoder(xs, ls)[:2]
+    # ------------------------------------------------------------------ collective of one row range
+    def _gather_range(self, lo: int, hi: int, out: torch.Tensor, out_len: torch.Tensor, global_batch: int, chunks: list):
+        world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
+        n = hi - lo
+        rows = ((torch.arange(lo, hi).view(1, n)) * world + torch.arange(world).view(world, 1)).reshape(-1)
+        keep = rows < global_batch
         if out.is_cuda:
-            if self._side is None:
-                self._side = torch.cuda.Stream(device=out.device)
-            self._side.wait_stream(torch.cuda.current_stream(out.device))
-            with torch.cuda.stream(self._side):
-                res = all_gather_outputs(out, out_len, x.shape[0], self.group, self.wire_dtype)
-            self.pending = self._side          # caller: torch.cuda.current_stream().wait_stream(enc.pending) before use
-            return res
-        return all_gather_outputs(out, out_len, x.shape[0], self.group, self.wire_dtype)
+            dev = out.device
+            if self._comm is None:
+                self._comm = torch.cuda.Stream(device=dev)
+            done = torch.cuda.Event()
+            done.record(torch.cuda.current_stream(dev))          # the range's stream: its last kernel is enqueued
+            self._comm.wait_event(done)
+            with torch.cuda.stream(self._comm):
+                wire = out[lo:hi] if self.wire_dtype is None else out[lo:hi].to(self.wire_dtype)
+                wl = out_len[lo:hi]
+                out.record_stream(self._comm); out_len.record_stream(self._comm)   # read here, owned by the caller's stream
+                g = wire.new_empty((world * n,) + tuple(wire.shape[1:]))
+                gl = wl.new_empty(world * n)
+                dist.all_gather_into_tensor(g, wire.contiguous(), group=self.group)
+                dist.all_gather_into_tensor(gl, wl.contiguous(), group=self.group)
+                ev = torch.cuda.Event()
+                ev.record(self._comm)
+            chunks.append(GatheredChunk(lo, hi, g, gl, rows.to(dev), keep.to(dev), ev, self._comm))
+        else:
+            wire = out[lo:hi] if self.wire_dtype is None else out[lo:hi].to(self.wire_dtype)
+            g = wire.new_empty((world * n,) + tuple(wire.shape[1:]))
+            gl = out_len.new_empty(world * n)
+            dist.all_gather_into_tensor(g, wire.contiguous(), group=self.group)
+            dist.all_gather_into_tensor(gl, out_len[lo:hi].contiguous(), group=self.group)
+            chunks.append(GatheredChunk(lo, hi, g, gl, rows, keep, None, None))
+
+    # ------------------------------------------------------------------ entry points
+    def encode_shard(self, xs: torch.Tensor, ls: torch.Tensor, global_batch: Optional[int] = None) -> Gathered:
+        """This rank's rows (already selected; the same number of rows on every rank) -> gathered chunks of the global batch."""
+        world = dist.get_world_size(self.group)
+        gb = global_batch if global_batch is not None else xs.shape[0] * world
+        chunks: List[GatheredChunk] = []
+        if self._hooked:
+            self.encoder(xs, ls, range_hook=lambda lo, hi, out, out_len: self._gather_range(lo, hi, out, out_len, gb, chunks))
+        else:
+            out, out_len = self.encoder(xs, ls)[:2]
+            self._gather_range(0, out.shape[0], out, out_len, gb, chunks)
+        return Gathered(chunks, gb)
+
+    def __call__(self, x: torch.Tensor, x_len: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Global (B, L) batch (the same tensor on every rank) -> (B, T, D) outputs + lengths in global order."""
+        rank, world = dist.get_rank(self.group), dist.get_world_size(self.group)
+        xs, ls = shard_batch(x, x_len, rank, world, uniform=True)
+        return self.encode_shard(xs, ls, x.shape[0]).assemble()

@@ -18,7 +18,7 @@ Differences from the reference, by design:
 from __future__ import annotations
 
 import ctypes as C
-from typing import Dict, List, Optional
+from typing import Callable, Dict, List, Optional
 
 import numpy as np
 import torch
@@ -88,6 +88,7 @@ class ConformerEncoder(nn.Module):
         self.blocks = nn.ModuleList([_BlockHolder(bp) for bp in plan.blocks])
         self._handle = None
         self._packed = False
+        self._packed_device = -1                  # the C library packs weights on the device that is current at pack time
         object.__setattr__(self, "_head", None)   # not a sub-module: keeps state_dict keys equal to the reference's
         self._ws: Dict[tuple, torch.Tensor] = {}
         # Sub-batch streams (opt-in here; bench.py runs with 2): `sub_batches = S > 1` runs a forward as S contiguous row ranges on concurrent HIP streams
@@ -100,6 +101,7 @@ class ConformerEncoder(nn.Module):
         # with any number of streams in flight.  One stream stays the default.
         self.sub_batches: Optional[int] = 1
         self.sub_batch_min = 64
+        self.stagger_ranges = False        # True: range 0's stream gets the higher priority (set by dist.ShardedEncoder)
         self._sub_streams: Dict[tuple, torch.cuda.Stream] = {}
         self.eval()
 
@@ -112,9 +114,17 @@ class ConformerEncoder(nn.Module):
     def repack(self):
         self._packed = False
 
+    def _param_device(self):
+        return self.linear.weight.device
+
     def set_option(self, name: str, value: int):
         """Forward a tuning / test option to the C library (see effconf_encoder_set_option)."""
-        self._ensure_packed()
+        dev = self._param_device()
+        if dev.type == "cuda":
+            with torch.cuda.device(dev):
+                self._ensure_packed()
+        else:
+            self._ensure_packed()
         _lib.check(_lib.load().effconf_encoder_set_option(self._handle, name.encode(), int(value)), "set_option(%s)" % name)
 
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
@@ -149,7 +159,8 @@ class ConformerEncoder(nn.Module):
         return cfg, blocks
 
     def _ensure_packed(self):
-        if self._packed:
+        dev = torch.cuda.current_device() if torch.cuda.is_available() else -1
+        if self._packed and self._packed_device == dev:
             return
         lib = _lib.load()
         if self._handle is not None:
@@ -175,6 +186,7 @@ class ConformerEncoder(nn.Module):
         _lib.check(lib.effconf_encoder_set_option(h, b"cache_pos_embeddings", 1), "set_option")
         self._ws.clear()
         self._packed = True
+        self._packed_device = dev
 
     def __del__(self):
         try:
@@ -198,7 +210,14 @@ class ConformerEncoder(nn.Module):
             _lib.check(_lib.load().effconf_encoder_set_option(self._handle, b"cache_pos_embeddings", 1), "set_option")
         return ws
 
-    def _run(self, x: torch.Tensor, x_len: Optional[torch.Tensor], from_audio: bool):
+    def _run(self, x: torch.Tensor, x_len: Optional[torch.Tensor], from_audio: bool, range_hook: Optional[Callable] = None):
+        if x.is_cuda:
+            # the C library allocates packed weights on, and launches on, the CURRENT device: make that the input's device
+            with torch.cuda.device(x.device):
+                return self._run_on_device(x, x_len, from_audio, range_hook)
+        return self._run_on_device(x, x_len, from_audio, range_hook)
+
+    def _run_on_device(self, x: torch.Tensor, x_len: Optional[torch.Tensor], from_audio: bool, range_hook: Optional[Callable]):
         if self.training:
             raise RuntimeError("efficientconformer_amd.ConformerEncoder is an inference path: call .eval()")
         if not x.is_cuda:
@@ -223,6 +242,8 @@ class ConformerEncoder(nn.Module):
         nsub = max(1, min(int(nsub), batch))
         if nsub == 1:
             launch(0, batch)
+            if range_hook is not None:
+                range_hook(0, batch, out, out_len)
         else:
             if from_audio:
                 # the whole batch's mel on the caller's stream (see __init__), then forward_mel per row range
@@ -237,35 +258,45 @@ class ConformerEncoder(nn.Module):
             for i in range(nsub):
                 key = (str(x.device), i)
                 if key not in self._sub_streams:
-                    self._sub_streams[key] = torch.cuda.Stream(device=x.device)
+                    # earlier row ranges get the higher priority: range 0 leaves the last stage first, so a `range_hook`
+                    # consumer (the all-gather of dist.ShardedEncoder) overlaps with the later ranges' last stage
+                    self._sub_streams[key] = torch.cuda.Stream(device=x.device, priority=-1 if (i == 0 and self.stagger_ranges) else 0)
                 st = self._sub_streams[key]
                 st.wait_stream(cur)                      # inputs (and anything queued before this forward) are ready
+                lo, hi = batch * i // nsub, batch * (i + 1) // nsub
                 with torch.cuda.stream(st):
-                    launch(batch * i // nsub, batch * (i + 1) // nsub)
-                    x.record_stream(st); lens.record_stream(st)
+                    launch(lo, hi)
+                    x.record_stream(st); lens.record_stream(st); out.record_stream(st); out_len.record_stream(st)
+                    if range_hook is not None:
+                        range_hook(lo, hi, out, out_len)     # called with the range's stream current: rows [lo, hi) of `out` are enqueued
                 streams.append(st)
             for st in streams:
                 cur.wait_stream(st)                      # joined: the caller continues on its own stream
         return out, (out_len if lens_given else None), [None] * len(self.plan.blocks)
 
-    def forward(self, x: torch.Tensor, x_len: Optional[torch.Tensor] = None):
+    def forward(self, x: torch.Tensor, x_len: Optional[torch.Tensor] = None, range_hook: Optional[Callable] = None):
         """x: (B, L) raw 16 kHz audio, x_len: (B,) samples -> (x (B, T_out, D_last), x_len, attentions)
-        (reference encoders.py:97-142)."""
-        return self._run(x, x_len, True)
+        (reference encoders.py:97-142).
 
-    def forward_mel(self, mel: torch.Tensor, mel_len: Optional[torch.Tensor] = None):
+        ``range_hook(lo, hi, out, out_len)`` (optional, not in the reference) is called once per sub-batch row range right after
+        that range's kernels were enqueued, with the range's HIP stream current: work enqueued from the hook (an all-gather of
+        ``out[lo:hi]``) starts when THAT range is done, while the other ranges are still in their last stage."""
+        return self._run(x, x_len, True, range_hook)
+
+    def forward_mel(self, mel: torch.Tensor, mel_len: Optional[torch.Tensor] = None, range_hook: Optional[Callable] = None):
         """Enter after AudioPreprocessing: mel (B, n_mels, Tm), lengths in frames (the parity boundary)."""
-        return self._run(mel, mel_len, False)
+        return self._run(mel, mel_len, False, range_hook)
 
     def mel_frontend(self, x: torch.Tensor, x_len: Optional[torch.Tensor] = None):
         """AudioPreprocessing.forward (reference modules.py:87-106) on the GPU."""
         lib = _lib.load()
-        self._ensure_packed()
         x = x.contiguous().float()
         tm = x.shape[1] // self.plan.hop_length + 1
-        mel = torch.empty(x.shape[0], self.plan.n_mels, tm, dtype=torch.float32, device=x.device)
-        _lib.check(lib.effconf_mel_frontend(self._handle, x.data_ptr(), x.shape[0], x.shape[1], mel.data_ptr(),
-                                            torch.cuda.current_stream(x.device).cuda_stream), "mel_frontend")
+        with torch.cuda.device(x.device):
+            self._ensure_packed()
+            mel = torch.empty(x.shape[0], self.plan.n_mels, tm, dtype=torch.float32, device=x.device)
+            _lib.check(lib.effconf_mel_frontend(self._handle, x.data_ptr(), x.shape[0], x.shape[1], mel.data_ptr(),
+                                                torch.cuda.current_stream(x.device).cuda_stream), "mel_frontend")
         if x_len is not None:
             x_len = torch.div(x_len, self.plan.hop_length, rounding_mode="floor") + 1
         return mel, x_len

@@ -39,8 +39,10 @@ class ModelCTC(nn.Module):
                    cfg.get("decoding_params"), cfg.get("model_name", "model"), tokenizer)
 
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
-        sd = {k.replace(".module.", "."): v for k, v in state_dict.items()        # DDP-saved checkpoints, model.py:367-370
-              if not k.startswith("encoder.preprocessing.")}
+        # strip the DDP / DataParallel infix first (model.py:367-370: "encoder.module.preprocessing.*" in a raw DDP state dict),
+        # then drop torchaudio's frontend buffers (the native frontend builds its own window / filterbank tables)
+        sd = {k.replace(".module.", "."): v for k, v in state_dict.items()}
+        sd = {k: v for k, v in sd.items() if not k.startswith("encoder.preprocessing.")}
         r = super().load_state_dict(sd, strict=strict, **kw)
         self.encoder.repack()
         return r
@@ -64,16 +66,22 @@ class ModelCTC(nn.Module):
 
     def _head(self, enc: torch.Tensor, enc_len: Optional[torch.Tensor], want_logits: bool = False):
         lib = _lib.load()
+        if not enc.is_cuda:
+            raise RuntimeError("efficientconformer_amd runs on a HIP device only (no CPU fallback)")
+        enc = enc.contiguous().float()
         b, t, _ = enc.shape
         if enc_len is None:
             enc_len = torch.full((b,), t, dtype=torch.int64, device=enc.device)
+        enc_len = enc_len.to(enc.device, torch.int64).contiguous()
         labels = torch.empty(b, t, dtype=torch.int32, device=enc.device)
         label_len = torch.empty(b, dtype=torch.int32, device=enc.device)
         logits = torch.empty(b, t, self.fc.out_features, dtype=torch.float32, device=enc.device) if want_logits else None
         ws = torch.empty(b * t * 4, dtype=torch.uint8, device=enc.device)
-        _lib.check(lib.effconf_ctc_greedy(self.encoder._handle, enc.data_ptr(), enc_len.data_ptr(), b, t, labels.data_ptr(),
-                                          label_len.data_ptr(), logits.data_ptr() if want_logits else None, ws.data_ptr(),
-                                          ws.numel(), torch.cuda.current_stream(enc.device).cuda_stream), "ctc_greedy")
+        with torch.cuda.device(enc.device):          # the C library launches on the current device
+            self.encoder._ensure_packed()
+            _lib.check(lib.effconf_ctc_greedy(self.encoder._handle, enc.data_ptr(), enc_len.data_ptr(), b, t, labels.data_ptr(),
+                                              label_len.data_ptr(), logits.data_ptr() if want_logits else None, ws.data_ptr(),
+                                              ws.numel(), torch.cuda.current_stream(enc.device).cuda_stream), "ctc_greedy")
         return logits, labels, label_len
 
     def greedy_labels(self, x: torch.Tensor, x_len: Optional[torch.Tensor], from_mel: bool = False) -> List[List[int]]:

@@ -80,8 +80,10 @@ class Transducer(nn.Module):
                    cfg.get("training_params"), cfg.get("decoding_params"), cfg.get("model_name", "model"), tokenizer)
 
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
-        sd = {k.replace(".module.", "."): v for k, v in state_dict.items()        # DDP-saved checkpoints, model.py:367-370
-              if not k.startswith("encoder.preprocessing.")}
+        # strip the DDP / DataParallel infix first (model.py:367-370: "encoder.module.preprocessing.*" in a raw DDP state dict),
+        # then drop torchaudio's frontend buffers (the native frontend builds its own window / filterbank tables)
+        sd = {k.replace(".module.", "."): v for k, v in state_dict.items()}
+        sd = {k: v for k, v in sd.items() if not k.startswith("encoder.preprocessing.")}
         r = super().load_state_dict(sd, strict=strict, **kw)
         self.encoder.repack()
         self._rnnt_packed = False
@@ -143,6 +145,10 @@ class Transducer(nn.Module):
         """Greedy RNN-T decode of encoder outputs f (B, T, Denc) fp32 on the GPU -> (tokens (B, max_tok) i32, token_len (B) i32)."""
         if not f.is_cuda:
             raise RuntimeError("efficientconformer_amd runs on a HIP device only (no CPU fallback)")
+        with torch.cuda.device(f.device):             # the C library allocates / launches on the current device
+            return self._decode_encoded(f, f_len)
+
+    def _decode_encoded(self, f: torch.Tensor, f_len: Optional[torch.Tensor]):
         self._ensure_rnnt()
         lib = _lib.load()
         f = f.contiguous().float()

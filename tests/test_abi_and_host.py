@@ -226,3 +226,43 @@ def test_pmc_summary_feeds_bench_traffic_only_for_the_profiled_command(tmp_path,
     for other in (dict(streams=1), dict(batch=128), dict(model="EfficientConformerCTCMedium")):
         a2 = types.SimpleNamespace(**{**vars(args), **other})
         assert bench.pmc_traffic(a2, pat) is None
+
+
+def _run_bench(argv, env_extra=None, timeout=240):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + argv, capture_output=True, text=True, timeout=timeout, env=env)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_gpus_flag_spawns_one_rank_per_gpu():
+    """`python bench.py --gpus 2` outside torchrun must start 2 ranks itself (the reference spawns one process per GPU:
+    main.py:217-220) and rank 0 prints ONE JSON line with n_gpus = 2; --dry-run takes the same launcher with gloo and no GPU."""
+    r, j = _run_bench(["--gpus", "2", "--dry-run", "--batch", "6"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len([l for l in r.stdout.splitlines() if l.startswith("{")]) == 1
+    assert j["n_gpus"] == 2 and j["dry_run"] and j["config"]["global_batch"] == 12 and j["padded_samples_equal_on_all_ranks"]
+    assert j["metric"] == "audio-frames/sec through encoder, EffConformerCTC-Small, 1/2/4/8 GPU"
+
+
+def test_bench_rejects_a_world_size_that_contradicts_gpus():
+    r, j = _run_bench(["--gpus", "1", "--dry-run"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
+
+
+def test_raw_ddp_state_dict_with_frontend_buffers_loads():
+    """A raw DDP state dict carries `encoder.module.preprocessing.*` torchaudio buffers (model.py:367-370 strips `.module.`):
+    the infix is stripped first, then the frontend buffers are dropped."""
+    cfg = named_config("Tiny")
+    m = ModelCTC.from_config(cfg)
+    sd = synth.make_state_dict(m.encoder.plan, 3, cfg["tokenizer_params"]["vocab_size"], prefix="encoder.")
+    ddp = {k.replace("encoder.", "encoder.module.", 1): torch.from_numpy(v) for k, v in sd.items()}
+    ddp["encoder.module.preprocessing.Spectrogram.window"] = torch.zeros(400)
+    ddp["encoder.module.preprocessing.MelScale.fb"] = torch.zeros(257, 80)
+    m.load_state_dict(ddp)                                   # strict
+    assert torch.equal(m.encoder.linear.weight, torch.from_numpy(sd["encoder.linear.weight"]))

@@ -10,7 +10,7 @@ import torch.multiprocessing as mp
 
 from efficientconformer_amd import named_config, synth
 from efficientconformer_amd.config import build_plan
-from efficientconformer_amd.dist import ShardedEncoder, shard_rows
+from efficientconformer_amd.dist import ShardedEncoder, shard_batch, shard_rows
 
 
 def _free_port():
@@ -33,6 +33,28 @@ def _worker(rank, world, port, q):
     full, full_len = enc(mel, lens)
     out, out_len = ShardedEncoder(enc)(mel, lens)
     ok = torch.equal(out, full) and torch.equal(out_len, full_len)
+
+    class Ranged:      # the ConformerEncoder protocol: forward(x, x_len, range_hook) calls back per sub-batch row range
+        def forward(self, m, l, range_hook=None):
+            o, ol = enc(m, l)
+            cut = (m.shape[0] + 1) // 2
+            for lo, hi in ((0, cut), (cut, m.shape[0])):
+                if hi > lo:
+                    range_hook(lo, hi, o, ol)
+            return o, ol, None
+        __call__ = forward
+    sh = ShardedEncoder(Ranged())
+    xs, ls = shard_batch(mel, lens, rank, world, uniform=True)
+    g = sh.encode_shard(xs, ls, mel.shape[0])
+    out2, out_len2 = g.assemble()
+    ok = ok and len(g.chunks) == 2 and torch.equal(out2, full) and torch.equal(out_len2, full_len)
+    # chunk rows map to global rows: a consumer working chunk by chunk (the CTC head in bench.py) sees every utterance once
+    seen = sorted(int(r) for c in g.chunks for r in c.rows[c.keep])
+    ok = ok and seen == list(range(mel.shape[0]))
+    for c in g.chunks:
+        ok = ok and torch.equal(c.out[c.keep], full[c.rows[c.keep]])
+    out3, _ = ShardedEncoder(enc, wire_dtype=torch.bfloat16)(mel, lens)
+    ok = ok and out3.dtype == torch.bfloat16 and torch.equal(out3, full.to(torch.bfloat16))
     q.put((rank, bool(ok), float((out - full).abs().max())))
     dist.barrier()
     dist.destroy_process_group()
