@@ -15,7 +15,14 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libeffconf.so")
-SOURCES = ["gemm.hip", "rsgemm.hip", "chain.hip", "norm.hip", "conv.hip", "sublinear.hip", "conv2.hip", "mel.hip", "ctc.hip", "rnnt.hip", "attention.hip", "encoder.hip"]
+SOURCES = ["gemm.hip", "rsgemm.hip", "chain.hip", "norm.hip", "conv.hip", "sublinear.hip", "conv2.hip", "mel.hip", "ctc.hip", "rnnt.hip", "attention.hip", "debug.hip", "encoder.hip"]
+# (source, object, extra flags): further compilations of a source under other flags
+# No packed-fp32 VALU instructions in product kernels: v_pk_{add,mul,fma}_f32 with an op_sel low-lane swizzle return wrong values
+# next to another wave's bf16 MFMA on gfx950 (measured: profiles/r2_mel_packed_fp32_hazard.txt; guard: tools/check_isa.py).
+# Cost of the flag for the whole library: 7.56 -> 7.60 ms per bench step.
+NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+DIAGNOSTIC_SOURCES = {"debug.hip"}        # the hazard reproducer needs the instructions it demonstrates
+VARIANT_OBJECTS = [("mel.hip", "mel_pk.o", ["-DMEL_PK_BUILD"])]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result",
          "-Wno-inline-asm"]   # rowstat.h clobbers m0 on purpose (LDS-DMA destination register)
 
@@ -42,22 +49,33 @@ def build(force: bool = False, verbose: bool = True) -> str:
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
 
-    def compile_one(src):
-        obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+    def compile_one(job):
+        src, objname, extra = job
+        obj = os.path.join(objdir, objname)
+        cmd = [hipcc] + FLAGS + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-4000:]))
         return obj
-    with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
-        objs = list(ex.map(compile_one, SOURCES))
+    jobs = [(s, s.replace(".hip", ".o"), [] if s in DIAGNOSTIC_SOURCES else NO_PACKED_FP32) for s in SOURCES] + VARIANT_OBJECTS
+    with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+        objs = list(ex.map(compile_one, jobs))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n%s" % r.stderr[-4000:])
     if verbose:
         print("built %s (%d KB)" % (LIB, os.path.getsize(LIB) // 1024))
+    check_isa()
     return LIB
+
+
+def check_isa() -> None:
+    """Fail the build if a product kernel carries a hazardous packed-fp32 form (tools/check_isa.py)."""
+    tool = os.path.join(HERE, "..", "tools", "check_isa.py")
+    r = subprocess.run([sys.executable, tool, LIB], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("ISA guard failed:\n%s" % (r.stdout[-3000:] + r.stderr[-1000:]))
 
 
 if __name__ == "__main__":

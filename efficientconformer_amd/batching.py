@@ -84,7 +84,9 @@ class FrontDoor:
             nxt = self._stage(waves, plan[k + 1]) if k + 1 < len(plan) else None       # copy of batch k+1 overlaps compute of k
             torch.cuda.current_stream(self.device).wait_event(ready)
             res = self.fn(dev, dlen)
+            # both were allocated on the copy stream and are consumed on the caller's stream
             dev.record_stream(torch.cuda.current_stream(self.device))
+            dlen.record_stream(torch.cuda.current_stream(self.device))
             for r, i in enumerate(idx):
                 out[i] = res[r]
             staged = nxt

@@ -987,6 +987,25 @@ int effconf_mel_frontend(EcEncoder* e, const float* audio, int32_t batch, int32_
     return 0;
 }
 
+int effconf_debug_mel(EcEncoder* e, int32_t variant, int32_t extra_lds, const float* audio, int32_t batch, int32_t n_samples, float* mel,
+                      uint32_t* counters, void* stream) {
+    if (!e || !e->finalized) return fail("encoder not finalized");
+    const int Tm = n_samples / e->cfg.hop_length + 1;
+    EC_TRY(launch_mel_debug(variant, extra_lds, audio, batch, n_samples, e->mel, e->cfg.n_fft, e->cfg.hop_length, e->cfg.n_mels, Tm,
+                            e->cfg.normalize, e->cfg.mean, e->cfg.std, mel, counters, (hipStream_t)stream));
+    return 0;
+}
+
+int effconf_debug_neighbour(int32_t kind, int32_t blocks, int32_t lds_bytes, int32_t iters, float* buf, size_t n_floats, void* stream) {
+    EC_TRY(launch_debug_neighbour(kind, blocks, lds_bytes, iters, buf, n_floats, (hipStream_t)stream));
+    return 0;
+}
+
+int effconf_debug_victim(int32_t kind, int32_t blocks, int32_t iters, float* out, void* stream) {
+    EC_TRY(launch_debug_victim(kind, blocks, iters, out, (hipStream_t)stream));
+    return 0;
+}
+
 int effconf_ctc_greedy(EcEncoder* e, const float* enc_out, const int64_t* out_len, int32_t batch, int32_t t_out,
                        int32_t* labels, int32_t* label_len, float* logits, void* workspace, size_t workspace_bytes, void* stream) {
     if (!e || !e->finalized) return fail("encoder not finalized");

@@ -145,6 +145,15 @@ struct MelTables {                 // device tables built once per encoder
 };
 int launch_mel(const float* audio, int B, int L, const MelTables& t, int n_fft, int hop, int n_mels, int Tm,
                int normalize, float mean, float std, float* mel, hipStream_t s);
+// diagnostics (tools/mel_repro.py): kernel variant (mel.hip), unused dynamic LDS per workgroup, counters dbg[8]
+int launch_mel_debug(int variant, int extra_lds, const float* audio, int B, int L, const MelTables& t, int n_fft, int hop, int n_mels,
+                     int Tm, int normalize, float mean, float std, float* mel, unsigned int* dbg, hipStream_t s);
+// synthetic single-resource neighbour kernels (debug.hip)
+int launch_debug_neighbour(int kind, int blocks, int lds_bytes, int iters, float* buf, size_t n, hipStream_t s);
+int launch_debug_victim(int kind, int blocks, int iters, float* out, hipStream_t s);
+// mel.hip compiled a second time WITH packed-fp32 VALU instructions (diagnostics: variant bit 8 = the hazardous round-1 kernel)
+int launch_mel_debug_pk(int variant, int extra_lds, const float* audio, int B, int L, const MelTables& t, int n_fft, int hop, int n_mels,
+                          int Tm, int normalize, float mean, float std, float* mel, unsigned int* dbg, hipStream_t s);
 
 // ---------------------------------------------------------------- lengths + CTC head  (ctc.hip)
 // stage lengths: mel frames -> per-stage frame counts (int32), final int64 out_len

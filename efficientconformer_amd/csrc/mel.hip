@@ -17,7 +17,21 @@
 //     of the (B, n_mels, Tm) output.
 #include "kernels.h"
 
-namespace {
+// libeffconf is compiled WITHOUT packed-fp32 VALU instructions (_build.py: -target-feature -packed-fp32-ops).  Measured on MI355X
+// (tools/mel_repro.py, tools/mel_repro2.py, profiles/r2_mel_packed_fp32_hazard.txt): v_pk_add_f32 / v_pk_mul_f32 whose `op_sel`
+// selects the HIGH half of a source pair for the low result lane - the forms the complex butterflies of this kernel compile to -
+// return wrong values while a bf16 MFMA of ANOTHER wave executes on the same SIMD.  That was round 1's "mel kernel next to another
+// stream's subsampling kernels" corruption.  MEL_PK_BUILD = a second compilation of this file WITH packed fp32, kept as diagnostic
+// variant 8 so that the reproducer can show the hazard; the product never launches it.
+#ifdef MEL_PK_BUILD
+#define launch_mel launch_mel_pk_unused
+#define launch_mel_debug launch_mel_debug_pk
+#define MEL_NS mel_pk_build
+#else
+#define MEL_NS
+#endif
+
+namespace MEL_NS {
 
 constexpr int NFFT = 512;
 constexpr int FRAMES_PER_BLOCK = 32;     // 4 waves x 4 iterations x 2 frames
@@ -58,15 +72,37 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Diagnostic variants (V != 0, tools/mel_repro.py; the product launches V = 0, whose code and LDS layout are unchanged):
+//   V & 1  canary words in front of and behind the per-wave exchange buffers, checked when the workgroup exits (dbg[0])
+//   V & 2  every wave-level hand-off verifies itself: own writes read back (dbg[1], [3], [5]) and every exchanged value read twice
+//          (dbg[2], [4], [6])
+//   V & 4  workgroup barriers instead of the wave-level hand-off
+__device__ __forceinline__ float2 reread(const float2* p) {           // a second, un-mergeable read of the same LDS word pair
+    const volatile float* q = reinterpret_cast<const volatile float*>(p);
+    return make_float2(q[0], q[1]);
+}
+
+template <int V>
 __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ audio, int L, MelTables tb, int hop,
                                                   int n_mels, int Tm, int normalize, float mean, float inv_std,
-                                                  float* __restrict__ mel) {
-    __shared__ float2 sbuf[4][2][8 * P1];                        // per wave: exchange buffers A (step 1, Z) and B (step 2, power)
-    __shared__ float2 stw[NFFT];                                 // W512^m
-    __shared__ float swin[NFFT];
-    __shared__ float sout[MAX_MELS][FRAMES_PER_BLOCK + 1];
-    __shared__ float sfw[MAX_FBW];                               // packed triangular weights (a global load per tap made the
+                                                  float* __restrict__ mel, unsigned int* __restrict__ dbg) {
+    constexpr int CAN = (V & 1) ? 512 : 0;                       // canary words on each side of the exchange buffers
+    constexpr int O_SBUF = CAN * 4, O_POST = O_SBUF + 4 * 2 * 8 * P1 * 8, O_STW = O_POST + CAN * 4, O_SWIN = O_STW + NFFT * 8,
+                  O_SOUT = O_SWIN + NFFT * 4, O_SFW = O_SOUT + MAX_MELS * (FRAMES_PER_BLOCK + 1) * 4, O_END = O_SFW + MAX_FBW * 4;
+    __shared__ __attribute__((aligned(16))) char lds[O_END];
+    float2 (*sbuf)[2][8 * P1] = reinterpret_cast<float2 (*)[2][8 * P1]>(lds + O_SBUF);   // per wave: exchange buffers A (step 1, Z) and B (step 2, power)
+    float2* stw = reinterpret_cast<float2*>(lds + O_STW);        // W512^m
+    float* swin = reinterpret_cast<float*>(lds + O_SWIN);
+    float (*sout)[FRAMES_PER_BLOCK + 1] = reinterpret_cast<float (*)[FRAMES_PER_BLOCK + 1]>(lds + O_SOUT);
+    float* sfw = reinterpret_cast<float*>(lds + O_SFW);          // packed triangular weights (a global load per tap made the
                                                                  // rolled per-mel loop one L1 round trip per bin)
+    if constexpr ((V & 1) != 0) {
+        unsigned int* c0 = reinterpret_cast<unsigned int*>(lds), *c1 = reinterpret_cast<unsigned int*>(lds + O_POST);
+        for (int i = threadIdx.x; i < CAN; i += 256) { c0[i] = 0xC0FFEE00u + i; c1[i] = 0xBADC0DE0u + i; }
+    }
+    auto hand_off = [&]() __attribute__((always_inline)) { if constexpr ((V & 4) != 0) __syncthreads(); else wave_sync(); };
+    unsigned int bad[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto neq = [](float2 a, float2 b) { return (__float_as_uint(a.x) != __float_as_uint(b.x)) | (__float_as_uint(a.y) != __float_as_uint(b.y)); };
     const int tiles = (Tm + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK;
     const int b = blockIdx.x / tiles, t0 = (blockIdx.x % tiles) * FRAMES_PER_BLOCK;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -127,26 +163,49 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ audi
             const int n2 = lane >> 3;
             dft8(v);
 #pragma unroll
-            for (int k1 = 0; k1 < 8; ++k1) A[k1 * P1 + lane] = cmul(v[k1], stw[(8 * n2 * k1) & 511]);
+            for (int k1 = 0; k1 < 8; ++k1) { v[k1] = cmul(v[k1], stw[(8 * n2 * k1) & 511]); A[k1 * P1 + lane] = v[k1]; }
         }
-        wave_sync();
+        hand_off();
+        if constexpr ((V & 2) != 0) {
+#pragma unroll
+            for (int k1 = 0; k1 < 8; ++k1) bad[1] += neq(A[k1 * P1 + lane], v[k1]);
+        }
         // ---- step 2: lane = 8*k1 + n3; DFT over n2, twiddle W512^{n3 (k1 + 8 k2)}
         {
             const int k1 = lane >> 3, n3 = lane & 7;
 #pragma unroll
             for (int n2 = 0; n2 < 8; ++n2) v[n2] = A[k1 * P1 + n2 * 8 + n3];
+            if constexpr ((V & 2) != 0) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int n2 = 0; n2 < 8; ++n2) bad[2] += neq(reread(&A[k1 * P1 + n2 * 8 + n3]), v[n2]);
+            }
             dft8(v);
 #pragma unroll
-            for (int k2 = 0; k2 < 8; ++k2) B[n3 * P2 + k1 + 8 * k2] = cmul(v[k2], stw[(n3 * (k1 + 8 * k2)) & 511]);
+            for (int k2 = 0; k2 < 8; ++k2) { v[k2] = cmul(v[k2], stw[(n3 * (k1 + 8 * k2)) & 511]); B[n3 * P2 + k1 + 8 * k2] = v[k2]; }
         }
-        wave_sync();
+        hand_off();
+        if constexpr ((V & 2) != 0) {
+            const int k1 = lane >> 3, n3 = lane & 7;
+#pragma unroll
+            for (int k2 = 0; k2 < 8; ++k2) bad[3] += neq(B[n3 * P2 + k1 + 8 * k2], v[k2]);
+        }
         // ---- step 3: lane = k1 + 8*k2; DFT over n3 -> Z[lane + 64*k3]
 #pragma unroll
         for (int n3 = 0; n3 < 8; ++n3) v[n3] = B[n3 * P2 + lane];
+        if constexpr ((V & 2) != 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int n3 = 0; n3 < 8; ++n3) bad[4] += neq(reread(&B[n3 * P2 + lane]), v[n3]);
+        }
         dft8(v);
 #pragma unroll
         for (int k3 = 0; k3 < 8; ++k3) A[lane + 64 * k3] = v[k3];
-        wave_sync();
+        hand_off();
+        if constexpr ((V & 2) != 0) {
+#pragma unroll
+            for (int k3 = 0; k3 < 8; ++k3) bad[5] += neq(A[lane + 64 * k3], v[k3]);
+        }
         // ---- separate the two real spectra, power for bins 0..256 -> B (as floats: [0..256] frame a, [264..520] frame b)
         float* Pa = reinterpret_cast<float*>(B);
         float* Pb = Pa + 264;
@@ -155,13 +214,17 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ audi
             const int k = lane + 64 * j;
             if (k <= NFFT / 2) {
                 const float2 z = A[k], zc = A[(NFFT - k) & (NFFT - 1)];
+                if constexpr ((V & 2) != 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    bad[6] += neq(reread(&A[k]), z) + neq(reread(&A[(NFFT - k) & (NFFT - 1)]), zc);
+                }
                 const float ar = 0.5f * (z.x + zc.x), ai = 0.5f * (z.y - zc.y);     // X_a = (Z[k] + conj Z[N-k]) / 2
                 const float br = 0.5f * (z.y + zc.y), bi = 0.5f * (zc.x - z.x);     // X_b = (Z[k] - conj Z[N-k]) / 2i
                 Pa[k] = ar * ar + ai * ai;
                 Pb[k] = br * br + bi * bi;
             }
         }
-        wave_sync();
+        hand_off();
         // ---- sparse triangular filterbank + log for both frames
 #pragma unroll
         for (int mj = 0; mj < 2; ++mj) {
@@ -190,7 +253,7 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ audi
             sout[m][fl] = ya;
             sout[m][fl + 1] = yb;
         }
-        wave_sync();
+        hand_off();
     }
     __syncthreads();
     // ---- coalesced store: rows of FRAMES_PER_BLOCK consecutive frames
@@ -198,16 +261,46 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ audi
         const int m = i / FRAMES_PER_BLOCK, fl = i - m * FRAMES_PER_BLOCK;
         if (t0 + fl < Tm) mel[((size_t)b * n_mels + m) * Tm + t0 + fl] = sout[m][fl];
     }
+    if constexpr ((V & 1) != 0) {
+        const unsigned int* c0 = reinterpret_cast<const unsigned int*>(lds), *c1 = reinterpret_cast<const unsigned int*>(lds + O_POST);
+        for (int i = threadIdx.x; i < CAN; i += 256) bad[0] += (c0[i] != 0xC0FFEE00u + i) + (c1[i] != 0xBADC0DE0u + i);
+    }
+    if constexpr (V != 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) if (bad[i]) atomicAdd(dbg + i, bad[i]);
+    }
 }
 
 }  // namespace
+#ifdef MEL_PK_BUILD
+using namespace mel_pk_build;
+#endif
 
 int launch_mel(const float* audio, int B, int L, const MelTables& t, int n_fft, int hop, int n_mels, int Tm,
                int normalize, float mean, float std, float* mel, hipStream_t s) {
     if (B <= 0) return 0;
     if (n_fft != NFFT || n_mels > MAX_MELS || L <= n_fft / 2) return -2;
     const int tiles = (Tm + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK;
-    hipLaunchKernelGGL(mel_kernel, dim3(B * tiles), dim3(256), 0, s, audio, L, t, hop, n_mels, Tm, normalize, mean,
-                       1.0f / std, mel);
+    hipLaunchKernelGGL(mel_kernel<0>, dim3(B * tiles), dim3(256), 0, s, audio, L, t, hop, n_mels, Tm, normalize, mean,
+                       1.0f / std, mel, (unsigned int*)nullptr);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// diagnostics only (tools/mel_repro.py): kernel variant V, `extra_lds` bytes of unused dynamic LDS per workgroup, counters dbg[8]
+int launch_mel_debug(int variant, int extra_lds, const float* audio, int B, int L, const MelTables& t, int n_fft, int hop, int n_mels,
+                     int Tm, int normalize, float mean, float std, float* mel, unsigned int* dbg, hipStream_t s) {
+    if (B <= 0) return 0;
+    if (n_fft != NFFT || n_mels > MAX_MELS || L <= n_fft / 2) return -2;
+#ifndef MEL_PK_BUILD
+    if (variant & 8) return launch_mel_debug_pk(variant & 7, extra_lds, audio, B, L, t, n_fft, hop, n_mels, Tm, normalize, mean, std, mel, dbg, s);
+#endif
+    const int tiles = (Tm + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK;
+#define MEL_DBG_CASE(VV) case VV: { static LdsAttr attr; ensure_dynamic_lds(reinterpret_cast<const void*>(&mel_kernel<VV>), extra_lds, attr); \
+        hipLaunchKernelGGL(mel_kernel<VV>, dim3(B * tiles), dim3(256), extra_lds, s, audio, L, t, hop, n_mels, Tm, normalize, mean, 1.0f / std, mel, dbg); break; }
+    switch (variant) {
+        MEL_DBG_CASE(0) MEL_DBG_CASE(1) MEL_DBG_CASE(2) MEL_DBG_CASE(3) MEL_DBG_CASE(4) MEL_DBG_CASE(5) MEL_DBG_CASE(6) MEL_DBG_CASE(7)
+        default: return -2;
+    }
+#undef MEL_DBG_CASE
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

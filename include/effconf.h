@@ -164,6 +164,18 @@ int32_t effconf_encoder_trace_count(const EcEncoder* enc);
 int effconf_encoder_trace_entry(const EcEncoder* enc, int32_t i, char* name64, int64_t* offset, int64_t* rows, int64_t* cols,
                                 int64_t* ld, int32_t* dtype);
 
+/* ---- diagnostics (tools/mel_repro.py; not on the product path) ------------------------------ */
+/* effconf_mel_frontend with a diagnostic variant of mel_kernel (csrc/mel.hip: 1 canaries, 2 self-verifying hand-offs,
+ * 4 workgroup barriers, 8 the build WITH packed-fp32 VALU instructions = round 1's hazardous kernel; bits combine), `extra_lds` bytes of unused dynamic LDS per workgroup, and 8 u32 counters (dev). */
+int effconf_debug_mel(EcEncoder* enc, int32_t variant, int32_t extra_lds, const float* audio, int32_t batch, int32_t n_samples,
+                      float* mel, uint32_t* counters, void* stream);
+/* One synthetic kernel that loads a single compute-unit resource (csrc/debug.hip): kind 0 LDS 16-byte hammer, 1 VALU +
+ * transcendental, 2 global loads, 3 global stores, 4 MFMA, 5 LDS publish + barrier loop, 6 LDS 4-byte hammer. */
+int effconf_debug_neighbour(int32_t kind, int32_t blocks, int32_t lds_bytes, int32_t iters, float* buf, size_t n_floats, void* stream);
+/* One self-contained victim: 16 chains per lane of a single instruction class (0 v_fma_f32, 1 v_pk_fma_f32, 2 v_pk_mul/add_f32,
+ * 3 v_log/v_exp_f32, 4 v_mul/v_add_f32, 5 integer, 6 wave-local LDS exchange); out dev f32 (blocks * 256 * 16). */
+int effconf_debug_victim(int32_t kind, int32_t blocks, int32_t iters, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -125,9 +125,134 @@ def test_mel_frontend_vs_oracle():
     assert mel_len.cpu().tolist() == ref_len.tolist()
     d = (mel.cpu() - ref).abs()
     print("mel err max %.2e" % float(d.max()))
-    assert float(d.max()) < 2e-3 and float(d.mean()) < 2e-5
+    assert float(d.max()) < 4e-4 and float(d.mean()) < 2e-6       # both sides fp32 (each within 2e-4 of the float64 restatement)
     # zero-padded tail frames are exactly log(1e-9) (SURVEY.md 8a parity traps)
     assert torch.allclose(mel[2, :, 110:].cpu(), torch.full_like(mel[2, :, 110:].cpu(), float(np.log(np.float32(1e-9)))), atol=1e-5)
+
+
+def _mel_fp64(audio, n_fft=512, win=400, hop=160, n_mels=80, sr=16000):
+    """Independent float64 restatement of Spectrogram(power=2) + MelScale(htk, norm=None) + log(x + 1e-9): explicit framing,
+    numpy rfft in float64 (no torch.stft, no fp32 anywhere)."""
+    a = np.asarray(audio, dtype=np.float64)
+    pad = n_fft // 2
+    a = np.pad(a, ((0, 0), (pad, pad)), mode="reflect")
+    tm = (a.shape[1] - n_fft) // hop + 1
+    idx = np.arange(n_fft)[None, :] + hop * np.arange(tm)[:, None]
+    w = np.zeros(n_fft)
+    off = (n_fft - win) // 2
+    w[off:off + win] = 0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(win) / win)
+    spec = np.fft.rfft(a[:, idx] * w, axis=-1)
+    power = spec.real ** 2 + spec.imag ** 2                                   # (B, Tm, 257)
+    freqs = np.linspace(0.0, sr / 2, n_fft // 2 + 1)
+    mel = lambda f: 2595.0 * np.log10(1.0 + f / 700.0)
+    m_pts = np.linspace(mel(0.0), mel(8000.0), n_mels + 2)
+    f_pts = 700.0 * (10.0 ** (m_pts / 2595.0) - 1.0)
+    down = (freqs[:, None] - f_pts[None, :-2]) / (f_pts[1:-1] - f_pts[:-2])[None, :]
+    up = (f_pts[None, 2:] - freqs[:, None]) / (f_pts[2:] - f_pts[1:-1])[None, :]
+    fb = np.maximum(0.0, np.minimum(down, up))                                # (257, n_mels)
+    return np.log(power @ fb + 1e-9).transpose(0, 2, 1)                       # (B, n_mels, Tm)
+
+
+def test_mel_frontend_vs_float64_dft():
+    """The mel kernel is all fp32: against an independent float64 DFT restatement it must hold 2e-4 abs in the log domain
+    (the fp32 oracle itself is within 2e-4 of the same float64 restatement: tests/test_oracle_golden.py)."""
+    m, _ = _model("Tiny", 7)
+    lens = np.array([48000, 31337, 16000, 2000], dtype=np.int64)
+    audio = synth.make_audio(lens, seed=11)
+    ref = _mel_fp64(audio)
+    mel, _ = m.encoder.mel_frontend(torch.from_numpy(audio).cuda(), torch.from_numpy(lens).cuda())
+    d = np.abs(mel.cpu().numpy().astype(np.float64) - ref)
+    print("mel vs float64 DFT: max %.2e mean %.2e" % (d.max(), d.mean()))
+    assert d.max() < 2e-4 and d.mean() < 2e-6
+
+
+def _dbg(lib_h):
+    from efficientconformer_amd import _lib
+    return _lib.load(), _lib
+
+
+def test_mel_kernel_is_bit_identical_next_to_mfma_kernels_of_another_stream():
+    """Round 1's corruption, named in round 2 (profiles/r2_mel_packed_fp32_hazard.txt): packed-fp32 VALU instructions with an op_sel
+    low-lane swizzle return wrong values while another wave's bf16 MFMA runs on the same SIMD.  libeffconf is built without packed
+    fp32; the product mel kernel must be bit-identical next to pure-MFMA aggressors on another stream (the diagnostic build WITH
+    packed fp32, variant 8, is reported for information)."""
+    m, _ = _model("EfficientConformerCTCSmall", 1)
+    enc = m.encoder
+    enc._ensure_packed()
+    lib, _lib = _dbg(enc)
+    lens = synth.libri_lengths(65, seed=3)
+    audio = torch.from_numpy(synth.make_audio(lens, seed=3)).cuda()
+    tm = audio.shape[1] // 160 + 1
+    s0, s1 = torch.cuda.Stream(), torch.cuda.Stream()
+    nbuf = torch.zeros(1 << 20, dtype=torch.float32, device="cuda")
+
+    def mel(variant, stream):
+        out = torch.empty(65, 80, tm, dtype=torch.float32, device="cuda")
+        cnt = torch.zeros(8, dtype=torch.int32, device="cuda")
+        _lib.check(lib.effconf_debug_mel(enc._handle, variant, 0, audio.data_ptr(), 65, audio.shape[1], out.data_ptr(), cnt.data_ptr(),
+                                         stream.cuda_stream), "debug_mel")
+        return out
+    with torch.cuda.stream(s1):
+        want = {v: mel(v, s1) for v in (0, 8)}
+    torch.cuda.synchronize()
+    assert torch.equal(want[0], enc.mel_frontend(audio)[0])          # variant 0 IS the product kernel
+    report = {}
+    for kind in (4, 9, 10):                                            # bf16 32x32x16, bf16 16x16x32, 50 % duty
+        for v in (0, 8):
+            diffs = 0
+            for _ in range(3):
+                g = torch.cuda.Event(); g.record(); s0.wait_event(g); s1.wait_event(g)
+                with torch.cuda.stream(s0):
+                    _lib.check(lib.effconf_debug_neighbour(kind, 4096, 0, 300, nbuf.data_ptr(), nbuf.numel(), s0.cuda_stream), "neighbour")
+                with torch.cuda.stream(s1):
+                    torch.cuda._sleep(400_000)
+                    got = mel(v, s1)
+                torch.cuda.synchronize()
+                diffs += int((got != want[v]).sum())
+            report[(kind, v)] = diffs
+    print("differing mel elements next to MFMA aggressors {(aggressor kind, variant): count}:", report)
+    assert all(n == 0 for (kind, v), n in report.items() if v == 0), report
+
+
+def test_two_independent_forwards_from_audio_on_two_streams_are_bit_identical():
+    """Two INDEPENDENT effconf_encoder_forward calls (from audio, each with its own mel kernel) in flight on two streams, 30 start
+    offsets: both must equal their serial runs bit for bit (outputs, lengths, labels)."""
+    m, _ = _model("EfficientConformerCTCSmall", 1)
+    enc = m.encoder
+    enc.sub_batches = 1
+    lens = synth.libri_lengths(129, seed=229)
+    lens[-1] = 2000
+    audio = torch.from_numpy(synth.make_audio(lens, seed=129)).cuda()
+    ln = torch.from_numpy(lens).cuda()
+    a0, l0, a1, l1 = audio[:64].contiguous(), ln[:64].contiguous(), audio[64:].contiguous(), ln[64:].contiguous()
+    s0, s1 = torch.cuda.Stream(), torch.cuda.Stream()
+
+    def run(a, l):
+        out, out_len, _ = enc(a, l)
+        _, labels, label_len = m._head(out, out_len)
+        return out, out_len, labels, label_len
+    with torch.cuda.stream(s0):
+        want0 = run(a0, l0)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s1):
+        want1 = run(a1, l1)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); torch.cuda._sleep(10_000_000); e1.record(); torch.cuda.synchronize()
+    cyc_per_ms = 10_000_000 / e0.elapsed_time(e1)
+    bad = []
+    for d in range(30):
+        g = torch.cuda.Event(); g.record(); s0.wait_event(g); s1.wait_event(g)
+        with torch.cuda.stream(s0):
+            torch.cuda._sleep(int(0.05 * cyc_per_ms))
+            got0 = run(a0, l0)
+        with torch.cuda.stream(s1):
+            torch.cuda._sleep(int((0.02 + 0.07 * d) * cyc_per_ms))
+            got1 = run(a1, l1)
+        torch.cuda.synchronize()
+        if not all(torch.equal(x, y) for x, y in zip(got0 + got1, want0 + want1)):
+            bad.append((d, int((got0[0] != want0[0]).sum()), int((got1[0] != want1[0]).sum())))
+    assert not bad, bad
 
 
 def test_audio_entry_and_none_lengths():
