@@ -185,11 +185,15 @@ _NAMED = {
     "EfficientConformerCTCSmall": ("CTC", _eff([120, 168, 240], 4, 15, [4, 9], 120), 256),
     "EfficientConformerCTCMedium": ("CTC", _eff([180, 256, 360], 4, 16, [4, 10], 180), 256),
     "EfficientConformerCTCLarge": ("CTC", _eff([360, 512, 720], 8, 16, [4, 10], 360), 256),
+    "EfficientConformerTransducerSmall": ("Transducer", _eff([100, 140, 200], 4, 15, [4, 9], 100), 1000),
     "EfficientConformerTransducerMedium": ("Transducer", _eff([180, 256, 360], 4, 15, [4, 9], 180), 1000),
     "EfficientConformerTransducerLarge": ("Transducer", _eff([360, 512, 720], 8, 15, [4, 9], 360), 1000),
     "ConformerCTCSmall": ("CTC", _plain(176, 4, 16), 256),
     "ConformerCTCMedium": ("CTC", _plain(256, 4, 18), 256),
     "ConformerCTCLarge": ("CTC", _plain(512, 8, 18), 256),
+    "ConformerTransducerSmall": ("Transducer", _plain(144, 6, 16), 1000),
+    "ConformerTransducerMedium": ("Transducer", _plain(256, 4, 16), 1000),
+    "ConformerTransducerLarge": ("Transducer", _plain(512, 8, 17), 1000),
     # not a shipped model: small dims for unit tests (exercises grouping, T % G != 0, both transitions)
     "Tiny": ("CTC", dict(_eff([24, 32, 48], 4, 6, [1, 3], 24), max_pos_encoding=2000), 32),
     # not a shipped model: the Small topology with widths whose per-head spans are 16-byte aligned (alignment experiments)
@@ -199,7 +203,8 @@ _NAMED = {
 
 # decoder_params["dim_model"] == joint_params["dim_model"] of the shipped Transducer configs
 # (reference configs/*Transducer*.json: 640 for Medium / Large, 320 for Small)
-_RNNT_DIM = {"EfficientConformerTransducerMedium": 640, "EfficientConformerTransducerLarge": 640, "TinyTransducer": 32}
+_RNNT_DIM = {"EfficientConformerTransducerSmall": 320, "EfficientConformerTransducerMedium": 640, "EfficientConformerTransducerLarge": 640,
+             "ConformerTransducerSmall": 320, "ConformerTransducerMedium": 640, "ConformerTransducerLarge": 640, "TinyTransducer": 32}
 
 
 def named_config(name: str) -> dict:

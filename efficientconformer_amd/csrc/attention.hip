@@ -117,7 +117,10 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 4 && DP <= 96) ? 2 : 1) void relp
 
     int nkeys = (p.lens[b] + p.G - 1) / p.G;          // unmasked key groups: G*j < lens[b]
     nkeys = nkeys < p.Tg ? nkeys : p.Tg;
-    nkeys = nkeys < 1 ? 1 : nkeys;
+    // an empty utterance (lens[b] = 0) has EVERY key masked: the reference adds -1e9 to all scores (attentions.py:698-701), which makes them
+    // equal in fp32, so its softmax is uniform over ALL Tg key groups - reproduced as scores * 0 over the full key range
+    const bool all_masked = nkeys < 1;
+    nkeys = all_masked ? p.Tg : nkeys;
     if constexpr (PROF) { asm volatile("s_nop 0" :: "s"(nkeys)); }
     AT_TICK(8);                                        // prologue a: arguments, tile indices, utterance length
 
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 4 && DP <= 96) ? 2 : 1) void relp
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_run = 0.f;
-    const float scale2 = p.scale * 1.44269504088896340736f;
+    const float scale2 = all_masked ? 0.f : p.scale * 1.44269504088896340736f;
     float* skew = sS + wave * 16 * SKEW_LD + c * SKEW_LD;
     const int woff = BI - 16 - 16 * wave;             // first band row of this wave inside the workgroup band
 

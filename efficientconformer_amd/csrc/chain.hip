@@ -612,8 +612,17 @@ void chain_prof_dump() {
 }  // namespace
 
 // LDS float-region layout shared by kernel, launcher and the packer (encoder.hip builds the constant block with it)
+// padded row width of the kernel instance launch_chain_kind picks for a width D (KS = 2, 4, 8, 12, 16 k-steps of 16 columns): the
+// constant block is laid out in THESE units.  (Round 1 used 32 * ceil(D / 32) here: equal for every CTC config shipped, but 160
+// instead of 192 for D = 140 / 144 - beta, v and every later array were read 32 floats off: EfficientConformerTransducerSmall,
+// ConformerTransducerSmall.)
+int chain_padded_width(int D) {
+    const int ks = 2 * ((D + 31) / 32);
+    return 16 * (ks <= 2 ? 2 : ks <= 4 ? 4 : ks <= 8 ? 8 : ks <= 12 ? 12 : 16);
+}
+
 int chain_const_layout(const ChainParams& p, int kind, int (&nf)[8]) {
-    const int DP = 32 * ((p.D + 31) / 32);
+    const int DP = chain_padded_width(p.D);
     const bool isb = kind == CHAIN_B, pre = kind == CHAIN_A_FULL || kind == CHAIN_A_TAIL, post = kind == CHAIN_A_FULL || kind == CHAIN_A_HEAD;
     int o = 0;
     nf[0] = o; o += (isb || pre) ? DP : 0;

@@ -15,13 +15,15 @@ __global__ void lengths_kernel(const int64_t* __restrict__ x_len, int B, int fro
                                const int* __restrict__ block_stride, int n_blocks, int* stage_lens, int64_t* out_len) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
+    // floor division as torch's `//` (modules.py:100, 243; encoders.py:139): an empty row (mel length 0) stays 0, it does not become 1
+    auto fdiv = [](long long a, long long d) { long long q = a / d; return (a % d != 0 && ((a < 0) != (d < 0))) ? q - 1 : q; };
     long long l = x_len[b];
-    if (from_audio) l = l / hop + 1;
-    for (int i = 0; i < sub_layers; ++i) l = (l - 1) / 2 + 1;
+    if (from_audio) l = fdiv(l, hop) + 1;
+    for (int i = 0; i < sub_layers; ++i) l = fdiv(l - 1, 2) + 1;
     stage_lens[b] = (int)l;                                  // lengths seen by block 0
     for (int k = 0; k < n_blocks; ++k) {
         const int s = block_stride[k];
-        if (s > 1) l = (l - 1) / s + 1;
+        if (s > 1) l = fdiv(l - 1, s) + 1;
         stage_lens[(size_t)(k + 1) * B + b] = (int)l;        // lengths after block k (= seen by block k+1)
     }
     if (out_len) out_len[b] = l;

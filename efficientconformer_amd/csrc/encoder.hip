@@ -97,6 +97,12 @@ struct EcEncoder {
     void e_cache_drop(const void* ws) {
         for (size_t i = 0; i < e_cache.size(); ++i) if (e_cache[i].ws == ws) { e_cache.erase(e_cache.begin() + i); break; }
     }
+    // fp32-operand "exact" mode (exact.hip): raw fp32 state-dict tensors on the device by key, fp32 sinusoid tables,
+    // per-layer BatchNorm scale / shift of the subsampling convs
+    bool exact_pack = false, exact_on = false;
+    std::map<std::string, const float*> xw;
+    std::map<std::pair<int, int>, const float*> xtab;
+    const float *xsub_scale[2] = {nullptr, nullptr}, *xsub_shift[2] = {nullptr, nullptr};
     // per-launch event profiler (bench / tuning only; off by default)
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev;          // pairs
@@ -638,6 +644,146 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
     return 0;
 }
 
+// ------------------------------------------------------------------ fp32-operand "exact" forward (kernels: exact.hip)
+struct XWorkspace { size_t total = 0, conv1, sub, x0, x1, a, h, q, k, v, e, o, p1, g, c, lens; };
+
+XWorkspace make_xworkspace(const EcEncoder* e, const Shapes& s) {
+    XWorkspace w;
+    size_t off = 0;
+    auto take = [&](size_t floats) { size_t o = off; off += al(floats * 4); return o; };
+    const size_t B = s.B;
+    size_t mx = 0, mh = 0, mq = 0, me = 0, mp = 0, mg = 0, mc = 0;
+    for (size_t k = 0; k < e->blocks.size(); ++k) {
+        const EcBlock& b = e->blocks[k];
+        const size_t T = s.Tin[k], To = s.Tout[k], D = b.dim_model, De = b.dim_expand;
+        const size_t Tp = ec_round_up((int)T, b.group_size);
+        mx = std::max(mx, std::max(B * T * D, B * To * De));
+        mh = std::max(mh, std::max(B * T * D, B * To * De) * b.ff_ratio);
+        mq = std::max(mq, B * Tp * D);
+        me = std::max(me, (2 * Tp - b.group_size) * D);
+        mp = std::max(mp, B * T * 2 * De);
+        mg = std::max(mg, B * T * De);
+        mc = std::max(mc, B * To * De);
+    }
+    const int L = e->cfg.sub_layers;
+    const size_t F1 = (e->cfg.n_mels - 1) / 2 + 1, T1 = (s.Tm - 1) / 2 + 1;
+    w.conv1 = take(L == 2 ? B * e->cfg.sub_filters[0] * F1 * T1 : 0);
+    int F = e->cfg.n_mels; for (int i = 0; i < L; ++i) F = (F - 1) / 2 + 1;
+    w.sub = take(B * s.T1 * (size_t)e->cfg.sub_filters[L - 1] * F);
+    w.x0 = take(mx); w.x1 = take(mx); w.a = take(mx); w.h = take(mh);
+    w.q = take(mq); w.k = take(mq); w.v = take(mq); w.e = take(me); w.o = take(mq);
+    w.p1 = take(mp); w.g = take(mg); w.c = take(mc);
+    w.lens = take((e->blocks.size() + 1) * B);
+    w.total = off;
+    return w;
+}
+
+const float* xget(EcEncoder* e, const std::string& k) {
+    auto it = e->xw.find(k);
+    return it == e->xw.end() ? nullptr : it->second;
+}
+
+int xgemm(EcEncoder* e, hipStream_t st, const float* A, int lda, int M, const std::string& prefix, int N, int K, float* C, int ldc, int epi = 0,
+          const float* R = nullptr, float alpha = 1.f, int a_rows = 0, int a_pitch = 0, int a_stride = 0, int c_rows = 0, int c_pitch = 0) {
+    ExGemmParams p{};
+    p.A = A; p.lda = lda; p.a_rows = a_rows; p.a_pitch = a_pitch; p.a_stride = a_stride;
+    p.W = xget(e, prefix + ".weight"); p.ldw = K; p.bias = xget(e, prefix + ".bias");
+    if (!p.W || !p.bias) return fail("exact mode: missing " + prefix);
+    p.M = M; p.N = N; p.K = K; p.C = C; p.ldc = ldc; p.c_rows = c_rows; p.c_pitch = c_pitch;
+    p.R = R; p.ldr = ldc; p.alpha = alpha; p.epi = epi;
+    PROF(PC_GEMM_OTHER, 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
+    return launch_ex_gemm(p, st);
+}
+
+int forward_core_exact(EcEncoder* e, const float* mel, const int64_t* in_len, int from_audio, const Shapes& s, const XWorkspace& w,
+                       char* ws, float* out, int64_t* out_len, hipStream_t st) {
+    const EcConfig& c = e->cfg;
+    const int B = s.B, nb = (int)e->blocks.size();
+    e->trace.clear(); e->trace_used = 0;
+    auto F32 = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
+    int* lens = reinterpret_cast<int*>(ws + w.lens);
+    EC_TRY(launch_lengths(in_len, B, from_audio, c.hop_length, c.sub_layers, e->block_stride, nb, lens, out_len, st));
+    if (from_audio) trace_add(e, st, "mel", mel, (int64_t)B * c.n_mels, s.Tm, s.Tm, 0);
+    // ---- Conv2dSubsampling (modules.py:232-249) + transpose + Linear (encoders.py:113-116)
+    float* sub = F32(w.sub);
+    const int C0 = c.sub_filters[0];
+    int Fl = c.n_mels, Cl = C0;
+    if (c.sub_layers == 1) {
+        EC_TRY(launch_ex_conv2d(mel, B, 1, c.n_mels, s.Tm, xget(e, "subsampling_module.layers.0.0.weight"), e->xsub_scale[0], e->xsub_shift[0], C0, sub, 1, st));
+        Fl = (c.n_mels - 1) / 2 + 1;
+    } else {
+        float* img = F32(w.conv1);
+        const int F1 = (c.n_mels - 1) / 2 + 1, T1 = (s.Tm - 1) / 2 + 1, C1 = c.sub_filters[1];
+        EC_TRY(launch_ex_conv2d(mel, B, 1, c.n_mels, s.Tm, xget(e, "subsampling_module.layers.0.0.weight"), e->xsub_scale[0], e->xsub_shift[0], C0, img, 0, st));
+        EC_TRY(launch_ex_conv2d(img, B, C0, F1, T1, xget(e, "subsampling_module.layers.1.0.weight"), e->xsub_scale[1], e->xsub_shift[1], C1, sub, 1, st));
+        Fl = (F1 - 1) / 2 + 1; Cl = C1;
+    }
+    const int Ksub = Cl * Fl;
+    trace_add(e, st, "subsample", sub, (int64_t)B * s.T1, Ksub, Ksub, 0);
+    float* x = F32(w.x0);
+    float* xalt = F32(w.x1);
+    const int D0 = e->blocks[0].dim_model;
+    EC_TRY(xgemm(e, st, sub, Ksub, B * s.T1, "linear", D0, Ksub, x, D0));
+    trace_add(e, st, "linear", x, (int64_t)B * s.T1, D0, D0, 0);
+    float *a = F32(w.a), *hb = F32(w.h), *q = F32(w.q), *kk = F32(w.k), *v = F32(w.v), *eb = F32(w.e), *o = F32(w.o), *p1 = F32(w.p1), *g = F32(w.g),
+          *cb = F32(w.c);
+    char nm[64];
+    for (int k = 0; k < nb; ++k) {
+        const EcBlock& b = e->blocks[k];
+        const BlockW& W = e->bw[k];
+        const int T = s.Tin[k], To = s.Tout[k], D = b.dim_model, De = b.dim_expand, M = B * T, Mo = B * To;
+        const int G = b.group_size, H = b.num_heads, Tp = ec_round_up(T, G), Tg = Tp / G, d = G * D / H;
+        const std::string p = "blocks." + std::to_string(k);
+        // ---- x += 1/2 FFN1(LN(x))   (blocks.py:122; modules.py:385-392)
+        EC_TRY(launch_layernorm(x, M, D, W.ln_ffn1.g, W.ln_ffn1.b, a, nullptr, 0, nullptr, nullptr, st));
+        EC_TRY(xgemm(e, st, a, D, M, p + ".feed_forward_module1.layers.1", D * b.ff_ratio, D, hb, D * b.ff_ratio, 1));
+        EC_TRY(xgemm(e, st, hb, D * b.ff_ratio, M, p + ".feed_forward_module1.layers.4", D, D * b.ff_ratio, x, D, 2, x, 0.5f));
+        snprintf(nm, sizeof(nm), "blocks.%d.x_ffn1", k); trace_add(e, st, nm, x, M, D, D, 0);
+        // ---- x += MHSA(LN(x))   (blocks.py:125-126; attentions.py:549-718)
+        const std::string m = p + ".multi_head_self_attention_module";
+        EC_TRY(launch_layernorm(x, M, D, W.ln_att.g, W.ln_att.b, a, nullptr, 0, nullptr, nullptr, st));
+        if (Tp != T) {      // chunk padding: zero rows AFTER the projections (attentions.py:107-138, 671)
+            if (hipMemsetAsync(q, 0, (size_t)B * Tp * D * 4, st) != hipSuccess || hipMemsetAsync(kk, 0, (size_t)B * Tp * D * 4, st) != hipSuccess ||
+                hipMemsetAsync(v, 0, (size_t)B * Tp * D * 4, st) != hipSuccess) return fail("memset failed");
+        }
+        EC_TRY(xgemm(e, st, a, D, M, m + ".mhsa.query_layer", D, D, q, D, 0, nullptr, 1.f, 0, 0, 0, T, Tp));
+        EC_TRY(xgemm(e, st, a, D, M, m + ".mhsa.key_layer", D, D, kk, D, 0, nullptr, 1.f, 0, 0, 0, T, Tp));
+        EC_TRY(xgemm(e, st, a, D, M, m + ".mhsa.value_layer", D, D, v, D, 0, nullptr, 1.f, 0, 0, 0, T, Tp));
+        if (Tp > b.max_pos) return fail("sequence longer than max_pos_encoding");
+        const float* tab = e->xtab[std::make_pair(b.max_pos, D)];
+        EC_TRY(xgemm(e, st, tab + (size_t)(b.max_pos - Tp + G / 2) * D, D, 2 * Tp - G, m + ".mhsa.pos_layer", D, D, eb, D));
+        ExAttnParams ap{};
+        ap.q = q; ap.k = kk; ap.v = v; ap.e = eb; ap.u = W.u; ap.vb = W.v; ap.lens = lens + (size_t)k * B;
+        ap.B = B; ap.H = H; ap.T = T; ap.Tp = Tp; ap.G = G; ap.D = D; ap.d = d; ap.Tg = Tg; ap.out = o;
+        { PROF(PC_ATTENTION, 2.0 * B * H * (double)Tg * Tg * d * 3.0, (double)M * D * 4 * 5); EC_TRY(launch_ex_attention(ap, st)); }
+        EC_TRY(xgemm(e, st, o, D, M, m + ".mhsa.output_layer", D, D, x, D, 2, x, 1.0f, T, Tp, 1));
+        snprintf(nm, sizeof(nm), "blocks.%d.x_mhsa", k); trace_add(e, st, nm, x, M, D, D, 0);
+        // ---- x = conv_res(x) + ConvModule(x)   (blocks.py:129; modules.py:511-522)
+        const std::string cm = p + ".convolution_module.layers";
+        EC_TRY(launch_layernorm(x, M, D, W.ln_conv.g, W.ln_conv.b, a, nullptr, 0, nullptr, nullptr, st));
+        EC_TRY(xgemm(e, st, a, D, M, cm + ".2", 2 * De, D, p1, 2 * De));
+        EC_TRY(launch_ex_glu(p1, M, De, g, st));
+        EC_TRY(launch_ex_dwconv(g, B, T, To, De, W.dw_w, W.dw_b, b.kernel_size, b.conv_stride, cb, st));
+        if (D != De) {      // 1x1 strided conv on frames 0, s, 2s, ...  (blocks.py:106-110)
+            EC_TRY(xgemm(e, st, x, D, Mo, p + ".conv_res.1", De, D, xalt, De, 0, nullptr, 1.f, To, T, b.conv_stride));
+            std::swap(x, xalt);
+        } else if (b.conv_stride > 1) {
+            return fail("strided block without expansion is not native (no shipped config uses it)");
+        }
+        EC_TRY(xgemm(e, st, cb, De, Mo, cm + ".7", De, De, x, De, 2, x, 1.0f));
+        snprintf(nm, sizeof(nm), "blocks.%d.x_conv", k); trace_add(e, st, nm, x, Mo, De, De, 0);
+        // ---- x += 1/2 FFN2(LN(x)); x = LN(x)   (blocks.py:132-135)
+        EC_TRY(launch_layernorm(x, Mo, De, W.ln_ffn2.g, W.ln_ffn2.b, a, nullptr, 0, nullptr, nullptr, st));
+        EC_TRY(xgemm(e, st, a, De, Mo, p + ".feed_forward_module2.layers.1", De * b.ff_ratio, De, hb, De * b.ff_ratio, 1));
+        EC_TRY(xgemm(e, st, hb, De * b.ff_ratio, Mo, p + ".feed_forward_module2.layers.4", De, De * b.ff_ratio, x, De, 2, x, 0.5f));
+        float* xo = (k == nb - 1) ? out : xalt;
+        EC_TRY(launch_layernorm(x, Mo, De, W.ln_out.g, W.ln_out.b, xo, nullptr, 0, nullptr, nullptr, st));
+        if (k != nb - 1) std::swap(x, xalt);
+        snprintf(nm, sizeof(nm), "blocks.%d.out", k); trace_add(e, st, nm, xo, Mo, De, De, 0);
+    }
+    return 0;
+}
+
 }  // namespace
 
 // =================================================================== C ABI
@@ -891,7 +1037,7 @@ int effconf_encoder_finalize(EcEncoder* e) {
             cp.g1.nchunks = isb ? pre->c_pw1_chunks : (post ? post->c_qkv_chunks : 0);
             int nf[8];
             const int nfl = chain_const_layout(cp, kind, nf);
-            const int DP = 32 * ((dim + 31) / 32);
+            const int DP = chain_padded_width(dim);
             std::vector<float> blk(nfl, 0.f);
             auto put = [&](int off, const std::vector<float>& src, int n) { for (int i = 0; i < n && i < (int)src.size(); ++i) blk[off + i] = src[i]; };
             if (isb) {
@@ -933,6 +1079,31 @@ int effconf_encoder_finalize(EcEncoder* e) {
         }
     }
     if (!build_mel_tables(e, &err)) return fail(err);
+    e->xw.clear(); e->xtab.clear();
+    if (e->exact_pack) {       // fp32-operand mode: the reference-layout fp32 tensors themselves, fp32 sinusoid tables, BatchNorm scale / shift
+        for (auto& kv : e->host) e->xw[kv.first] = upload(e, kv.second.data);
+        for (int l = 0; l < c.sub_layers; ++l) {
+            const std::string sp = "subsampling_module.layers." + std::to_string(l);
+            const int C = c.sub_filters[l];
+            const HostTensor* cbias = find(e, sp + ".0.bias");
+            std::vector<float> sc, sh;
+            if (!cbias || (int)cbias->data.size() != C || !bn_fold(e, sp + ".1", C, &sc, &sh, &err)) return fail("exact mode: " + err);
+            for (int ch = 0; ch < C; ++ch) sh[ch] += cbias->data[ch] * sc[ch];
+            e->xsub_scale[l] = upload(e, sc); e->xsub_shift[l] = upload(e, sh);
+        }
+        for (const EcBlock& b : e->blocks) {
+            auto key = std::make_pair(b.max_pos, b.dim_model);
+            if (e->xtab.count(key)) continue;
+            const int rows = 2 * b.max_pos - 1, D = b.dim_model;
+            std::vector<float> t((size_t)rows * D, 0.f), denom(D / 2);
+            for (int i = 0; i < D / 2; ++i) denom[i] = std::pow(10000.0f, (2.0f * (float)i) / (float)D);
+            for (int r = 0; r < rows; ++r) {
+                const float pos = (float)(b.max_pos - 1 - r);
+                for (int i = 0; i < D / 2; ++i) { const float a = pos / denom[i]; t[(size_t)r * D + 2 * i] = std::sin(a); t[(size_t)r * D + 2 * i + 1] = std::cos(a); }
+            }
+            e->xtab[key] = upload(e, t);
+        }
+    }
     for (void* p : e->allocs) if (!p) return fail("device allocation failed");
     if (hipDeviceSynchronize() != hipSuccess) return fail("upload failed");
     e->host.clear();
@@ -944,7 +1115,10 @@ int effconf_encoder_finalize(EcEncoder* e) {
 size_t effconf_encoder_workspace_bytes(const EcEncoder* e, int32_t batch, int32_t n, int32_t from_audio) {
     if (!e || batch <= 0 || n <= 0) return 0;
     const int Tm = from_audio ? n / e->cfg.hop_length + 1 : n;
-    return make_workspace(e, make_shapes(e, batch, Tm), from_audio != 0).total;
+    const Shapes s = make_shapes(e, batch, Tm);
+    size_t bytes = make_workspace(e, s, from_audio != 0).total;
+    if (e->exact_pack) bytes = std::max(bytes, make_xworkspace(e, s).total + (from_audio ? al((size_t)batch * e->cfg.n_mels * Tm * 4) : 0));
+    return bytes;
 }
 
 int32_t effconf_encoder_out_frames(const EcEncoder* e, int32_t n, int32_t from_audio) {
@@ -958,6 +1132,11 @@ int effconf_encoder_forward_mel(EcEncoder* e, const float* mel, const int64_t* m
     if (!e || !e->finalized) return fail("encoder not finalized");
     if (!mel || !mel_len || !out || !workspace || batch <= 0 || n_frames <= 0) return fail("bad argument");
     const Shapes s = make_shapes(e, batch, n_frames);
+    if (e->exact_on) {
+        const XWorkspace xw = make_xworkspace(e, s);
+        if (workspace_bytes < xw.total) return fail("workspace too small");
+        return forward_core_exact(e, mel, mel_len, 0, s, xw, reinterpret_cast<char*>(workspace), out, out_len, (hipStream_t)stream);
+    }
     const Workspace w = make_workspace(e, s, false);
     if (workspace_bytes < w.total) return fail("workspace too small");
     return forward_core(e, mel, mel_len, 0, s, w, reinterpret_cast<char*>(workspace), out, out_len, (hipStream_t)stream);
@@ -969,6 +1148,15 @@ int effconf_encoder_forward(EcEncoder* e, const float* audio, const int64_t* x_l
     if (!audio || !x_len || !out || !workspace || batch <= 0 || n_samples <= e->cfg.n_fft / 2) return fail("bad argument");
     const int Tm = n_samples / e->cfg.hop_length + 1;
     const Shapes s = make_shapes(e, batch, Tm);
+    if (e->exact_on) {       // mel at the tail of the exact workspace (the mel kernel is fp32 in both modes)
+        const XWorkspace xw = make_xworkspace(e, s);
+        if (workspace_bytes < xw.total + al((size_t)batch * e->cfg.n_mels * Tm * 4)) return fail("workspace too small");
+        char* ws = reinterpret_cast<char*>(workspace);
+        float* mel = reinterpret_cast<float*>(ws + xw.total);
+        hipStream_t st = (hipStream_t)stream;
+        EC_TRY(launch_mel(audio, batch, n_samples, e->mel, e->cfg.n_fft, e->cfg.hop_length, e->cfg.n_mels, Tm, e->cfg.normalize, e->cfg.mean, e->cfg.std, mel, st));
+        return forward_core_exact(e, mel, x_len, 1, s, xw, ws, out, out_len, st);
+    }
     const Workspace w = make_workspace(e, s, true);
     if (workspace_bytes < w.total) return fail("workspace too small");
     char* ws = reinterpret_cast<char*>(workspace);
@@ -1024,6 +1212,12 @@ int effconf_encoder_set_option(EcEncoder* e, const char* name, int32_t value) {
     if (!strcmp(name, "fuse_subsample")) { e->fuse_subsample = value != 0; return 0; }
     if (!strcmp(name, "fuse_chain")) { e->fuse_chain = value != 0; return 0; }
     if (!strcmp(name, "cache_pos_embeddings")) { e->e_cache_on = value != 0; e->e_cache.clear(); return 0; }
+    if (!strcmp(name, "exact_fp32")) {
+        if (!e->finalized) { e->exact_pack = e->exact_on = value != 0; return 0; }
+        if (value && !e->exact_pack) return fail("exact_fp32 must be requested before effconf_encoder_finalize (the fp32 weights are uploaded there)");
+        e->exact_on = value != 0;
+        return 0;
+    }
     return fail(std::string("unknown option ") + name);
 }
 

@@ -1,0 +1,205 @@
+// fp32-operand ("exact") kernels: the opt-in precision mode of libeffconf (effconf_encoder_set_option "exact_fp32").
+//
+// The product path rounds MFMA operands to bf16 (DESIGN.md numerics policy); on random-weight models a few per-frame top-2 logit
+// margins are smaller than that rounding, so greedy labels can flip.  This mode runs the same forward (reference
+// models/encoders.py:97-142, blocks.py:119-137, attentions.py:549-718, modules.py:232-249, 385-395, 511-525) with fp32 operands
+// end to end - fp32 MFMA (v_mfma_f32_32x32x2_f32: exact products, fp32 accumulation) for every GEMM, fp32 attention, fp32
+// convolutions, accurate expf / IEEE division for the sigmoids - so that label sequences are identical to the reference's CPU
+// fp32 path wherever its margins exceed fp32 summation-order noise (~1e-5).  It is a correctness mode, built simply: ~10x
+// slower than the bf16 path and not tuned.
+#include "kernels.h"
+
+namespace {
+
+__device__ __forceinline__ float ex_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+constexpr int XBM = 64, XBN = 64, XBK = 16, XPAD = 68;
+
+__global__ __launch_bounds__(256) void ex_gemm_kernel(ExGemmParams p) {
+    __shared__ float sA[XBK][XPAD], sB[XBK][XPAD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.x * XBM, n0 = blockIdx.y * XBN;
+    const int lrow = tid >> 2, kq = (tid & 3) * 4;
+    int am = m0 + lrow; am = am < p.M ? am : p.M - 1;
+    const long long arow = p.a_rows ? (long long)(am / p.a_rows) * p.a_pitch + (long long)(am % p.a_rows) * p.a_stride : am;
+    int bn = n0 + lrow; bn = bn < p.N ? bn : p.N - 1;
+    const float* ap = p.A + arow * p.lda;
+    const float* bp = p.W + (long long)bn * p.ldw;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int k0 = 0; k0 < p.K; k0 += XBK) {
+        const int k = k0 + kq;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+        if (k < p.K) { a = *reinterpret_cast<const float4*>(ap + k); b = *reinterpret_cast<const float4*>(bp + k); }
+        sA[kq + 0][lrow] = a.x; sA[kq + 1][lrow] = a.y; sA[kq + 2][lrow] = a.z; sA[kq + 3][lrow] = a.w;
+        sB[kq + 0][lrow] = b.x; sB[kq + 1][lrow] = b.y; sB[kq + 2][lrow] = b.z; sB[kq + 3][lrow] = b.w;
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < XBK; kk += 2) {
+            const float fa = sA[kk + (lane >> 5)][wm * 32 + (lane & 31)];
+            const float fb = sB[kk + (lane >> 5)][wn * 32 + (lane & 31)];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const int n = n0 + wn * 32 + (lane & 31);
+    if (n >= p.N) return;
+    const float bz = p.bias ? p.bias[n] : 0.f;
+    float* cbase = p.C;
+    int ncol = n;
+    if (p.split_cols > 0) { cbase += (size_t)(n / p.split_cols) * p.split_stride; ncol = n % p.split_cols; }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m >= p.M) continue;
+        float v = acc[r] + bz;
+        if (p.epi == 1) v = v * ex_sigmoid(v);
+        else if (p.epi == 2) v = p.R[(size_t)m * p.ldr + n] + p.alpha * v;
+        const long long crow = p.c_rows ? (long long)(m / p.c_rows) * p.c_pitch + m % p.c_rows : m;
+        cbase[crow * p.ldc + ncol] = v;
+    }
+}
+
+// 3x3 stride-2 pad-1 conv + BatchNorm(eval, as per-channel scale / shift with the conv bias folded in) + Swish  (modules.py:232-249)
+// in (B, Cin, F, T) -> out (B, Co, Fo, To), or flat = 1: (B, To, Co*Fo) with feature index co*Fo + fo (modules.py:247 + encoders.py:113)
+__global__ __launch_bounds__(256) void ex_conv2d_kernel(const float* __restrict__ in, int B, int Cin, int F, int T, const float* __restrict__ w,
+                                                        const float* __restrict__ scale, const float* __restrict__ shift, int Co, int Fo, int To,
+                                                        float* __restrict__ out, int flat) {
+    const long long total = (long long)B * Co * Fo * To;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int to = (int)(idx % To);
+        long long q = idx / To;
+        const int fo = (int)(q % Fo); q /= Fo;
+        const int co = (int)(q % Co);
+        const int b = (int)(q / Co);
+        float acc = 0.f;
+        for (int ci = 0; ci < Cin; ++ci) {
+            const float* ip = in + ((size_t)b * Cin + ci) * F * T;
+            const float* wp = w + ((size_t)co * Cin + ci) * 9;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int f = 2 * fo - 1 + i;
+                if (f < 0 || f >= F) continue;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int t = 2 * to - 1 + j;
+                    if (t < 0 || t >= T) continue;
+                    acc = fmaf(ip[(size_t)f * T + t], wp[i * 3 + j], acc);
+                }
+            }
+        }
+        float y = acc * scale[co] + shift[co];
+        y = y * ex_sigmoid(y);
+        if (flat) out[((size_t)b * To + to) * ((size_t)Co * Fo) + (size_t)co * Fo + fo] = y;
+        else out[(((size_t)b * Co + co) * Fo + fo) * To + to] = y;
+    }
+}
+
+__global__ __launch_bounds__(256) void ex_glu_kernel(const float* __restrict__ in, long long M, int N, float* __restrict__ out) {
+    const long long total = M * N;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const long long m = idx / N; const int n = (int)(idx % N);
+        const float a = in[m * 2 * N + n], g = in[m * 2 * N + N + n];
+        out[idx] = a * ex_sigmoid(g);                               // GLU over channels (activations.py:37-39)
+    }
+}
+
+// depthwise conv, k taps, "same" zero padding, stride s, BatchNorm folded into w_kc / bias, Swish (modules.py:516-518; layers.py:100, 122-136)
+__global__ __launch_bounds__(256) void ex_dwconv_kernel(const float* __restrict__ g, int B, int T, int To, int C, const float* __restrict__ w_kc,
+                                                        const float* __restrict__ bias, int ks, int stride, float* __restrict__ out) {
+    const long long total = (long long)B * To * C;
+    const int half = (ks - 1) / 2;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int c = (int)(idx % C);
+        const long long q = idx / C;
+        const int to = (int)(q % To), b = (int)(q / To);
+        float acc = 0.f;
+        for (int j = 0; j < ks; ++j) {
+            const int t = stride * to + j - half;
+            if (t >= 0 && t < T) acc = fmaf(w_kc[(size_t)j * C + c], g[((size_t)b * T + t) * C + c], acc);
+        }
+        const float y = acc + bias[c];
+        out[idx] = y * ex_sigmoid(y);
+    }
+}
+
+// one wave per (utterance, head, grouped query row): S = ((Q+u) K^T + (Q+v) E[Tg-1+j-i]^T) / sqrt(d), additive -1e9 key mask,
+// softmax, P V  (attentions.py:549-718; closed form SURVEY.md 8a-6)
+__global__ __launch_bounds__(64) void ex_attention_kernel(ExAttnParams p) {
+    extern __shared__ float sm[];
+    float* qu = sm;
+    float* qv = sm + p.d;
+    float* sc = sm + 2 * p.d;
+    const int i = blockIdx.x, h = blockIdx.y, b = blockIdx.z, lane = threadIdx.x;
+    const size_t row0 = ((size_t)b * p.Tp + (size_t)p.G * i) * p.D + (size_t)h * p.d;
+    for (int x = lane; x < p.d; x += 64) {
+        const int n = (h * p.d + x) % p.D;
+        const float q = p.q[row0 + x];
+        qu[x] = q + p.u[n];
+        qv[x] = q + p.vb[n];
+    }
+    __syncthreads();
+    const int len = p.lens[b];
+    const float rs = sqrtf((float)p.d);
+    float mx = -INFINITY;
+    for (int j = lane; j < p.Tg; j += 64) {
+        const float* kr = p.k + ((size_t)b * p.Tp + (size_t)p.G * j) * p.D + (size_t)h * p.d;
+        const float* er = p.e + (size_t)p.G * (p.Tg - 1 + j - i) * p.D + (size_t)h * p.d;
+        float s1 = 0.f, s2 = 0.f;
+        for (int x = 0; x < p.d; ++x) { s1 = fmaf(qu[x], kr[x], s1); s2 = fmaf(qv[x], er[x], s2); }
+        float s = (s1 + s2) / rs;
+        if (p.G * j >= len) s += -1e9f;                             // attentions.py:698-701 (additive mask, as the reference)
+        sc[j] = s;
+        mx = fmaxf(mx, s);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+    for (int j = lane; j < p.Tg; j += 64) { const float e = expf(sc[j] - mx); sc[j] = e; sum += e; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    __syncthreads();
+    for (int x = lane; x < p.d; x += 64) {
+        float acc = 0.f;
+        for (int j = 0; j < p.Tg; ++j) acc = fmaf(sc[j] / sum, p.v[((size_t)b * p.Tp + (size_t)p.G * j) * p.D + (size_t)h * p.d + x], acc);
+        p.out[row0 + x] = acc;
+    }
+}
+
+inline int grid_for(long long total) { long long g = (total + 255) / 256; return (int)(g < 1 ? 1 : (g > 65535 ? 65535 : g)); }
+
+}  // namespace
+
+int launch_ex_gemm(const ExGemmParams& p, hipStream_t s) {
+    if (p.M <= 0 || p.N <= 0) return 0;
+    if (p.K % 4 || p.lda % 4 || p.ldw % 4) return -2;
+    hipLaunchKernelGGL(ex_gemm_kernel, dim3((p.M + XBM - 1) / XBM, (p.N + XBN - 1) / XBN), dim3(256), 0, s, p);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_ex_conv2d(const float* in, int B, int Cin, int F, int T, const float* w, const float* scale, const float* shift, int Co,
+                     float* out, int flat, hipStream_t s) {
+    const int Fo = (F - 1) / 2 + 1, To = (T - 1) / 2 + 1;
+    hipLaunchKernelGGL(ex_conv2d_kernel, dim3(grid_for((long long)B * Co * Fo * To)), dim3(256), 0, s, in, B, Cin, F, T, w, scale, shift, Co, Fo, To, out, flat);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_ex_glu(const float* in, long long M, int N, float* out, hipStream_t s) {
+    if (M <= 0) return 0;
+    hipLaunchKernelGGL(ex_glu_kernel, dim3(grid_for(M * N)), dim3(256), 0, s, in, M, N, out);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_ex_dwconv(const float* g, int B, int T, int To, int C, const float* w_kc, const float* bias, int ks, int stride, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(ex_dwconv_kernel, dim3(grid_for((long long)B * To * C)), dim3(256), 0, s, g, B, T, To, C, w_kc, bias, ks, stride, out);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_ex_attention(const ExAttnParams& p, hipStream_t s) {
+    const size_t lds = (size_t)(2 * p.d + p.Tg) * 4;
+    if (lds > 64 * 1024) return -2;
+    hipLaunchKernelGGL(ex_attention_kernel, dim3(p.Tg, p.H, p.B), dim3(64), lds, s, p);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}

@@ -80,6 +80,7 @@ struct ChainParams {
 };
 enum { CHAIN_B = 0, CHAIN_A_FULL = 1, CHAIN_A_HEAD = 2, CHAIN_A_TAIL = 3 };   // HEAD: first block (no previous tail); TAIL: last block (no next head)
 bool chain_supported(int D);
+int chain_padded_width(int D);       // padded row width of the kernel instance used for width D (units of the constant block)
 int chain_const_layout(const ChainParams& p, int kind, int (&nf)[8]);   // float offsets of the constant block; returns its size in floats
 bool chain_head_supported(int D);   // FFN1 + Q/K/V half (chain A head / full)
 bool chain_tail_supported(int D);   // pointwise-2 + FFN2 + block norm half
@@ -132,6 +133,32 @@ int launch_conv2_igemm(const bf16_t* act1, int B, int F1, int T1, int Cp, const 
 // g (B, T, ld) bf16 -> (B, To, ld) bf16: depthwise conv k taps ("same" zero pad), stride s, folded BN, Swish
 int launch_dwconv(const bf16_t* g, int B, int T, int To, int C, int ld, const float* w_kc, const float* bias,
                   int ksize, int stride, bf16_t* out, hipStream_t s);
+
+// ---------------------------------------------------------------- fp32-operand "exact" mode  (exact.hip)
+struct ExGemmParams {              // C = epi(A W^T + bias), everything fp32 (v_mfma_f32_32x32x2_f32)
+    const float* A; int lda;
+    int a_rows, a_pitch, a_stride; // src_row(m) = a_rows ? (m / a_rows) * a_pitch + (m % a_rows) * a_stride : m
+    const float* W; int ldw;       // [N][K] row-major (reference nn.Linear / 1x1 Conv1d layout)
+    const float* bias;             // [N] or null
+    int M, N, K;
+    float* C; int ldc;
+    int c_rows, c_pitch;           // dst_row(m) = c_rows ? (m / c_rows) * c_pitch + m % c_rows : m
+    int split_cols; size_t split_stride;   // split_cols > 0: column n -> buffer C + (n / split_cols) * split_stride, column n % split_cols
+    const float* R; int ldr; float alpha;  // epi 2: C = R + alpha * (acc + bias)   (R may alias C)
+    int epi;                       // 0 plain, 1 Swish, 2 residual
+};
+int launch_ex_gemm(const ExGemmParams& p, hipStream_t s);
+int launch_ex_conv2d(const float* in, int B, int Cin, int F, int T, const float* w, const float* scale, const float* shift, int Co,
+                     float* out, int flat, hipStream_t s);
+int launch_ex_glu(const float* in, long long M, int N, float* out, hipStream_t s);
+int launch_ex_dwconv(const float* g, int B, int T, int To, int C, const float* w_kc, const float* bias, int ks, int stride, float* out, hipStream_t s);
+struct ExAttnParams {              // natural-layout fp32 Q, K, V [B*Tp][D], E [2Tp-G][D]; out [B*Tp][D]
+    const float *q, *k, *v, *e, *u, *vb;
+    const int* lens;
+    int B, H, T, Tp, G, D, d, Tg;
+    float* out;
+};
+int launch_ex_attention(const ExAttnParams& p, hipStream_t s);
 
 // ---------------------------------------------------------------- mel frontend  (mel.hip)
 struct MelTables {                 // device tables built once per encoder

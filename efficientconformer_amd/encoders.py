@@ -101,6 +101,8 @@ class ConformerEncoder(nn.Module):
         # with any number of streams in flight.  One stream stays the default.
         self.sub_batches: Optional[int] = 1
         self.sub_batch_min = 64
+        self._exact = False                # precision = "fp32": fp32-operand mode of the library (csrc/exact.hip)
+        self._exact_packed = False
         self.stagger_ranges = False        # True: range 0's stream gets the higher priority (set by dist.ShardedEncoder)
         self._sub_streams: Dict[tuple, torch.cuda.Stream] = {}
         self.eval()
@@ -113,6 +115,26 @@ class ConformerEncoder(nn.Module):
 
     def repack(self):
         self._packed = False
+
+    @property
+    def precision(self) -> str:
+        """"bf16" (default: bf16 MFMA operands, fp32 accumulation / residual stream) or "fp32": the library's exact mode - fp32
+        operands end to end, greedy label sequences identical to the reference's CPU fp32 path wherever its top-2 logit margins
+        exceed fp32 summation noise (reference model_ctc.py:99-133); about 10x slower."""
+        return "fp32" if self._exact else "bf16"
+
+    @precision.setter
+    def precision(self, value: str):
+        if value not in ("bf16", "fp32"):
+            raise ValueError("precision must be 'bf16' or 'fp32'")
+        want = value == "fp32"
+        if want == self._exact:
+            return
+        self._exact = want
+        if self._packed and (self._exact_packed or not want):
+            _lib.check(_lib.load().effconf_encoder_set_option(self._handle, b"exact_fp32", int(want)), "set_option(exact_fp32)")
+        else:
+            self._packed = False           # the fp32 tensors are uploaded at finalize: pack again
 
     def _param_device(self):
         return self.linear.weight.device
@@ -171,6 +193,9 @@ class ConformerEncoder(nn.Module):
         if not h:
             raise _lib.EffconfError("effconf_encoder_create: %s" % lib.effconf_last_error().decode())
         self._handle = h
+        if self._exact:
+            _lib.check(lib.effconf_encoder_set_option(h, b"exact_fp32", 1), "set_option(exact_fp32)")
+        self._exact_packed = self._exact
         tensors = dict(super().state_dict())
         if self._head is not None:
             tensors["fc.weight"], tensors["fc.bias"] = self._head.weight, self._head.bias

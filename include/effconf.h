@@ -145,7 +145,11 @@ int effconf_rnnt_greedy(EcRnnt* r, const float* enc_out, const int64_t* out_len,
  * workspace is freed and its address may be reused.  Host calls on one handle must not run concurrently (they only enqueue).
  * "fuse_subsample" (default 1): 0 selects the unfused conv-subsampling + Linear kernels (kept for tests / odd shapes).
  * "fuse_chain" (default 1): 0 runs every GEMM of a block as its own kernel instead of the fused row-local chains (chain.hip);
- *   with the debug trace this exposes the intermediate residual-stream states that otherwise only exist in registers. */
+ *   with the debug trace this exposes the intermediate residual-stream states that otherwise only exist in registers.
+ * "exact_fp32" (default 0): fp32-operand precision mode (csrc/exact.hip): every GEMM on fp32 MFMA, fp32 attention / convolutions,
+ *   so that greedy CTC label sequences equal the reference's CPU fp32 path (model_ctc.py:99-133) wherever its top-2 logit margins
+ *   exceed fp32 summation-order noise; ~10x slower than the default bf16-operand path.  Set to 1 BEFORE effconf_encoder_finalize
+ *   (the fp32 tensors are uploaded there; the workspace query then covers both modes); afterwards it toggles the mode per handle. */
 int effconf_encoder_set_option(EcEncoder* enc, const char* name, int32_t value);
 
 /* ---- per-launch event profiler (bench / tuning only) --------------------------------------- */

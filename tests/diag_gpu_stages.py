@@ -20,6 +20,12 @@ def main():
     sd = synth.make_state_dict(m.encoder.plan, 7, cfg["tokenizer_params"]["vocab_size"], prefix="encoder.")
     m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     m = m.cuda()
+    if len(sys.argv) > 3:
+        m.encoder.set_option("fuse_chain", int(sys.argv[3]))
+    if len(sys.argv) > 4:
+        m.encoder.set_option("fuse_subsample", int(sys.argv[4]))
+    if len(sys.argv) > 5:
+        m.encoder.precision = sys.argv[5]
     osd = {k[len("encoder."):] if k.startswith("encoder.") else k: v for k, v in sd.items()}
     lens = [tm, int(tm * 0.77), int(tm * 0.52)]
     mel, ln = synth.make_mel(3, 80, tm, lens, seed=4321 + tm)
@@ -34,7 +40,9 @@ def main():
         if k.startswith("blocks."):
             refs[k] = v.reshape(-1, v.shape[-1])
     for k, v in got.items():
-        if k in refs:
+        if k in refs and tuple(v.shape) != tuple(refs[k].shape):
+            print("%-22s shape %s vs ref %s" % (k, tuple(v.shape), tuple(refs[k].shape)))
+        elif k in refs:
             d = (v.double() - refs[k].double()).abs()
             print("%-22s shape %-14s max %.4e mean %.4e  refmax %.3f nan %d" % (
                 k, tuple(v.shape), d.max(), d.mean(), refs[k].abs().max(), int(torch.isnan(v).sum())))

@@ -286,3 +286,36 @@ def test_no_product_kernel_carries_a_hazardous_packed_fp32_form():
     assert all(packed == 0 and hazard == 0 for packed, hazard in product.values()), {n: v for n, v in product.items() if v[0] or v[1]}
     # the diagnostic build of the mel kernel (variant 8) is the one that carries the hazardous forms
     assert any(v[1] > 0 for k, v in rows.items() if "mel_pk_build" in names[k])
+
+
+SHIPPED = ["ConformerCTCSmall", "ConformerCTCMedium", "ConformerCTCLarge", "ConformerTransducerSmall", "ConformerTransducerMedium",
+           "ConformerTransducerLarge", "EfficientConformerCTCSmall", "EfficientConformerCTCMedium", "EfficientConformerCTCLarge",
+           "EfficientConformerTransducerSmall", "EfficientConformerTransducerMedium", "EfficientConformerTransducerLarge"]
+
+
+@pytest.mark.parametrize("name", SHIPPED)
+def test_every_shipped_config_has_a_name_and_a_plan(name):
+    """All 12 model configs the reference ships (configs/*.json) resolve by name; where the reference tree is present (build
+    container) the named config must equal the JSON file key for key on everything the hot path reads."""
+    import json
+    cfg = named_config(name)
+    plan = build_plan(cfg["encoder_params"])
+    assert len(plan.blocks) == cfg["encoder_params"]["num_blocks"]
+    path = os.path.join("/root/reference/configs", name + ".json")
+    if not os.path.exists(path):
+        return
+    ref = json.load(open(path))
+    ours, theirs = cfg["encoder_params"], ref["encoder_params"]
+    for k in ("arch", "num_blocks", "dim_model", "ff_ratio", "num_heads", "kernel_size", "conv_stride", "att_stride", "strided_blocks", "expand_blocks",
+              "att_group_size", "relative_pos_enc", "max_pos_encoding", "subsampling_module", "subsampling_layers", "subsampling_filters",
+              "sample_rate", "win_length_ms", "hop_length_ms", "n_fft", "n_mels", "normalize", "mean", "std"):
+        if k in theirs:
+            assert ours.get(k) == theirs[k], (name, k, ours.get(k), theirs[k])
+    assert cfg["tokenizer_params"]["vocab_size"] == ref["tokenizer_params"]["vocab_size"]
+    for sect in ("decoder_params", "joint_params"):
+        if sect in ref:
+            for k, v in cfg[sect].items():
+                assert ref[sect][k] == v, (name, sect, k)
+    p2 = build_plan(theirs)
+    assert [(b.dim_model, b.dim_expand, b.num_heads, b.kernel_size, b.group_size, b.conv_stride, b.max_pos) for b in plan.blocks] == \
+           [(b.dim_model, b.dim_expand, b.num_heads, b.kernel_size, b.group_size, b.conv_stride, b.max_pos) for b in p2.blocks]

@@ -281,7 +281,7 @@ def test_other_configs_vs_reference_golden(golden_dir, name, tm):
     assert out_len.cpu().tolist() == g["out_len"].tolist()
     mx, mean = _err(out[:, ::8].cpu(), torch.from_numpy(g["out_rows"]))
     print("%s err max %.4f mean %.5f" % (name, mx, mean))
-    assert mx < 0.15 and mean < 0.015
+    assert mx < OUT_MAX and mean < OUT_MEAN          # the stated tolerance of the bf16 path
 
 
 def test_batch_rows_are_independent_given_the_padded_length():
