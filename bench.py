@@ -61,6 +61,8 @@ def parse():
     ap.add_argument("--gather", default="outputs", choices=["outputs", "labels"],
                     help="N > 1: all-gather the encoder outputs before the CTC head (north_star) or the label ids after it")
     ap.add_argument("--wire", default="fp32", choices=["fp32", "bf16"], help="dtype of the gathered encoder outputs on xGMI")
+    ap.add_argument("--attention", type=int, default=-1, choices=[-1, 0, 1, 2],
+                    help="attention kernel: 0 attention.hip, 1 / 2 attention2.hip variants (-1: the library's default = 1)")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU work: build the batch plan, join the process group (gloo) and print the JSON skeleton (CPU tests)")
     return ap.parse_args()
@@ -302,6 +304,8 @@ def main():
     # Sub-batch streams live in the library's host layer (ConformerEncoder.sub_batches): the batch runs as `--streams` contiguous
     # row ranges on concurrent HIP streams and is joined before forward() returns.
     model.encoder.sub_batches = max(args.streams, 1)
+    if args.attention >= 0:
+        model.encoder.set_option("attention_v2", args.attention)
     sharded = head_stream = None
     if world > 1:
         from efficientconformer_amd.dist import ShardedEncoder

@@ -57,6 +57,7 @@ SIGNATURES = {
     "effconf_profile_enable": (C.c_int, [_P, _I32]),
     "effconf_profile_read": (C.c_int, [_P, _I32, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                        C.POINTER(C.c_double)]),
+    "effconf_relpos_attention": (C.c_int, [_P, _P, _P, _P, _F32P, _I32, _P, _I32, _I32, _I32, _I32, _I32, _P, _I32, _I32, _P]),
     "effconf_debug_mel": (C.c_int, [_P, _I32, _I32, _F32P, _I32, _I32, _F32P, _P, _P]),
     "effconf_debug_neighbour": (C.c_int, [_I32, _I32, _I32, _I32, _F32P, _SZ, _P]),
     "effconf_debug_victim": (C.c_int, [_I32, _I32, _I32, _F32P, _P]),

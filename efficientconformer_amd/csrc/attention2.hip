@@ -1,0 +1,448 @@
+// relpos_attention2_kernel: the second generation of the fused (grouped) relative-position attention (same math and the same
+// buffers as attention.hip: S[b,h,i,j] = (Qu_i . K_j + Qv_i . E[Tg-1+j-i]) / sqrt(d), key mask from lens[b], online softmax, P V;
+// reference models/attentions.py:549-718).
+//
+// Round 1's kernel (attention.hip) is instruction-issue bound: a wave owns 16 queries, so every K / E / V^T fragment it reads from
+// LDS feeds ONE 16x16x32 MFMA, V is transposed on the way into LDS (8 v_perm + 8 ds_write_b32 per 16-byte chunk), and its phase
+// profile shows the MFMA pipe 6 % busy (profiles/r1_14_phase_profiles.txt).  This kernel halves the instructions per query:
+//   * a wave owns 32 queries (two 16-query column tiles): every K fragment feeds two MFMAs, the positional band of the pair is 96
+//     rows instead of 2 x 80 (6 fragment rows for 10 MFMA row tiles), every V^T fragment feeds two MFMAs;
+//   * V is staged row-major with plain 16-byte stores and its MFMA fragments come from ds_read_b64_tr_b16 (hardware 4x4
+//     transpose): lane (c, g) supplies the address of keys 4g + (c >> 2), columns 4 (c & 3) .. +3 and receives column c of the
+//     4-key x 16-column block of its 16-lane group; row pitch DP * 2 + 32 bytes keeps the 8 rows of a 32-lane half on disjoint banks;
+//   * one wave per SIMD (two 2-wave workgroups per CU, or one 4-wave workgroup): the whole register file per wave, both tiles'
+//     accumulators, scores and positional tiles stay in registers, two skew buffers per wave (one per tile) remove the
+//     write-after-read hand-off.
+// Operand order, skew realignment (write PE[r'][i], read at r' = j - i + 15), contraction-slot permutation of P and the online
+// softmax are those of attention.hip, so the two kernels are interchangeable (option "attention_v2", tests compare both).
+#include "kernels.h"
+
+namespace {
+
+constexpr int BJ = 64;          // keys per block
+constexpr int SKEW_LD = 84;     // floats per query row of a skew buffer
+constexpr float RESCALE_T = 4.0f;   // deferred accumulator rescale: threshold on the growth of a row maximum, log2 units
+
+__device__ __forceinline__ uint4 ld16(const bf16_t* p) {       // 16-byte global load from a 2-byte aligned address (natural layout, odd d)
+    typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(2)));
+    const u32x4_a4 v = *reinterpret_cast<const u32x4_a4*>(p);
+    return make_uint4(v[0], v[1], v[2], v[3]);
+}
+
+__device__ __forceinline__ uint4 ld16b(const char* p) { return ld16(reinterpret_cast<const bf16_t*>(p)); }
+
+__device__ __forceinline__ void wave_sync() {                   // per-wave LDS hand-off (LDS operations of one wave execute in order)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint2 lds_tr16(const char* p) {      // ds_read_b64_tr_b16
+    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+    union { s16x4 s; uint2 u; } c;
+    c.s = v;
+    return c.u;
+}
+
+template <int DP, int NWV, int QT>
+struct Attn2Smem {
+    static constexpr int BI = NWV * 16 * QT;                     // QT = 16-query tiles per wave
+    static constexpr int ERING = 2 * BI;                         // power of two >= BI + BJ - 1
+    static constexpr bool SWZ = (DP == 64);
+    static constexpr int KROW = SWZ ? DP * 2 : DP * 2 + 16;      // bytes per K / E row (layouts of attention.hip)
+    static __device__ __forceinline__ int koff(int row, int chunk) { return row * KROW + ((SWZ ? (chunk ^ (2 * ((row >> 1) & 3))) : chunk) << 4); }
+    static constexpr int VP = DP * 2 + 32;                       // bytes per V row (key-major)
+    static constexpr int K_BYTES = BJ * KROW, V_BYTES = BJ * VP, E_BYTES = ERING * KROW;
+    static constexpr int S_BYTES = NWV * QT * 16 * SKEW_LD * 4;
+    static constexpr int TOTAL = K_BYTES + V_BYTES + E_BYTES + S_BYTES;
+};
+
+template <int DP, int NWV, int QT>
+__global__ __launch_bounds__(NWV * 64, (QT == 1 && NWV == 4 && DP <= 96) ? 2 : 1) void relpos_attention2_kernel(const AttnParams p) {
+    using SM = Attn2Smem<DP, NWV, QT>;
+    constexpr int KS = DP / 32, DT = DP / 16, BI = SM::BI, NTHR = NWV * 64, CPR = DP / 8, ERING = SM::ERING;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sK = smem;
+    char* sV = sK + SM::K_BYTES;
+    char* sE = sV + SM::V_BYTES;
+    float* sS = reinterpret_cast<float*>(sE + SM::E_BYTES);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int qtiles = (p.Tg + BI - 1) / BI;
+    int id = blockIdx.x;
+    if ((p.B & 7) == 0) {                 // utterance b on XCD b % 8: all heads / query tiles of an utterance share one L2 (attention.hip)
+        const int per_b = p.H * qtiles, xcd = id & 7, slot = id >> 3;
+        const int j = slot / per_b;
+        id = (xcd + 8 * j) * per_b + (slot - j * per_b);
+    }
+    const int qt_wg = id % qtiles; id /= qtiles;
+    const int h = id % p.H; const int b = id / p.H;
+    const int i0 = qt_wg * BI, iw0 = i0 + wave * 16 * QT;
+    const size_t qoff = (size_t)b * p.q_bstride + (size_t)h * p.q_hstride;
+    const bf16_t* Qu = p.qu + qoff;
+    const bf16_t* Kh = p.kh + qoff;
+    const bf16_t* Vh = p.vt + qoff;
+    const bf16_t* Eh = p.eh + (size_t)h * p.e_hstride;
+    const int RS = p.q_rowstride, ERS = p.e_rowstride;
+    const int erows = 2 * p.Tg - 1;
+    const int dceil = (p.d + 7) & ~7;
+
+    int nkeys = (p.lens[b] + p.G - 1) / p.G;
+    nkeys = nkeys < p.Tg ? nkeys : p.Tg;
+    const bool all_masked = nkeys < 1;                          // empty utterance: uniform softmax over all key groups (attention.hip)
+    nkeys = all_masked ? p.Tg : nkeys;
+
+    // ---- the wave's two query tiles: B operands of S^T = K Q^T (Q + u) and of the positional product (Q + v = (Q + u) + (v - u))
+    bf16x8 qu[QT][KS], qv[QT][KS];
+    {
+        const float* dv = p.dvu + (size_t)h * p.dvu_ld;
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            const int i = iw0 + 16 * t + c, ic = i < p.Tg ? i : p.Tg - 1;
+            uint4 ra[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int x = ks * 32 + g * 8;
+                ra[ks] = ld16(Qu + (size_t)ic * RS + (x < dceil ? x : 0));
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int x = ks * 32 + g * 8;
+                const float4 da = *reinterpret_cast<const float4*>(dv + x), db = *reinterpret_cast<const float4*>(dv + x + 4);
+                const int valid = i < p.Tg ? p.d - x : 0;
+                const uint4 m = mask_chunk(ra[ks], valid);
+                qu[t][ks] = as_bf16x8(m);
+                const uint4 w = make_uint4(pack_bf2(__uint_as_float(m.x << 16) + da.x, __uint_as_float(m.x & 0xFFFF0000u) + da.y),
+                                           pack_bf2(__uint_as_float(m.y << 16) + da.z, __uint_as_float(m.y & 0xFFFF0000u) + da.w),
+                                           pack_bf2(__uint_as_float(m.z << 16) + db.x, __uint_as_float(m.z & 0xFFFF0000u) + db.y),
+                                           pack_bf2(__uint_as_float(m.w << 16) + db.z, __uint_as_float(m.w & 0xFFFF0000u) + db.w));
+                qv[t][ks] = as_bf16x8(mask_chunk(w, valid));
+            }
+        }
+    }
+    // ---- first positional band of the workgroup: absolute E rows R0 .. R0 + BI + 62
+    const int R0 = p.Tg - 1 - i0 - (BI - 1);
+    {
+        constexpr int NB = ((BI + 63) * CPR + NTHR - 1) / NTHR;
+        uint4 fb[NB];
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+            const int q = tid + NTHR * n;
+            const int rr = q / CPR, x = (q - rr * CPR) * 8;
+            const int r = R0 + (rr < BI + 63 ? rr : BI + 62);
+            const int rc = r < 0 ? 0 : (r >= erows ? erows - 1 : r);
+            fb[n] = ld16(Eh + (size_t)rc * ERS + (x < dceil ? x : 0));
+        }
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+            const int q = tid + NTHR * n;
+            const int rr = q / CPR, x = (q - rr * CPR) * 8;
+            if (q < (BI + 63) * CPR)      // ring row = band row + key offset (mod 2 BI): block 0's band sits at rows 0 .. BI + 62
+                *reinterpret_cast<uint4*>(sE + SM::koff(rr, x >> 3)) = mask_chunk(fb[n], p.d - x);
+        }
+    }
+
+    f32x4 acc[QT][DT];
+    float m_run[QT], l_run[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        m_run[t] = -INFINITY; l_run[t] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) acc[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const float scale2 = all_masked ? 0.f : p.scale * 1.44269504088896340736f;
+    float* skew0 = sS + (wave * QT) * 16 * SKEW_LD + c * SKEW_LD;          // tile t: skew0 + t * 16 * SKEW_LD
+    const int woff1 = BI - 16 * QT - 16 * QT * wave;             // first band row (workgroup band) of the wave's (64 + 16 QT)-row band: the LAST tile starts here, tile t 16 (QT - 1 - t) rows later
+    const char* vbase = sV + (4 * g + (c >> 2)) * SM::VP + (c & 3) * 8;
+
+    // ---- K / V / new-E staging registers, two sets (loads run two key blocks ahead)
+    constexpr int NK = (BJ * CPR + NTHR - 1) / NTHR;
+    struct Stage { uint4 lk[NK], lv[NK], le[NK]; };
+    Stage sa, sb;
+#pragma unroll
+    for (int n = 0; n < NK; ++n) { sa.lk[n] = make_uint4(0, 0, 0, 0); sa.lv[n] = sa.lk[n]; sa.le[n] = sa.lk[n]; sb.lk[n] = sa.lk[n]; sb.lv[n] = sa.lk[n]; sb.le[n] = sa.lk[n]; }
+
+    // per-thread element offsets of its K / V chunks inside a key block and of its E chunks inside a 64-row batch: computed once;
+    // per block only the block's row offset is added.  Rows past the last key group / outside the table are clamped to valid rows
+    // (wave-uniform tail path): their scores are masked, their probabilities are zero, so any FINITE value serves - no zero fill.
+    // Column masks (elements >= d of a chunk: the next head's data, finite, times the queries' zero pad columns) are only applied on
+    // the tail paths, i.e. to the loads that can run past the END of a buffer (last rows of the last head), where the bytes are not
+    // the library's own and may be NaN patterns.
+    uint32_t koffs[NK];                                          // K, V and E share the row stride (launch check), so one offset serves all three
+    auto chunk_row = [&](int n) { int q = tid + NTHR * n; q = q < BJ * CPR ? q : BJ * CPR - 1; return q / CPR; };
+    auto tail_mask = [&](uint4 a, int n) {                      // tail paths only: recomputed there instead of living in registers
+        int q = tid + NTHR * n; q = q < BJ * CPR ? q : BJ * CPR - 1;
+        return mask_chunk(a, p.d - (q - (q / CPR) * CPR) * 8);
+    };
+#pragma unroll
+    for (int n = 0; n < NK; ++n) {
+        int q = tid + NTHR * n;
+        q = q < BJ * CPR ? q : BJ * CPR - 1;
+        const int r = q / CPR, x = (q - r * CPR) * 8, xc = x < dceil ? x : 0;
+        koffs[n] = (uint32_t)(r * RS + xc) * 2u;                // BYTE offsets: wave-uniform base + 32-bit lane offset
+    }
+    auto issue_loads = [&](Stage& st_, int jn) __attribute__((always_inline)) {
+        if (jn + BJ <= p.Tg) {
+            const char* kb = reinterpret_cast<const char*>(Kh + (size_t)jn * RS);
+            const char* vb = reinterpret_cast<const char*>(Vh + (size_t)jn * RS);
+#pragma unroll
+            for (int n = 0; n < NK; ++n) { st_.lk[n] = ld16b(kb + koffs[n]); st_.lv[n] = ld16b(vb + koffs[n]); }
+        } else {
+#pragma unroll
+            for (int n = 0; n < NK; ++n) {
+                const int kr = chunk_row(n), j = jn + kr;
+                const size_t o = (size_t)(j < p.Tg ? j : p.Tg - 1) * RS * 2 + (koffs[n] - (uint32_t)(kr * RS) * 2u);
+                st_.lk[n] = tail_mask(ld16b(reinterpret_cast<const char*>(Kh) + o), n); st_.lv[n] = ld16b(reinterpret_cast<const char*>(Vh) + o);
+            }
+        }
+        if (jn > 0) {
+            const int rnew = R0 + jn + BI - 1;                   // first new absolute E row of the block
+            if (rnew >= 0 && rnew + 63 < erows) {
+                const char* eb = reinterpret_cast<const char*>(Eh + (size_t)rnew * ERS);
+#pragma unroll
+                for (int n = 0; n < NK; ++n) st_.le[n] = ld16b(eb + koffs[n]);
+            } else {
+#pragma unroll
+                for (int n = 0; n < NK; ++n) {
+                    const int er = chunk_row(n);
+                    int r = rnew + er;
+                    r = r < 0 ? 0 : (r >= erows ? erows - 1 : r);
+                    st_.le[n] = tail_mask(ld16b(reinterpret_cast<const char*>(Eh) + (size_t)r * ERS * 2 + (koffs[n] - (uint32_t)(er * RS) * 2u)), n);
+                }
+            }
+        }
+    };
+    // LDS byte offsets of the thread's chunks: K / V tile rows, and the ring rows of a new-row batch for even / odd key blocks
+    // (ring row = band row + key offset mod 2 BI = 128: the batch starts at row BI - 1 + 64 * parity)
+    static_assert(BI == 64, "ring phases: two (BI == BJ)");
+    uint32_t ldk[NK], ldv[NK], lde[2][NK];
+#pragma unroll
+    for (int n = 0; n < NK; ++n) {
+        int q = tid + NTHR * n;
+        q = q < BJ * CPR ? q : BJ * CPR - 1;
+        const int r = q / CPR, ch = q - r * CPR;
+        ldk[n] = (uint32_t)SM::koff(r, ch);
+        ldv[n] = (uint32_t)(r * SM::VP + ch * 16);
+        lde[0][n] = (uint32_t)SM::koff((BI - 1 + r) & (ERING - 1), ch);
+        lde[1][n] = (uint32_t)SM::koff((BI - 1 + r + 64) & (ERING - 1), ch);
+    }
+    constexpr bool FULL = (BJ * CPR) % NTHR == 0;                // every thread owns NK real chunks
+    auto publish = [&](const Stage& st_, int j0, int par) __attribute__((always_inline)) {
+        __syncthreads();                                         // the previous block's LDS reads are done
+#pragma unroll
+        for (int n = 0; n < NK; ++n) {
+            if (FULL || tid + NTHR * n < BJ * CPR) {
+                *reinterpret_cast<uint4*>(sK + ldk[n]) = st_.lk[n];
+                *reinterpret_cast<uint4*>(sV + ldv[n]) = st_.lv[n];
+                if (j0 > 0) *reinterpret_cast<uint4*>(sE + lde[par][n]) = st_.le[n];
+            }
+        }
+        __syncthreads();
+    };
+
+    auto compute_block = [&](int j0, int par) __attribute__((always_inline)) {
+        // ---- S^T tiles of both query tiles: every K fragment feeds two MFMAs
+        f32x4 st[QT][4];
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+#pragma unroll
+            for (int t = 0; t < QT; ++t) st[t][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(sK + SM::koff(jt * 16 + c, ks * 4 + g));
+#pragma unroll
+                for (int t = 0; t < QT; ++t) st[t][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qu[t][ks], st[t][jt], 0, 0, 0);
+            }
+        }
+        // ---- positional band of the pair: 96 rows = 6 fragment rows; tile 1 uses rows 0 .. 79, tile 0 rows 16 .. 95
+        const int rw1 = woff1 + 64 * par;                       // ring row of the wave's band row 0 (ring row = band row + key offset mod 128)
+        f32x4 pe[QT][5];
+#pragma unroll
+        for (int t = 0; t < QT; ++t)
+#pragma unroll
+            for (int u = 0; u < 5; ++u) pe[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 4 + QT; ++u) {
+            const int er = ((rw1 + u * 16) & (ERING - 1)) + c;      // (multiples of 16) + c: no carry into the wrap
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(sE + SM::koff(er, ks * 4 + g));
+#pragma unroll
+                for (int t = 0; t < QT; ++t) {                 // tile t covers fragment rows QT - 1 - t .. QT + 3 - t
+                    const int ut = u - (QT - 1 - t);
+                    if (ut >= 0 && ut < 5) pe[t][ut] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qv[t][ks], pe[t][ut], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < QT; ++t)
+#pragma unroll
+            for (int u = 0; u < 5; ++u) *reinterpret_cast<f32x4*>(skew0 + t * 16 * SKEW_LD + u * 16 + g * 4) = pe[t][u];
+        wave_sync();
+
+        // ---- realign, mask, online softmax, per tile.  Raw scores s = S + PE; the running maximum is tracked in raw units and
+        //      p = exp2(s * scale2 - m * scale2) is one fma + one v_exp_f32 per score (scale2 = scale * log2 e > 0).  The accumulators
+        //      are rescaled only when some row's maximum grew by more than RESCALE_T (log2 units) since the last rescale (always in the
+        //      first block): between rescales p <= 2^RESCALE_T, harmless for bf16 P and fp32 sums; the choice is wave-uniform.
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            const float* skew = skew0 + t * 16 * SKEW_LD;
+            float mloc = -INFINITY;
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int jl = jt * 16 + g * 4 + r;
+                    st[t][jt][r] += skew[jl + 15 - c];
+                }
+            if (j0 + BJ > nkeys) {
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) st[t][jt][r] = (j0 + jt * 16 + g * 4 + r < nkeys) ? st[t][jt][r] : -INFINITY;
+            }
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mloc = fmaxf(mloc, st[t][jt][r]);
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 16));
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32));             // finite: key j0 of every visited block is unmasked
+            if (!__all((mloc - m_run[t]) * scale2 <= RESCALE_T)) {   // m_run = -inf in the first block: always taken there
+                const float m_new = fmaxf(m_run[t], mloc);
+                const float alpha = __builtin_amdgcn_exp2f((m_run[t] - m_new) * scale2);
+                l_run[t] *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) { acc[t][dt][0] *= alpha; acc[t][dt][1] *= alpha; acc[t][dt][2] *= alpha; acc[t][dt][3] *= alpha; }
+                m_run[t] = m_new;
+            }
+            const float nm = -m_run[t] * scale2;
+            float lsum = 0.f;
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(fmaf(st[t][jt][r], scale2, nm));
+                    st[t][jt][r] = e;
+                    lsum += e;
+                }
+            l_run[t] += lsum;
+        }
+        // ---- O^T += V^T P^T for both tiles; contraction slot (g, e) <-> key (2*c2 + (e>>2))*16 + g*4 + (e&3) on both operands;
+        //      the V^T fragment is two transposing reads of the key-major V tile
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+            bf16x8 pf[QT];
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                uint4 pb;
+                pb.x = pack_bf2(st[t][2 * c2][0], st[t][2 * c2][1]);
+                pb.y = pack_bf2(st[t][2 * c2][2], st[t][2 * c2][3]);
+                pb.z = pack_bf2(st[t][2 * c2 + 1][0], st[t][2 * c2 + 1][1]);
+                pb.w = pack_bf2(st[t][2 * c2 + 1][2], st[t][2 * c2 + 1][3]);
+                pf[t] = as_bf16x8(pb);
+            }
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const uint2 lo = lds_tr16(vbase + (2 * c2) * 16 * SM::VP + dt * 32);
+                const uint2 hi = lds_tr16(vbase + (2 * c2 + 1) * 16 * SM::VP + dt * 32);
+                const bf16x8 a = as_bf16x8(make_uint4(lo.x, lo.y, hi.x, hi.y));
+#pragma unroll
+                for (int t = 0; t < QT; ++t) acc[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pf[t], acc[t][dt], 0, 0, 0);
+            }
+        }
+    };
+
+    // two staging sets (loads two key blocks ahead) while they fit the register file; one set (one block ahead) for the widest heads
+    // of the 2-wave workgroup, whose threads stage twice as many chunks
+    constexpr bool TWO_SETS = !(NWV == 2 && DP >= 96);
+    issue_loads(sa, 0);
+    if constexpr (TWO_SETS) {
+        if (BJ < nkeys) issue_loads(sb, BJ);
+        for (int jb = 0; jb < nkeys; jb += 2 * BJ)
+#pragma unroll
+        for (int half2 = 0; half2 < 2; ++half2) {
+            const int j0 = jb + half2 * BJ;
+            if (j0 >= nkeys) break;
+            if (half2 == 0) publish(sa, j0, 0); else publish(sb, j0, 1);
+            if (j0 + 2 * BJ < nkeys) { if (half2 == 0) issue_loads(sa, j0 + 2 * BJ); else issue_loads(sb, j0 + 2 * BJ); }
+            compute_block(j0, half2);
+        }
+    } else {
+        for (int jb = 0; jb < nkeys; jb += 2 * BJ)
+#pragma unroll
+        for (int half2 = 0; half2 < 2; ++half2) {
+            const int j0 = jb + half2 * BJ;
+            if (j0 >= nkeys) break;
+            publish(sa, j0, half2);
+            if (j0 + BJ < nkeys) issue_loads(sa, j0 + BJ);
+            compute_block(j0, half2);
+        }
+    }
+
+    // ---- normalise and scatter back to the un-grouped (B*T, D) layout (attention.hip)
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        float l_tot = l_run[t] + __shfl_xor(l_run[t], 16);
+        l_tot += __shfl_xor(l_tot, 32);
+        const float inv = 1.0f / l_tot;
+        const int i = iw0 + 16 * t + c;
+        if (i >= p.Tg) continue;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const int x0 = dt * 16 + g * 4;
+            if (x0 >= p.d) continue;
+            int n0 = h * p.d + x0, toff = 0;
+            while (n0 >= p.D) { n0 -= p.D; ++toff; }
+            const int t0 = i * p.G + toff;
+            if (x0 + 3 < p.d && n0 + 3 < p.D && (n0 & 1) == 0) {
+                if (t0 < p.T) {
+                    typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+                    u32x2_a4 w;
+                    w[0] = pack_bf2(acc[t][dt][0] * inv, acc[t][dt][1] * inv);
+                    w[1] = pack_bf2(acc[t][dt][2] * inv, acc[t][dt][3] * inv);
+                    *reinterpret_cast<u32x2_a4*>(p.out + ((size_t)b * p.T + t0) * p.ldo + n0) = w;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int x = x0 + r;
+                    if (x >= p.d) continue;
+                    int n = h * p.d + x, tf = 0;
+                    while (n >= p.D) { n -= p.D; ++tf; }
+                    const int tt = i * p.G + tf;
+                    if (tt < p.T) p.out[((size_t)b * p.T + tt) * p.ldo + n] = f2bf(acc[t][dt][r] * inv);
+                }
+            }
+        }
+    }
+}
+
+template <int DP, int NWV, int QT>
+int launch2(const AttnParams& p, hipStream_t s) {
+    using SM = Attn2Smem<DP, NWV, QT>;
+    static_assert(SM::TOTAL <= 160 * 1024, "LDS");
+    static LdsAttr attr;
+    ensure_dynamic_lds(reinterpret_cast<const void*>(&relpos_attention2_kernel<DP, NWV, QT>), SM::TOTAL, attr);
+    const int qtiles = (p.Tg + SM::BI - 1) / SM::BI;
+    hipLaunchKernelGGL((relpos_attention2_kernel<DP, NWV, QT>), dim3(p.B * p.H * qtiles), dim3(NWV * 64), SM::TOTAL, s, p);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+}  // namespace
+
+bool relpos_attention2_supported(int dpad) { return dpad == 32 || dpad == 64 || dpad == 96 || dpad == 128; }      // wider heads spill: attention.hip
+
+// variant: 1 = 16 queries per wave, 4-wave 64-query workgroups, two per CU (attention.hip's shape: the default);
+//          2 = 32 queries per wave, 2-wave 64-query workgroups (one wave per SIMD: measured slower, kept for experiments)
+int launch_relpos_attention2(const AttnParams& p, int waves, hipStream_t s) {
+    if (p.B <= 0 || p.Tg <= 0) return 0;
+    if (p.dpad < p.d || p.q_rowstride != p.e_rowstride) return -2;
+#define ATT2_CASE(DPV) case DPV: return waves == 1 ? launch2<DPV, 4, 1>(p, s) : launch2<DPV, 2, 2>(p, s);
+    switch (p.dpad) {
+        ATT2_CASE(32) ATT2_CASE(64) ATT2_CASE(96) ATT2_CASE(128)
+    }
+#undef ATT2_CASE
+    return -3;
+}

@@ -69,6 +69,7 @@ struct EcEncoder {
     const bf16_t* lin_fused = nullptr; int lin_fused_ld = 0;   // Linear weight in the fused kernel's K order (sublinear.hip)
     bool fuse_subsample = true;
     bool fuse_chain = true;                  // row-local chains (chain.hip) where supported
+    int attention_v2 = 1;                    // 0: attention.hip; 1 (default) / 2: attention2.hip variants where they support the head width (<= 128)
     // two-layer subsampler (plain Conformer configs): layer-2 implicit-GEMM weight [N][9*Cp] (tap, c_in), folded bias, Cp
     const bf16_t* sub2_w = nullptr; const float* sub2_b = nullptr; int sub2_cp = 0;
     std::vector<BlockW> bw;
@@ -558,7 +559,9 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
             else { ap.q_bstride = (long long)H * Tg * dpad; ap.q_hstride = (long long)Tg * dpad; ap.q_rowstride = dpad;
                    ap.e_hstride = (long long)(2 * Tg - 1) * dpad; ap.e_rowstride = dpad; }
             ap.out = o; ap.ldo = ld8(D); ap.scale = 1.0f / std::sqrt((float)d);
-            { PROF(PC_ATTENTION, 2.0 * B * H * (double)Tg * Tg * d * 3.0, (double)M * D * 2 * 5); EC_TRY(launch_relpos_attention(ap, st)); }
+            { PROF(PC_ATTENTION, 2.0 * B * H * (double)Tg * Tg * d * 3.0, (double)M * D * 2 * 5);
+              if (e->attention_v2 && relpos_attention2_supported(dpad)) EC_TRY(launch_relpos_attention2(ap, e->attention_v2, st));
+              else EC_TRY(launch_relpos_attention(ap, st)); }
             snprintf(nm, sizeof(nm), "blocks.%d.att_o", k); trace_add(e, st, nm, o, M, D, ld8(D), 1);
             if (chain_b) {
                 ChainParams cp{};
@@ -1189,6 +1192,24 @@ int effconf_debug_neighbour(int32_t kind, int32_t blocks, int32_t lds_bytes, int
     return 0;
 }
 
+int effconf_relpos_attention(const uint16_t* qu, const uint16_t* k, const uint16_t* v, const uint16_t* e, const float* dvu, int32_t dvu_ld,
+                             const int32_t* lens, int32_t batch, int32_t heads, int32_t frames, int32_t group, int32_t dim, uint16_t* out,
+                             int32_t ld_out, int32_t variant, void* stream) {
+    if (!qu || !k || !v || !e || !dvu || !lens || !out) return fail("null argument");
+    if (batch <= 0 || heads <= 0 || frames <= 0 || group <= 0 || !(group & 1) || dim <= 0 || (group * dim) % heads) return fail("bad attention shape");
+    AttnParams ap{};
+    const int Tp = ec_round_up(frames, group), Tg = Tp / group, d = group * dim / heads, dpad = ec_round_up(d, 32);
+    if (dpad > 192 || dvu_ld < dpad || ld_out < dim) return fail("unsupported head width / leading dimension");
+    ap.qu = qu; ap.kh = k; ap.vt = v; ap.eh = e; ap.dvu = dvu; ap.dvu_ld = dvu_ld; ap.lens = lens;
+    ap.B = batch; ap.H = heads; ap.T = frames; ap.G = group; ap.D = dim; ap.d = d; ap.dpad = dpad; ap.Tg = Tg; ap.Tgp = ec_round_up(Tg, 8);
+    ap.q_bstride = (long long)Tp * dim; ap.q_hstride = d; ap.q_rowstride = group * dim; ap.e_hstride = d; ap.e_rowstride = group * dim;
+    ap.out = out; ap.ldo = ld_out; ap.scale = 1.0f / std::sqrt((float)d);
+    if (variant == 0) { EC_TRY(launch_relpos_attention(ap, (hipStream_t)stream)); return 0; }
+    if ((variant != 1 && variant != 2) || !relpos_attention2_supported(dpad)) return fail("attention variant not available for this head width");
+    EC_TRY(launch_relpos_attention2(ap, variant, (hipStream_t)stream));
+    return 0;
+}
+
 int effconf_debug_victim(int32_t kind, int32_t blocks, int32_t iters, float* out, void* stream) {
     EC_TRY(launch_debug_victim(kind, blocks, iters, out, (hipStream_t)stream));
     return 0;
@@ -1211,6 +1232,7 @@ int effconf_encoder_set_option(EcEncoder* e, const char* name, int32_t value) {
     if (!e || !name) return fail("null argument");
     if (!strcmp(name, "fuse_subsample")) { e->fuse_subsample = value != 0; return 0; }
     if (!strcmp(name, "fuse_chain")) { e->fuse_chain = value != 0; return 0; }
+    if (!strcmp(name, "attention_v2")) { if (value != 0 && value != 1 && value != 2) return fail("attention_v2: 0, 1 or 2"); e->attention_v2 = value; return 0; }
     if (!strcmp(name, "cache_pos_embeddings")) { e->e_cache_on = value != 0; e->e_cache.clear(); return 0; }
     if (!strcmp(name, "exact_fp32")) {
         if (!e->finalized) { e->exact_pack = e->exact_on = value != 0; return 0; }

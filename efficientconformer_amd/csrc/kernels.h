@@ -113,6 +113,9 @@ struct AttnParams {
     float scale;                            // 1/sqrt(d)
 };
 int launch_relpos_attention(const AttnParams& p, hipStream_t s);
+// second generation (attention2.hip): 32 queries per wave, transposing LDS reads for V; waves = 2 (64-query workgroups) or 4
+bool relpos_attention2_supported(int dpad);
+int launch_relpos_attention2(const AttnParams& p, int waves, hipStream_t s);
 // rows t in [T, Tp) of the grouped view: Qu=u, Qv=v, K=V=0  (attentions.py:107-138, 671-675)
 int launch_attn_pad_rows(const GemmParams& p, int B, hipStream_t s);       // head-major buffers
 int launch_attn_pad_rows_nat(const GemmParams& p, int B, hipStream_t s);   // natural [B*Tp][D] buffers

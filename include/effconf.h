@@ -98,6 +98,16 @@ int effconf_mel_frontend(EcEncoder* enc, const float* audio, int32_t batch, int3
 int effconf_ctc_greedy(EcEncoder* enc, const float* enc_out, const int64_t* out_len, int32_t batch, int32_t t_out,
                        int32_t* labels, int32_t* label_len, float* logits, void* workspace, size_t workspace_bytes, void* stream);
 
+/* (Grouped)RelPosMultiHeadSelfAttention core alone (reference attentions.py:549-718 between the input projections and the output
+ * projection): natural-layout bf16 device buffers qu = Q + u, k, v of (batch * Tp, dim) rows (Tp = frames rounded up to the group
+ * size; pad rows: qu = u, k = v = 0), e = pos_layer(R) of (2 Tp - group, dim) rows, dvu = (v - u) per head column as fp32
+ * [heads][dvu_ld] (dvu_ld >= head width rounded up to 32, zero beyond the head width), lens = valid frames per utterance (i32).
+ * out: bf16 (batch * frames, ld_out) un-grouped attention output.  variant 0 = attention.hip, 1 / 2 = attention2.hip (see the
+ * "attention_v2" option).  Needs 512 bytes of readable slack behind qu / k / v / e (16-byte chunk loads may run past a head span). */
+int effconf_relpos_attention(const uint16_t* qu, const uint16_t* k, const uint16_t* v, const uint16_t* e, const float* dvu, int32_t dvu_ld,
+                             const int32_t* lens, int32_t batch, int32_t heads, int32_t frames, int32_t group, int32_t dim, uint16_t* out,
+                             int32_t ld_out, int32_t variant, void* stream);
+
 /* ---- RNN-T greedy decode (next row after the encoder: BASELINE.json configs[3]) ------------------ */
 /* Replaces Transducer.gready_search_decoding's per-utterance Python loop (reference models/transducer.py:139-186) for
  * the shipped Transducer configs: RnnDecoder = Embedding + 1-layer LSTM (models/decoders.py:41-70) and
@@ -146,6 +156,10 @@ int effconf_rnnt_greedy(EcRnnt* r, const float* enc_out, const int64_t* out_len,
  * "fuse_subsample" (default 1): 0 selects the unfused conv-subsampling + Linear kernels (kept for tests / odd shapes).
  * "fuse_chain" (default 1): 0 runs every GEMM of a block as its own kernel instead of the fused row-local chains (chain.hip);
  *   with the debug trace this exposes the intermediate residual-stream states that otherwise only exist in registers.
+ * "attention_v2" (default 1): 0 = attention.hip; 1 = attention2.hip (same tiling; V read through ds_read_b64_tr_b16 instead of being
+ *   transposed on the way into LDS, hoisted staging addresses, no column masks off the buffer tails, deferred accumulator rescale);
+ *   2 = attention2.hip with 32 queries per wave (one wave per SIMD: measured slower, kept for experiments).  Head widths above 128
+ *   always use attention.hip.  Results agree to fp32 summation order (variant 1's deferred rescale: to bf16 rounding of P).
  * "exact_fp32" (default 0): fp32-operand precision mode (csrc/exact.hip): every GEMM on fp32 MFMA, fp32 attention / convolutions,
  *   so that greedy CTC label sequences equal the reference's CPU fp32 path (model_ctc.py:99-133) wherever its top-2 logit margins
  *   exceed fp32 summation-order noise; ~10x slower than the default bf16-operand path.  Set to 1 BEFORE effconf_encoder_finalize

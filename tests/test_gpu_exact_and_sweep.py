@@ -266,3 +266,72 @@ def test_front_door_labels_equal_the_oracle_on_the_collated_batches():
     decidable = [i for i in range(len(waves)) if margins[i] > EXACT_MARGIN]
     assert len(decidable) >= len(waves) - 2
     assert [got[i] for i in decidable] == [want[i] for i in decidable]
+
+
+def _attention_case(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    w = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w/")}
+    x = torch.from_numpy(g["x"])
+    bsz, t, dim = x.shape
+    heads, group = int(g["heads"]), int(g["group"])
+    lin = lambda n: torch.nn.functional.linear(x, w[n + ".weight"], w[n + ".bias"])
+    q, k, v = lin("query_layer"), lin("key_layer"), lin("value_layer")
+    tp = (t + group - 1) // group * group
+    pad = lambda z: torch.nn.functional.pad(z, (0, 0, 0, tp - t))
+    qu = pad(q) + w["u"]                                           # pad rows: Q = 0 -> Q + u = u (attentions.py:671-675)
+    e = torch.nn.functional.linear(R.rel_sinusoid_rows(tp, dim, group), w["pos_layer.weight"], w["pos_layer.bias"])
+    d = group * dim // heads
+    dpad = (d + 31) // 32 * 32
+    dvu = torch.zeros(heads, dpad)
+    for h in range(heads):
+        idx = (h * d + torch.arange(d)) % dim
+        dvu[h, :d] = (w["v"] - w["u"])[idx]
+    return dict(g=g, w=w, bsz=bsz, t=t, tp=tp, dim=dim, heads=heads, group=group, qu=qu, k=pad(k), v=pad(v), e=e, dvu=dvu, dpad=dpad)
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("name", ["att_G1_T47", "att_G3_T47", "att_G3_T48", "att_G1_T126", "att_G3_T250"])
+def test_attention_kernel_alone_vs_the_reference_attention_classes(golden_dir, name, variant):
+    """Kernel-level parity: effconf_relpos_attention on bf16 Q + u, K, V, E built from the golden's weights, then the
+    fp32 output projection, against the output the reference's own (Grouped)RelPosMultiHeadSelfAttention produced
+    (attentions.py:549-718; tools/make_goldens.py) - both kernel generations, ragged lengths, T % G != 0."""
+    from efficientconformer_amd import _lib
+    lib = _lib.load()
+    a = _attention_case(golden_dir, name)
+
+    def dev_bf16(z):                                               # + 512 bytes of readable slack behind the rows
+        flat = torch.zeros(z.numel() + 256, dtype=torch.bfloat16, device="cuda")
+        flat[:z.numel()] = z.reshape(-1).to(torch.bfloat16).cuda()
+        return flat
+    qu, k, v, e = dev_bf16(a["qu"]), dev_bf16(a["k"]), dev_bf16(a["v"]), dev_bf16(a["e"])
+    dvu = a["dvu"].cuda().contiguous()
+    lens = torch.from_numpy(a["g"]["lens"]).to(torch.int32).cuda()
+    out = torch.zeros(a["bsz"] * a["t"], a["dim"], dtype=torch.bfloat16, device="cuda")
+    _lib.check(lib.effconf_relpos_attention(qu.data_ptr(), k.data_ptr(), v.data_ptr(), e.data_ptr(), dvu.data_ptr(), a["dpad"], lens.data_ptr(),
+                                            a["bsz"], a["heads"], a["t"], a["group"], a["dim"], out.data_ptr(), a["dim"], variant,
+                                            torch.cuda.current_stream().cuda_stream), "relpos_attention")
+    o = out.float().cpu().view(a["bsz"], a["t"], a["dim"])
+    got = torch.nn.functional.linear(o, a["w"]["output_layer.weight"], a["w"]["output_layer.bias"])
+    mx, mean = _err(got, torch.from_numpy(a["g"]["out"]))
+    print("attention kernel variant %d, %s: err max %.4f mean %.5f" % (variant, name, mx, mean))
+    assert mx < 0.05 and mean < 0.006, (mx, mean)
+
+
+@pytest.mark.parametrize("waves", [1, 2])
+def test_attention_v2_end_to_end_matches_v1_and_the_reference(golden_dir, waves):
+    """The whole Small encoder with attention2.hip (32 queries per wave) against the reference golden and against attention.hip."""
+    g = np.load(os.path.join(golden_dir, "small_B4_T1001.npz"))
+    m, sd = _model("EfficientConformerCTCSmall", int(g["weight_seed"]))
+    mel, ln = synth.make_mel(4, 80, 1001, g["mel_len"].tolist(), seed=int(g["mel_seed"]))
+    mel_d, ln_d = torch.from_numpy(mel).cuda(), torch.from_numpy(ln).cuda()
+    m.encoder.set_option("attention_v2", 0)
+    v1, _, _ = m.encoder.forward_mel(mel_d, ln_d)
+    m.encoder.set_option("attention_v2", waves)
+    v2, out_len, _ = m.encoder.forward_mel(mel_d, ln_d)
+    assert out_len.cpu().tolist() == g["out_len"].tolist()
+    mx, mean = _err(v2.cpu(), torch.from_numpy(g["out"]))
+    dx, _ = _err(v2.cpu(), v1.cpu())
+    print("attention_v2 = %d: err vs reference max %.4f mean %.5f; vs attention.hip max %.4f" % (waves, mx, mean, dx))
+    assert mx < OUT_MAX and mean < OUT_MEAN and dx < 0.05
+    again, _, _ = m.encoder.forward_mel(mel_d, ln_d)
+    assert torch.equal(again, v2)
