@@ -61,6 +61,8 @@ def parse():
     ap.add_argument("--gather", default="outputs", choices=["outputs", "labels"],
                     help="N > 1: all-gather the encoder outputs before the CTC head (north_star) or the label ids after it")
     ap.add_argument("--wire", default="fp32", choices=["fp32", "bf16"], help="dtype of the gathered encoder outputs on xGMI")
+    ap.add_argument("--no-trim", action="store_true",
+                    help="pad every row range to the whole batch's longest utterance (round-1 workload) instead of its own longest")
     ap.add_argument("--attention", type=int, default=-1, choices=[-1, 0, 1, 2],
                     help="attention kernel: 0 attention.hip, 1 / 2 attention2.hip variants (-1: the library's default = 1)")
     ap.add_argument("--dry-run", action="store_true",
@@ -121,8 +123,8 @@ def head(model, enc, enc_len):
     return labels, label_len
 
 
-def step(model, audio, lens):
-    enc, enc_len, _ = model.encoder(audio, lens)
+def step(model, audio, lens, range_pad=None):
+    enc, enc_len, _ = model.encoder(audio, lens, range_pad=range_pad)
     labels, label_len = head(model, enc, enc_len)
     return enc, enc_len, labels, label_len
 
@@ -304,6 +306,15 @@ def main():
     # Sub-batch streams live in the library's host layer (ConformerEncoder.sub_batches): the batch runs as `--streams` contiguous
     # row ranges on concurrent HIP streams and is joined before forward() returns.
     model.encoder.sub_batches = max(args.streams, 1)
+    nsub = max(args.streams, 1)
+    # Row ranges padded to their own longest utterance (ConformerEncoder.trim_sub_batches): the batch is length-sorted, so range i
+    # of every rank is padded to the longest utterance any rank holds in range i (known from the seeds: no exchange, equal shapes)
+    model.encoder.trim_sub_batches = not args.no_trim and nsub > 1 and args.workload == "libri"
+    range_pad = None
+    if model.encoder.trim_sub_batches:
+        all_lens = [synth.libri_lengths(args.batch, seed=1234 + r) for r in range(world)]
+        range_pad = [max(int(l[args.batch * i // nsub: args.batch * (i + 1) // nsub].max()) for l in all_lens) for i in range(nsub)]
+        padded_frames = int(sum((args.batch * (i + 1) // nsub - args.batch * i // nsub) * (range_pad[i] // plan.hop_length + 1) for i in range(nsub)))
     if args.attention >= 0:
         model.encoder.set_option("attention_v2", args.attention)
     sharded = head_stream = None
@@ -315,14 +326,14 @@ def main():
 
     def full_step():
         if world == 1:
-            enc, enc_len, _ = model.encoder(audio, lens)
+            enc, enc_len, _ = model.encoder(audio, lens, range_pad=range_pad)
             last["labels"] = head(model, enc, enc_len)
             return
         cur = torch.cuda.current_stream(dev)
         if args.gather == "outputs":
             # encoder on this rank's utterances; per-row-range all-gather on the comm stream (dist.py); the head consumes the
             # gathered chunks on its own stream, so the next step's encoder is not queued behind the collectives
-            g = sharded.encode_shard(audio, lens, args.batch * world)
+            g = sharded.encode_shard(audio, lens, args.batch * world, range_pad=range_pad)
             head_stream.wait_stream(cur)
             with torch.cuda.stream(head_stream):
                 res = []
@@ -331,7 +342,7 @@ def main():
                     res.append(head(model, ch.out if ch.out.dtype == torch.float32 else ch.out.float(), ch.out_len))
             last["labels"] = res
         else:
-            enc, enc_len, _ = model.encoder(audio, lens)
+            enc, enc_len, _ = model.encoder(audio, lens, range_pad=range_pad)
             labels, label_len = head(model, enc, enc_len)
             head_stream.wait_stream(cur)
             with torch.cuda.stream(head_stream):
@@ -373,7 +384,10 @@ def main():
         if world > 1:
             par += ", RCCL all-gather of %s per row range on a comm stream, wire %s" % ("encoder outputs" if args.gather == "outputs" else "label ids", args.wire)
         result = result_skeleton(args, world, all_valid * args.steps / elapsed, 1000.0 * elapsed / args.steps, args.batch * world,
-                                 {"padded_frames_per_s": all_padded * args.steps / elapsed, "parallelism": par + ")"})
+                                 {"padded_frames_per_s": all_padded * args.steps / elapsed, "parallelism": par + ")",
+                                  "row_ranges": ("%d row ranges per GPU, each padded to ITS longest utterance %s samples (length bucketing inside the forward; "
+                                                 "--no-trim pads all to the batch maximum as in round 1)" % (nsub, range_pad)) if range_pad
+                                                else "%d row range(s) per GPU padded to the batch maximum" % nsub})
         if isinstance(model, Transducer):
             result["config"]["workload"] += " (RNN-T greedy token ids, synthetic blank bias %.1f)" % RNNT_BLANK_BIAS
 
@@ -383,7 +397,6 @@ def main():
         h = model.encoder._handle
         _lib.check(lib.effconf_profile_enable(h, 1), "profile_enable")
         nprof = min(args.steps, 5)
-        nsub = max(args.streams, 1)
 
         def read_classes():
             torch.cuda.synchronize()
@@ -401,7 +414,7 @@ def main():
         for _ in range(nprof):
             for i in range(nsub):
                 lo, hi = args.batch * i // nsub, args.batch * (i + 1) // nsub
-                step(model, audio[lo:hi], lens[lo:hi])
+                step(model, audio[lo:hi, :range_pad[i]].contiguous() if range_pad else audio[lo:hi], lens[lo:hi])
         per = read_classes()
         model.encoder.sub_batches = nsub
         # the dominant class is the one that takes the most time in THIS model's step (gemm_ffn for Small; Large's tiled GEMMs too)
@@ -410,7 +423,7 @@ def main():
         if nsub > 1:
             _lib.check(lib.effconf_profile_enable(h, 1), "profile_enable")
             for _ in range(nprof):
-                step(model, audio, lens)
+                step(model, audio, lens, range_pad)
             flight = read_classes()[dom_name]
         _lib.check(lib.effconf_profile_enable(h, 0), "profile_enable")
         for cname, c in per.items():      # every class against its own bound

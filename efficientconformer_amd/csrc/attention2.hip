@@ -152,7 +152,7 @@ __global__ __launch_bounds__(NWV * 64, (QT == 1 && NWV == 4 && DP <= 96) ? 2 : 1
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) acc[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    const float scale2 = all_masked ? 0.f : p.scale * 1.44269504088896340736f;
+    const float scale2 = p.scale * 1.44269504088896340736f;
     float* skew0 = sS + (wave * QT) * 16 * SKEW_LD + c * SKEW_LD;          // tile t: skew0 + t * 16 * SKEW_LD
     const int woff1 = BI - 16 * QT - 16 * QT * wave;             // first band row (workgroup band) of the wave's (64 + 16 QT)-row band: the LAST tile starts here, tile t 16 (QT - 1 - t) rows later
     const char* vbase = sV + (4 * g + (c >> 2)) * SM::VP + (c & 3) * 8;
@@ -297,6 +297,12 @@ __global__ __launch_bounds__(NWV * 64, (QT == 1 && NWV == 4 && DP <= 96) ? 2 : 1
                     const int jl = jt * 16 + g * 4 + r;
                     st[t][jt][r] += skew[jl + 15 - c];
                 }
+            if (all_masked) {                                  // empty utterance: all scores equal (attention.hip) -> uniform softmax over every key group
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) st[t][jt][r] = 0.f;
+            }
             if (j0 + BJ > nkeys) {
 #pragma unroll
                 for (int jt = 0; jt < 4; ++jt)

@@ -139,13 +139,16 @@ class ShardedEncoder:
             chunks.append(GatheredChunk(lo, hi, g, gl, rows, keep, None, None))
 
     # ------------------------------------------------------------------ entry points
-    def encode_shard(self, xs: torch.Tensor, ls: torch.Tensor, global_batch: Optional[int] = None) -> Gathered:
-        """This rank's rows (already selected; the same number of rows on every rank) -> gathered chunks of the global batch."""
+    def encode_shard(self, xs: torch.Tensor, ls: torch.Tensor, global_batch: Optional[int] = None, range_pad=None) -> Gathered:
+        """This rank's rows (already selected; the same number of rows on every rank) -> gathered chunks of the global batch.
+        `range_pad`: padded length per row range for `ConformerEncoder.trim_sub_batches` - the SAME list on every rank (the maximum
+        over the ranks' shards), so that every rank launches identical shapes and the collectives stay fixed-size."""
         world = dist.get_world_size(self.group)
         gb = global_batch if global_batch is not None else xs.shape[0] * world
         chunks: List[GatheredChunk] = []
         if self._hooked:
-            self.encoder(xs, ls, range_hook=lambda lo, hi, out, out_len: self._gather_range(lo, hi, out, out_len, gb, chunks))
+            kw = {"range_pad": range_pad} if range_pad is not None else {}
+            self.encoder(xs, ls, range_hook=lambda lo, hi, out, out_len: self._gather_range(lo, hi, out, out_len, gb, chunks), **kw)
         else:
             out, out_len = self.encoder(xs, ls)[:2]
             self._gather_range(0, out.shape[0], out, out_len, gb, chunks)

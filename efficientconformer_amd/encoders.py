@@ -104,6 +104,13 @@ class ConformerEncoder(nn.Module):
         self._exact = False                # precision = "fp32": fp32-operand mode of the library (csrc/exact.hip)
         self._exact_packed = False
         self.stagger_ranges = False        # True: range 0's stream gets the higher priority (set by dist.ShardedEncoder)
+        # Trimmed row ranges (opt-in; bench.py's default): with `sub_batches` > 1 every row range runs as ITS OWN batch, padded to its
+        # longest utterance instead of the whole batch's - length bucketing inside one forward.  A length-sorted LibriSpeech-shaped
+        # batch of 256 spends 29 % of its frames on padding as one batch, 12 % as two ranges.  Pad frames are live in the reference
+        # (SURVEY.md 8a), so a trimmed range reproduces the reference run on THAT sub-batch (its rows collated alone), not the run on
+        # the whole batch; outputs beyond a range's own T_out are zero-filled.  Needs the lengths on the host (`x_len_host`, or one
+        # device sync) or explicit `range_pad` lengths.
+        self.trim_sub_batches = False
         self._sub_streams: Dict[tuple, torch.cuda.Stream] = {}
         self.eval()
 
@@ -235,14 +242,32 @@ class ConformerEncoder(nn.Module):
             _lib.check(_lib.load().effconf_encoder_set_option(self._handle, b"cache_pos_embeddings", 1), "set_option")
         return ws
 
-    def _run(self, x: torch.Tensor, x_len: Optional[torch.Tensor], from_audio: bool, range_hook: Optional[Callable] = None):
+    def _run(self, x: torch.Tensor, x_len: Optional[torch.Tensor], from_audio: bool, range_hook: Optional[Callable] = None,
+             x_len_host=None, range_pad=None):
         if x.is_cuda:
             # the C library allocates packed weights on, and launches on, the CURRENT device: make that the input's device
             with torch.cuda.device(x.device):
-                return self._run_on_device(x, x_len, from_audio, range_hook)
-        return self._run_on_device(x, x_len, from_audio, range_hook)
+                return self._run_on_device(x, x_len, from_audio, range_hook, x_len_host, range_pad)
+        return self._run_on_device(x, x_len, from_audio, range_hook, x_len_host, range_pad)
 
-    def _run_on_device(self, x: torch.Tensor, x_len: Optional[torch.Tensor], from_audio: bool, range_hook: Optional[Callable]):
+    def _range_pads(self, ranges, n, from_audio, lens, lens_given, x_len_host, range_pad):
+        """Padded length (samples / mel frames) of every row range in trimmed mode, or None (every range keeps the batch's)."""
+        if not self.trim_sub_batches or len(ranges) < 2 or (range_pad is None and not lens_given):
+            return None
+        if range_pad is not None:
+            pads = [int(v) for v in range_pad]
+            if len(pads) != len(ranges):
+                raise ValueError("range_pad needs one length per row range (%d)" % len(ranges))
+        else:
+            hl = x_len_host if x_len_host is not None else lens.cpu()          # without host lengths: one device sync
+            hl = [int(v) for v in (hl.tolist() if hasattr(hl, "tolist") else hl)]
+            pads = [max(hl[lo:hi]) for lo, hi in ranges]
+        floor = self.plan.n_fft // 2 + 1 if from_audio else 1
+        pads = [min(n, max(v, floor)) for v in pads]
+        return None if all(v == n for v in pads) else pads
+
+    def _run_on_device(self, x: torch.Tensor, x_len: Optional[torch.Tensor], from_audio: bool, range_hook: Optional[Callable],
+                       x_len_host=None, range_pad=None):
         if self.training:
             raise RuntimeError("efficientconformer_amd.ConformerEncoder is an inference path: call .eval()")
         if not x.is_cuda:
@@ -265,12 +290,27 @@ class ConformerEncoder(nn.Module):
 
         nsub = self.sub_batches if self.sub_batches is not None else (2 if batch >= self.sub_batch_min else 1)
         nsub = max(1, min(int(nsub), batch))
+        ranges = [(batch * i // nsub, batch * (i + 1) // nsub) for i in range(nsub)]
+        pads = self._range_pads(ranges, n, from_audio, lens, lens_given, x_len_host, range_pad)
+
+        def launch_trimmed(lo: int, hi: int, ni: int):
+            # the rows as their own batch, padded to ni <= n: what the reference computes when these utterances are collated alone
+            xi = (x[lo:hi, :ni] if from_audio else x[lo:hi, :, :ni]).contiguous()
+            ti = lib.effconf_encoder_out_frames(self._handle, ni, int(from_audio))
+            oi = out[lo:hi] if ti == t_out else torch.empty(hi - lo, ti, self.plan.dim_out, dtype=torch.float32, device=x.device)
+            ws = self._workspace(hi - lo, ni, from_audio, x.device)
+            _lib.check(fn(self._handle, xi.data_ptr(), lens[lo:].data_ptr(), hi - lo, ni, oi.data_ptr(), out_len[lo:].data_ptr(),
+                          ws.data_ptr(), ws.numel(), torch.cuda.current_stream(x.device).cuda_stream), "encoder_forward")
+            if ti != t_out:
+                out[lo:hi, :ti] = oi
+                out[lo:hi, ti:] = 0
+
         if nsub == 1:
             launch(0, batch)
             if range_hook is not None:
                 range_hook(0, batch, out, out_len)
         else:
-            if from_audio:
+            if from_audio and pads is None:
                 # the whole batch's mel on the caller's stream (see __init__), then forward_mel per row range
                 tm = n // self.plan.hop_length + 1
                 mel = torch.empty(batch, self.plan.n_mels, tm, dtype=torch.float32, device=x.device)
@@ -288,9 +328,12 @@ class ConformerEncoder(nn.Module):
                     self._sub_streams[key] = torch.cuda.Stream(device=x.device, priority=-1 if (i == 0 and self.stagger_ranges) else 0)
                 st = self._sub_streams[key]
                 st.wait_stream(cur)                      # inputs (and anything queued before this forward) are ready
-                lo, hi = batch * i // nsub, batch * (i + 1) // nsub
+                lo, hi = ranges[i]
                 with torch.cuda.stream(st):
-                    launch(lo, hi)
+                    if pads is None:
+                        launch(lo, hi)
+                    else:
+                        launch_trimmed(lo, hi, pads[i])
                     x.record_stream(st); lens.record_stream(st); out.record_stream(st); out_len.record_stream(st)
                     if range_hook is not None:
                         range_hook(lo, hi, out, out_len)     # called with the range's stream current: rows [lo, hi) of `out` are enqueued
@@ -299,18 +342,21 @@ class ConformerEncoder(nn.Module):
                 cur.wait_stream(st)                      # joined: the caller continues on its own stream
         return out, (out_len if lens_given else None), [None] * len(self.plan.blocks)
 
-    def forward(self, x: torch.Tensor, x_len: Optional[torch.Tensor] = None, range_hook: Optional[Callable] = None):
+    def forward(self, x: torch.Tensor, x_len: Optional[torch.Tensor] = None, range_hook: Optional[Callable] = None,
+                x_len_host=None, range_pad=None):
         """x: (B, L) raw 16 kHz audio, x_len: (B,) samples -> (x (B, T_out, D_last), x_len, attentions)
         (reference encoders.py:97-142).
 
         ``range_hook(lo, hi, out, out_len)`` (optional, not in the reference) is called once per sub-batch row range right after
         that range's kernels were enqueued, with the range's HIP stream current: work enqueued from the hook (an all-gather of
-        ``out[lo:hi]``) starts when THAT range is done, while the other ranges are still in their last stage."""
-        return self._run(x, x_len, True, range_hook)
+        ``out[lo:hi]``) starts when THAT range is done, while the other ranges are still in their last stage.
+        ``x_len_host`` (the lengths as a host sequence) / ``range_pad`` (one padded length per row range) serve ``trim_sub_batches``."""
+        return self._run(x, x_len, True, range_hook, x_len_host, range_pad)
 
-    def forward_mel(self, mel: torch.Tensor, mel_len: Optional[torch.Tensor] = None, range_hook: Optional[Callable] = None):
+    def forward_mel(self, mel: torch.Tensor, mel_len: Optional[torch.Tensor] = None, range_hook: Optional[Callable] = None,
+                    x_len_host=None, range_pad=None):
         """Enter after AudioPreprocessing: mel (B, n_mels, Tm), lengths in frames (the parity boundary)."""
-        return self._run(mel, mel_len, False, range_hook)
+        return self._run(mel, mel_len, False, range_hook, x_len_host, range_pad)
 
     def mel_frontend(self, x: torch.Tensor, x_len: Optional[torch.Tensor] = None):
         """AudioPreprocessing.forward (reference modules.py:87-106) on the GPU."""

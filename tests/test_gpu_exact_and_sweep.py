@@ -335,3 +335,30 @@ def test_attention_v2_end_to_end_matches_v1_and_the_reference(golden_dir, waves)
     assert mx < OUT_MAX and mean < OUT_MEAN and dx < 0.05
     again, _, _ = m.encoder.forward_mel(mel_d, ln_d)
     assert torch.equal(again, v2)
+
+
+def test_trimmed_row_ranges_equal_their_sub_batches_run_alone_and_the_oracle():
+    """ConformerEncoder.trim_sub_batches: every row range is padded to ITS longest utterance - it must reproduce, bit for bit, the
+    encoder run on that sub-batch alone (and the oracle = the reference on that collated sub-batch), zero-filled beyond its T_out."""
+    m, sd = _model("Tiny", 7)
+    enc = m.encoder
+    lens = np.array([48000, 41000, 30000, 22000, 12000, 9000], dtype=np.int64)
+    audio = torch.from_numpy(synth.make_audio(lens, seed=4)).cuda()
+    ln = torch.from_numpy(lens).cuda()
+    enc.sub_batches, enc.trim_sub_batches = 2, True
+    out, out_len, _ = enc(audio, ln, x_len_host=lens)
+    out_sync, _, _ = enc(audio, ln)                                     # lengths fetched from the device
+    out_pad, _, _ = enc(audio, ln, range_pad=[48000, 22000])
+    assert torch.equal(out, out_sync) and torch.equal(out, out_pad)
+    enc.sub_batches, enc.trim_sub_batches = 1, False
+    for lo, hi in ((0, 3), (3, 6)):
+        li = int(lens[lo:hi].max())
+        alone, alone_len, _ = enc(audio[lo:hi, :li].contiguous(), ln[lo:hi].contiguous())
+        ti = alone.shape[1]
+        assert torch.equal(out[lo:hi, :ti], alone) and torch.equal(out_len[lo:hi], alone_len)
+        assert float(out[lo:hi, ti:].abs().sum()) == 0.0
+        with torch.no_grad():
+            ref, ref_len = R.encoder(audio[lo:hi, :li].cpu(), ln[lo:hi].cpu(), sd, enc.plan)
+        assert ref_len.tolist() == alone_len.cpu().tolist() and _err(alone.cpu(), ref)[0] < 0.08
+    whole, _, _ = enc(audio, ln)                                        # one batch padded to the global maximum: the round-1 semantics
+    assert torch.equal(whole[:3], out[:3]) and not torch.equal(whole[3:, :out_len[3]], out[3:, :out_len[3]])   # pad frames are live
