@@ -111,6 +111,7 @@ class ConformerEncoder(nn.Module):
         # the whole batch; outputs beyond a range's own T_out are zero-filled.  Needs the lengths on the host (`x_len_host`, or one
         # device sync) or explicit `range_pad` lengths.
         self.trim_sub_batches = False
+        self.sub_batch_bounds = None       # optional row boundaries of the ranges (nsub - 1 increasing indices); default: equal row counts
         self._sub_streams: Dict[tuple, torch.cuda.Stream] = {}
         self.eval()
 
@@ -290,7 +291,13 @@ class ConformerEncoder(nn.Module):
 
         nsub = self.sub_batches if self.sub_batches is not None else (2 if batch >= self.sub_batch_min else 1)
         nsub = max(1, min(int(nsub), batch))
-        ranges = [(batch * i // nsub, batch * (i + 1) // nsub) for i in range(nsub)]
+        if self.sub_batch_bounds is not None and nsub > 1:      # explicit row boundaries (e.g. equal padded work per range)
+            cuts = [0] + [int(b) for b in self.sub_batch_bounds] + [batch]
+            if len(cuts) != nsub + 1 or any(cuts[i] >= cuts[i + 1] for i in range(nsub)):
+                raise ValueError("sub_batch_bounds must be %d increasing row indices inside (0, %d)" % (nsub - 1, batch))
+            ranges = [(cuts[i], cuts[i + 1]) for i in range(nsub)]
+        else:
+            ranges = [(batch * i // nsub, batch * (i + 1) // nsub) for i in range(nsub)]
         pads = self._range_pads(ranges, n, from_audio, lens, lens_given, x_len_host, range_pad)
 
         def launch_trimmed(lo: int, hi: int, ni: int):
