@@ -96,6 +96,88 @@ __global__ __launch_bounds__(256) void ctc_argmax_kernel(const float* __restrict
     }
 }
 
+// fc + argmax on the fp32 MFMA (v_mfma_f32_32x32x2_f32: a k-ordered fmaf chain, so logits are bit-identical to ctc_argmax_kernel's).
+// One workgroup = ROWS frames x 256 vocabulary columns per pass (wave = 64 columns: RT x 2 accumulator tiles); the frame tile sits in
+// LDS (row pitch D + 1 floats: conflict-free column reads), fc^T streams from L2 as MFMA B fragments (two rows of 32 consecutive
+// floats per load).  The logits tile goes back through LDS for the per-row argmax (first maximum wins) and the optional row-major
+// logits output.  6.3 GFLOP per 256 x 201 frames: 222 us on the VALU kernel above, fp32-MFMA bound here.
+template <int ROWS>
+__global__ __launch_bounds__(256) void ctc_argmax_mfma_kernel(const float* __restrict__ x, int M, int D, const float* __restrict__ Wt,
+                                                              const float* __restrict__ bias, int V, int* __restrict__ preds,
+                                                              float* __restrict__ logits, int tile_off) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int RT = ROWS / 32, TPR = 256 / ROWS, CPT = 256 / TPR, LDT = 257;
+    float* sx = reinterpret_cast<float*>(smem);                         // [ROWS][D + 1]
+    float* st = sx + tile_off;                                          // [ROWS][LDT] logits tile (aliases sx when V <= 256: one pass)
+    const int LDX = D + 1;
+    const int m0 = blockIdx.x * ROWS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid * 4; i < ROWS * D; i += 1024) {
+        const int r = i / D, k = i - r * D;
+        const int mr = m0 + r < M ? m0 + r : M - 1;
+        const float4 v = *reinterpret_cast<const float4*>(x + (size_t)mr * D + k);
+        float* d = sx + r * LDX + k;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    __syncthreads();
+    const int prow = tid / TPR, part = tid - prow * TPR;                // argmax: TPR adjacent threads per row, CPT columns each
+    float best = -INFINITY;
+    int bidx = 0x7fffffff;
+    const int kh = lane >> 5, lc = lane & 31;
+    for (int v0 = 0; v0 < V; v0 += 256) {
+        f32x16 acc[RT][2];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[rt][ct][r] = 0.f;
+        const int c0 = v0 + wave * 64 + lc, c1 = c0 + 32;
+        const float* w0 = Wt + (c0 < V ? c0 : V - 1) + (size_t)kh * V;
+        const float* w1 = Wt + (c1 < V ? c1 : V - 1) + (size_t)kh * V;
+        const float* xa = sx + lc * LDX + kh;
+#pragma unroll 4
+        for (int k = 0; k < D; k += 2) {
+            const float b0 = w0[(size_t)k * V], b1 = w1[(size_t)k * V];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const float a = xa[rt * 32 * LDX + k];
+                acc[rt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[rt][0], 0, 0, 0);
+                acc[rt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[rt][1], 0, 0, 0);
+            }
+        }
+        if (tile_off == 0 || v0 > 0) __syncthreads();                  // aliasing tile: every wave is done with the frame tile; later passes: the previous tile was consumed
+        const float bz0 = bias[c0 < V ? c0 : V - 1], bz1 = bias[c1 < V ? c1 : V - 1];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                st[row * LDT + wave * 64 + lc] = acc[rt][0][r] + bz0;
+                st[row * LDT + wave * 64 + 32 + lc] = acc[rt][1][r] + bz1;
+            }
+        __syncthreads();
+        if (logits) {
+            for (int i = tid; i < ROWS * 256; i += 256) {
+                const int r = i >> 8, cc = i & 255;
+                if (m0 + r < M && v0 + cc < V) logits[(size_t)(m0 + r) * V + v0 + cc] = st[r * LDT + cc];
+            }
+        }
+#pragma unroll 8
+        for (int j = 0; j < CPT; ++j) {
+            const int cc = part * CPT + j;
+            const float val = st[prow * LDT + cc];
+            if (v0 + cc < V && val > best) { best = val; bidx = v0 + cc; }   // ascending columns, strictly greater: first maximum wins
+        }
+    }
+#pragma unroll
+    for (int o = 1; o < TPR; o <<= 1) {
+        const float ov = __shfl_xor(best, o); const int oi = __shfl_xor(bidx, o);
+        if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+    }
+    if (part == 0 && m0 + prow < M) preds[m0 + prow] = bidx;
+}
+
 // one wave per utterance: 64 frames per step, keep = (c != 0 && c != previous frame's c), output position = running count +
 // prefix popcount of the keep ballot
 __global__ __launch_bounds__(64) void ctc_collapse_kernel(const int* __restrict__ preds, const int64_t* __restrict__ lens, int B, int T,
@@ -130,10 +212,25 @@ int launch_lengths(const int64_t* x_len, int B, int from_audio, int hop, int sub
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+template <int ROWS>
+int launch_ctc_mfma(const float* x, int M, int D, const float* Wt, const float* bias, int V, int* preds, float* logits, hipStream_t s) {
+    const size_t frame = (size_t)ROWS * (D + 1) * 4, tile = (size_t)ROWS * 257 * 4;
+    const bool alias = V <= 256;                                       // one pass: the logits tile may reuse the frame tile
+    const size_t lds = alias ? (frame > tile ? frame : tile) : frame + tile;
+    if (lds > 160 * 1024) return -2;
+    static LdsAttr attr;
+    ensure_dynamic_lds(reinterpret_cast<const void*>(&ctc_argmax_mfma_kernel<ROWS>), (int)lds, attr);
+    hipLaunchKernelGGL((ctc_argmax_mfma_kernel<ROWS>), dim3((M + ROWS - 1) / ROWS), dim3(256), lds, s, x, M, D, Wt, bias, V, preds, logits,
+                       alias ? 0 : (int)(frame / 4));
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 int launch_ctc_argmax(const float* x, int M, int D, const float* Wt, const float* bias, int V,
-                      int* preds, float* logits_or_null, hipStream_t s) {
+                      int* preds, float* logits_or_null, hipStream_t s, int use_mfma) {
     if (M <= 0) return 0;
     if (D % 4) return -2;
+    if (use_mfma && D <= 256) return launch_ctc_mfma<64>(x, M, D, Wt, bias, V, preds, logits_or_null, s);
+    if (use_mfma && D <= 1024 && V <= 256) return launch_ctc_mfma<32>(x, M, D, Wt, bias, V, preds, logits_or_null, s);
     // rows per workgroup: as many as keep the frame tile within the default 64 KB of dynamic LDS
     const int rows = D <= 384 ? 32 : (D <= 768 ? 16 : 8);
     const size_t lds = (size_t)rows * D * sizeof(float) + rows * 4 * (sizeof(float) + sizeof(int));

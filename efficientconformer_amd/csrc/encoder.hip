@@ -69,6 +69,7 @@ struct EcEncoder {
     const bf16_t* lin_fused = nullptr; int lin_fused_ld = 0;   // Linear weight in the fused kernel's K order (sublinear.hip)
     bool fuse_subsample = true;
     bool fuse_chain = true;                  // row-local chains (chain.hip) where supported
+    int ctc_mfma = 1;                        // CTC head on the fp32 MFMA (bit-identical logits); 0: the VALU kernel
     int attention_v2 = 1;                    // 0: attention.hip; 1 (default) / 2: attention2.hip variants where they support the head width (<= 128)
     // two-layer subsampler (plain Conformer configs): layer-2 implicit-GEMM weight [N][9*Cp] (tap, c_in), folded bias, Cp
     const bf16_t* sub2_w = nullptr; const float* sub2_b = nullptr; int sub2_cp = 0;
@@ -601,7 +602,7 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
             bool next_head = false;
             if (!last) {
                 const EcBlock& nbk = e->blocks[k + 1];
-                next_head = W.cc_full && e->bw[k + 1].chain_in && chain_full_supported(De) && (((nbk.group_size * nbk.dim_model / nbk.num_heads) % 2) == 0 || !getenv("EFFCONF_HEAD_MAJOR_ODD")) && nbk.dim_model == De;
+                next_head = W.cc_full && e->bw[k + 1].chain_in && chain_full_supported(De) && (((nbk.group_size * nbk.dim_model / nbk.num_heads) % 2) == 0 || !head_major_odd) && nbk.dim_model == De;
             }
             ChainParams cp{};
             cp.M = Mo; cp.D = De; cp.X = x; cp.ldx = De; cp.Y = xo; cp.ldy = De; cp.A = cbuf; cp.lda = ld8(De);
@@ -1223,7 +1224,7 @@ int effconf_ctc_greedy(EcEncoder* e, const float* enc_out, const int64_t* out_le
     int* preds = reinterpret_cast<int*>(workspace);
     hipStream_t st = (hipStream_t)stream;
     EC_TRY(launch_ctc_argmax(enc_out, batch * t_out, e->blocks.back().dim_expand, e->fc_wt, e->fc_b, e->cfg.vocab_size,
-                             preds, logits, st));
+                             preds, logits, st, e->ctc_mfma));
     EC_TRY(launch_ctc_collapse(preds, out_len, batch, t_out, labels, label_len, st));
     return 0;
 }
@@ -1232,6 +1233,7 @@ int effconf_encoder_set_option(EcEncoder* e, const char* name, int32_t value) {
     if (!e || !name) return fail("null argument");
     if (!strcmp(name, "fuse_subsample")) { e->fuse_subsample = value != 0; return 0; }
     if (!strcmp(name, "fuse_chain")) { e->fuse_chain = value != 0; return 0; }
+    if (!strcmp(name, "ctc_mfma")) { e->ctc_mfma = value != 0; return 0; }
     if (!strcmp(name, "attention_v2")) { if (value != 0 && value != 1 && value != 2) return fail("attention_v2: 0, 1 or 2"); e->attention_v2 = value; return 0; }
     if (!strcmp(name, "cache_pos_embeddings")) { e->e_cache_on = value != 0; e->e_cache.clear(); return 0; }
     if (!strcmp(name, "exact_fp32")) {

@@ -191,6 +191,6 @@ int launch_lengths(const int64_t* x_len, int B, int from_audio, int hop, int sub
                    int n_blocks, int* stage_lens /*[n_blocks+1][B]*/, int64_t* out_len, hipStream_t s);
 // logits = x W^T + b in fp32 (Wt is [D][V]), argmax per frame (first max), optional logits out
 int launch_ctc_argmax(const float* x, int M, int D, const float* Wt, const float* bias, int V,
-                      int* preds, float* logits_or_null, hipStream_t s);
+                      int* preds, float* logits_or_null, hipStream_t s, int use_mfma = 1);   // use_mfma: fp32-MFMA kernel where the frame tile fits LDS
 // drop blanks (0), collapse repeats, stop at len[b]  (model_ctc.py:99-133)
 int launch_ctc_collapse(const int* preds, const int64_t* lens, int B, int T, int* labels, int* label_len, hipStream_t s);

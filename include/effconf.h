@@ -160,6 +160,8 @@ int effconf_rnnt_greedy(EcRnnt* r, const float* enc_out, const int64_t* out_len,
  *   transposed on the way into LDS, hoisted staging addresses, no column masks off the buffer tails, deferred accumulator rescale);
  *   2 = attention2.hip with 32 queries per wave (one wave per SIMD: measured slower, kept for experiments).  Head widths above 128
  *   always use attention.hip.  Results agree to fp32 summation order (variant 1's deferred rescale: to bf16 rounding of P).
+ * "ctc_mfma" (default 1): the CTC head (fc + argmax) on the fp32 MFMA; 0 selects the VALU kernel.  Both are k-ordered fp32 fma chains:
+ *   bit-identical logits and labels.
  * "exact_fp32" (default 0): fp32-operand precision mode (csrc/exact.hip): every GEMM on fp32 MFMA, fp32 attention / convolutions,
  *   so that greedy CTC label sequences equal the reference's CPU fp32 path (model_ctc.py:99-133) wherever its top-2 logit margins
  *   exceed fp32 summation-order noise; ~10x slower than the default bf16-operand path.  Set to 1 BEFORE effconf_encoder_finalize

@@ -362,3 +362,27 @@ def test_trimmed_row_ranges_equal_their_sub_batches_run_alone_and_the_oracle():
         assert ref_len.tolist() == alone_len.cpu().tolist() and _err(alone.cpu(), ref)[0] < 0.08
     whole, _, _ = enc(audio, ln)                                        # one batch padded to the global maximum: the round-1 semantics
     assert torch.equal(whole[:3], out[:3]) and not torch.equal(whole[3:, :out_len[3]], out[3:, :out_len[3]])   # pad frames are live
+
+
+@pytest.mark.parametrize("name,vocab", [("EfficientConformerCTCSmall", 256), ("ConformerCTCLarge", 256), ("Tiny", 32), ("Tiny", 300), ("EfficientConformerCTCLarge", 256)])
+def test_ctc_head_on_fp32_mfma_is_bit_identical_to_the_valu_kernel(name, vocab):
+    """fc + argmax on v_mfma_f32_32x32x2_f32 (a k-ordered fmaf chain) against the VALU kernel: logits and labels bit for bit, including a
+    vocabulary that needs two 256-column passes and frame counts that are no multiple of the row tile; both against the oracle's fc."""
+    cfg = named_config(name)
+    m = ModelCTC(cfg["encoder_params"], {"vocab_size": vocab})
+    sd = synth.make_state_dict(m.encoder.plan, 5, vocab, prefix="encoder.")
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m = m.cuda()
+    m.encoder._ensure_packed()
+    g = torch.Generator().manual_seed(3)
+    enc = torch.randn(3, 77, m.encoder.plan.dim_out, generator=g).cuda()
+    ln = torch.tensor([77, 50, 9]).cuda()
+    m.encoder.set_option("ctc_mfma", 0)
+    l0, lab0, n0 = m._head(enc, ln, want_logits=True)
+    m.encoder.set_option("ctc_mfma", 1)
+    l1, lab1, n1 = m._head(enc, ln, want_logits=True)
+    assert torch.equal(l0, l1) and torch.equal(lab0, lab1) and torch.equal(n0, n1)
+    ref = R.ctc_logits(enc.cpu(), {"fc.weight": sd["fc.weight"], "fc.bias": sd["fc.bias"]})
+    assert float((l1.cpu() - ref).abs().max()) < 2e-4
+    _, lab2, n2 = m._head(enc, ln)                                     # without the logits output
+    assert torch.equal(lab2, lab1) and torch.equal(n2, n1)
