@@ -67,6 +67,9 @@ def parse():
                     help="pad every row range to the whole batch's longest utterance (round-1 workload) instead of its own longest")
     ap.add_argument("--attention", type=int, default=-1, choices=[-1, 0, 1, 2],
                     help="attention kernel: 0 attention.hip, 1 / 2 attention2.hip variants (-1: the library's default = 1)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for N > 1 (nccl = RCCL over xGMI; gloo + --one-device: N ranks on ONE GPU, a test of the multi-rank path)")
+    ap.add_argument("--one-device", action="store_true", help="every rank uses cuda:0 (tests on a single-GPU box; never a benchmark)")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU work: build the batch plan, join the process group (gloo) and print the JSON skeleton (CPU tests)")
     return ap.parse_args()
@@ -316,10 +319,13 @@ def main():
         return
 
     assert torch.cuda.is_available(), "bench.py needs a GPU (HIP path only)"
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", 0 if args.one_device else local_rank)
     torch.cuda.set_device(dev)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     cfg, model, sd = build_model(args.model)
     model = model.to(dev)
@@ -381,8 +387,9 @@ def main():
             with torch.cuda.stream(head_stream):
                 gl = labels.new_empty((world,) + tuple(labels.shape)); gn = label_len.new_empty((world,) + tuple(label_len.shape))
                 labels.record_stream(head_stream); label_len.record_stream(head_stream)
-                dist.all_gather_into_tensor(gl, labels)
-                dist.all_gather_into_tensor(gn, label_len)
+                from efficientconformer_amd.dist import _all_gather
+                _all_gather(gl, labels)
+                _all_gather(gn, label_len)
             last["labels"] = (gl, gn)
 
     def drain():
@@ -413,7 +420,7 @@ def main():
 
     result = None
     if rank == 0:
-        par = "dp%d (utterance shards" % world
+        par = "dp%d%s (utterance shards" % (world, ", ALL RANKS ON ONE GPU over gloo: a functional test, not a benchmark" if args.one_device else "")
         if world > 1:
             par += ", RCCL all-gather of %s per row range on a comm stream, wire %s" % ("encoder outputs" if args.gather == "outputs" else "label ids", args.wire)
         result = result_skeleton(args, world, all_valid * args.steps / elapsed, 1000.0 * elapsed / args.steps, args.batch * world,

@@ -27,6 +27,17 @@ import torch
 import torch.distributed as dist
 
 
+def _all_gather(dst: torch.Tensor, src: torch.Tensor, group=None):
+    """Fixed-size all-gather into one tensor.  RCCL ("nccl") and gloo-on-CPU take `all_gather_into_tensor`; gloo with device tensors (a
+    2-rank test on ONE GPU) goes through host copies."""
+    if src.is_cuda and dist.get_backend(group) == "gloo":
+        host = [torch.empty(src.shape, dtype=src.dtype) for _ in range(dist.get_world_size(group))]
+        dist.all_gather(host, src.cpu(), group=group)
+        dst.copy_(torch.cat(host, 0).view(dst.shape), non_blocking=False)
+    else:
+        dist.all_gather_into_tensor(dst, src, group=group)
+
+
 def shard_rows(batch: int, rank: int, world: int) -> torch.Tensor:
     return torch.arange(rank, batch, world) if rank < batch else torch.empty(0, dtype=torch.int64)
 
@@ -125,8 +136,8 @@ class ShardedEncoder:
                 out.record_stream(self._comm); out_len.record_stream(self._comm)   # read here, owned by the caller's stream
                 g = wire.new_empty((world * n,) + tuple(wire.shape[1:]))
                 gl = wl.new_empty(world * n)
-                dist.all_gather_into_tensor(g, wire.contiguous(), group=self.group)
-                dist.all_gather_into_tensor(gl, wl.contiguous(), group=self.group)
+                _all_gather(g, wire.contiguous(), self.group)
+                _all_gather(gl, wl.contiguous(), self.group)
                 ev = torch.cuda.Event()
                 ev.record(self._comm)
             chunks.append(GatheredChunk(lo, hi, g, gl, rows.to(dev), keep.to(dev), ev, self._comm))

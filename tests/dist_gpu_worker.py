@@ -1,0 +1,59 @@
+"""Worker of tests/test_gpu_dist.py: launched twice by torch.distributed.run on ONE GPU (gloo process group, device tensors).
+The real HIP encoder behind dist.ShardedEncoder with two sub-batch row ranges: per-range hooks, comm stream, chunk protocol,
+record_stream - everything of the multi-GPU path except the RCCL transport.  Prints DIST_GPU_OK on success."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from efficientconformer_amd import ModelCTC, named_config, synth  # noqa: E402
+from efficientconformer_amd.dist import ShardedEncoder, shard_batch  # noqa: E402
+
+
+def main():
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    torch.cuda.set_device(0)
+    cfg = named_config("Tiny")
+    m = ModelCTC.from_config(cfg)
+    sd = synth.make_state_dict(m.encoder.plan, 7, cfg["tokenizer_params"]["vocab_size"], prefix="encoder.")
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m = m.cuda()
+    enc = m.encoder
+    lens = np.array([48000, 41000, 37000, 30000, 22000, 12000, 9000], dtype=np.int64)        # odd batch: shards of 4 and 3 rows
+    audio = torch.from_numpy(synth.make_audio(lens, seed=4)).cuda()
+    ln = torch.from_numpy(lens).cuda()
+    enc.sub_batches = 1
+    full, full_len, _ = enc(audio, ln)
+    _, labels_full, n_full = m._head(full, full_len)
+    enc.sub_batches = 2
+    sh = ShardedEncoder(enc)
+    ok = True
+    for it in range(3):                                   # repeated: buffers of call k are recycled while call k+1 runs
+        out, out_len = sh(audio, ln)
+        ok = ok and torch.equal(out, full) and torch.equal(out_len, full_len)
+        xs, ls = shard_batch(audio, ln, rank, world, uniform=True)
+        g = sh.encode_shard(xs, ls, audio.shape[0])
+        seen = {}
+        for ch in g.chunks:                               # consumer on the current stream, chunk by chunk (bench.py's head)
+            ch.wait()
+            _, lab, n = m._head(ch.out, ch.out_len)
+            for r in torch.nonzero(ch.keep).flatten().tolist():
+                seen[int(ch.rows[r])] = lab[r, :int(n[r])].tolist()
+        want = {b: labels_full[b, :int(n_full[b])].tolist() for b in range(audio.shape[0])}
+        ok = ok and len(g.chunks) == 2 and seen == want
+    torch.cuda.synchronize()
+    flag = torch.tensor([1.0 if ok else 0.0])
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        print("DIST_GPU_OK" if float(flag) == 1.0 else "DIST_GPU_FAILED")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
