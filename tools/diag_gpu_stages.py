@@ -6,7 +6,7 @@ import sys
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # tools/ -> repo root
 sys.path.insert(0, ROOT)
 from efficientconformer_amd import ModelCTC, named_config, synth  # noqa: E402
 from oracle import ref_encoder as R  # noqa: E402

@@ -55,13 +55,7 @@ def reference_rnnt_greedy(f, f_len, dec_params, joint_params, sd):
     """Execute the reference's own Transducer.gready_search_decoding (transducer.py:139-186) on given encoder
     outputs: a Transducer object is assembled around the reference's RnnDecoder / JointNetwork classes (without
     Model.__init__: no tokenizer file, optimizer or loss here) and its real method is called."""
-    for n, attrs in (("jiwer", ()), ("kenlm", ()), ("warp_rnnt", ("rnnt_loss",)), ("ctcdecode", ("CTCBeamDecoder",)),
-                     ("torch.utils.tensorboard", ("SummaryWriter",)), ("sentencepiece", ("SentencePieceProcessor", "SentencePieceTrainer"))):
-        if n not in sys.modules or n == "sentencepiece":
-            m = types.ModuleType(n)
-            for a in attrs:
-                setattr(m, a, object)
-            sys.modules.setdefault(n, m)
+    _stub_third_party()
     import models.transducer as tr
     import models.decoders as dec
     import models.joint_networks as jn
@@ -123,23 +117,25 @@ def run_encoder(enc_mod, name, mel, lens, seed, hooks=False):
     return plan, x, out_len, logits, atts, trace
 
 
+def _stub_third_party():
+    for n, attrs in (("jiwer", ()), ("kenlm", ()), ("warp_rnnt", ("rnnt_loss",)), ("ctcdecode", ("CTCBeamDecoder",)),
+                     ("torch.utils.tensorboard", ("SummaryWriter",)), ("sentencepiece", ("SentencePieceProcessor", "SentencePieceTrainer"))):
+        if n not in sys.modules or n == "sentencepiece":
+            m = types.ModuleType(n)
+            for a in attrs:
+                setattr(m, a, object)
+            sys.modules.setdefault(n, m)
+
+
 def greedy_reference(logits, lens):
-    """The reference's greedy loop (model_ctc.py:99-133) executed on its own logits."""
-    preds = logits.log_softmax(dim=-1).argmax(dim=-1)
-    out = []
-    for b in range(logits.size(0)):
-        blank, pl = False, []
-        for t in range(int(lens[b])):
-            if preds[b, t] == 0:
-                blank = True
-                continue
-            if len(pl) == 0:
-                pl.append(preds[b, t].item())
-            elif pl[-1] != preds[b, t] or blank:
-                pl.append(preds[b, t].item())
-            blank = False
-        out.append(pl)
-    return out
+    """The reference's OWN greedy method (models/model_ctc.py:90-136), called as imported: a stand-in `self` whose encoder returns the
+    given logits, whose fc is the identity and whose tokenizer keeps the id lists."""
+    _stub_third_party()
+    import models.model_ctc as mc
+    fake = types.SimpleNamespace(encoder=lambda x, x_len: (x, x_len, None), fc=lambda x: x,
+                                 tokenizer=types.SimpleNamespace(decode=lambda lists: [list(map(int, l)) for l in lists]))
+    with torch.no_grad():
+        return mc.ModelCTC.gready_search_decoding(fake, logits, lens)
 
 
 def pack_labels(lists):
