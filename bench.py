@@ -65,6 +65,8 @@ def parse():
                     help="cut the row ranges for equal PADDED FRAMES per range instead of equal utterance counts (measured: no gain at B = 256)")
     ap.add_argument("--no-trim", action="store_true",
                     help="pad every row range to the whole batch's longest utterance (round-1 workload) instead of its own longest")
+    ap.add_argument("--subsample", type=int, default=-1, choices=[-1, 0, 1, 2],
+                    help="conv subsampling + Linear: 0 separate kernels, 1 sublinear.hip, 2 sublinear2.hip (-1: the library's default = 2)")
     ap.add_argument("--attention", type=int, default=-1, choices=[-1, 0, 1, 2],
                     help="attention kernel: 0 attention.hip, 1 / 2 attention2.hip variants (-1: the library's default = 1)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -356,6 +358,8 @@ def main():
         padded_frames = int(sum((cuts[i + 1] - cuts[i]) * (range_pad[i] // plan.hop_length + 1) for i in range(nsub)))
     if args.attention >= 0:
         model.encoder.set_option("attention_v2", args.attention)
+    if args.subsample >= 0:
+        model.encoder.set_option("fuse_subsample", args.subsample)
     sharded = head_stream = None
     if world > 1:
         from efficientconformer_amd.dist import ShardedEncoder

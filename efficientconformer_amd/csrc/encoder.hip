@@ -67,7 +67,8 @@ struct EcEncoder {
     const float *sub_w9 = nullptr, *sub_b = nullptr;
     PackedLinear lin;
     const bf16_t* lin_fused = nullptr; int lin_fused_ld = 0;   // Linear weight in the fused kernel's K order (sublinear.hip)
-    bool fuse_subsample = true;
+    const bf16_t* lin_rs = nullptr; const float* conv_tab = nullptr;   // sublinear2.hip: Linear weight [F/2][32 NT][32 CG] (K-permuted per 16), conv taps [32 CG][16]
+    int fuse_subsample = 2;                  // 0: separate conv + GEMM kernels, 1: sublinear.hip, 2: sublinear2.hip where it supports the shape (else 1)
     bool fuse_chain = true;                  // row-local chains (chain.hip) where supported
     int ctc_mfma = 1;                        // CTC head on the fp32 MFMA (bit-identical logits); 0: the VALU kernel
     int attention_v2 = 1;                    // 0: attention.hip; 1 (default) / 2: attention2.hip variants where they support the head width (<= 128)
@@ -463,6 +464,10 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
           EC_TRY(launch_conv2_igemm(act1, B, F1, Tl1, e->sub2_cp, e->sub2_w, 9 * e->sub2_cp, e->sub2_b, C1, F2q, s.T1, sub, st)); }
         trace_add(e, st, "subsample", sub, (int64_t)B * s.T1, F2q * C1, F2q * C1, 1);
         EC_TRY(run_gemm(e, PC_GEMM_OTHER, st, sub, F2q * C1, B * s.T1, e->lin, EPI_F32, x, e->lin.N));
+    } else if (e->fuse_subsample == 2 && e->lin_rs) {
+        PROF(PC_SUBCONV, 2.0 * 9 * B * s.T1 * (double)Ksub + 2.0 * B * s.T1 * (double)Ksub * e->lin.N,
+             (double)B * c.n_mels * s.Tm * 4 + (double)B * s.T1 * e->lin.N * 4);
+        EC_TRY(launch_sublinear2(mel, B, c.n_mels, s.Tm, s.T1, e->conv_tab, e->lin_rs, e->lin.bias, C0, e->lin.N, x, e->lin.N, st));
     } else if (e->fuse_subsample && e->lin_fused) {
         PROF(PC_SUBCONV, 2.0 * 9 * B * s.T1 * (double)Ksub + 2.0 * B * s.T1 * (double)Ksub * e->lin.N,
              (double)B * c.n_mels * s.Tm * 4 + (double)B * s.T1 * e->lin.N * 4);
@@ -900,6 +905,32 @@ int effconf_encoder_finalize(EcEncoder* e) {
                             wf[(size_t)n * Kp + ((size_t)fc * Cp + ch) * 8 + ee] = h_f2bf(lw->data[(size_t)n * (C * F2) + ch * F2 + fc * 8 + ee]);
             e->lin_fused = upload(e, wf); e->lin_fused_ld = Kp;
         }
+        e->lin_rs = nullptr; e->conv_tab = nullptr;
+        if (c.sub_layers == 1) {
+            const int N = e->blocks[0].dim_model, F2 = c.n_mels / 2;
+            const int CGr = sublinear2_groups(c.n_mels, C, N);
+            if (CGr > 0) {
+                // sublinear2.hip: per output frequency f a slab [32 NT rows n][32 CG columns]: natural column = channel c (reference feature
+                // c*(F/2) + f, modules.py:247), K index permuted inside every group of 16 (packed position 8h+e <-> column 4h + 8(e>>2) + (e&3)):
+                // the Swish-ed accumulator registers of the conv MFMA are the B fragments directly (chain.hip's register hand-off)
+                const HostTensor* lw = find(e, "linear.weight");
+                const int NT = CGr, Cp = 32 * CGr, rows = 32 * NT;
+                std::vector<uint16_t> wr((size_t)F2 * rows * Cp, 0);
+                for (int f = 0; f < F2; ++f)
+                    for (int n = 0; n < N; ++n)
+                        for (int k = 0; k < Cp; ++k) {
+                            const int g16 = k / 16, pp = k % 16, hh = pp >> 3, ee = pp & 7;
+                            const int ch = g16 * 16 + 4 * hh + 8 * (ee >> 2) + (ee & 3);
+                            if (ch < C) wr[((size_t)f * rows + n) * Cp + k] = h_f2bf(lw->data[(size_t)n * (C * F2) + (size_t)ch * F2 + f]);
+                        }
+                std::vector<float> tab((size_t)Cp * 16, 0.f);
+                for (int ch = 0; ch < C; ++ch) {
+                    for (int j = 0; j < 9; ++j) tab[(size_t)ch * 16 + j] = w9[ch * 9 + j];
+                    tab[(size_t)ch * 16 + 9] = bb[ch];
+                }
+                e->lin_rs = upload(e, wr); e->conv_tab = upload(e, tab);
+            }
+        }
     }
     std::map<std::pair<int, int>, const bf16_t*> tables;
     std::vector<int> strides;
@@ -1231,7 +1262,7 @@ int effconf_ctc_greedy(EcEncoder* e, const float* enc_out, const int64_t* out_le
 
 int effconf_encoder_set_option(EcEncoder* e, const char* name, int32_t value) {
     if (!e || !name) return fail("null argument");
-    if (!strcmp(name, "fuse_subsample")) { e->fuse_subsample = value != 0; return 0; }
+    if (!strcmp(name, "fuse_subsample")) { if (value < 0 || value > 2) return fail("fuse_subsample: 0, 1 or 2"); e->fuse_subsample = value; return 0; }
     if (!strcmp(name, "fuse_chain")) { e->fuse_chain = value != 0; return 0; }
     if (!strcmp(name, "ctc_mfma")) { e->ctc_mfma = value != 0; return 0; }
     if (!strcmp(name, "attention_v2")) { if (value != 0 && value != 1 && value != 2) return fail("attention_v2: 0, 1 or 2"); e->attention_v2 = value; return 0; }

@@ -128,6 +128,10 @@ int launch_subsample_conv(const float* mel, int B, int F, int Tm, int T1, const 
 bool sublinear_fused_supported(int F, int N);
 int launch_sublinear_fused(const float* mel, int B, int F, int Tm, int T1, const float* w9, const float* cbias, int C,
                            const bf16_t* W, int ldw, const float* bias, int N, float* out, int ldc, hipStream_t s);
+// second generation (sublinear2.hip): row-stationary, the 3x3 conv on the MFMA pipe.  groups = 32-channel groups (0: shape not supported)
+int sublinear2_groups(int F, int C, int N);
+int launch_sublinear2(const float* mel, int B, int F, int Tm, int T1, const float* ctab, const bf16_t* Wp, const float* bias, int C, int N,
+                      float* out, int ldc, hipStream_t s);
 // two-layer subsampling (conv2.hip): layer 1 channel-last, layer 2 implicit GEMM
 int launch_subsample_conv_cl(const float* mel, int B, int F, int Tm, int T1, const float* w9, const float* bias, int C, int Cp,
                              bf16_t* out, hipStream_t s);
