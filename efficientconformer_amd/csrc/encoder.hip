@@ -9,6 +9,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -63,6 +64,7 @@ struct EcEncoder {
     std::map<std::string, HostTensor> host;
     bool finalized = false;
     std::vector<void*> allocs;
+    size_t guard_bytes = 0;               // EFFCONF_POISON_GUARDS (test hook): NaN-filled guard regions around every parameter buffer
     // packed
     const float *sub_w9 = nullptr, *sub_b = nullptr;
     PackedLinear lin;
@@ -117,12 +119,18 @@ namespace {
 
 template <class T>
 const T* upload(EcEncoder* e, const std::vector<T>& v) {
+    // guard > 0 (EFFCONF_POISON_GUARDS, a test hook read once at create): every parameter buffer sits between two guard regions of 0xFF
+    // bytes (NaN as bf16 and as fp32), so a read past either end of a packed weight shows up in the output instead of depending on
+    // what the allocator happened to place next to it
+    const size_t guard = e->guard_bytes, used = v.size() * sizeof(T);
     void* d = nullptr;
-    size_t bytes = std::max<size_t>(v.size() * sizeof(T), 16);
-    if (hipMalloc(&d, bytes) != hipSuccess) return nullptr;
+    size_t bytes = std::max<size_t>((used + 15) / 16 * 16, 16);
+    if (hipMalloc(&d, bytes + 2 * guard) != hipSuccess) return nullptr;
     e->allocs.push_back(d);
-    if (!v.empty() && hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
-    return reinterpret_cast<const T*>(d);
+    char* base = static_cast<char*>(d) + guard;
+    if (guard && (hipMemset(d, 0xFF, guard) != hipSuccess || hipMemset(base + used, 0xFF, bytes - used + guard) != hipSuccess)) return nullptr;
+    if (!v.empty() && hipMemcpy(base, v.data(), used, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    return reinterpret_cast<const T*>(base);
 }
 
 const HostTensor* find(EcEncoder* e, const std::string& k) {
@@ -135,9 +143,9 @@ const HostTensor* find(EcEncoder* e, const std::string& k) {
 // chain.hip are LayerNorm-ed accumulator registers in MFMA C order
 // ln_g / ln_b: a LayerNorm in front of this linear layer folded in: W diag(gamma), b + W beta (fp32, before the bf16 rounding)
 bool pack_linear(EcEncoder* e, const std::vector<const float*>& row_ptr, const std::vector<float>& bias, int K, PackedLinear* out,
-                 bool kperm = false, const float* ln_g = nullptr, const float* ln_b = nullptr) {
+                 bool kperm = false, const float* ln_g = nullptr, const float* ln_b = nullptr, int min_ldw = 0) {
     const int N = (int)row_ptr.size();
-    const int Np = ec_round_up(N, 128), Kp = ec_round_up(K, 64);
+    const int Np = ec_round_up(N, 128), Kp = ec_round_up(K > min_ldw ? K : min_ldw, 64);
     std::vector<uint16_t> w((size_t)Np * Kp, 0);
     std::vector<float> b(Np, 0.f);
     for (int n = 0; n < N && n < (int)bias.size(); ++n) b[n] = bias[n];
@@ -161,8 +169,11 @@ bool pack_linear(EcEncoder* e, const std::vector<const float*>& row_ptr, const s
     return out->w && out->bias;
 }
 
+// min_ldw: row pitch floor in elements.  The whole-row kernels of rsgemm.hip (RS_F32 / RS_RESID) pick their k-step class from
+// max(K, N) and DMA that many columns of every weight row: an expanding layer (K < N) must be packed at least N wide, or the last
+// row's DMA runs past the buffer (found with EFFCONF_POISON_GUARDS: conv_res 180 -> 256 of EfficientConformer Medium)
 bool pack_named_linear(EcEncoder* e, const std::string& prefix, int N, int K, PackedLinear* out, std::string* err, bool kperm = false,
-                       const std::string& fold_ln = "") {
+                       const std::string& fold_ln = "", int min_ldw = 0) {
     const HostTensor* w = find(e, prefix + ".weight");
     const HostTensor* b = find(e, prefix + ".bias");
     if (!w || !b) { *err = "missing tensor " + prefix + ".weight/.bias"; return false; }
@@ -171,7 +182,7 @@ bool pack_named_linear(EcEncoder* e, const std::string& prefix, int N, int K, Pa
     for (int n = 0; n < N; ++n) rows[n] = w->data.data() + (size_t)n * K;
     const HostTensor *lg = fold_ln.empty() ? nullptr : find(e, fold_ln + ".weight"), *lb = fold_ln.empty() ? nullptr : find(e, fold_ln + ".bias");
     if (!fold_ln.empty() && (!lg || !lb || (int)lg->data.size() != K || (int)lb->data.size() != K)) { *err = "missing LayerNorm " + fold_ln; return false; }
-    return pack_linear(e, rows, b->data, K, out, kperm, lg ? lg->data.data() : nullptr, lb ? lb->data.data() : nullptr);
+    return pack_linear(e, rows, b->data, K, out, kperm, lg ? lg->data.data() : nullptr, lb ? lb->data.data() : nullptr, min_ldw);
 }
 
 // second FFN weight [D][F] with the hidden (K) index permuted inside every group of 16 so that the first GEMM's
@@ -818,6 +829,7 @@ EcEncoder* effconf_encoder_create(const EcConfig* cfg) {
     e->cfg = *cfg;
     e->blocks.assign(cfg->blocks, cfg->blocks + cfg->num_blocks);
     e->cfg.blocks = e->blocks.data();
+    if (const char* g = getenv("EFFCONF_POISON_GUARDS")) e->guard_bytes = atoi(g) > 0 ? (size_t)(atoi(g) > 16 ? atoi(g) : 16) * 1024 : 0;   // value = guard size in KiB (at least 16)   // once per encoder, never on the forward path
     return e;
 }
 
@@ -1056,7 +1068,7 @@ int effconf_encoder_finalize(EcEncoder* e) {
             W.dw_w = upload(e, wk); W.dw_b = upload(e, bz);
         }
         if (!pack_named_linear(e, cm + ".7", De, De, &W.pw2, &err)) return fail(err);
-        if (D != De && !pack_named_linear(e, p + ".conv_res.1", De, D, &W.res, &err)) return fail(err);
+        if (D != De && !pack_named_linear(e, p + ".conv_res.1", De, D, &W.res, &err, false, "", De)) return fail(err);
     }
     // ---- constant blocks of the fused chains (one LDS-DMA per workgroup instead of a dozen small strided copies)
     for (size_t k = 0; k < e->blocks.size(); ++k) {

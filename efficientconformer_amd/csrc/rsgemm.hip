@@ -682,6 +682,7 @@ template <int KS, int G, int RT, int NW, int NBUF, int EPI>
 int launch_rs_t(const RsDev& gd, hipStream_t s) {
     const int lds = NBUF * CH * KS * 32 + gd.nchunks * CH * 4 + KS * 32 * 4 + ((EPI == RS_QKV || EPI == RS_QKV_NAT) ? ((gd.p.D + 3) & ~3) * 4 : 0);
     if (lds > 160 * 1024) return -4;
+    if (gd.p.ldw < KS * 16) return -6;      // every weight row is read KS * 16 columns wide: the packing must be at least that wide
     if ((EPI == RS_RESID || EPI == RS_F32) && gd.nchunks > G) return -5;
     static LdsAttr attr;
     ensure_dynamic_lds(reinterpret_cast<const void*>(&rs_gemm_kernel<KS, G, RT, NW, NBUF, EPI>), lds, attr);

@@ -43,14 +43,20 @@ __device__ __forceinline__ void store_rows(char* yb, size_t pitch, int N, int m_
     }
 }
 
+// one wave-wide 4-byte LDS-DMA: lane i's dword at g lands at lds_wave_base + 4 i (rowstat.h's glds16 with the dword opcode)
+__device__ __forceinline__ void glds4(const void* g, char* lds_wave_base) {
+    const uint32_t l = (uint32_t)(uintptr_t)(lds_void_t*)lds_wave_base;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(l), "v"(g) : "memory", "m0");
+}
+
 __device__ __forceinline__ uint32_t split_hi(float x) { return __float_as_uint(x) & 0xFFFF0000u; }   // bf16 by truncation: hi + lo = x exactly in 16 + 8 bits
 
 // CG = 32-channel groups (C <= 32 CG), NT = 32-column output tiles (D0 <= 32 NT), NBUF ring slabs
-template <int CG, int NT, int NBUF>
-__global__ __launch_bounds__(512, 2) void sublinear2_kernel(const float* __restrict__ mel, int F, int Tm, int T1, int M,
+template <int CG, int NT, int NBUF, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void sublinear2_kernel(const float* __restrict__ mel, int F, int Tm, int T1, int M,
                                                             const float* __restrict__ ctab /*[CG*32][16]*/, const bf16_t* __restrict__ Wp,
                                                             const float* __restrict__ bias, int N, float* __restrict__ out, int ldc) {
-    constexpr int NW = 8, KSF = 2 * CG, P1 = 2 * KSF;            // k-steps and 16-byte pieces per weight row of one f
+    constexpr int KSF = 2 * CG, P1 = 2 * KSF;                    // k-steps and 16-byte pieces per weight row of one f
     constexpr int SLAB = NT * CH * P1 * 16;                      // bytes of one f's weight slab
     constexpr int NDMA = NT * CH * P1 / 64, PER = NDMA / NW;     // wave-DMAs per slab
     static_assert(NDMA % NW == 0, "uniform DMA count per wave");
@@ -96,27 +102,41 @@ __global__ __launch_bounds__(512, 2) void sublinear2_kernel(const float* __restr
 #pragma unroll
     for (int g = 0; g < CG; ++g) asm volatile("" :: "v"(whi[g]), "v"(wlo[g]));      // the compiler's own waits for these loads end HERE, not inside the DMA loop
 
-    // ---- this lane's frame.  The mel patch is a rolling 3-row window; its loads are issued by hand (the compiler cannot count them next to
-    //      the LDS-DMAs: it would drain the DMA queue at every use) and retired by the counted wait at the top of the next iteration.
+    // ---- this lane's frame.  The mel patch is a rolling 3-row window.  Its look-ahead rows arrive by LDS-DMA as well (6 dword pieces per
+    //      wave and frequency into a private two-slot stage): no register is ever written behind the compiler's back - hand-issued loads
+    //      into VGPRs were tried first and broke as soon as the allocator moved one of those registers (AGPR / scratch copies taken before
+    //      the data had landed: NaNs on Medium) - and the queue stays countable: per iteration 6 row pieces, then the slab's PER pieces.
     const int m = m_base + lr, mc = m < M ? m : M - 1;
     const int b = mc / T1, t = mc - b * T1;
     const float* melb = mel + (size_t)b * F * Tm;
     int col[3]; bool cok[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) { const int tc = 2 * t - 1 + j; cok[j] = tc >= 0 && tc < Tm; col[j] = tc < 0 ? 0 : (tc < Tm ? tc : Tm - 1); }
-    auto load_row = [&](int fr, float (&r)[3]) __attribute__((always_inline)) {     // asynchronous: r is valid after the next counted wait
-        const float* p = melb + (size_t)(fr < 0 ? 0 : (fr < F ? fr : F - 1)) * Tm;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) asm volatile("global_load_dword %0, %1, off" : "=v"(r[j]) : "v"(p + col[j]) : "memory");
-    };
+    auto row_ptr = [&](int fr) { return melb + (size_t)(fr < 0 ? 0 : (fr < F ? fr : F - 1)) * Tm; };
     auto mask_row = [&](int fr, float (&r)[3]) __attribute__((always_inline)) {     // zero outside the image (conv padding 1)
         const bool ok = fr >= 0 && fr < F;
 #pragma unroll
         for (int j = 0; j < 3; ++j) r[j] = (ok && cok[j]) ? r[j] : 0.f;
     };
-    float r0[3], r1[3], r2[3], n1[3], n2[3];
-    load_row(-1, r0); load_row(0, r1); load_row(1, r2);
-    load_row(2, n1); load_row(3, n2);
+    char* mstage = smem + NBUF * SLAB + wave * (2 * 6 * 256);     // [2 slots][6 pieces][64 lanes] floats
+    auto issue_rows = [&](int fr, int slot) __attribute__((always_inline)) {         // rows fr, fr + 1 -> stage slot
+        const float* p0 = row_ptr(fr);
+        const float* p1 = row_ptr(fr + 1);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) glds4(p0 + col[j], mstage + (slot * 6 + j) * 256);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) glds4(p1 + col[j], mstage + (slot * 6 + 3 + j) * 256);
+    };
+    float r0[3], r1[3], r2[3];
+    {   // the first window by ordinary loads, retired before the loop (the empty asm makes the compiler place its wait here)
+        const float* pa = row_ptr(-1); const float* pb = row_ptr(0); const float* pc = row_ptr(1);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { r0[j] = pa[col[j]]; r1[j] = pb[col[j]]; r2[j] = pc[col[j]]; }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) asm volatile("" :: "v"(r0[j]), "v"(r1[j]), "v"(r2[j]));
+        mask_row(-1, r0); mask_row(0, r1); mask_row(1, r2);
+    }
+    issue_rows(2, 0);                                             // rows 2, 3: consumed in iteration 0
 #pragma unroll
     for (int c = 0; c < NBUF - 1; ++c)
         if (c < F2) issue(c);
@@ -129,17 +149,16 @@ __global__ __launch_bounds__(512, 2) void sublinear2_kernel(const float* __restr
 
     const int q0 = (half + lr) % P1;
     for (int f = 0; f < F2; ++f) {
-        // Counted wait: the queue holds (oldest first) ... slab f, the mel rows issued in iteration f - 1, then - only with a three-slab
-        // ring - slab f + 1.  Everything but that youngest slab must have landed; the window registers ride through the asm so that no
-        // use can be scheduled above the wait.
-        if (NBUF >= 3 && f + 1 < F2)
-            asm volatile("s_waitcnt vmcnt(%15)" : "+v"(r0[0]), "+v"(r0[1]), "+v"(r0[2]), "+v"(r1[0]), "+v"(r1[1]), "+v"(r1[2]), "+v"(r2[0]), "+v"(r2[1]), "+v"(r2[2]),
-                         "+v"(n1[0]), "+v"(n1[1]), "+v"(n1[2]), "+v"(n2[0]), "+v"(n2[1]), "+v"(n2[2]) : "n"(PER) : "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0[0]), "+v"(r0[1]), "+v"(r0[2]), "+v"(r1[0]), "+v"(r1[1]), "+v"(r1[2]), "+v"(r2[0]), "+v"(r2[1]), "+v"(r2[2]),
-                         "+v"(n1[0]), "+v"(n1[1]), "+v"(n1[2]), "+v"(n2[0]), "+v"(n2[1]), "+v"(n2[2]) :: "memory");
+        // Counted wait: the queue holds (oldest first) ... slab f, the row pieces issued in iteration f - 1, then - only with a three-slab
+        // ring - slab f + 1.  Everything but that youngest slab must have landed.
+        if (NBUF >= 3 && f + 1 < F2) wait_vmcnt<PER>(); else wait_vmcnt<0>();
         wg_barrier();                                             // everybody's pieces of slab f are in; everybody is done with slab f - 1
-        if (f == 0) { mask_row(-1, r0); mask_row(0, r1); mask_row(1, r2); }
+        float n1[3], n2[3];                                       // rows 2f + 2, 2f + 3 from the stage (this wave's own pieces: its wait above covers them)
+        {
+            const float* st = reinterpret_cast<const float*>(mstage + (f & 1) * 6 * 256) + lane;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { n1[j] = st[j * 64]; n2[j] = st[(3 + j) * 64]; }
+        }
         mask_row(2 * f + 2, n1); mask_row(2 * f + 3, n2);
         // ---- patch fragments of this frame at frequency f: tap = 3 i + j; half 0 holds taps 0..7, half 1 tap 8, the constant 1 (bias), zeros
         float tp[8];
@@ -156,7 +175,8 @@ __global__ __launch_bounds__(512, 2) void sublinear2_kernel(const float* __restr
         // roll the window to rows 2f+1 .. 2f+3 (frequency f + 1), then fetch rows 2f+4, 2f+5 (frequency f + 2) and the next slab - in THIS order
 #pragma unroll
         for (int j = 0; j < 3; ++j) { r0[j] = r2[j]; r1[j] = n1[j]; r2[j] = n2[j]; }
-        load_row(2 * f + 4, n1); load_row(2 * f + 5, n2);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the stage reads above are done before their slot's next refill is issued... (the other slot is refilled now; this orders slot f & 1 for iteration f + 1's issue)
+        issue_rows(2 * f + 4, (f + 1) & 1);
         if (f + NBUF - 1 < F2) issue(f + NBUF - 1);
 
         // ---- convolution of all channels on the MFMA pipe, Swish, round: the Linear GEMM's B fragments of this f
@@ -182,18 +202,22 @@ __global__ __launch_bounds__(512, 2) void sublinear2_kernel(const float* __restr
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const char* w = buf + nt * CH * P1 * 16;
-            bf16x8 wa[KSF];
+            constexpr int FB = 4;                               // fragment batches: KSF = 8 / 12 registers' worth of weight fragments at a time
 #pragma unroll
-            for (int s = 0; s < KSF; ++s) {
-                int q = q0 + 2 * s;
-                q -= q >= P1 ? P1 : 0;
-                wa[s] = *reinterpret_cast<const bf16x8*>(w + q * 16);
+            for (int s0 = 0; s0 < KSF; s0 += FB) {
+                bf16x8 wa[FB];
+#pragma unroll
+                for (int i = 0; i < FB; ++i) {
+                    int q = q0 + 2 * (s0 + i);
+                    q -= q >= P1 ? P1 : 0;
+                    wa[i] = *reinterpret_cast<const bf16x8*>(w + q * 16);
+                }
+#pragma unroll
+                for (int i = 0; i < FB; ++i) xc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[i], xf[s0 + i], xc[nt], 0, 0, 0);
             }
-#pragma unroll
-            for (int s = 0; s < KSF; ++s) xc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[s], xf[s], xc[nt], 0, 0, 0);
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the last iterations' look-ahead rows (never used)
+    wait_vmcnt<0>();                                              // the last iterations' look-ahead rows (never used)
     // ---- epilogue: + bias, rows out through the staging region (the ring is free: barrier first)
     __syncthreads();
 #pragma unroll
@@ -207,26 +231,28 @@ __global__ __launch_bounds__(512, 2) void sublinear2_kernel(const float* __restr
     store_rows<NT>(reinterpret_cast<char*>(out), (size_t)ldc * 4, N, m_base, M, smem + wave * STG_BYTES, lane, xc);
 }
 
-template <int CG, int NT, int NBUF>
+template <int CG, int NT, int NBUF, int NW>
 int launch2(const float* mel, int B, int F, int Tm, int T1, const float* ctab, const bf16_t* Wp, const float* bias, int N, float* out, int ldc,
             hipStream_t s) {
     constexpr int P1 = 4 * CG, SLAB = NT * CH * P1 * 16;
     const int M = B * T1;
-    const int lds = NBUF * SLAB > 8 * STG_BYTES ? NBUF * SLAB : 8 * STG_BYTES;
+    const int lds = NBUF * SLAB + NW * 2 * 6 * 256 > NW * STG_BYTES ? NBUF * SLAB + NW * 2 * 6 * 256 : NW * STG_BYTES;
     if (lds > 160 * 1024) return -4;
     static LdsAttr attr;
-    ensure_dynamic_lds(reinterpret_cast<const void*>(&sublinear2_kernel<CG, NT, NBUF>), lds, attr);
-    hipLaunchKernelGGL((sublinear2_kernel<CG, NT, NBUF>), dim3((M + 255) / 256), dim3(512), lds, s, mel, F, Tm, T1, M, ctab, Wp, bias, N, out, ldc);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(&sublinear2_kernel<CG, NT, NBUF, NW>), lds, attr);
+    hipLaunchKernelGGL((sublinear2_kernel<CG, NT, NBUF, NW>), dim3((M + NW * 32 - 1) / (NW * 32)), dim3(NW * 64), lds, s, mel, F, Tm, T1, M, ctab, Wp, bias, N, out, ldc);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 }  // namespace
 
-// supported: F = 80, C <= 128 with D0 <= 128 (Small, Transducer-Small).  The 6-group instance (C, D0 <= 192: Medium) needs 256 VGPRs + spills
-// at two waves per SIMD and faulted in its first run; until it is re-cut (one wave per SIMD or 16-row tiles) wider front ends use sublinear.hip.
+// supported: F = 80, C <= 128 with D0 <= 128 (Small, Transducer-Small: 8 waves, two per SIMD) and C, D0 <= 192 (Medium, Transducer-Medium:
+// 4 waves, one per SIMD - at two per SIMD the 6-group instance spills, and a spill of a hand-loaded window register breaks the counted
+// waits: its first run ended in a memory fault).  Wider front ends (Large: D0 = 360) use sublinear.hip / the separate kernels.
 int sublinear2_groups(int F, int C, int N) {
     if (F != 80 || N % 4) return 0;
     if (C <= 128 && N <= 128) return 4;
+    if (C <= 192 && N <= 192) return 6;
     return 0;
 }
 
@@ -235,7 +261,8 @@ int launch_sublinear2(const float* mel, int B, int F, int Tm, int T1, const floa
                       float* out, int ldc, hipStream_t s) {
     if (B <= 0 || T1 <= 0) return 0;
     switch (sublinear2_groups(F, C, N)) {
-        case 4: return launch2<4, 4, 3>(mel, B, F, Tm, T1, ctab, Wp, bias, N, out, ldc, s);
+        case 4: return launch2<4, 4, 3, 8>(mel, B, F, Tm, T1, ctab, Wp, bias, N, out, ldc, s);
+        case 6: return launch2<6, 6, 2, 4>(mel, B, F, Tm, T1, ctab, Wp, bias, N, out, ldc, s);
     }
     return -2;
 }

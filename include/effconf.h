@@ -58,6 +58,11 @@ int effconf_abi_version(void);
 const char* effconf_last_error(void);
 
 /* ---- lifetime + weights ------------------------------------------------------------------- */
+/* Test hook: with EFFCONF_POISON_GUARDS=<KiB> (>0; at least 16 KiB is used) in the environment at create time, finalize places every
+ * packed parameter buffer between two guard regions of 0xFF bytes (NaN as bf16 and fp32), so an out-of-bounds parameter read shows
+ * up in the output (tests/test_gpu_exact_and_sweep.py::test_no_kernel_reads_past_a_parameter_buffer, tools/poison_sweep.py).  Read
+ * once here, never on the forward path.  The Python wrapper has the matching EFFCONF_POISON_WORKSPACE=<byte> hook for the
+ * caller-owned workspace (efficientconformer_amd/encoders.py). */
 EcEncoder* effconf_encoder_create(const EcConfig* cfg);
 void effconf_encoder_destroy(EcEncoder* enc);
 /* Hand over one reference state_dict tensor (HOST fp32, contiguous, reference layout) by its key

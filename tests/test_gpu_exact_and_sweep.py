@@ -193,6 +193,33 @@ def test_every_shipped_config_encoder_vs_oracle(name):
 
 
 @pytest.mark.parametrize("precision", ["bf16", "fp32"])
+@pytest.mark.parametrize("name", SHIPPED + ["SmallAligned", "Tiny"])
+def test_no_kernel_reads_past_a_parameter_buffer(name, precision, monkeypatch):
+    """EFFCONF_POISON_GUARDS (read once at effconf_encoder_create) puts 16 KiB of 0xFF bytes - NaN as bf16 and as fp32 - on both
+    sides of every packed parameter buffer.  A kernel that reads past a buffer (a weight-slab DMA wider than the packing, a
+    look-ahead one row too far) turns the output NaN instead of depending on what the allocator placed next to the buffer:
+    the output with guards must be finite and bit-identical to the output without them, for every shipped configuration, every
+    subsampler variant and both precision modes.  (Found this way: the strided blocks' conv_res GEMM 180 -> 256 of
+    EfficientConformer Medium read its last weight row 128 bytes too far.)"""
+    mel, ln = synth.make_mel(2, 80, 301, [301, 190], seed=5)
+    mel_d, ln_d = torch.from_numpy(mel).cuda(), torch.from_numpy(ln).cuda()
+    outs = {}
+    for guards in ("0", "1"):
+        monkeypatch.setenv("EFFCONF_POISON_GUARDS", guards)
+        m, _ = _model(name, 3, precision)
+        for fs in ((0, 1, 2) if precision == "bf16" else (2,)):
+            m.encoder.set_option("fuse_subsample", fs)
+            out, out_len, _ = m.encoder.forward_mel(mel_d, ln_d)
+            assert torch.isfinite(out).all(), (name, precision, guards, fs)
+            outs[guards, fs] = out.cpu()
+        del m
+    for (guards, fs), o in outs.items():
+        if guards == "1":
+            d = (o - outs["0", fs]).abs()
+            assert torch.equal(o, outs["0", fs]), (name, precision, fs, float(d.max()), int((d.amax(-1) > 0).sum()), [torch.equal(outs["0", fs], outs["0", f2]) for f2 in (0, 1, 2) if ("0", f2) in outs], [torch.equal(outs["1", fs], outs["1", f2]) for f2 in (0, 1, 2) if ("1", f2) in outs])
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
 def test_empty_row_in_a_batch_follows_the_reference(precision):
     """x_len[b] = 0 (mel entry): every key of that row is masked; the reference's additive -1e9 makes its softmax uniform over ALL
     key groups (attentions.py:698-701) and its lengths stay 0 (floor division, modules.py:243).  The other rows are unaffected."""
