@@ -69,6 +69,8 @@ def parse():
                     help="conv subsampling + Linear: 0 separate kernels, 1 sublinear.hip, 2 sublinear2.hip (-1: the library's default = 2)")
     ap.add_argument("--attention", type=int, default=-1, choices=[-1, 0, 1, 2],
                     help="attention kernel: 0 attention.hip, 1 / 2 attention2.hip variants (-1: the library's default = 1)")
+    ap.add_argument("--wide-gemm", type=int, default=-1, choices=[-1, 0, 1, 2, 3],
+                    help="tiled GEMM layers: 0 tile by shape, 1 gemm.hip only, 2 / 3 gemm256.hip 256x256 / 256x128 wherever it applies (-1: default = 0)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1 (nccl = RCCL over xGMI; gloo + --one-device: N ranks on ONE GPU, a test of the multi-rank path)")
     ap.add_argument("--one-device", action="store_true", help="every rank uses cuda:0 (tests on a single-GPU box; never a benchmark)")
@@ -360,6 +362,8 @@ def main():
         model.encoder.set_option("attention_v2", args.attention)
     if args.subsample >= 0:
         model.encoder.set_option("fuse_subsample", args.subsample)
+    if args.wide_gemm >= 0:
+        model.encoder.set_option("wide_gemm", args.wide_gemm)
     sharded = head_stream = None
     if world > 1:
         from efficientconformer_amd.dist import ShardedEncoder

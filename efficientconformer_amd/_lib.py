@@ -61,6 +61,7 @@ SIGNATURES = {
     "effconf_debug_mel": (C.c_int, [_P, _I32, _I32, _F32P, _I32, _I32, _F32P, _P, _P]),
     "effconf_debug_neighbour": (C.c_int, [_I32, _I32, _I32, _I32, _F32P, _SZ, _P]),
     "effconf_debug_victim": (C.c_int, [_I32, _I32, _I32, _F32P, _P]),
+    "effconf_debug_gemm": (C.c_int, [_P, _I32, _P, _I32, _P, _I32, _I32, _I32, _I32, _I32, _P, _I32, _P, _I32, C.c_float, _P]),
     "effconf_encoder_set_trace": (C.c_int, [_P, _P, _SZ]),
     "effconf_encoder_trace_count": (_I32, [_P]),
     "effconf_encoder_trace_entry": (C.c_int, [_P, _I32, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64),

@@ -64,6 +64,7 @@ struct EcEncoder {
     std::map<std::string, HostTensor> host;
     bool finalized = false;
     std::vector<void*> allocs;
+    int wide_gemm = 0;                    // option "wide_gemm": GemmParams::wide of every tiled GEMM (0 by shape, 1 never, 2 / 3 forced)
     size_t guard_bytes = 0;               // EFFCONF_POISON_GUARDS (test hook): NaN-filled guard regions around every parameter buffer
     // packed
     const float *sub_w9 = nullptr, *sub_b = nullptr;
@@ -403,6 +404,7 @@ int run_gemm(EcEncoder* e, int cls, hipStream_t st, const bf16_t* A, int lda, in
     GemmParams p{};
     p.A = A; p.lda = lda; p.W = L.w; p.ldw = L.ldw; p.bias = L.bias;
     p.M = M; p.N = L.N; p.K = L.K; p.C = C; p.ldc = ldc; p.R = R; p.ldr = ldr; p.alpha = alpha;
+    p.wide = e->wide_gemm;
     return launch_gemm(p, epi, st);
 }
 
@@ -547,6 +549,7 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
                   p.X = x; p.ldx = D; p.ln_g = W.ln_att.g; p.ln_b = W.ln_att.b;
                   EC_TRY(launch_rs_gemm(p, nat ? 4 : 3, st));
               } else {
+                  p.wide = e->wide_gemm;
                   EC_TRY(launch_gemm(p, nat ? EPI_QKV_NAT : EPI_QKV, st));
               } }
         }
@@ -1254,6 +1257,19 @@ int effconf_relpos_attention(const uint16_t* qu, const uint16_t* k, const uint16
     return 0;
 }
 
+int effconf_debug_gemm(const uint16_t* a, int32_t lda, const uint16_t* w, int32_t ldw, const float* bias, int32_t m, int32_t n, int32_t k,
+                       int32_t epi, int32_t wide, void* c, int32_t ldc, const float* r, int32_t ldr, float alpha, void* stream) {
+    if (!a || !w || !bias || !c) return fail("null argument");
+    if (epi < EPI_F32 || epi > EPI_GLU_BF16 || (epi == EPI_RESID_F32 && !r)) return fail("epilogue: 0 f32, 1 bf16, 2 swish bf16, 3 residual f32, 4 GLU bf16");
+    if (wide < 0 || wide > 3) return fail("wide: 0 .. 3");
+    GemmParams p{};
+    p.A = a; p.lda = lda; p.W = w; p.ldw = ldw; p.bias = bias; p.M = m; p.N = n; p.K = k;
+    p.C = c; p.ldc = ldc; p.R = r; p.ldr = ldr; p.alpha = alpha; p.wide = wide;
+    if (wide >= 2 && !gemm256_supported(p, epi)) return fail("gemm256 does not take this shape / alignment");
+    EC_TRY(launch_gemm(p, epi, (hipStream_t)stream));
+    return 0;
+}
+
 int effconf_debug_victim(int32_t kind, int32_t blocks, int32_t iters, float* out, void* stream) {
     EC_TRY(launch_debug_victim(kind, blocks, iters, out, (hipStream_t)stream));
     return 0;
@@ -1277,6 +1293,7 @@ int effconf_encoder_set_option(EcEncoder* e, const char* name, int32_t value) {
     if (!strcmp(name, "fuse_subsample")) { if (value < 0 || value > 2) return fail("fuse_subsample: 0, 1 or 2"); e->fuse_subsample = value; return 0; }
     if (!strcmp(name, "fuse_chain")) { e->fuse_chain = value != 0; return 0; }
     if (!strcmp(name, "ctc_mfma")) { e->ctc_mfma = value != 0; return 0; }
+    if (!strcmp(name, "wide_gemm")) { if (value < 0 || value > 3) return fail("wide_gemm: 0 (by shape), 1 (never), 2 (256-column tile), 3 (128-column tile)"); e->wide_gemm = value; return 0; }
     if (!strcmp(name, "attention_v2")) { if (value != 0 && value != 1 && value != 2) return fail("attention_v2: 0, 1 or 2"); e->attention_v2 = value; return 0; }
     if (!strcmp(name, "cache_pos_embeddings")) { e->e_cache_on = value != 0; e->e_cache.clear(); return 0; }
     if (!strcmp(name, "exact_fp32")) {

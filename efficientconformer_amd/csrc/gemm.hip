@@ -417,6 +417,14 @@ int launch_bn(const GemmDev& gd, hipStream_t s) {
 int launch_gemm(const GemmParams& p, int epi, hipStream_t s) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return 0;
     if (p.lda % 8 || p.ldw % 64) return -2;
+    if (p.wide != 1 && gemm256_supported(p, epi)) {
+        // gemm256.hip when its 256 x 256 tiles fill the chip (256 CUs, one 8-wave workgroup each).  Measured on the Large layer shapes
+        // (tools/gemm_bench.py, in situ with bench.py --wide-gemm): >= 200 tiles: up to 1.4x over the 128 x 128 kernel (FFN, D = 720),
+        // never behind; fewer tiles, or its 256 x 128 tile at any size: behind.  `wide` 2 / 3 force a tile (kernel-level tests).
+        const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
+        if (p.wide == 2 || (p.wide == 0 && p.N >= 192 && t256 >= 200)) return launch_gemm256(p, epi, 256, s);
+        if (p.wide == 3) return launch_gemm256(p, epi, 128, s);
+    }
     GemmDev gd;
     gd.p = p;
     {

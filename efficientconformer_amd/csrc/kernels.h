@@ -32,8 +32,12 @@ struct GemmParams {
     // row-stationary kernels only: if X != null the A operand is LayerNorm(X[m][0..K)) (eps 1e-6, fp32 two-pass statistics)
     // computed in the prologue from the fp32 residual stream instead of being read from A
     const float* X; int ldx; const float *ln_g, *ln_b;
+    int wide;                          // launch_gemm only: 0 pick by shape, 1 never gemm256.hip, 2 / 3 force its 256- / 128-column tile
 };
 int launch_gemm(const GemmParams& p, int epi, hipStream_t s);
+// gemm256.hip: 256 x bn x 64 tiles, both operands by LDS-DMA (bn = 256 or 128); the same operands and epilogues as launch_gemm
+bool gemm256_supported(const GemmParams& p, int epi);
+int launch_gemm256(const GemmParams& p, int epi, int bn, hipStream_t s);
 
 // ---------------------------------------------------------------- row-stationary fused kernels  (rsgemm.hip)
 // y = x + alpha * (Swish(a W1^T + b1) W2^T + b2);  a = bf16 LayerNorm(x) [M][lda], x/y fp32 [M][ld] (may alias)

@@ -167,6 +167,8 @@ int effconf_rnnt_greedy(EcRnnt* r, const float* enc_out, const int64_t* out_len,
  *   transposed on the way into LDS, hoisted staging addresses, no column masks off the buffer tails, deferred accumulator rescale);
  *   2 = attention2.hip with 32 queries per wave (one wave per SIMD: measured slower, kept for experiments).  Head widths above 128
  *   always use attention.hip.  Results agree to fp32 summation order (variant 1's deferred rescale: to bf16 rounding of P).
+ * "wide_gemm" (default 0): tile choice of the tiled GEMM layers (the widths the row-stationary kernels do not hold): 0 by shape,
+ *     1 always csrc/gemm.hip (128 x 128, register staged), 2 / 3 csrc/gemm256.hip with 256 x 256 / 256 x 128 tiles wherever it applies.
  * "ctc_mfma" (default 1): the CTC head (fc + argmax) on the fp32 MFMA; 0 selects the VALU kernel.  Both are k-ordered fp32 fma chains:
  *   bit-identical logits and labels.
  * "exact_fp32" (default 0): fp32-operand precision mode (csrc/exact.hip): every GEMM on fp32 MFMA, fp32 attention / convolutions,
@@ -199,6 +201,14 @@ int effconf_debug_mel(EcEncoder* enc, int32_t variant, int32_t extra_lds, const 
 /* One synthetic kernel that loads a single compute-unit resource (csrc/debug.hip): kind 0 LDS 16-byte hammer, 1 VALU +
  * transcendental, 2 global loads, 3 global stores, 4 MFMA, 5 LDS publish + barrier loop, 6 LDS 4-byte hammer. */
 int effconf_debug_neighbour(int32_t kind, int32_t blocks, int32_t lds_bytes, int32_t iters, float* buf, size_t n_floats, void* stream);
+/* One Linear layer on the tiled bf16 GEMM kernels alone (kernel-level tests and tuning of csrc/gemm.hip and csrc/gemm256.hip; reference
+ * models/layers.py:57-67): c = epilogue(a w^T + bias).  a: bf16 [m][lda]; w: bf16 [>= round_up(n, 128)][ldw = round_up(k, 64)], zero
+ * padded (for GLU: rows interleaved per 32 channels, a | b); bias: [>= round_up(n, 128)].  epi: 0 fp32 [m][ldc], 1 bf16, 2 Swish
+ * bf16, 3 fp32 r + alpha * (...), 4 GLU bf16 [m][n / 2].  wide: 0 tile picked by shape, 1 the 128 x 128 kernel, 2 / 3 the LDS-DMA
+ * kernel with 256 x 256 / 256 x 128 tiles.  All pointers are device pointers. */
+int effconf_debug_gemm(const uint16_t* a, int32_t lda, const uint16_t* w, int32_t ldw, const float* bias, int32_t m, int32_t n, int32_t k,
+                       int32_t epi, int32_t wide, void* c, int32_t ldc, const float* r, int32_t ldr, float alpha, void* stream);
+
 /* One self-contained victim: 16 chains per lane of a single instruction class (0 v_fma_f32, 1 v_pk_fma_f32, 2 v_pk_mul/add_f32,
  * 3 v_log/v_exp_f32, 4 v_mul/v_add_f32, 5 integer, 6 wave-local LDS exchange); out dev f32 (blocks * 256 * 16). */
 int effconf_debug_victim(int32_t kind, int32_t blocks, int32_t iters, float* out, void* stream);
