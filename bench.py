@@ -7,8 +7,8 @@
 
 A "step" is one pass of the hot path (ConformerEncoder.forward: mel frontend -> conv subsampling -> 15
 Conformer blocks, then fc + argmax + CTC collapse) over one synthetic LibriSpeech-shaped batch that is
-already resident in HBM (default: 256 utterances per GPU, `--streams 2`).  `--streams 2` runs the batch as two contiguous row
-ranges on two HIP streams inside ConformerEncoder.forward (`sub_batches`, efficientconformer_amd/encoders.py): every kernel of the
+already resident in HBM (default: 256 utterances per GPU, `--streams 3`).  `--streams S` runs the batch as S contiguous row
+ranges on S HIP streams inside ConformerEncoder.forward (`sub_batches`, efficientconformer_amd/encoders.py): every kernel of the
 path is a one-round launch that alternates HBM-bound load/store bursts with compute, and a second stream fills one's bursts with the
 other's compute (+10-13 %, bit-identical to `--streams 1`; the mel frontend stays one launch: DESIGN.md section 5).
 
@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=256, help="utterances per GPU per step")
     ap.add_argument("--workload", default="libri", choices=["libri", "fixed"],
                     help="libri: lognormal LibriSpeech-shaped lengths (SURVEY.md 8d W-libri); fixed: 10 s each")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=3,
                     help="ConformerEncoder.sub_batches: contiguous row ranges of the batch on concurrent HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
