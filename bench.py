@@ -56,6 +56,8 @@ def parse():
                     help="libri: lognormal LibriSpeech-shaped lengths (SURVEY.md 8d W-libri); fixed: 10 s each")
     ap.add_argument("--streams", type=int, default=3,
                     help="ConformerEncoder.sub_batches: contiguous row ranges of the batch on concurrent HIP streams")
+    ap.add_argument("--ranges", type=int, default=0,
+                    help="row ranges per GPU (0: one per stream); more ranges than streams = finer length buckets, range i on stream i %% streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--gather", default="outputs", choices=["outputs", "labels"],
@@ -63,6 +65,7 @@ def parse():
     ap.add_argument("--wire", default="fp32", choices=["fp32", "bf16"], help="dtype of the gathered encoder outputs on xGMI")
     ap.add_argument("--balanced-split", action="store_true",
                     help="cut the row ranges for equal PADDED FRAMES per range instead of equal utterance counts (measured: no gain at B = 256)")
+    ap.add_argument("--cuts", default="", help="explicit row boundaries of the ranges, e.g. 80,168 (tuning; overrides --balanced-split)")
     ap.add_argument("--no-trim", action="store_true",
                     help="pad every row range to the whole batch's longest utterance (round-1 workload) instead of its own longest")
     ap.add_argument("--subsample", type=int, default=-1, choices=[-1, 0, 1, 2],
@@ -341,13 +344,16 @@ def main():
 
     # Sub-batch streams live in the library's host layer (ConformerEncoder.sub_batches): the batch runs as `--streams` contiguous
     # row ranges on concurrent HIP streams and is joined before forward() returns.
-    model.encoder.sub_batches = max(args.streams, 1)
-    nsub = max(args.streams, 1)
+    nsub = max(args.ranges, 1) if args.ranges > 0 else max(args.streams, 1)
+    model.encoder.sub_batches = nsub
+    model.encoder.sub_batch_streams = max(args.streams, 1)
     # Row ranges padded to their own longest utterance (ConformerEncoder.trim_sub_batches): the batch is length-sorted, so range i
     # of every rank is padded to the longest utterance any rank holds in range i (known from the seeds: no exchange, equal shapes)
     model.encoder.trim_sub_batches = not args.no_trim and nsub > 1 and args.workload == "libri"
     range_pad = None
     cuts = [args.batch * i // nsub for i in range(nsub + 1)]
+    if args.batch >= 32 * nsub:      # ConformerEncoder's own default boundaries (multiples of 16 rows)
+        cuts = [c - c % 16 for c in cuts[:-1]] + [args.batch]
     if model.encoder.trim_sub_batches:
         all_lens = [synth.libri_lengths(args.batch, seed=1234 + r) for r in range(world)]
         if args.balanced_split:
@@ -356,6 +362,10 @@ def main():
             fr = all_lens[0] // plan.hop_length + 1
             cuts = balanced_cuts(fr, nsub)
             model.encoder.sub_batch_bounds = cuts[1:-1]
+        if args.cuts:
+            cuts = [0] + [int(v) for v in args.cuts.split(",")] + [args.batch]
+            model.encoder.sub_batch_bounds = cuts[1:-1]
+        model.encoder.sub_batch_bounds = cuts[1:-1]      # the boundaries range_pad is computed for
         range_pad = [max(int(l[cuts[i]:cuts[i + 1]].max()) for l in all_lens) for i in range(nsub)]
         padded_frames = int(sum((cuts[i + 1] - cuts[i]) * (range_pad[i] // plan.hop_length + 1) for i in range(nsub)))
     if args.attention >= 0:
