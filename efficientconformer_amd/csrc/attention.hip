@@ -94,12 +94,16 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 4 && DP <= 96) ? 2 : 1) void relp
     // XCD-aware order: hardware places block i on XCD i % 8.  All heads and query tiles of one utterance re-read the same K / V
     // rows, so they should share an L2: utterance b goes to XCD b % 8 (utterances are sorted by length, so dealing them round-robin
     // also keeps the XCDs balanced; a contiguous range per XCD was 16 % slower).  Un-remapped, K / V / E were fetched from HBM
-    // ~3x (profiles/r1_10_pmc_hbm_traffic.txt).
-    int id = blockIdx.x;
-    if ((p.B & 7) == 0) {
-        const int per_b = p.H * qtiles, xcd = id & 7, slot = id >> 3;
-        const int j = slot / per_b;
-        id = (xcd + 8 * j) * per_b + (slot - j * per_b);
+    // ~3x (profiles/r1_10_pmc_hbm_traffic.txt).  Any B: the utterances in the order (0, 8, 16, .. | 1, 9, .. | ..) form a list
+    // that is cut into the 8 contiguous, equally long chunks of logical ids xcd_remap hands the XCDs (with B % 8 != 0 a chunk
+    // border falls inside an utterance: 7 utterances are shared by two L2s).
+    int id = xcd_remap(blockIdx.x, gridDim.x);
+    {
+        const int per_b = p.H * qtiles, u = id / per_b, q8 = p.B >> 3, r8 = p.B & 7;
+        int x, j;
+        if (u < r8 * (q8 + 1)) { x = u / (q8 + 1); j = u - x * (q8 + 1); }
+        else { const int u2 = u - r8 * (q8 + 1); x = u2 / q8; j = u2 - x * q8; x += r8; }
+        id = (x + 8 * j) * per_b + (id - u * per_b);
     }
     const int qt = id % qtiles; id /= qtiles;
     const int h = id % p.H; const int b = id / p.H;

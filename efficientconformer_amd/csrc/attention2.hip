@@ -71,11 +71,17 @@ __global__ __launch_bounds__(NWV * 64, (QT == 1 && NWV == 4 && DP <= 96) ? 2 : 1
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, g = lane >> 4;
     const int qtiles = (p.Tg + BI - 1) / BI;
-    int id = blockIdx.x;
-    if ((p.B & 7) == 0) {                 // utterance b on XCD b % 8: all heads / query tiles of an utterance share one L2 (attention.hip)
-        const int per_b = p.H * qtiles, xcd = id & 7, slot = id >> 3;
-        const int j = slot / per_b;
-        id = (xcd + 8 * j) * per_b + (slot - j * per_b);
+    // utterance b on XCD b % 8: all heads / query tiles of an utterance share one L2, and a length-sorted batch spreads evenly over
+    // the XCDs.  Any B: the utterances in the order (0, 8, 16, .. | 1, 9, .. | ..) form a list that is cut into the 8 contiguous,
+    // equally long chunks of logical ids xcd_remap hands the XCDs (with B % 8 != 0 a chunk border falls inside an utterance: 7
+    // utterances are shared by two L2s).  Round 2 applied this only for B % 8 == 0: B = 85 ran 16 % slower per utterance than 80.
+    int id = xcd_remap(blockIdx.x, gridDim.x);
+    {
+        const int per_b = p.H * qtiles, u = id / per_b, q8 = p.B >> 3, r8 = p.B & 7;
+        int x, j;
+        if (u < r8 * (q8 + 1)) { x = u / (q8 + 1); j = u - x * (q8 + 1); }
+        else { const int u2 = u - r8 * (q8 + 1); x = u2 / q8; j = u2 - x * q8; x += r8; }
+        id = (x + 8 * j) * per_b + (id - u * per_b);
     }
     const int qt_wg = id % qtiles; id /= qtiles;
     const int h = id % p.H; const int b = id / p.H;

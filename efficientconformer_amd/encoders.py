@@ -304,10 +304,10 @@ class ConformerEncoder(nn.Module):
                 raise ValueError("sub_batch_bounds must be %d increasing row indices inside (0, %d)" % (nsub - 1, batch))
             ranges = [(cuts[i], cuts[i + 1]) for i in range(nsub)]
         else:
-            # equal utterance counts, boundaries floored to multiples of 16 rows when the ranges are large enough: measured on the
-            # LibriSpeech-shaped B = 256 batch in 3 ranges (bench.py), rows (80, 80, 96) run 2 - 4 % faster than (85, 85, 86) and
-            # than (81, 80, 95): range sizes that are multiples of 16 utterances, and - with a length-sorted batch - a few rows
-            # moved from the longest range to the shortest
+            # equal utterance counts, boundaries floored to multiples of 16 rows when the ranges are large enough: with a length-sorted
+            # batch this moves a few rows from the longest range to the shortest one (B = 256 in 3 ranges: 80 / 80 / 96 rows,
+            # +1 % over 85 / 85 / 86 on the LibriSpeech-shaped bench batch; the 4 % first measured for it was the attention kernels'
+            # XCD mapping, which only handled B % 8 == 0 - fixed in attention.hip / attention2.hip)
             cuts = [batch * i // nsub for i in range(nsub + 1)]
             if batch >= 32 * nsub:
                 cuts = [c - c % 16 for c in cuts[:-1]] + [batch]
