@@ -36,28 +36,41 @@ __global__ __launch_bounds__(256) void subsample_conv_kernel(const float* __rest
         sw[i] = j < 9 ? w9[c * 9 + j] : bias[c];
     }
     __syncthreads();
-    const int pairs = C * F2 / 2;                      // two adjacent f per thread (F2 is even for F = 80)
-    for (int tl = 0; tl < SUB_TT; ++tl) {
-        const int t = t0 + tl;
-        if (t >= T1) break;
-        bf16_t* orow = out + ((size_t)b * T1 + t) * ldo;
-        for (int q = tid; q < pairs; q += 256) {
-            const int c = q / (F2 / 2), f = 2 * (q - c * (F2 / 2));
-            const float* w = sw + c * 10;
-            float r[2];
+    // a thread owns (channel c, two adjacent output frequencies f, f+1) for ALL frames of the tile: the channel's 9 taps + bias live in
+    // registers and every LDS row of the 5 x (2 SUB_TT + 1) input window is read once (85 LDS reads per 16 outputs).  The first version
+    // looped frames outermost and fetched taps and window per output: 19 LDS reads per output, 70 % of the wave cycles in LDS waits
+    // (profiles/r2_02_large_sq_counters.txt), 1.03 ms per launch on Large's C = 360 front end.
+    const int pairs = C * F2 / 2;                      // F2 is even for F = 80
+    const int nt = (T1 - t0) < SUB_TT ? (T1 - t0) : SUB_TT;
+    for (int q = tid; q < pairs; q += 256) {
+        const int c = q / (F2 / 2), f = 2 * (q - c * (F2 / 2));
+        float w[10];
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                // output (f+e, t): input rows 2(f+e)-1 .. +1 -> LDS rows 2(f+e) .. +2 ; cols 2tl .. 2tl+2
-                const float* m = sm + (2 * (f + e)) * (TW + 1) + 2 * tl;
-                float a = w[9];
+        for (int i = 0; i < 10; ++i) w[i] = sw[c * 10 + i];
+        float acc[2][SUB_TT];
 #pragma unroll
-                for (int i = 0; i < 3; ++i)
+        for (int e = 0; e < 2; ++e)
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) a = fmaf(w[i * 3 + j], m[i * (TW + 1) + j], a);
-                r[e] = swishf_(a);
-            }
-            *reinterpret_cast<uint32_t*>(orow + c * F2 + f) = pack_bf2(r[0], r[1]);
+            for (int tl = 0; tl < SUB_TT; ++tl) acc[e][tl] = w[9];
+        // input rows 2f-1 .. 2f+3 = LDS rows 2f .. 2f+4: row i feeds output f with tap row i (i < 3) and output f+1 with tap row i-2 (i >= 2)
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const float* m = sm + (2 * f + i) * (TW + 1);
+            float row[TW];
+#pragma unroll
+            for (int j = 0; j < TW; ++j) row[j] = m[j];
+#pragma unroll
+            for (int tl = 0; tl < SUB_TT; ++tl)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    if (i < 3) acc[0][tl] = fmaf(w[i * 3 + j], row[2 * tl + j], acc[0][tl]);
+                    if (i >= 2) acc[1][tl] = fmaf(w[(i - 2) * 3 + j], row[2 * tl + j], acc[1][tl]);
+                }
         }
+        bf16_t* ocol = out + ((size_t)b * T1 + t0) * ldo + c * F2 + f;
+#pragma unroll
+        for (int tl = 0; tl < SUB_TT; ++tl)
+            if (tl < nt) *reinterpret_cast<uint32_t*>(ocol + (size_t)tl * ldo) = pack_bf2(swishf_(acc[0][tl]), swishf_(acc[1][tl]));
     }
 }
 

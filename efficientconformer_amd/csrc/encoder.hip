@@ -439,12 +439,25 @@ int run_ffn(EcEncoder* e, hipStream_t st, const bf16_t* a, int M, int D, const P
     return run_gemm(e, PC_GEMM_FFN, st, hbuf, F, M, L2, EPI_RESID_F32, x, D, x, D, 0.5f);
 }
 
+// Widths 257 .. 384 (EfficientConformer Large stage 1, Medium stage 3) fit the row-stationary kernels, but at 24 k-steps those run one
+// wave per SIMD and stream every weight per 32-row tile: 60 - 200 TFLOP/s (profiles/r2_02_large_kernel_stats.txt).  When gemm256.hip's
+// 256 x 256 tiles fill the chip the layer goes there instead (LayerNorm as its own kernel in front).  `wide_gemm` 2 / 3 force it (tests).
+bool prefer_tiled(const EcEncoder* e, int M, int N, int K) {
+    if (e->wide_gemm == 1 || K <= 256 || K % 8) return false;
+    if (e->wide_gemm >= 2) return true;
+    return N >= 192 && (long)((M + 255) / 256) * ((N + 255) / 256) >= 200;
+}
+
 // row-stationary single GEMM when K <= 384, else the tiled kernel
 int run_rs_or_tiled(EcEncoder* e, int cls, hipStream_t st, const bf16_t* A, int lda, int M, const PackedLinear& L, int rs_epi,
                     int tiled_epi, void* C, int ldc, const float* R = nullptr, int ldr = 0, float alpha = 1.f,
                     const float* lnX = nullptr, const LNp* ln = nullptr) {
     const bool ok = (rs_epi == 0 || rs_epi == 1) ? rs_gemm_resident_supported(L.K, L.N) : rs_gemm_supported(L.K);
     if (!ok) return run_gemm(e, cls, st, A, lda, M, L, tiled_epi, C, ldc, R, ldr, alpha);
+    if (prefer_tiled(e, M, L.N, L.K)) {
+        if (lnX && ln) { PROF(PC_LAYERNORM, 0, (double)M * L.K * 6); EC_TRY(launch_layernorm(lnX, M, L.K, ln->g, ln->b, nullptr, const_cast<bf16_t*>(A), lda, nullptr, nullptr, st)); }
+        return run_gemm(e, cls, st, A, lda, M, L, tiled_epi, C, ldc, R, ldr, alpha);
+    }
     const double out_b = (tiled_epi == EPI_F32) ? 4.0 : (tiled_epi == EPI_RESID_F32 ? 8.0 : 2.0);
     PROF(cls, 2.0 * M * (double)L.N * L.K, (double)M * L.K * 2 + (double)L.N * L.K * 2 + (double)M * L.N * out_b);
     GemmParams p{};
@@ -541,10 +554,11 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
             { PROF(PC_LAYERNORM, 0, (double)M * D * 6); if (!have_a) EC_TRY(launch_layernorm(x, M, D, W.ln_ffn1.g, W.ln_ffn1.b, nullptr, a, ld8(D), nullptr, nullptr, st)); }
             EC_TRY(run_ffn(e, st, a, M, D, W.ffn1_a, W.ffn1_b, W.ffn1_bp, x, hbuf));
             // ---- Q/K/V of LN(x)   (modules.py:472-488; attentions.py:651-686)
-            const bool ln_fused = rs_gemm_supported(D);      // pre-norm computed in the QKV kernel's prologue
+            const bool qkv_tiled = nat && prefer_tiled(e, M, 3 * D, D);
+            const bool ln_fused = rs_gemm_supported(D) && !qkv_tiled;      // pre-norm computed in the QKV kernel's prologue
             if (!ln_fused) { PROF(PC_LAYERNORM, 0, (double)M * D * 6); EC_TRY(launch_layernorm(x, M, D, W.ln_att.g, W.ln_att.b, nullptr, a, ld8(D), nullptr, nullptr, st)); }
             { PROF(PC_GEMM_OTHER, 2.0 * M * 3.0 * D * D, (double)M * D * 2 + 3.0 * D * D * 2 + (double)M * D * 8);
-              if (rs_gemm_supported(D)) {
+              if (ln_fused) {
                   if (nat) { p.W = W.qkv_nat.w; p.ldw = W.qkv_nat.ldw; p.bias = W.qkv_nat.bias; }
                   p.X = x; p.ldx = D; p.ln_g = W.ln_att.g; p.ln_b = W.ln_att.b;
                   EC_TRY(launch_rs_gemm(p, nat ? 4 : 3, st));

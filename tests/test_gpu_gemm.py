@@ -124,10 +124,12 @@ def test_operand_row_pitch_larger_than_k_and_poisoned_tail_columns():
 
 
 @pytest.mark.parametrize("wide", [2, 3])
-@pytest.mark.parametrize("name,tm", [("EfficientConformerCTCLarge", 1001), ("ConformerCTCLarge", 501)])
+@pytest.mark.parametrize("name,tm", [("EfficientConformerCTCLarge", 1001), ("ConformerCTCLarge", 501), ("EfficientConformerCTCMedium", 1001)])
 def test_wide_configurations_end_to_end_on_the_lds_dma_gemm(golden_dir, name, tm, wide):
-    """The whole encoder with every tiled GEMM layer forced onto gemm256.hip (by shape it is only picked at bench-size row counts):
-    same tolerance against the reference goldens as the default path, and the fp32-output layers make it bit-identical to it."""
+    """The whole encoder with every tiled GEMM layer forced onto gemm256.hip (by shape it is only picked at bench-size row counts),
+    including the 257 .. 384-wide layers that otherwise run on the row-stationary kernels (LayerNorm as its own kernel then): same
+    tolerance against the reference goldens as the default path; where only the tile differs (ConformerCTC-Large: every layer is
+    tiled either way) the result is bit-identical to the 128 x 128 kernel's."""
     import os
 
     import numpy as np
@@ -148,4 +150,7 @@ def test_wide_configurations_end_to_end_on_the_lds_dma_gemm(golden_dir, name, tm
     d = (out[:, ::8].cpu().double() - torch.from_numpy(g["out_rows"]).double()).abs()
     print("%s wide %d: err max %.4f mean %.5f; max |wide - 128x128| %.3g" % (name, wide, float(d.max()), float(d.mean()), float((out.cpu() - base).abs().max())))
     assert float(d.max()) < 0.10 and float(d.mean()) < 0.012
-    assert torch.equal(out.cpu(), base)
+    if name == "ConformerCTCLarge":
+        assert torch.equal(out.cpu(), base)
+    else:
+        assert float((out.cpu() - base).abs().max()) < 0.08
