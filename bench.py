@@ -383,8 +383,12 @@ def main():
 
     def full_step():
         if world == 1:
-            enc, enc_len, _ = model.encoder(audio, lens, range_pad=range_pad)
-            last["labels"] = head(model, enc, enc_len)
+            if isinstance(model, Transducer):
+                enc, enc_len, _ = model.encoder(audio, lens, range_pad=range_pad)
+                last["labels"] = head(model, enc, enc_len)
+            else:      # fc + argmax + collapse of every row range on that range's stream (ModelCTC.encode_greedy)
+                _, _, labels, label_len = model.encode_greedy(audio, lens, range_pad=range_pad)
+                last["labels"] = (labels, label_len)
             return
         cur = torch.cuda.current_stream(dev)
         if args.gather == "outputs":

@@ -84,6 +84,32 @@ class ModelCTC(nn.Module):
                                               ws.numel(), torch.cuda.current_stream(enc.device).cuda_stream), "ctc_greedy")
         return logits, labels, label_len
 
+    def encode_greedy(self, x: torch.Tensor, x_len: Optional[torch.Tensor], from_mel: bool = False, **encoder_kwargs):
+        """Encoder + CTC head with the head launched PER ROW RANGE on that range's stream (``ConformerEncoder.sub_batches``): the
+        fc + argmax + collapse of range i overlaps the other ranges' encoder kernels instead of running after the join
+        (reference: model_ctc.py:90-133 runs them one after the other).  Returns (enc, enc_len, labels, label_len); the labels are
+        the same as ``_head(enc, enc_len)`` on the joined output - the head is row-local."""
+        lib = _lib.load()
+        state = {}
+
+        def hook(lo, hi, out, out_len):
+            if "labels" not in state:
+                b, t = out.shape[0], out.shape[1]
+                state["labels"] = torch.empty(b, t, dtype=torch.int32, device=out.device)
+                state["label_len"] = torch.empty(b, dtype=torch.int32, device=out.device)
+            t = out.shape[1]
+            st = torch.cuda.current_stream(out.device)
+            ws = torch.empty((hi - lo) * t * 4, dtype=torch.uint8, device=out.device)
+            _lib.check(lib.effconf_ctc_greedy(self.encoder._handle, out[lo:].data_ptr(), out_len[lo:].data_ptr(), hi - lo, t,
+                                              state["labels"][lo:].data_ptr(), state["label_len"][lo:].data_ptr(), None, ws.data_ptr(),
+                                              ws.numel(), st.cuda_stream), "ctc_greedy")
+            for tns in (state["labels"], state["label_len"]):
+                tns.record_stream(st)
+
+        with torch.cuda.device(x.device):
+            enc, enc_len, _ = (self.encoder.forward_mel if from_mel else self.encoder)(x, x_len, range_hook=hook, **encoder_kwargs)
+        return enc, enc_len, state["labels"], state["label_len"]
+
     def greedy_labels(self, x: torch.Tensor, x_len: Optional[torch.Tensor], from_mel: bool = False) -> List[List[int]]:
         """Greedy CTC label-id sequences (blank 0 removed, repeats collapsed), one list per utterance."""
         enc, enc_len, _ = self.encoder.forward_mel(x, x_len) if from_mel else self.encoder(x, x_len)

@@ -413,3 +413,20 @@ def test_ctc_head_on_fp32_mfma_is_bit_identical_to_the_valu_kernel(name, vocab):
     assert float((l1.cpu() - ref).abs().max()) < 2e-4
     _, lab2, n2 = m._head(enc, ln)                                     # without the logits output
     assert torch.equal(lab2, lab1) and torch.equal(n2, n1)
+
+
+@pytest.mark.parametrize("nsub,trim", [(1, False), (3, False), (3, True)])
+def test_per_range_ctc_head_equals_the_head_on_the_joined_output(nsub, trim):
+    """ModelCTC.encode_greedy launches fc + argmax + collapse per row range on the range's stream (the head is row-local): labels and
+    lengths identical to the head run once on the joined encoder output (reference order, model_ctc.py:90-133)."""
+    m, _ = _model("EfficientConformerCTCSmall", 5)
+    lens = [64000, 61000, 52000, 47000, 33000, 30000, 21000]
+    audio = torch.from_numpy(synth.make_audio(np.asarray(lens), seed=3)).cuda()
+    x_len = torch.tensor(lens, dtype=torch.int64).cuda()
+    m.encoder.sub_batches, m.encoder.trim_sub_batches = nsub, trim
+    enc, enc_len, labels, label_len = m.encode_greedy(audio, x_len)
+    _, ref_labels, ref_len = m._head(enc, enc_len)
+    assert torch.equal(label_len.cpu(), ref_len.cpu())
+    for b in range(len(lens)):
+        n = int(ref_len[b])
+        assert torch.equal(labels[b, :n].cpu(), ref_labels[b, :n].cpu())
