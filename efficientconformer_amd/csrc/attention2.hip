@@ -444,7 +444,7 @@ int launch2(const AttnParams& p, hipStream_t s) {
 
 }  // namespace
 
-bool relpos_attention2_supported(int dpad) { return dpad == 32 || dpad == 64 || dpad == 96 || dpad == 128; }      // wider heads spill: attention.hip
+bool relpos_attention2_supported(int dpad) { return dpad == 32 || dpad == 64 || dpad == 96 || dpad == 128 || dpad == 160; }   // 192: attention.hip
 
 // variant: 1 = 16 queries per wave, 4-wave 64-query workgroups, two per CU (attention.hip's shape: the default);
 //          2 = 32 queries per wave, 2-wave 64-query workgroups (one wave per SIMD: measured slower, kept for experiments)
@@ -454,6 +454,7 @@ int launch_relpos_attention2(const AttnParams& p, int waves, hipStream_t s) {
 #define ATT2_CASE(DPV) case DPV: return waves == 1 ? launch2<DPV, 4, 1>(p, s) : launch2<DPV, 2, 2>(p, s);
     switch (p.dpad) {
         ATT2_CASE(32) ATT2_CASE(64) ATT2_CASE(96) ATT2_CASE(128)
+        case 160: return launch2<160, 4, 1>(p, s);       // d = 135 (Medium / Large stage 1): one wave per SIMD either way; the 32-query variant spills
     }
 #undef ATT2_CASE
     return -3;

@@ -74,7 +74,7 @@ struct EcEncoder {
     int fuse_subsample = 2;                  // 0: separate conv + GEMM kernels, 1: sublinear.hip, 2: sublinear2.hip where it supports the shape (else 1)
     bool fuse_chain = true;                  // row-local chains (chain.hip) where supported
     int ctc_mfma = 1;                        // CTC head on the fp32 MFMA (bit-identical logits); 0: the VALU kernel
-    int attention_v2 = 1;                    // 0: attention.hip; 1 (default) / 2: attention2.hip variants where they support the head width (<= 128)
+    int attention_v2 = 1;                    // 0: attention.hip; 1 (default) / 2: attention2.hip variants where they support the head width (padded <= 160)
     // two-layer subsampler (plain Conformer configs): layer-2 implicit-GEMM weight [N][9*Cp] (tap, c_in), folded bias, Cp
     const bf16_t* sub2_w = nullptr; const float* sub2_b = nullptr; int sub2_cp = 0;
     std::vector<BlockW> bw;

@@ -165,7 +165,7 @@ int effconf_rnnt_greedy(EcRnnt* r, const float* enc_out, const int64_t* out_len,
  *   with the debug trace this exposes the intermediate residual-stream states that otherwise only exist in registers.
  * "attention_v2" (default 1): 0 = attention.hip; 1 = attention2.hip (same tiling; V read through ds_read_b64_tr_b16 instead of being
  *   transposed on the way into LDS, hoisted staging addresses, no column masks off the buffer tails, deferred accumulator rescale);
- *   2 = attention2.hip with 32 queries per wave (one wave per SIMD: measured slower, kept for experiments).  Head widths above 128
+ *   2 = attention2.hip with 32 queries per wave (one wave per SIMD: measured slower, kept for experiments).  Head widths above 160 (padded)
  *   always use attention.hip.  Results agree to fp32 summation order (variant 1's deferred rescale: to bf16 rounding of P).
  * "wide_gemm" (default 0): tile choice of the tiled GEMM layers (the widths the row-stationary kernels do not hold): 0 by shape,
  *     1 always csrc/gemm.hip (128 x 128, register staged), 2 / 3 csrc/gemm256.hip with 256 x 256 / 256 x 128 tiles wherever it applies.
