@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void subsample_conv_kernel(const float* __rest
     // a thread owns (channel c, two adjacent output frequencies f, f+1) for ALL frames of the tile: the channel's 9 taps + bias live in
     // registers and every LDS row of the 5 x (2 SUB_TT + 1) input window is read once (85 LDS reads per 16 outputs).  The first version
     // looped frames outermost and fetched taps and window per output: 19 LDS reads per output, 70 % of the wave cycles in LDS waits
-    // (profiles/r2_02_large_sq_counters.txt), 1.03 ms per launch on Large's C = 360 front end.
+    // (profiles/r2_03_large_sq_counters.txt), 1.03 ms per launch on Large's C = 360 front end.
     const int pairs = C * F2 / 2;                      // F2 is even for F = 80
     const int nt = (T1 - t0) < SUB_TT ? (T1 - t0) : SUB_TT;
     for (int q = tid; q < pairs; q += 256) {

@@ -440,7 +440,7 @@ int run_ffn(EcEncoder* e, hipStream_t st, const bf16_t* a, int M, int D, const P
 }
 
 // Widths 257 .. 384 (EfficientConformer Large stage 1, Medium stage 3) fit the row-stationary kernels, but at 24 k-steps those run one
-// wave per SIMD and stream every weight per 32-row tile: 60 - 200 TFLOP/s (profiles/r2_02_large_kernel_stats.txt).  When gemm256.hip's
+// wave per SIMD and stream every weight per 32-row tile: 60 - 200 TFLOP/s (profiles/r2_03_large_kernel_stats.txt).  When gemm256.hip's
 // 256 x 256 tiles fill the chip the layer goes there instead (LayerNorm as its own kernel in front).  `wide_gemm` 2 / 3 force it (tests).
 bool prefer_tiled(const EcEncoder* e, int M, int N, int K) {
     if (e->wide_gemm == 1 || K <= 256 || K % 8) return false;
