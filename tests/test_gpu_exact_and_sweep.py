@@ -387,6 +387,16 @@ def test_trimmed_row_ranges_equal_their_sub_batches_run_alone_and_the_oracle():
         with torch.no_grad():
             ref, ref_len = R.encoder(audio[lo:hi, :li].cpu(), ln[lo:hi].cpu(), sd, enc.plan)
         assert ref_len.tolist() == alone_len.cpu().tolist() and _err(alone.cpu(), ref)[0] < 0.08
+    # more ranges than streams (sub_batch_streams) and explicit boundaries: the same rows, the same results
+    enc.sub_batches, enc.trim_sub_batches, enc.sub_batch_streams = 3, True, 2
+    out3, len3, _ = enc(audio, ln, x_len_host=lens)
+    enc.sub_batch_streams = None
+    out3b, _, _ = enc(audio, ln, x_len_host=lens)
+    assert torch.equal(out3, out3b) and torch.equal(len3, out_len)
+    enc.sub_batches, enc.sub_batch_bounds = 2, [3]
+    out_b, _, _ = enc(audio, ln, x_len_host=lens)
+    assert torch.equal(out_b, out)
+    enc.sub_batches, enc.trim_sub_batches, enc.sub_batch_bounds = 1, False, None
     whole, _, _ = enc(audio, ln)                                        # one batch padded to the global maximum: the round-1 semantics
     assert torch.equal(whole[:3], out[:3]) and not torch.equal(whole[3:, :out_len[3]], out[3:, :out_len[3]])   # pad frames are live
 
