@@ -440,12 +440,13 @@ int run_ffn(EcEncoder* e, hipStream_t st, const bf16_t* a, int M, int D, const P
 }
 
 // Widths 257 .. 384 (EfficientConformer Large stage 1, Medium stage 3) fit the row-stationary kernels, but at 24 k-steps those run one
-// wave per SIMD and stream every weight per 32-row tile: 60 - 200 TFLOP/s (profiles/r2_03_large_kernel_stats.txt).  When gemm256.hip's
-// 256 x 256 tiles fill the chip the layer goes there instead (LayerNorm as its own kernel in front).  `wide_gemm` 2 / 3 force it (tests).
+// wave per SIMD and stream every weight per 32-row tile: 60 - 200 TFLOP/s (profiles/r2_03_large_kernel_stats.txt).  `wide_gemm` 2 / 3
+// sends these layers to LayerNorm + the tiled GEMMs instead.  Only when forced: chosen by row count (gemm256.hip's tiles filling the
+// chip) it was -3 % kernel time on Large and wall-neutral, and it made a forward's bits depend on how the batch is split into row ranges
+// (the two paths round differently; tools/robustness_sweep.py) - the gemm.hip / gemm256.hip choice does not (bit-identical kernels).
 bool prefer_tiled(const EcEncoder* e, int M, int N, int K) {
-    if (e->wide_gemm == 1 || K <= 256 || K % 8) return false;
-    if (e->wide_gemm >= 2) return true;
-    return N >= 192 && (long)((M + 255) / 256) * ((N + 255) / 256) >= 200;
+    (void)M; (void)N;
+    return e->wide_gemm >= 2 && K > 256 && K % 8 == 0;
 }
 
 // row-stationary single GEMM when K <= 384, else the tiled kernel
@@ -594,7 +595,9 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
                    ap.e_hstride = (long long)(2 * Tg - 1) * dpad; ap.e_rowstride = dpad; }
             ap.out = o; ap.ldo = ld8(D); ap.scale = 1.0f / std::sqrt((float)d);
             { PROF(PC_ATTENTION, 2.0 * B * H * (double)Tg * Tg * d * 3.0, (double)M * D * 2 * 5);
-              if (e->attention_v2 && relpos_attention2_supported(dpad)) EC_TRY(launch_relpos_attention2(ap, e->attention_v2, st));
+              // attention2.hip reads the natural layout only (its column masks assume the next head's finite data behind a head span); the
+              // head-major test layout of odd head widths (EFFCONF_HEAD_MAJOR_ODD) stays on attention.hip
+              if (e->attention_v2 && nat && relpos_attention2_supported(dpad)) EC_TRY(launch_relpos_attention2(ap, e->attention_v2, st));
               else EC_TRY(launch_relpos_attention(ap, st)); }
             snprintf(nm, sizeof(nm), "blocks.%d.att_o", k); trace_add(e, st, nm, o, M, D, ld8(D), 1);
             if (chain_b) {
