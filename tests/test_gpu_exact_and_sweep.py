@@ -440,3 +440,21 @@ def test_per_range_ctc_head_equals_the_head_on_the_joined_output(nsub, trim):
     for b in range(len(lens)):
         n = int(ref_len[b])
         assert torch.equal(labels[b, :n].cpu(), ref_labels[b, :n].cpu())
+
+
+@pytest.mark.parametrize("name,batch", [("EfficientConformerCTCMedium", 65), ("EfficientConformerCTCLarge", 33)])
+def test_row_range_splits_do_not_change_a_single_bit_on_the_wide_configurations(name, batch):
+    """Kernel choices that depend on the row count (tile shapes of the tiled GEMMs) must be bit-identical kernels: a batch run as 1, 2 or 3
+    un-trimmed row ranges gives the same bits (tools/robustness_sweep.py is the long version; round 2 briefly routed the 257..384-wide
+    layers by row count between two paths that round differently - this test is the guard)."""
+    m, _ = _model(name, 2)
+    lens = synth.libri_lengths(batch, seed=100 + batch)[:batch]
+    lens[-1] = 2000
+    audio = torch.from_numpy(synth.make_audio(lens, seed=batch)).cuda()
+    ln = torch.from_numpy(lens).cuda()
+    m.encoder.sub_batches = 1
+    ref, ref_len, _ = m.encoder(audio, ln)
+    for ns in (2, 3):
+        m.encoder.sub_batches = ns
+        got, got_len, _ = m.encoder(audio, ln)
+        assert torch.equal(got, ref) and torch.equal(got_len, ref_len), (name, ns)
