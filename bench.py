@@ -77,6 +77,10 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1 (nccl = RCCL over xGMI; gloo + --one-device: N ranks on ONE GPU, a test of the multi-rank path)")
     ap.add_argument("--one-device", action="store_true", help="every rank uses cuda:0 (tests on a single-GPU box; never a benchmark)")
+    ap.add_argument("--no-check", action="store_true",
+                    help="skip the un-timed self-check of the benchmarked step (single-stream per-range rerun + oracle samples)")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"],
+                    help="bf16: bf16 MFMA operands / fp32 accumulate (default); fp32: the library's label-exact mode")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU work: build the batch plan, join the process group (gloo) and print the JSON skeleton (CPU tests)")
     return ap.parse_args()
@@ -163,6 +167,67 @@ def step(model, audio, lens, range_pad=None):
     enc, enc_len, _ = model.encoder(audio, lens, range_pad=range_pad)
     labels, label_len = head(model, enc, enc_len)
     return enc, enc_len, labels, label_len
+
+
+def edit_distance(a, b):
+    prev = list(range(len(b) + 1))
+    for i, x in enumerate(a, 1):
+        cur = [i]
+        for j, y in enumerate(b, 1):
+            cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (x != y)))
+        prev = cur
+    return prev[-1]
+
+
+def self_check(model, sd, plan, audio, lens, lens_np, cuts, range_pad, nsub, last, args):
+    """Verify the outputs of the LAST timed step.  Returns the `check` object of the JSON line; ok = every comparison passed."""
+    from oracle import ref_encoder as R
+    enc, enc_len = last["enc"]
+    labels, label_len = last["labels"]
+    torch.cuda.synchronize()
+    tol_max, tol_mean = (0.10, 0.012) if args.precision == "bf16" else (2e-4, 2e-5)
+    osd = {k[len("encoder."):] if k.startswith("encoder.") else k: torch.from_numpy(v) for k, v in sd.items()}
+    saved = (model.encoder.sub_batches, model.encoder.trim_sub_batches)
+    model.encoder.sub_batches, model.encoder.trim_sub_batches = 1, False
+    bit_ok, finite = True, bool(torch.isfinite(enc).all())
+    worst_max = worst_mean = 0.0
+    n_oracle = flips = frames = dist = nlab = 0
+    seq_equal = True
+    try:
+        for i in range(nsub):
+            lo, hi = cuts[i], cuts[i + 1]
+            ni = range_pad[i] if range_pad else audio.shape[1]
+            alone, alone_len, _ = model.encoder(audio[lo:hi, :ni].contiguous(), lens[lo:hi].contiguous())
+            _, lab, n = model._head(alone, alone_len)
+            ti = alone.shape[1]
+            bit_ok = bit_ok and torch.equal(enc[lo:hi, :ti], alone) and float(enc[lo:hi, ti:].abs().sum()) == 0.0 and \
+                torch.equal(enc_len[lo:hi], alone_len) and torch.equal(label_len[lo:hi], n) and torch.equal(labels[lo:hi, :ti], lab)
+            rows = sorted({lo, lo + (hi - lo) // 3, lo + 2 * (hi - lo) // 3, hi - 1})
+            with torch.no_grad():
+                ref, ref_len = R.encoder(audio[rows, :ni].cpu(), lens[rows].cpu(), osd, plan)
+                ref_logits = R.ctc_logits(ref, osd)
+                want = R.ctc_greedy(ref_logits, ref_len)
+            got = enc[rows, :ref.shape[1]].cpu()
+            d = (got - ref).abs()
+            worst_max, worst_mean = max(worst_max, float(d.max())), max(worst_mean, float(d.mean()))
+            n_oracle += len(rows)
+            am = R.ctc_logits(got, osd).argmax(-1)
+            for j, r in enumerate(rows):
+                t = int(ref_len[j])
+                flips += int((am[j, :t] != ref_logits[j, :t].argmax(-1)).sum()); frames += t
+                mine = labels[r, :int(label_len[r])].cpu().tolist()
+                dist += edit_distance(mine, want[j]); nlab += len(want[j])
+                seq_equal = seq_equal and mine == want[j]
+    finally:
+        model.encoder.sub_batches, model.encoder.trim_sub_batches = saved
+    ok = bit_ok and finite and worst_max <= tol_max and worst_mean <= tol_mean and (args.precision == "bf16" or seq_equal)
+    return {"ok": bool(ok), "finite": finite, "bit_identical_to_each_range_run_alone_on_one_stream": bool(bit_ok),
+            "oracle_utterances": n_oracle, "max_abs_err_vs_oracle": worst_max, "mean_abs_err_vs_oracle": worst_mean,
+            "tolerance": {"max": tol_max, "mean": tol_mean},
+            "argmax_flips_vs_oracle": flips, "frames_compared": frames, "label_edit_distance_vs_oracle": dist, "oracle_labels": nlab,
+            "label_sequences_identical_to_oracle": bool(seq_equal),
+            "note": "encoder output + greedy labels of the last timed step; oracle = fp32 CPU restatement of the reference "
+                    "(oracle/ref_encoder.py) on sampled utterances collated with their range's longest utterance"}
 
 
 def host_cpu():
@@ -277,16 +342,19 @@ CLASS_INFO = {
 
 
 def result_skeleton(args, world, value, ms_per_step, gb, extra_cfg):
+    extra_cfg = dict(extra_cfg)
+    padding = extra_cfg.pop("_padding", "")
     label = args.model.replace("EfficientConformer", "EffConformer").replace("CTCSmall", "CTC-Small")
     return {
         "metric": "audio-frames/sec through encoder, %s, 1/2/4/8 GPU" % label,
         "value": value, "unit": "mel-frames/s (valid, 10 ms hop)",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
         "config": dict({"workload": "%s: %s, B=%d utterances/GPU, %s lengths, audio in HBM -> encoder out + greedy labels"
-                                    % (args.model, "bf16 operands / fp32 accumulate", args.batch,
-                                       "lognormal 1.5-16 s (LibriSpeech-shaped), sorted desc, zero-padded to the batch max"
+                                    % (args.model, "bf16 operands / fp32 accumulate" if args.precision == "bf16" else "fp32 operands (label-exact mode)",
+                                       args.batch,
+                                       ("lognormal 1.5-16 s (LibriSpeech-shaped), sorted desc; " + padding)
                                        if args.workload == "libri" else "10 s"),
                         "global_batch": gb, "streams_per_gpu": args.streams}, **extra_cfg),
     }
@@ -317,7 +385,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         if rank == 0:
-            r = result_skeleton(args, world, 0.0, 0.0, args.batch * world, {"parallelism": "dp%d" % world})
+            r = result_skeleton(args, world, 0.0, 0.0, args.batch * world, {"parallelism": "dp%d" % world, "_padding": "dry run"})
             r.update({"dry_run": True, "padded_samples_equal_on_all_ranks": bool(t[0] == lo[0] * world), "valid_frames_per_step": float(t[1])})
             print(json.dumps(r))
         if world > 1:
@@ -335,6 +403,7 @@ def main():
             dist.init_process_group("gloo")
 
     cfg, model, sd = build_model(args.model)
+    model.encoder.precision = args.precision
     model = model.to(dev)
     plan = model.encoder.plan
     audio_np, lens_np = make_batch(args, rank, world)
@@ -387,8 +456,9 @@ def main():
                 enc, enc_len, _ = model.encoder(audio, lens, range_pad=range_pad)
                 last["labels"] = head(model, enc, enc_len)
             else:      # fc + argmax + collapse of every row range on that range's stream (ModelCTC.encode_greedy)
-                _, _, labels, label_len = model.encode_greedy(audio, lens, range_pad=range_pad)
+                enc, enc_len, labels, label_len = model.encode_greedy(audio, lens, range_pad=range_pad)
                 last["labels"] = (labels, label_len)
+            last["enc"] = (enc, enc_len)
             return
         cur = torch.cuda.current_stream(dev)
         if args.gather == "outputs":
@@ -424,9 +494,14 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    # per-step distribution: one event per step on the caller's stream (every step joins its range streams there); no synchronisation
+    # inside the timed region - `value` comes from the wall clock around all K steps
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         full_step()
+        marks[i + 1].record()
     drain()
     torch.cuda.synchronize()
     if world > 1:
@@ -445,13 +520,26 @@ def main():
         par = "dp%d%s (utterance shards" % (world, ", ALL RANKS ON ONE GPU over gloo: a functional test, not a benchmark" if args.one_device else "")
         if world > 1:
             par += ", RCCL all-gather of %s per row range on a comm stream, wire %s" % ("encoder outputs" if args.gather == "outputs" else "label ids", args.wire)
+        step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+        pct = lambda q: step_ms[min(len(step_ms) - 1, int(q * len(step_ms)))]
         result = result_skeleton(args, world, all_valid * args.steps / elapsed, 1000.0 * elapsed / args.steps, args.batch * world,
                                  {"padded_frames_per_s": all_padded * args.steps / elapsed, "parallelism": par + ")",
+                                  "step_ms": {"p10": pct(0.10), "median": pct(0.50), "p90": pct(0.90), "note": "HIP events between steps on the caller's stream (rank 0); "
+                                              "ms_per_step / value are wall clock over all steps"},
+                                  "padded_fraction": 1.0 - all_valid / all_padded,
+                                  "_padding": ("each of the %d row ranges zero-padded to ITS longest utterance (length bucketing inside the forward)" % nsub) if range_pad
+                                              else "zero-padded to the batch's longest utterance",
                                   "row_ranges": ("%d row ranges per GPU (rows %s), each padded to ITS longest utterance %s samples (length bucketing inside "
                                                  "the forward; --no-trim pads all to the batch maximum as in round 1)" % (nsub, cuts, range_pad)) if range_pad
                                                 else "%d row range(s) per GPU padded to the batch maximum" % nsub})
         if isinstance(model, Transducer):
             result["config"]["workload"] += " (RNN-T greedy token ids, synthetic blank bias %.1f)" % RNNT_BLANK_BIAS
+
+    # ---- self-check of the benchmarked step (un-timed): the step's outputs against (1) every row range run ALONE on one stream
+    #      (bit-identical) and (2) the oracle = the reference path on sampled utterances of each range, collated with the range's
+    #      longest utterance (pad frames are live), within the bf16 tolerance of tests/test_gpu_encoder.py
+    if rank == 0 and world == 1 and not args.no_check and not isinstance(model, Transducer):
+        result["check"] = self_check(model, sd, plan, audio, lens, lens_np, cuts, range_pad, nsub, last, args)
 
     # ---- roofline leg: the same steps again with every launch bracketed by HIP events on the launch stream
     if rank == 0 and not args.no_roofline:
@@ -515,8 +603,20 @@ def main():
                 toks, tok_len = model.decode_encoded(enc, enc_len)
             e1.record()
             torch.cuda.synchronize()
-            per["rnnt_greedy"] = {"ms_per_step": e0.elapsed_time(e1) / nprof, "launches_per_step": 2,
+            dec_ms = e0.elapsed_time(e1) / nprof
+            e0.record()
+            for _ in range(nprof):
+                model.encoder(audio, lens, range_pad=range_pad)
+            e1.record()
+            torch.cuda.synchronize()
+            enc_ms = e0.elapsed_time(e1) / nprof
+            per["rnnt_greedy"] = {"ms_per_step": dec_ms, "launches_per_step": 2,
                                   "tokens_per_step": int(tok_len.sum()), "encoder_frames_per_step": int(enc_len.sum())}
+            # the encoder by the headline metric, the greedy decode as utterances/s, each timed alone
+            result["transducer_legs"] = {"encoder_valid_mel_frames_per_s": valid_frames / (enc_ms * 1e-3), "encoder_ms": enc_ms,
+                                         "decode_utterances_per_s": args.batch / (dec_ms * 1e-3), "decode_ms": dec_ms,
+                                         "decode_tokens_per_s": int(tok_len.sum()) / (dec_ms * 1e-3),
+                                         "note": "each leg alone on one stream after the timed region; `value` is the whole step (encoder + decode)"}
         tot_ms = sum(c["ms_per_step"] for k, c in per.items() if k in PROF_CLASSES)
         tot_gf = sum(c["gflop_per_step"] for k, c in per.items() if k in PROF_CLASSES)
         result["roofline"] = {"kernel": "%s: %s" % (dom_name, CLASS_INFO[dom_name][0]),
@@ -530,7 +630,10 @@ def main():
                               "alg_gflop_per_launch": dom["gflop_per_step"] / n_l,
                               "alg_hbm_gbs": dom["alg_mb_per_step"] / max(dom["ms_per_step"], 1e-9),
                               "share_of_step": dom["ms_per_step"] / max(tot_ms, 1e-9),
-                              "whole_step": {"sum_kernel_ms": tot_ms, "alg_gflop": tot_gf, "mfma_frac": tot_gf / max(tot_ms, 1e-9) / PEAK_BF16_TFLOPS},
+                              "whole_step": {"sum_kernel_ms": tot_ms, "alg_gflop": tot_gf, "wall_ms": result["ms_per_step"],
+                                             "mfma_frac": tot_gf / max(result["ms_per_step"], 1e-9) / PEAK_BF16_TFLOPS,
+                                             "mfma_frac_of_serial_kernel_time": tot_gf / max(tot_ms, 1e-9) / PEAK_BF16_TFLOPS,
+                                             "note": "mfma_frac = algorithmic flop of one step / wall step time / 2.5 PF (padded frames: the work the kernels do)"},
                               "note": "dominant class = most time per step; HIP events around every launch of the class on the launch stream, %d extra "
                                       "steps after the timed region (the step's %d row ranges one after the other on one stream, so launches do not "
                                       "overlap); kernel_classes lists every class against its own bound" % (nprof, nsub)}
@@ -548,6 +651,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0 and result.get("check") and not result["check"]["ok"]:
+        sys.exit("bench.py: self-check of the benchmarked step FAILED: %s" % json.dumps(result["check"]))
 
 
 if __name__ == "__main__":

@@ -18,7 +18,7 @@ LIB = os.path.join(HERE, "libeffconf.so")
 SOURCES = ["gemm.hip", "gemm256.hip", "rsgemm.hip", "chain.hip", "norm.hip", "conv.hip", "sublinear.hip", "sublinear2.hip", "conv2.hip", "mel.hip", "ctc.hip", "rnnt.hip", "attention.hip", "attention2.hip", "exact.hip", "debug.hip", "encoder.hip"]
 # (source, object, extra flags): further compilations of a source under other flags
 # No packed-fp32 VALU instructions in product kernels: v_pk_{add,mul,fma}_f32 with an op_sel low-lane swizzle return wrong values
-# next to another wave's bf16 MFMA on gfx950 (measured: profiles/r2_mel_packed_fp32_hazard.txt; guard: tools/check_isa.py).
+# next to another wave's bf16 MFMA on gfx950 (measured: profiles/r2_mel_packed_fp32_hazard.txt; guard: _isa_guard.py).
 # Cost of the flag for the whole library: 7.56 -> 7.60 ms per bench step.
 NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 DIAGNOSTIC_SOURCES = {"debug.hip"}        # the hazard reproducer needs the instructions it demonstrates
@@ -60,22 +60,31 @@ def build(force: bool = False, verbose: bool = True) -> str:
     jobs = [(s, s.replace(".hip", ".o"), [] if s in DIAGNOSTIC_SOURCES else NO_PACKED_FP32) for s in SOURCES] + VARIANT_OBJECTS
     with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
         objs = list(ex.map(compile_one, jobs))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    # link to a temporary name, run the ISA guard on it, and only then move it into place: a library that fails the guard never
+    # becomes importable (before: the first build raised AFTER writing libeffconf.so and the next import passed silently)
+    tmp = LIB + ".tmp"
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n%s" % r.stderr[-4000:])
+    try:
+        check_isa(tmp)
+    except Exception:
+        os.remove(tmp)
+        raise
+    os.replace(tmp, LIB)
     if verbose:
         print("built %s (%d KB)" % (LIB, os.path.getsize(LIB) // 1024))
-    check_isa()
     return LIB
 
 
-def check_isa() -> None:
-    """Fail the build if a product kernel carries a hazardous packed-fp32 form (tools/check_isa.py)."""
-    tool = os.path.join(HERE, "..", "tools", "check_isa.py")
-    r = subprocess.run([sys.executable, tool, LIB], capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError("ISA guard failed:\n%s" % (r.stdout[-3000:] + r.stderr[-1000:]))
+def check_isa(lib: str = LIB) -> None:
+    """Fail the build if a product kernel carries a hazardous packed-fp32 form (efficientconformer_amd/_isa_guard.py)."""
+    from . import _isa_guard
+    lines = []
+    n, bad = _isa_guard.check(lib, lines)
+    if bad:
+        raise RuntimeError("ISA guard failed: %d product kernels with hazardous packed-fp32 forms\n%s" % (bad, "\n".join(lines)[-3000:]))
 
 
 if __name__ == "__main__":

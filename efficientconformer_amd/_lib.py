@@ -58,6 +58,11 @@ SIGNATURES = {
     "effconf_profile_read": (C.c_int, [_P, _I32, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                        C.POINTER(C.c_double)]),
     "effconf_relpos_attention": (C.c_int, [_P, _P, _P, _P, _F32P, _I32, _P, _I32, _I32, _I32, _I32, _I32, _P, _I32, _I32, _P]),
+    "effconf_module_workspace_bytes": (_SZ, [_P, _I32, _I32]),
+    "effconf_ffn": (C.c_int, [_P, _I32, _I32, _F32P, _I32, _F32P, _P, _SZ, _P]),
+    "effconf_conv_module": (C.c_int, [_P, _I32, _F32P, _I32, _I32, _F32P, _P, _SZ, _P]),
+    "effconf_subsample": (C.c_int, [_P, _F32P, _I32, _I32, _F32P, _P, _SZ, _P]),
+    "effconf_layernorm_residual": (C.c_int, [_P, _I32, _I32, _F32P, _F32P, C.c_float, _I32, _F32P, _P]),
     "effconf_debug_mel": (C.c_int, [_P, _I32, _I32, _F32P, _I32, _I32, _F32P, _P, _P]),
     "effconf_debug_neighbour": (C.c_int, [_I32, _I32, _I32, _I32, _F32P, _SZ, _P]),
     "effconf_debug_victim": (C.c_int, [_I32, _I32, _I32, _F32P, _P]),

@@ -509,9 +509,8 @@ template <int DP>
 int launch_dp(const AttnParams& p, hipStream_t s) {
     // 64-query (4-wave) workgroups, two per CU: the kernel is latency-bound on its K / V / E loads (phase profile above), and two
     // independent workgroups per CU hide more of it than one 128-query workgroup that stages K / V half as often (1.31 -> 1.23 ms
-    // per step once the loads run two key blocks ahead).  EFFCONF_ATTN_WAVES=8 selects the 128-query variant.
-    static const char* ev = getenv("EFFCONF_ATTN_WAVES");
-    const int force = ev ? atoi(ev) : 0;
+    // per step once the loads run two key blocks ahead).  Option "attn_waves" = 8 selects the 128-query variant.
+    const int force = p.force_waves;
     constexpr bool fits8 = AttnSmem<DP, 8>::TOTAL <= 160 * 1024;
     if constexpr (fits8)
         if (force == 8) return launch_dp_w<DP, 8>(p, s);

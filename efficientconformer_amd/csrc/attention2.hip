@@ -94,6 +94,7 @@ __global__ __launch_bounds__(NWV * 64, (QT == 1 && NWV == 4 && DP <= 96) ? 2 : 1
     const int RS = p.q_rowstride, ERS = p.e_rowstride;
     const int erows = 2 * p.Tg - 1;
     const int dceil = (p.d + 7) & ~7;
+    const bool ragged_d = dceil != p.d;
 
     int nkeys = (p.lens[b] + p.G - 1) / p.G;
     nkeys = nkeys < p.Tg ? nkeys : p.Tg;
@@ -190,7 +191,11 @@ __global__ __launch_bounds__(NWV * 64, (QT == 1 && NWV == 4 && DP <= 96) ? 2 : 1
         koffs[n] = (uint32_t)(r * RS + xc) * 2u;                // BYTE offsets: wave-uniform base + 32-bit lane offset
     }
     auto issue_loads = [&](Stage& st_, int jn) __attribute__((always_inline)) {
-        if (jn + BJ <= p.Tg) {
+        // unmasked fast path: every 16-byte chunk of the block stays inside the library's own (finite) data.  With a head width that
+        // is not a multiple of 8 (d = 90 / 135 / 42) the chunk that closes a head span reads dceil - d elements of the NEXT span; behind
+        // the last key row of the last head of the last utterance that is the never-written slack of the buffer (NaN patterns times the
+        // queries' zero pad columns = NaN), so the block holding row Tg - 1 takes the masked tail path then.
+        if (jn + BJ <= p.Tg - (ragged_d ? 1 : 0)) {
             const char* kb = reinterpret_cast<const char*>(Kh + (size_t)jn * RS);
             const char* vb = reinterpret_cast<const char*>(Vh + (size_t)jn * RS);
 #pragma unroll
@@ -200,12 +205,12 @@ __global__ __launch_bounds__(NWV * 64, (QT == 1 && NWV == 4 && DP <= 96) ? 2 : 1
             for (int n = 0; n < NK; ++n) {
                 const int kr = chunk_row(n), j = jn + kr;
                 const size_t o = (size_t)(j < p.Tg ? j : p.Tg - 1) * RS * 2 + (koffs[n] - (uint32_t)(kr * RS) * 2u);
-                st_.lk[n] = tail_mask(ld16b(reinterpret_cast<const char*>(Kh) + o), n); st_.lv[n] = ld16b(reinterpret_cast<const char*>(Vh) + o);
+                st_.lk[n] = tail_mask(ld16b(reinterpret_cast<const char*>(Kh) + o), n); st_.lv[n] = tail_mask(ld16b(reinterpret_cast<const char*>(Vh) + o), n);
             }
         }
         if (jn > 0) {
             const int rnew = R0 + jn + BI - 1;                   // first new absolute E row of the block
-            if (rnew >= 0 && rnew + 63 < erows) {
+            if (rnew >= 0 && rnew + 63 < erows - (ragged_d ? 1 : 0)) {      // the batch holding the table's last row: masked path (see above)
                 const char* eb = reinterpret_cast<const char*>(Eh + (size_t)rnew * ERS);
 #pragma unroll
                 for (int n = 0; n < NK; ++n) st_.le[n] = ld16b(eb + koffs[n]);

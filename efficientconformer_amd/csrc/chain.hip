@@ -687,8 +687,7 @@ int launch_chain_kind(const ChainParams& p, hipStream_t s) {
     const int ks = 2 * ((p.D + 31) / 32);
     if (ks <= 2) return launch_chain_t<2, 4, 4, KIND>(p, s);
     if (ks <= 4) return launch_chain_t<4, 8, 4, KIND>(p, s);
-    static const int var = getenv("EFFCONF_CHAIN_VARIANT") ? atoi(getenv("EFFCONF_CHAIN_VARIANT")) : 0;
-    if (ks <= 8) return var == 1 ? launch_chain_t<8, 4, 2, KIND>(p, s) : launch_chain_t<8, 8, 4, KIND>(p, s);
+    if (ks <= 8) return p.variant == 1 ? launch_chain_t<8, 4, 2, KIND>(p, s) : launch_chain_t<8, 8, 4, KIND>(p, s);
     if (ks <= 12) return launch_chain_t<12, 8, 3, KIND>(p, s);
     return launch_chain_t<16, 4, 3, KIND>(p, s);
 }
@@ -704,10 +703,7 @@ bool chain_head_supported(int D) { return chain_supported(D); }      // D % 4 ==
 bool chain_tail_supported(int D) { return chain_supported(D); }
 // tail + next head in ONE kernel: up to D = 192 the whole state fits the register file; at D = 240 (KS = 16) the combined kernel spills
 // (199 us per block against 181 us for the five per-GEMM kernels) while the tail and the head as TWO chain launches do not
-bool chain_full_supported(int D) {
-    static const int dmax = [] { const char* e = getenv("EFFCONF_CHAIN_FULL_MAX"); return e ? atoi(e) : 192; }();   // tuning knob
-    return chain_head_supported(D) && D <= dmax;
-}
+bool chain_full_supported(int D, int dmax) { return chain_head_supported(D) && D <= dmax; }
 
 int launch_chain(const ChainParams& p, int kind, hipStream_t s) {
     if (p.M <= 0) return 0;

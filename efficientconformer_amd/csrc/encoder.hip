@@ -75,6 +75,9 @@ struct EcEncoder {
     bool fuse_chain = true;                  // row-local chains (chain.hip) where supported
     int ctc_mfma = 1;                        // CTC head on the fp32 MFMA (bit-identical logits); 0: the VALU kernel
     int attention_v2 = 1;                    // 0: attention.hip; 1 (default) / 2: attention2.hip variants where they support the head width (padded <= 160)
+    // tuning / test options that used to be process-global environment switches (effconf_encoder_set_option)
+    int chain_variant = 0, chain_full_max = 192, attn_waves = 4, rs_variant = 0, ffn_variant = 0;
+    bool head_major_odd = false;             // odd grouped head widths on the head-major Q/K/V layout (tests; the default reads the natural layout unaligned)
     // two-layer subsampler (plain Conformer configs): layer-2 implicit-GEMM weight [N][9*Cp] (tap, c_in), folded bias, Cp
     const bf16_t* sub2_w = nullptr; const float* sub2_b = nullptr; int sub2_cp = 0;
     std::vector<BlockW> bw;
@@ -430,7 +433,7 @@ int run_ffn(EcEncoder* e, hipStream_t st, const bf16_t* a, int M, int D, const P
         FfnParams p{};
         p.A = a; p.lda = ld8(D); p.X = x; p.ldx = D; p.Y = x; p.ldy = D;
         p.W1 = L1.w; p.ldw1 = L1.ldw; p.b1 = L1.bias; p.W2 = w2p; p.ldw2 = L2.ldw; p.b2 = L2.bias;
-        p.M = M; p.D = D; p.Fp = ec_round_up(F, 32); p.alpha = 0.5f;
+        p.M = M; p.D = D; p.Fp = ec_round_up(F, 32); p.alpha = 0.5f; p.variant = e->ffn_variant;
         if (ln) { p.ln_g = ln->g; p.ln_b = ln->b; }
         return launch_ffn_fused(p, st);
     }
@@ -464,8 +467,39 @@ int run_rs_or_tiled(EcEncoder* e, int cls, hipStream_t st, const bf16_t* A, int 
     GemmParams p{};
     p.A = A; p.lda = lda; p.W = L.w; p.ldw = L.ldw; p.bias = L.bias;
     p.M = M; p.N = L.N; p.K = L.K; p.C = C; p.ldc = ldc; p.R = R; p.ldr = ldr; p.alpha = alpha;
+    p.rs_variant = e->rs_variant;
     if (lnX && ln) { p.X = lnX; p.ldx = L.K; p.ln_g = ln->g; p.ln_b = ln->b; }
     return launch_rs_gemm(p, rs_epi, st);
+}
+
+// Conv2dSubsampling (modules.py:232-249) + transpose + Linear (encoders.py:113-116): mel (B, n_mels, Tm) -> x fp32 (B * T1, D0).
+// sub / act1: bf16 scratch of the unfused variants (the subsampler's output rows / the two-layer subsampler's layer-1 image).
+int run_subsample_linear(EcEncoder* e, hipStream_t st, const float* mel, int B, int Tm, int T1, bf16_t* sub, bf16_t* act1, float* x) {
+    const EcConfig& c = e->cfg;
+    const int C0 = c.sub_filters[0], F2 = c.n_mels / 2, Ksub = C0 * F2;
+    if (c.sub_layers == 2) {
+        const int Tl1 = (Tm - 1) / 2 + 1, F1 = c.n_mels / 2, F2q = c.n_mels / 4, C1 = c.sub_filters[1];
+        { PROF(PC_SUBCONV, 2.0 * 9 * B * Tl1 * (double)C0 * F1, (double)B * c.n_mels * Tm * 4 + (double)B * Tl1 * F1 * e->sub2_cp * 2);
+          EC_TRY(launch_subsample_conv_cl(mel, B, c.n_mels, Tm, Tl1, e->sub_w9, e->sub_b, C0, e->sub2_cp, act1, st)); }
+        { PROF(PC_GEMM_OTHER, 2.0 * 9 * (double)B * F2q * T1 * C0 * C1, (double)B * Tl1 * F1 * e->sub2_cp * 2 + (double)B * T1 * F2q * C1 * 2);
+          EC_TRY(launch_conv2_igemm(act1, B, F1, Tl1, e->sub2_cp, e->sub2_w, 9 * e->sub2_cp, e->sub2_b, C1, F2q, T1, sub, st)); }
+        trace_add(e, st, "subsample", sub, (int64_t)B * T1, F2q * C1, F2q * C1, 1);
+        EC_TRY(run_gemm(e, PC_GEMM_OTHER, st, sub, F2q * C1, B * T1, e->lin, EPI_F32, x, e->lin.N));
+    } else if (e->fuse_subsample == 2 && e->lin_rs) {
+        PROF(PC_SUBCONV, 2.0 * 9 * B * T1 * (double)Ksub + 2.0 * B * T1 * (double)Ksub * e->lin.N,
+             (double)B * c.n_mels * Tm * 4 + (double)B * T1 * e->lin.N * 4);
+        EC_TRY(launch_sublinear2(mel, B, c.n_mels, Tm, T1, e->conv_tab, e->lin_rs, e->lin.bias, C0, e->lin.N, x, e->lin.N, st));
+    } else if (e->fuse_subsample && e->lin_fused) {
+        PROF(PC_SUBCONV, 2.0 * 9 * B * T1 * (double)Ksub + 2.0 * B * T1 * (double)Ksub * e->lin.N,
+             (double)B * c.n_mels * Tm * 4 + (double)B * T1 * e->lin.N * 4);
+        EC_TRY(launch_sublinear_fused(mel, B, c.n_mels, Tm, T1, e->sub_w9, e->sub_b, C0, e->lin_fused, e->lin_fused_ld,
+                                      e->lin.bias, e->lin.N, x, e->lin.N, st));
+    } else {
+        { PROF(PC_SUBCONV, 2.0 * 9 * B * T1 * (double)Ksub, (double)B * c.n_mels * Tm * 4 + (double)B * T1 * Ksub * 2); EC_TRY(launch_subsample_conv(mel, B, c.n_mels, Tm, T1, e->sub_w9, e->sub_b, C0, sub, Ksub, st)); }
+        trace_add(e, st, "subsample", sub, (int64_t)B * T1, Ksub, Ksub, 1);
+        EC_TRY(run_gemm(e, PC_GEMM_OTHER, st, sub, Ksub, B * T1, e->lin, EPI_F32, x, e->lin.N));
+    }
+    return 0;
 }
 
 int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from_audio, const Shapes& s, const Workspace& w,
@@ -478,33 +512,9 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
     if (from_audio) trace_add(e, st, "mel", mel, (int64_t)B * c.n_mels, s.Tm, s.Tm, 0);
 
     // ---- Conv2dSubsampling (modules.py:232-249) + transpose + Linear (encoders.py:113-116)
-    bf16_t* sub = reinterpret_cast<bf16_t*>(ws + w.sub);
-    const int C0 = c.sub_filters[0], F2 = c.n_mels / 2, Ksub = C0 * F2;
     float* x = reinterpret_cast<float*>(ws + w.x0);
     float* xalt = reinterpret_cast<float*>(ws + w.x1);
-    if (c.sub_layers == 2) {
-        const int Tl1 = (s.Tm - 1) / 2 + 1, F1 = c.n_mels / 2, F2q = c.n_mels / 4, C1 = c.sub_filters[1];
-        bf16_t* act1 = reinterpret_cast<bf16_t*>(ws + w.sub1);
-        { PROF(PC_SUBCONV, 2.0 * 9 * B * Tl1 * (double)C0 * F1, (double)B * c.n_mels * s.Tm * 4 + (double)B * Tl1 * F1 * e->sub2_cp * 2);
-          EC_TRY(launch_subsample_conv_cl(mel, B, c.n_mels, s.Tm, Tl1, e->sub_w9, e->sub_b, C0, e->sub2_cp, act1, st)); }
-        { PROF(PC_GEMM_OTHER, 2.0 * 9 * (double)B * F2q * s.T1 * C0 * C1, (double)B * Tl1 * F1 * e->sub2_cp * 2 + (double)B * s.T1 * F2q * C1 * 2);
-          EC_TRY(launch_conv2_igemm(act1, B, F1, Tl1, e->sub2_cp, e->sub2_w, 9 * e->sub2_cp, e->sub2_b, C1, F2q, s.T1, sub, st)); }
-        trace_add(e, st, "subsample", sub, (int64_t)B * s.T1, F2q * C1, F2q * C1, 1);
-        EC_TRY(run_gemm(e, PC_GEMM_OTHER, st, sub, F2q * C1, B * s.T1, e->lin, EPI_F32, x, e->lin.N));
-    } else if (e->fuse_subsample == 2 && e->lin_rs) {
-        PROF(PC_SUBCONV, 2.0 * 9 * B * s.T1 * (double)Ksub + 2.0 * B * s.T1 * (double)Ksub * e->lin.N,
-             (double)B * c.n_mels * s.Tm * 4 + (double)B * s.T1 * e->lin.N * 4);
-        EC_TRY(launch_sublinear2(mel, B, c.n_mels, s.Tm, s.T1, e->conv_tab, e->lin_rs, e->lin.bias, C0, e->lin.N, x, e->lin.N, st));
-    } else if (e->fuse_subsample && e->lin_fused) {
-        PROF(PC_SUBCONV, 2.0 * 9 * B * s.T1 * (double)Ksub + 2.0 * B * s.T1 * (double)Ksub * e->lin.N,
-             (double)B * c.n_mels * s.Tm * 4 + (double)B * s.T1 * e->lin.N * 4);
-        EC_TRY(launch_sublinear_fused(mel, B, c.n_mels, s.Tm, s.T1, e->sub_w9, e->sub_b, C0, e->lin_fused, e->lin_fused_ld,
-                                      e->lin.bias, e->lin.N, x, e->lin.N, st));
-    } else {
-        { PROF(PC_SUBCONV, 2.0 * 9 * B * s.T1 * (double)Ksub, (double)B * c.n_mels * s.Tm * 4 + (double)B * s.T1 * Ksub * 2); EC_TRY(launch_subsample_conv(mel, B, c.n_mels, s.Tm, s.T1, e->sub_w9, e->sub_b, C0, sub, Ksub, st)); }
-        trace_add(e, st, "subsample", sub, (int64_t)B * s.T1, Ksub, Ksub, 1);
-        EC_TRY(run_gemm(e, PC_GEMM_OTHER, st, sub, Ksub, B * s.T1, e->lin, EPI_F32, x, e->lin.N));
-    }
+    EC_TRY(run_subsample_linear(e, st, mel, B, s.Tm, s.T1, reinterpret_cast<bf16_t*>(ws + w.sub), reinterpret_cast<bf16_t*>(ws + w.sub1), x));
     trace_add(e, st, "linear", x, (int64_t)B * s.T1, e->lin.N, e->lin.N, 0);
 
     bf16_t* a = reinterpret_cast<bf16_t*>(ws + w.a);
@@ -515,7 +525,11 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
     bf16_t* xs = reinterpret_cast<bf16_t*>(ws + w.xs);
     bool have_a = false, head_done = false;
     char nm[64];
-    const bool e_cached = e->e_cache_on && e->e_cache_hit(ws, B, s.Tm);
+    // While the stream is being CAPTURED into a hipGraph nothing executes: the positional projections must be part of the graph (a replay
+    // recomputes them) and the workspace must not be tagged warm (an eager forward before the first replay would read E nobody wrote)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+    const bool e_cached = !capturing && e->e_cache_on && e->e_cache_hit(ws, B, s.Tm);
     if (!e_cached) e->e_cache_drop(ws);       // re-tagged only after every projection of this forward was enqueued
 
     for (int k = 0; k < nb; ++k) {
@@ -529,8 +543,8 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
         // Q/K/V/E layout: "natural" row-major [B*Tp][D] (16-byte row stores from the GEMM, head split = pointer arithmetic in
         // the attention kernel).  An odd grouped head width (d = 135: Medium / Large stage 0) makes the head spans only 2-byte
         // aligned; gfx950 global loads are alignment-free, so the attention kernel reads them as they are - the head-major
-        // fallback (a scatter epilogue of 2-byte stores, 9 % of Medium's step) is kept behind EFFCONF_HEAD_MAJOR_ODD=1 for tests.
-        static const bool head_major_odd = getenv("EFFCONF_HEAD_MAJOR_ODD") != nullptr;
+        // fallback (a scatter epilogue of 2-byte stores, 9 % of Medium's step) is kept behind the option "head_major_odd" for tests.
+        const bool head_major_odd = e->head_major_odd;
         const bool nat = (d % 2) == 0 || !head_major_odd;
         const bool chain_head = e->fuse_chain && W.chain_in && nat && chain_head_supported(D);          // FFN1 + QKV of this block as a fused chain
         const bool chain_b = e->fuse_chain && W.chain_in;                      // out-proj + LN + pointwise-1/GLU
@@ -541,11 +555,12 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
         p.T = T; p.G = G; p.H = H; p.D = D; p.d = d; p.dpad = dpad; p.Tg = Tg; p.Tgp = Tgp;
         p.qu = reinterpret_cast<bf16_t*>(ws + w.qu);
         p.kh = reinterpret_cast<bf16_t*>(ws + w.kh); p.vt = reinterpret_cast<bf16_t*>(ws + w.vt);
-        p.u = W.u; p.v = W.v;
+        p.u = W.u; p.v = W.v; p.rs_variant = e->rs_variant;
         if (head_done) {
             // FFN1 and the Q/K/V projection of this block already ran inside the previous block's tail chain
         } else if (chain_head) {
             ChainParams cp{};
+            cp.variant = e->chain_variant;
             fill_chain_head(cp, W, D, F1c(b), T, Tp, p);
             cp.M = M; cp.X = x; cp.ldx = D; cp.Y = x; cp.ldy = D; cp.consts = W.cc_head;
             PROF(PC_GEMM_FFN, 2.0 * M * (double)D * (2.0 * D * b.ff_ratio + 3.0 * D), (double)M * D * 16 + 22.0 * D * D);
@@ -593,7 +608,7 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
             if (nat) { ap.q_bstride = (long long)Tp * D; ap.q_hstride = d; ap.q_rowstride = G * D; ap.e_hstride = d; ap.e_rowstride = G * D; }
             else { ap.q_bstride = (long long)H * Tg * dpad; ap.q_hstride = (long long)Tg * dpad; ap.q_rowstride = dpad;
                    ap.e_hstride = (long long)(2 * Tg - 1) * dpad; ap.e_rowstride = dpad; }
-            ap.out = o; ap.ldo = ld8(D); ap.scale = 1.0f / std::sqrt((float)d);
+            ap.out = o; ap.ldo = ld8(D); ap.scale = 1.0f / std::sqrt((float)d); ap.force_waves = e->attn_waves;
             { PROF(PC_ATTENTION, 2.0 * B * H * (double)Tg * Tg * d * 3.0, (double)M * D * 2 * 5);
               // attention2.hip reads the natural layout only (its column masks assume the next head's finite data behind a head span); the
               // head-major test layout of odd head widths (EFFCONF_HEAD_MAJOR_ODD) stays on attention.hip
@@ -602,6 +617,7 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
             snprintf(nm, sizeof(nm), "blocks.%d.att_o", k); trace_add(e, st, nm, o, M, D, ld8(D), 1);
             if (chain_b) {
                 ChainParams cp{};
+                cp.variant = e->chain_variant;
                 cp.M = M; cp.D = D; cp.X = x; cp.ldx = D; cp.Y = x; cp.ldy = D; cp.A = o; cp.lda = ld8(D);
                 cp.g0 = ChainGemm{W.c_outp.w, W.c_outp.ldw, W.c_outp.bias, 0};
                 cp.ln[0] = ChainLn{W.ln_conv.g, W.ln_conv.b};
@@ -638,9 +654,10 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
             bool next_head = false;
             if (!last) {
                 const EcBlock& nbk = e->blocks[k + 1];
-                next_head = W.cc_full && e->bw[k + 1].chain_in && chain_full_supported(De) && (((nbk.group_size * nbk.dim_model / nbk.num_heads) % 2) == 0 || !head_major_odd) && nbk.dim_model == De;
+                next_head = W.cc_full && e->bw[k + 1].chain_in && chain_full_supported(De, e->chain_full_max) && (((nbk.group_size * nbk.dim_model / nbk.num_heads) % 2) == 0 || !head_major_odd) && nbk.dim_model == De;
             }
             ChainParams cp{};
+            cp.variant = e->chain_variant;
             cp.M = Mo; cp.D = De; cp.X = x; cp.ldx = De; cp.Y = xo; cp.ldy = De; cp.A = cbuf; cp.lda = ld8(De);
             cp.g0 = ChainGemm{W.c_pw2.w, W.c_pw2.ldw, W.c_pw2.bias, 0};
             cp.ln[0] = ChainLn{W.ln_ffn2.g, W.ln_ffn2.b};
@@ -680,7 +697,7 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
         have_a = !last;
         snprintf(nm, sizeof(nm), "blocks.%d.out", k); trace_add(e, st, nm, xo, Mo, De, De, 0);
     }
-    e->e_cache_put(ws, B, s.Tm);
+    if (!capturing) e->e_cache_put(ws, B, s.Tm);
     return 0;
 }
 
@@ -740,6 +757,9 @@ int forward_core_exact(EcEncoder* e, const float* mel, const int64_t* in_len, in
     const EcConfig& c = e->cfg;
     const int B = s.B, nb = (int)e->blocks.size();
     e->trace.clear(); e->trace_used = 0;
+    // this forward lays its own buffers over the caller's workspace: a positional-embedding cache the bf16 path left there is gone
+    // (fp32 -> bf16 -> fp32 -> bf16 on one workspace otherwise ends with attention reading fp32 activations as E)
+    e->e_cache_drop(ws);
     auto F32 = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
     int* lens = reinterpret_cast<int*>(ws + w.lens);
     EC_TRY(launch_lengths(in_len, B, from_audio, c.hop_length, c.sub_layers, e->block_stride, nb, lens, out_len, st));
@@ -1130,7 +1150,7 @@ int effconf_encoder_finalize(EcEncoder* e) {
         }
         if (W.chain_out && chain_tail_supported(De)) {
             W.cc_tail = build(CHAIN_A_TAIL, De, &W, nullptr, &b, nullptr);
-            if (chain_full_supported(De) && k + 1 < e->blocks.size() && e->bw[k + 1].chain_in && e->blocks[k + 1].dim_model == De)
+            if (chain_full_supported(De, e->chain_full_max) && k + 1 < e->blocks.size() && e->bw[k + 1].chain_in && e->blocks[k + 1].dim_model == De)
                 W.cc_full = build(CHAIN_A_FULL, De, &W, &e->bw[k + 1], &b, &e->blocks[k + 1]);
         }
     }
@@ -1274,6 +1294,101 @@ int effconf_relpos_attention(const uint16_t* qu, const uint16_t* k, const uint16
     return 0;
 }
 
+// ---- per-kernel entry points: one module of a block on the product kernels, unit-testable against the reference's
+// per-module outputs (tests/golden/tiny_*.npz: trace/blocks.N.ffn1 | conv | out, trace/linear)
+size_t effconf_module_workspace_bytes(const EcEncoder* e, int32_t batch, int32_t frames) {
+    if (!e || batch <= 0 || frames <= 0) return 0;
+    size_t mx = 0;
+    for (const EcBlock& b : e->blocks) {
+        const size_t D = (size_t)std::max(b.dim_model, b.dim_expand);
+        mx = std::max(mx, D * ((size_t)b.ff_ratio + 4) * 2 + 64);
+    }
+    const size_t rows = (size_t)batch * frames;
+    size_t sub = 0;
+    {   // subsampler scratch: frames = mel frames here
+        const int L = e->cfg.sub_layers, C = e->cfg.sub_filters[L - 1];
+        int F = e->cfg.n_mels; for (int i = 0; i < L; ++i) F /= 2;
+        const size_t t1 = (frames - 1) / 2 + 1;
+        sub = al((size_t)batch * t1 * C * F * 2) + (L == 2 ? al((size_t)batch * (e->cfg.n_mels / 2) * t1 * ec_round_up(e->cfg.sub_filters[0], 64) * 2) : 0);
+    }
+    return std::max(al(rows * mx) + 4 * 256, sub + 256);
+}
+
+int effconf_ffn(EcEncoder* e, int32_t block, int32_t which, const float* x, int32_t rows, float* y, void* workspace, size_t workspace_bytes,
+                void* stream) {
+    if (!e || !e->finalized) return fail("encoder not finalized");
+    if (block < 0 || block >= (int)e->blocks.size() || (which != 1 && which != 2) || !x || !y || rows <= 0 || !workspace) return fail("bad argument");
+    const EcBlock& b = e->blocks[block];
+    const BlockW& W = e->bw[block];
+    const int D = which == 1 ? b.dim_model : b.dim_expand, F = D * b.ff_ratio;
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = reinterpret_cast<char*>(workspace);
+    const size_t a_bytes = al((size_t)rows * ld8(D) * 2), h_bytes = al((size_t)rows * F * 2);
+    if (workspace_bytes < a_bytes + h_bytes) return fail("workspace too small");
+    bf16_t* a = reinterpret_cast<bf16_t*>(ws);
+    bf16_t* hbuf = reinterpret_cast<bf16_t*>(ws + a_bytes);
+    if (y != x && hipMemcpyAsync(y, x, (size_t)rows * D * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail("copy failed");
+    const LNp& ln = which == 1 ? W.ln_ffn1 : W.ln_ffn2;
+    const PackedLinear &L1 = which == 1 ? W.ffn1_a : W.ffn2_a, &L2 = which == 1 ? W.ffn1_b : W.ffn2_b;
+    const bf16_t* w2p = which == 1 ? W.ffn1_bp : W.ffn2_bp;
+    if (ffn_fused_supported(D)) return run_ffn(e, st, a, rows, D, L1, L2, w2p, y, hbuf, &ln);       // pre-norm in the kernel's prologue
+    EC_TRY(launch_layernorm(y, rows, D, ln.g, ln.b, nullptr, a, ld8(D), nullptr, nullptr, st));
+    return run_ffn(e, st, a, rows, D, L1, L2, w2p, y, hbuf);
+}
+
+int effconf_conv_module(EcEncoder* e, int32_t block, const float* x, int32_t batch, int32_t frames, float* y, void* workspace,
+                        size_t workspace_bytes, void* stream) {
+    if (!e || !e->finalized) return fail("encoder not finalized");
+    if (block < 0 || block >= (int)e->blocks.size() || !x || !y || batch <= 0 || frames <= 0 || !workspace) return fail("bad argument");
+    const EcBlock& b = e->blocks[block];
+    const BlockW& W = e->bw[block];
+    const int D = b.dim_model, De = b.dim_expand, T = frames, To = (T - 1) / b.conv_stride + 1, M = batch * T, Mo = batch * To;
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = reinterpret_cast<char*>(workspace);
+    const size_t a_bytes = al((size_t)M * ld8(D) * 2), g_bytes = al((size_t)M * ld8(De) * 2), c_bytes = al((size_t)Mo * ld8(De) * 2);
+    if (workspace_bytes < a_bytes + g_bytes + c_bytes) return fail("workspace too small");
+    bf16_t* a = reinterpret_cast<bf16_t*>(ws);
+    bf16_t* gbuf = reinterpret_cast<bf16_t*>(ws + a_bytes);
+    bf16_t* cbuf = reinterpret_cast<bf16_t*>(ws + a_bytes + g_bytes);
+    // LayerNorm -> pointwise-1 + GLU (modules.py:511-514)
+    if (rs_gemm_supported(D)) {
+        EC_TRY(run_rs_or_tiled(e, PC_GEMM_OTHER, st, a, ld8(D), M, W.pw1, 2, EPI_GLU_BF16, gbuf, ld8(De), nullptr, 0, 1.f, x, &W.ln_conv));
+    } else {
+        EC_TRY(launch_layernorm(x, M, D, W.ln_conv.g, W.ln_conv.b, nullptr, a, ld8(D), nullptr, nullptr, st));
+        EC_TRY(run_rs_or_tiled(e, PC_GEMM_OTHER, st, a, ld8(D), M, W.pw1, 2, EPI_GLU_BF16, gbuf, ld8(De)));
+    }
+    // depthwise conv + BatchNorm + Swish (modules.py:516-518), pointwise-2 (modules.py:519)
+    EC_TRY(launch_dwconv(gbuf, batch, T, To, De, ld8(De), W.dw_w, W.dw_b, b.kernel_size, b.conv_stride, cbuf, st));
+    return run_rs_or_tiled(e, PC_GEMM_OTHER, st, cbuf, ld8(De), Mo, W.pw2, 1, EPI_F32, y, De);
+}
+
+int effconf_subsample(EcEncoder* e, const float* mel, int32_t batch, int32_t n_frames, float* y, void* workspace, size_t workspace_bytes,
+                      void* stream) {
+    if (!e || !e->finalized) return fail("encoder not finalized");
+    if (!mel || !y || batch <= 0 || n_frames <= 0 || !workspace) return fail("bad argument");
+    const Shapes s = make_shapes(e, batch, n_frames);
+    const int L = e->cfg.sub_layers, C = e->cfg.sub_filters[L - 1];
+    int F = e->cfg.n_mels; for (int i = 0; i < L; ++i) F /= 2;
+    const size_t sub_bytes = al((size_t)batch * s.T1 * C * F * 2);
+    const size_t tl1 = (n_frames - 1) / 2 + 1;
+    const size_t act_bytes = L == 2 ? al((size_t)batch * (e->cfg.n_mels / 2) * tl1 * ec_round_up(e->cfg.sub_filters[0], 64) * 2) : 0;
+    if (workspace_bytes < sub_bytes + act_bytes) return fail("workspace too small");
+    char* ws = reinterpret_cast<char*>(workspace);
+    return run_subsample_linear(e, (hipStream_t)stream, mel, batch, n_frames, s.T1, reinterpret_cast<bf16_t*>(ws), reinterpret_cast<bf16_t*>(ws + sub_bytes), y);
+}
+
+int effconf_layernorm_residual(EcEncoder* e, int32_t block, int32_t which, const float* x, const float* r, float alpha, int32_t rows, float* y,
+                               void* stream) {
+    if (!e || !e->finalized) return fail("encoder not finalized");
+    if (block < 0 || block >= (int)e->blocks.size() || which < 0 || which > 4 || !x || !y || rows <= 0) return fail("bad argument");
+    const EcBlock& b = e->blocks[block];
+    const BlockW& W = e->bw[block];
+    const LNp* ln[5] = {&W.ln_ffn1, &W.ln_att, &W.ln_conv, &W.ln_ffn2, &W.ln_out};
+    const int D = which >= 3 ? b.dim_expand : b.dim_model;
+    EC_TRY(launch_layernorm_residual(x, r, alpha, rows, D, ln[which]->g, ln[which]->b, y, (hipStream_t)stream));
+    return 0;
+}
+
 int effconf_debug_gemm(const uint16_t* a, int32_t lda, const uint16_t* w, int32_t ldw, const float* bias, int32_t m, int32_t n, int32_t k,
                        int32_t epi, int32_t wide, void* c, int32_t ldc, const float* r, int32_t ldr, float alpha, void* stream) {
     if (!a || !w || !bias || !c) return fail("null argument");
@@ -1312,6 +1427,13 @@ int effconf_encoder_set_option(EcEncoder* e, const char* name, int32_t value) {
     if (!strcmp(name, "ctc_mfma")) { e->ctc_mfma = value != 0; return 0; }
     if (!strcmp(name, "wide_gemm")) { if (value < 0 || value > 3) return fail("wide_gemm: 0 (by shape), 1 (never), 2 (256-column tile), 3 (128-column tile)"); e->wide_gemm = value; return 0; }
     if (!strcmp(name, "attention_v2")) { if (value != 0 && value != 1 && value != 2) return fail("attention_v2: 0, 1 or 2"); e->attention_v2 = value; return 0; }
+    // former EFFCONF_* environment switches (process-global statics): per-handle options now
+    if (!strcmp(name, "chain_variant")) { if (value != 0 && value != 1) return fail("chain_variant: 0 (8-wave chain workgroups) or 1 (4-wave, two per CU, at 65..128-wide stages)"); e->chain_variant = value; return 0; }
+    if (!strcmp(name, "chain_full_max")) { if (value < 0 || value > 256) return fail("chain_full_max: widest stage (0..256) that runs chain A as ONE kernel"); e->chain_full_max = value; return 0; }   // widening takes effect at the next finalize (the combined constant blocks are built there)
+    if (!strcmp(name, "attn_waves")) { if (value != 4 && value != 8) return fail("attn_waves: 4 or 8 (attention.hip workgroup size)"); e->attn_waves = value; return 0; }
+    if (!strcmp(name, "rs_variant")) { if (value != 0 && value != 1) return fail("rs_variant: 0 or 1 (8-wave row-stationary GEMM workgroups)"); e->rs_variant = value; return 0; }
+    if (!strcmp(name, "ffn_variant")) { if (value < 0 || value > 2) return fail("ffn_variant: 0, 1 or 2 (fused-FFN workgroup shapes)"); e->ffn_variant = value; return 0; }
+    if (!strcmp(name, "head_major_odd")) { e->head_major_odd = value != 0; return 0; }
     if (!strcmp(name, "cache_pos_embeddings")) { e->e_cache_on = value != 0; e->e_cache.clear(); return 0; }
     if (!strcmp(name, "exact_fp32")) {
         if (!e->finalized) { e->exact_pack = e->exact_on = value != 0; return 0; }

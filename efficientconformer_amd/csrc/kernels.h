@@ -33,6 +33,7 @@ struct GemmParams {
     // computed in the prologue from the fp32 residual stream instead of being read from A
     const float* X; int ldx; const float *ln_g, *ln_b;
     int wide;                          // launch_gemm only: 0 pick by shape, 1 never gemm256.hip, 2 / 3 force its 256- / 128-column tile
+    int rs_variant;                    // launch_rs_gemm only (option "rs_variant"): 1 = 8-wave workgroups (256 rows) at KS = 8 / 16
 };
 int launch_gemm(const GemmParams& p, int epi, hipStream_t s);
 // gemm256.hip: 256 x bn x 64 tiles, both operands by LDS-DMA (bn = 256 or 128); the same operands and epilogues as launch_gemm
@@ -52,6 +53,7 @@ struct FfnParams {
     int M, D, Fp;
     float alpha;
     const float *ln_g, *ln_b;          // if non-null: a = LayerNorm(X) computed in the prologue (A is ignored)
+    int variant;                       // option "ffn_variant": workgroup shape overrides (tuning)
 };
 // single row-stationary GEMM (K <= 384); epi: 0 residual fp32, 1 fp32, 2 GLU bf16 (N = packed a|b rows), 3 QKV head-major
 // scatter, 4 QKV natural layout (weight rows permuted inside every 32-row chunk, see pack_linear_chunkperm)
@@ -81,6 +83,7 @@ struct ChainParams {
     bf16_t *qu, *kh, *vt; const float *u, *v; int T, Tp;          // QKV outputs (Q + u, K, V): rows (b, t) -> (b*Tp + t)*D
     bf16_t* glu; int ldg, Ng;           // GLU output [M][ldg], Ng channels
     const float* consts;                // biases / block-norm gamma, beta / u, v as ONE zero padded block laid out by chain_const_layout
+    int variant;                        // option "chain_variant": 1 = 4-wave workgroups (two per CU) at KS = 8
 };
 enum { CHAIN_B = 0, CHAIN_A_FULL = 1, CHAIN_A_HEAD = 2, CHAIN_A_TAIL = 3 };   // HEAD: first block (no previous tail); TAIL: last block (no next head)
 bool chain_supported(int D);
@@ -88,7 +91,7 @@ int chain_padded_width(int D);       // padded row width of the kernel instance 
 int chain_const_layout(const ChainParams& p, int kind, int (&nf)[8]);   // float offsets of the constant block; returns its size in floats
 bool chain_head_supported(int D);   // FFN1 + Q/K/V half (chain A head / full)
 bool chain_tail_supported(int D);   // pointwise-2 + FFN2 + block norm half
-bool chain_full_supported(int D);   // tail + next block's head in one kernel
+bool chain_full_supported(int D, int dmax = 192);   // tail + next block's head in one kernel (dmax: option "chain_full_max")
 int launch_chain(const ChainParams& p, int kind, hipStream_t s);
 
 // ---------------------------------------------------------------- normalisation / casts  (norm.hip)
@@ -99,6 +102,8 @@ int launch_chain(const ChainParams& p, int kind, hipStream_t s);
 int launch_layernorm(const float* x, int M, int D, const float* gamma, const float* beta,
                      float* out_f32, bf16_t* out_bf16, int ld_bf16,
                      const float* gamma2, const float* beta2, hipStream_t s);
+// y = LayerNorm(x + alpha * r) (r may be null), fp32 in / out, eps 1e-6
+int launch_layernorm_residual(const float* x, const float* r, float alpha, int M, int D, const float* gamma, const float* beta, float* y, hipStream_t s);
 // out[m][:] = bf16(x[src_row(m)][:])   (strided frame decimation + cast for conv_res, blocks.py:106-110)
 int launch_cast_rows(const float* x, int D, int rows_per_batch, int stride, int out_rows_per_batch, int batch,
                      bf16_t* out, int ld_out, hipStream_t s);
@@ -115,6 +120,7 @@ struct AttnParams {
     int B, H, T, G, D, d, dpad, Tg, Tgp;
     bf16_t* out; int ldo;                   // [B*T][ldo] un-grouped attention output (rows t >= T dropped)
     float scale;                            // 1/sqrt(d)
+    int force_waves;                        // attention.hip only (option "attn_waves"): 8 = one 128-query workgroup per CU where LDS allows
 };
 int launch_relpos_attention(const AttnParams& p, hipStream_t s);
 // second generation (attention2.hip): 32 queries per wave, transposing LDS reads for V; waves = 2 (64-query workgroups) or 4

@@ -102,7 +102,47 @@ __global__ __launch_bounds__(256) void cast_rows_kernel(const float* __restrict_
     }
 }
 
+// y = LayerNorm(x + alpha * r): the residual + norm glue of ConformerBlock.forward as ONE unit-testable kernel (per-kernel C ABI
+// entry effconf_layernorm_residual; the forward itself keeps this inside the chain / GEMM epilogues).  One wave per row.
+__global__ __launch_bounds__(256) void layernorm_residual_kernel(const float* __restrict__ x, const float* __restrict__ r, float alpha, int M, int D,
+                                                                 const float* __restrict__ g, const float* __restrict__ b, float* __restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + (size_t)row * D;
+    const float* rr = r ? r + (size_t)row * D : nullptr;
+    float s = 0.f;
+    for (int c = lane * 4; c < D; c += 256) {
+        float4 v = *reinterpret_cast<const float4*>(xr + c);
+        if (rr) { const float4 w = *reinterpret_cast<const float4*>(rr + c); v.x += alpha * w.x; v.y += alpha * w.y; v.z += alpha * w.z; v.w += alpha * w.w; }
+        s += (v.x + v.y) + (v.z + v.w);
+    }
+    const float mean = group_sum<64>(s) / (float)D;
+    float q = 0.f;
+    for (int c = lane * 4; c < D; c += 256) {
+        float4 v = *reinterpret_cast<const float4*>(xr + c);
+        if (rr) { const float4 w = *reinterpret_cast<const float4*>(rr + c); v.x += alpha * w.x; v.y += alpha * w.y; v.z += alpha * w.z; v.w += alpha * w.w; }
+        const float a0 = v.x - mean, a1 = v.y - mean, a2 = v.z - mean, a3 = v.w - mean;
+        q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+    }
+    const float rstd = rsqrtf(group_sum<64>(q) / (float)D + LN_EPS);
+    for (int c = lane * 4; c < D; c += 256) {
+        float4 v = *reinterpret_cast<const float4*>(xr + c);
+        if (rr) { const float4 w = *reinterpret_cast<const float4*>(rr + c); v.x += alpha * w.x; v.y += alpha * w.y; v.z += alpha * w.z; v.w += alpha * w.w; }
+        const float4 gg = *reinterpret_cast<const float4*>(g + c), bb = *reinterpret_cast<const float4*>(b + c);
+        *reinterpret_cast<float4*>(y + (size_t)row * D + c) = make_float4((v.x - mean) * rstd * gg.x + bb.x, (v.y - mean) * rstd * gg.y + bb.y,
+                                                                          (v.z - mean) * rstd * gg.z + bb.z, (v.w - mean) * rstd * gg.w + bb.w);
+    }
+}
+
 }  // namespace
+
+int launch_layernorm_residual(const float* x, const float* r, float alpha, int M, int D, const float* gamma, const float* beta, float* y, hipStream_t s) {
+    if (M <= 0) return 0;
+    if (D % 4) return -2;
+    hipLaunchKernelGGL(layernorm_residual_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, r, alpha, M, D, gamma, beta, y);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
 
 int launch_layernorm(const float* x, int M, int D, const float* gamma, const float* beta,
                      float* out_f32, bf16_t* out_bf16, int ld_bf16,

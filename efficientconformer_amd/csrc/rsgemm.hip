@@ -692,11 +692,6 @@ int launch_rs_t(const RsDev& gd, hipStream_t s) {
 }
 
 // configuration class from max(K, N_resident): KS k-steps; residual variants keep KS/2 output tiles, the others 4
-inline int env_variant(const char* name) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : -1;
-}
-
 // Shape heuristics (tuned on MI355X, see profiles/): small-N GEMMs are dominated by per-workgroup fixed latency, so
 // they use 4-wave workgroups (128 rows) at several workgroups per CU; variant 1 = 8 waves (256 rows).
 template <int EPI>
@@ -704,8 +699,7 @@ int launch_rs_ks(const RsDev& gd, hipStream_t s) {
     constexpr bool whole = (EPI == RS_RESID || EPI == RS_F32);
     const int width = whole ? (gd.p.K > gd.p.N ? gd.p.K : gd.p.N) : gd.p.K;
     const int ks = (width + 15) / 16;
-    static const int var = env_variant("EFFCONF_RS_VARIANT");
-    const bool big = var == 1;
+    const bool big = gd.p.rs_variant == 1;
     if constexpr (whole) {      // KS/2 resident output tiles per row
         if (ks <= 2) return launch_rs_t<2, 1, 2, 2, 4, EPI>(gd, s);
         if (ks <= 4) return launch_rs_t<4, 2, 2, 4, 4, EPI>(gd, s);
@@ -733,8 +727,8 @@ int launch_ffn_fused(const FfnParams& p, hipStream_t s) {
     if (p.M <= 0) return 0;
     if (!ffn_fused_supported(p.D) || p.Fp % CH || p.lda % 8 || p.ldw1 % 8 || p.ldw2 % 8) return -2;
     const int ks = (p.D + 15) / 16;
-    // rows per workgroup / waves per SIMD trade-offs, selected per width class (EFFCONF_FFN_VARIANT overrides for tuning)
-    static const int var = env_variant("EFFCONF_FFN_VARIANT");
+    // rows per workgroup / waves per SIMD trade-offs, selected per width class (option "ffn_variant" overrides for tuning)
+    const int var = p.variant;
     if (ks <= 2) return launch_ffn_t<2, 1, 1, 4, 4>(p, s);
     if (ks <= 4) return launch_ffn_t<4, 2, 1, 8, 4>(p, s);
     if (ks <= 8) {

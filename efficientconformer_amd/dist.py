@@ -109,6 +109,7 @@ class ShardedEncoder:
     def __init__(self, encoder: Callable, group=None, wire_dtype: Optional[torch.dtype] = None):
         self.encoder, self.group, self.wire_dtype = encoder, group, wire_dtype
         self._comm: Optional["torch.cuda.Stream"] = None
+        self._maps = {}
         fwd = getattr(encoder, "forward", encoder)
         try:
             self._hooked = "range_hook" in inspect.signature(fwd).parameters
@@ -121,8 +122,14 @@ class ShardedEncoder:
     def _gather_range(self, lo: int, hi: int, out: torch.Tensor, out_len: torch.Tensor, global_batch: int, chunks: list):
         world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
         n = hi - lo
-        rows = ((torch.arange(lo, hi).view(1, n)) * world + torch.arange(world).view(world, 1)).reshape(-1)
-        keep = rows < global_batch
+        # row map of the gathered chunk, built ON the output's device and cached per (lo, hi, world, global batch): a pageable
+        # host -> device copy here would make PyTorch synchronise the range's compute stream, i.e. block the host until range i's whole
+        # encoder has finished before range i + 1 is enqueued (the overlap this class exists for)
+        key = (lo, hi, world, global_batch, str(out.device))
+        if key not in self._maps:
+            rows = ((torch.arange(lo, hi, device=out.device).view(1, n)) * world + torch.arange(world, device=out.device).view(world, 1)).reshape(-1)
+            self._maps[key] = (rows, rows < global_batch)
+        rows, keep = self._maps[key]
         if out.is_cuda:
             dev = out.device
             if self._comm is None:
@@ -140,7 +147,7 @@ class ShardedEncoder:
                 _all_gather(gl, wl.contiguous(), self.group)
                 ev = torch.cuda.Event()
                 ev.record(self._comm)
-            chunks.append(GatheredChunk(lo, hi, g, gl, rows.to(dev), keep.to(dev), ev, self._comm))
+            chunks.append(GatheredChunk(lo, hi, g, gl, rows, keep, ev, self._comm))
         else:
             wire = out[lo:hi] if self.wire_dtype is None else out[lo:hi].to(self.wire_dtype)
             g = wire.new_empty((world * n,) + tuple(wire.shape[1:]))

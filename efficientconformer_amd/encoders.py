@@ -92,14 +92,14 @@ class ConformerEncoder(nn.Module):
         self._packed_device = -1                  # the C library packs weights on the device that is current at pack time
         object.__setattr__(self, "_head", None)   # not a sub-module: keeps state_dict keys equal to the reference's
         self._ws: Dict[tuple, torch.Tensor] = {}
-        # Sub-batch streams (opt-in here; bench.py runs with 2): `sub_batches = S > 1` runs a forward as S contiguous row ranges on concurrent HIP streams
-        # (None = automatic: 2 from `sub_batch_min` utterances on).  Every kernel of the path is a one-round launch that alternates
-        # HBM-bound load / store bursts with compute; a second stream fills the first one's bursts (+12 % frames/s).
-        # The mel frontend is NOT split: it runs once for the whole batch on the caller's stream and the streams fork at the mel
-        # boundary.  Measured on the MI355X ("mel kernel next to another kernel's workgroups"): mel_kernel
-        # workgroups that share a CU with workgroups of the subsampling kernels of ANOTHER stream return perturbed spectra for
-        # some frame pairs - the one sensitivity the stream sweep found; everything from the mel boundary on is bit-identical
-        # with any number of streams in flight.  One stream stays the default.
+        self._options: Dict[str, int] = {}
+        # Sub-batch streams (opt-in here; bench.py runs with 3): `sub_batches = S > 1` runs a forward as S contiguous row ranges on
+        # concurrent HIP streams (None = automatic: 2 from `sub_batch_min` utterances on).  Every kernel of the path is a one-round
+        # launch that alternates HBM-bound load / store bursts with compute; the other streams' kernels fill one stream's bursts.
+        # Un-trimmed ranges share ONE mel launch for the whole batch on the caller's stream (fewer, fuller launches); trimmed ranges
+        # run their own mel frontend.  (Round 1 forked at the mel boundary for correctness: its mel kernel returned perturbed spectra
+        # next to another stream's MFMA kernels - a packed-fp32 `op_sel` hazard, fixed by building the library without packed-fp32
+        # VALU instructions; any number of independent forwards may overlap now.)
         self.sub_batches: Optional[int] = 1
         # at most this many HIP streams for the row ranges (None: one per range).  More ranges than streams = finer length buckets
         # (less padding with trim_sub_batches) at the same concurrency: range i runs on stream i % sub_batch_streams, in order.
@@ -152,7 +152,11 @@ class ConformerEncoder(nn.Module):
         return self.linear.weight.device
 
     def set_option(self, name: str, value: int):
-        """Forward a tuning / test option to the C library (see effconf_encoder_set_option)."""
+        """Forward a tuning / test option to the C library (see effconf_encoder_set_option).  Options are remembered and re-applied
+        whenever the weights are packed again (a new handle), before `finalize` - some (chain_full_max) shape what finalize builds."""
+        self._options[name] = int(value)
+        if name in ("chain_full_max",):
+            self._packed = False
         dev = self._param_device()
         if dev.type == "cuda":
             with torch.cuda.device(dev):
@@ -208,6 +212,8 @@ class ConformerEncoder(nn.Module):
         if self._exact:
             _lib.check(lib.effconf_encoder_set_option(h, b"exact_fp32", 1), "set_option(exact_fp32)")
         self._exact_packed = self._exact
+        for oname, oval in self._options.items():
+            _lib.check(lib.effconf_encoder_set_option(h, oname.encode(), oval), "set_option(%s)" % oname)
         tensors = dict(super().state_dict())
         if self._head is not None:
             tensors["fc.weight"], tensors["fc.bias"] = self._head.weight, self._head.bias
@@ -234,13 +240,13 @@ class ConformerEncoder(nn.Module):
 
     # ------------------------------------------------------------------ forward
     def _workspace(self, batch: int, n: int, from_audio: bool, device) -> torch.Tensor:
-        # one workspace per (shape, stream): forwards enqueued on different streams may overlap on the GPU
-        key = (batch, n, from_audio, str(device), torch.cuda.current_stream(device).cuda_stream)
+        # one workspace per (device, stream, entry point), grown to the largest forward seen: forwards enqueued on different streams may
+        # overlap on the GPU, forwards on one stream are ordered and share the buffer.  (Keyed by shape, real variable-length traffic
+        # went through a fresh allocation - and a reset of every positional-embedding cache - on nearly every forward.)
+        key = (str(device), torch.cuda.current_stream(device).cuda_stream, bool(from_audio))
+        nbytes = _lib.load().effconf_encoder_workspace_bytes(self._handle, batch, n, int(from_audio))
         ws = self._ws.get(key)
-        if ws is None:
-            nbytes = _lib.load().effconf_encoder_workspace_bytes(self._handle, batch, n, int(from_audio))
-            if len(self._ws) > 16:
-                self._ws.clear()
+        if ws is None or ws.numel() < nbytes:
             ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
             fill = os.environ.get("EFFCONF_POISON_WORKSPACE", "")
             if fill:                # test hook (include/effconf.h): the byte a fresh workspace is filled with - 255 = NaN patterns, 127 =
@@ -343,11 +349,12 @@ class ConformerEncoder(nn.Module):
             streams = []
             smax = nsub if not self.sub_batch_streams else max(1, min(int(self.sub_batch_streams), nsub))
             for i in range(nsub):
-                key = (str(x.device), i % smax)
+                # earlier row ranges get the higher priority: range 0 leaves the last stage first, so a `range_hook`
+                # consumer (the all-gather of dist.ShardedEncoder) overlaps with the later ranges' last stage
+                prio = -1 if (i == 0 and self.stagger_ranges) else 0
+                key = (str(x.device), i % smax, prio)        # the priority is part of the key: `stagger_ranges` may change after the first forward
                 if key not in self._sub_streams:
-                    # earlier row ranges get the higher priority: range 0 leaves the last stage first, so a `range_hook`
-                    # consumer (the all-gather of dist.ShardedEncoder) overlaps with the later ranges' last stage
-                    self._sub_streams[key] = torch.cuda.Stream(device=x.device, priority=-1 if (i == 0 and self.stagger_ranges) else 0)
+                    self._sub_streams[key] = torch.cuda.Stream(device=x.device, priority=prio)
                 st = self._sub_streams[key]
                 if i < smax:
                     st.wait_stream(cur)                  # inputs (and anything queued before this forward) are ready

@@ -113,6 +113,29 @@ int effconf_relpos_attention(const uint16_t* qu, const uint16_t* k, const uint16
                              const int32_t* lens, int32_t batch, int32_t heads, int32_t frames, int32_t group, int32_t dim, uint16_t* out,
                              int32_t ld_out, int32_t variant, void* stream);
 
+/* ---- per-kernel entry points (unit tests of ONE module on the product kernels) -------------------------------- */
+/* Each runs one module of Conformer block `block` of a finalized encoder on caller-owned device buffers and is tested against the
+ * reference's per-module outputs (tests/golden/tiny_*.npz `trace/blocks.N.*`).  `workspace`: effconf_module_workspace_bytes(enc,
+ * batch, frames) bytes (for effconf_subsample: frames = mel frames).  fp32 rows are dense: (rows, D) row-major. */
+size_t effconf_module_workspace_bytes(const EcEncoder* enc, int32_t batch, int32_t frames);
+/* FeedForwardModule + half-step residual (reference modules.py:385-395, blocks.py:122, 132): y = x + 1/2 FFN_which(LayerNorm(x));
+ * which = 1 (feed_forward_module1, width dim_model) or 2 (feed_forward_module2, width dim_expand).  y may alias x. */
+int effconf_ffn(EcEncoder* enc, int32_t block, int32_t which, const float* x, int32_t rows, float* y, void* workspace, size_t workspace_bytes,
+                void* stream);
+/* ConvolutionModule (reference modules.py:511-525; layers.py:122-136): LayerNorm -> pointwise-1 + GLU -> depthwise conv (stride of the
+ * block) + BatchNorm(eval) + Swish -> pointwise-2; NO residual.  x f32 (batch * frames, dim_model) -> y f32 (batch * frames_out, dim_expand),
+ * frames_out = (frames - 1) / conv_stride + 1. */
+int effconf_conv_module(EcEncoder* enc, int32_t block, const float* x, int32_t batch, int32_t frames, float* y, void* workspace,
+                        size_t workspace_bytes, void* stream);
+/* Conv2dSubsampling + transpose + Linear (reference modules.py:232-249, encoders.py:113-116): mel f32 (batch, n_mels, n_frames) ->
+ * y f32 (batch * T1, dim_model of block 0), T1 = frames after the subsampling layers.  Honours the "fuse_subsample" option. */
+int effconf_subsample(EcEncoder* enc, const float* mel, int32_t batch, int32_t n_frames, float* y, void* workspace, size_t workspace_bytes,
+                      void* stream);
+/* y = LayerNorm_which(x + alpha * r), r may be NULL: the residual / norm glue of ConformerBlock.forward (reference blocks.py:119-137).
+ * which: 0 FFN1 pre-norm, 1 attention pre-norm, 2 conv-module pre-norm (width dim_model); 3 FFN2 pre-norm, 4 block-final norm (dim_expand). */
+int effconf_layernorm_residual(EcEncoder* enc, int32_t block, int32_t which, const float* x, const float* r, float alpha, int32_t rows,
+                               float* y, void* stream);
+
 /* ---- RNN-T greedy decode (next row after the encoder: BASELINE.json configs[3]) ------------------ */
 /* Replaces Transducer.gready_search_decoding's per-utterance Python loop (reference models/transducer.py:139-186) for
  * the shipped Transducer configs: RnnDecoder = Embedding + 1-layer LSTM (models/decoders.py:41-70) and
@@ -171,6 +194,10 @@ int effconf_rnnt_greedy(EcRnnt* r, const float* enc_out, const int64_t* out_len,
  *     1 always csrc/gemm.hip (128 x 128, register staged), 2 / 3 csrc/gemm256.hip with 256 x 256 / 256 x 128 tiles wherever it applies.
  * "ctc_mfma" (default 1): the CTC head (fc + argmax) on the fp32 MFMA; 0 selects the VALU kernel.  Both are k-ordered fp32 fma chains:
  *   bit-identical logits and labels.
+ * "chain_variant" (0 / 1), "chain_full_max" (widest stage that runs chain A as one kernel; set before finalize to widen), "attn_waves"
+ *   (4 / 8, attention.hip), "rs_variant" (0 / 1), "ffn_variant" (0 .. 2), "head_major_odd" (0 / 1): tuning / test switches of the kernel launchers that were
+ *   process-global EFFCONF_* environment variables until round 2; per handle now.  (Still read from the environment, once, as
+ *   profiling / test hooks: EFFCONF_POISON_GUARDS at create, EFFCONF_{CHAIN,ATTN,FFN}_PHASES for the in-kernel phase profilers.)
  * "exact_fp32" (default 0): fp32-operand precision mode (csrc/exact.hip): every GEMM on fp32 MFMA, fp32 attention / convolutions,
  *   so that greedy CTC label sequences equal the reference's CPU fp32 path (model_ctc.py:99-133) wherever its top-2 logit margins
  *   exceed fp32 summation-order noise; ~10x slower than the default bf16-operand path.  Set to 1 BEFORE effconf_encoder_finalize

@@ -22,9 +22,10 @@ def _env():
     return env
 
 
-def test_sharded_encoder_two_ranks_on_one_gpu_equals_unsharded():
+@pytest.mark.parametrize("name", ["Tiny", "EfficientConformerCTCLarge"])      # Large = BASELINE.json configs[2], the data-parallel headline
+def test_sharded_encoder_two_ranks_on_one_gpu_equals_unsharded(name):
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                        "--master-port", str(_port()), os.path.join(ROOT, "tests", "dist_gpu_worker.py")],
+                        "--master-port", str(_port()), os.path.join(ROOT, "tests", "dist_gpu_worker.py"), name],
                        capture_output=True, text=True, timeout=600, env=_env())
     assert "DIST_GPU_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
 

@@ -1,0 +1,209 @@
+"""-m gpu tests added in round 3: per-kernel C-ABI entries against the reference's per-module outputs, the benchmarked path at its
+own size, workspace / cache hazards named by the round-2 advisor, hipGraph capture of a forward.
+Tolerances: bf16-operand kernels 2 % of the tensor's magnitude (max) / 0.3 % (mean), as tests/test_gpu_encoder.py; "bit-identical"
+means torch.equal."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from efficientconformer_amd import ModelCTC, _lib, named_config, synth
+from oracle import ref_encoder as R
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(name, seed, precision="bf16"):
+    cfg = named_config(name)
+    m = ModelCTC.from_config(cfg)
+    sd = synth.make_state_dict(m.encoder.plan, seed, cfg["tokenizer_params"]["vocab_size"], prefix="encoder.")
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m.encoder.precision = precision
+    osd = {k[len("encoder."):] if k.startswith("encoder.") else k: v for k, v in sd.items()}
+    return m.cuda(), osd
+
+
+def _rel(got, ref):
+    d = (got.double() - ref.double()).abs()
+    scale = max(float(ref.abs().max()), 1.0)
+    return float(d.max()) / scale, float(d.mean()) / scale
+
+
+# ------------------------------------------------------------------ per-kernel C ABI entries vs the reference's module outputs
+@pytest.mark.parametrize("gname", ["tiny_T47.npz", "tiny_T100.npz"])
+def test_per_kernel_entries_vs_reference_module_outputs(golden_dir, gname):
+    """effconf_subsample / effconf_ffn / effconf_conv_module / effconf_layernorm_residual, each alone, fed with the REFERENCE's own
+    module inputs (rebuilt from the per-module outputs the golden holds: blocks.py:119-137) and compared with the reference's output
+    of that module (hooks on feed_forward_module1/2, convolution_module, the block: tools/make_goldens.py)."""
+    g = np.load(os.path.join(golden_dir, gname))
+    m, sd = _model("Tiny", int(g["weight_seed"]))
+    enc, lib = m.encoder, _lib.load()
+    enc._ensure_packed()
+    h = enc._handle
+    plan = enc.plan
+    b = len(g["mel_len"])
+    tm = int(g["mel_len"].max())
+    mel, _ = synth.make_mel(b, 80, tm, g["mel_len"].tolist(), seed=int(g["mel_seed"]))
+    st = torch.cuda.current_stream().cuda_stream
+    ws = torch.empty(lib.effconf_module_workspace_bytes(h, b, tm), dtype=torch.uint8, device="cuda")
+
+    def t(key):
+        return torch.from_numpy(g["trace/" + key]).cuda()
+    lin = t("linear")                                                        # (B, T1, D0)
+    y = torch.empty_like(lin)
+    _lib.check(lib.effconf_subsample(h, torch.from_numpy(mel).cuda().data_ptr(), b, tm, y.data_ptr(), ws.data_ptr(), ws.numel(), st), "subsample")
+    worst = {"linear": _rel(y.cpu(), lin.cpu())}
+    x = lin
+    for k, bp in enumerate(plan.blocks):
+        p = "blocks.%d" % k
+        rows = x.shape[0] * x.shape[1]
+        # ---- FFN1: y = x + 1/2 ffn1(x)
+        y = torch.empty_like(x)
+        _lib.check(lib.effconf_ffn(h, k, 1, x.contiguous().data_ptr(), rows, y.data_ptr(), ws.data_ptr(), ws.numel(), st), "ffn")
+        worst[p + ".ffn1"] = _rel((2.0 * (y - x)).cpu(), t(p + ".ffn1").cpu())
+        x1 = x + 0.5 * t(p + ".ffn1")
+        x2 = x1 + t(p + ".mhsa")
+        # ---- conv module (no residual)
+        conv_ref = t(p + ".conv")
+        yc = torch.empty_like(conv_ref)
+        _lib.check(lib.effconf_conv_module(h, k, x2.contiguous().data_ptr(), x2.shape[0], x2.shape[1], yc.data_ptr(), ws.data_ptr(), ws.numel(), st), "conv_module")
+        worst[p + ".conv"] = _rel(yc.cpu(), conv_ref.cpu())
+        if bp.transition:        # conv_res = Conv1d(D -> De, k = 1, stride 2) on frames 0, 2, 4, ... (blocks.py:106-110)
+            w = torch.from_numpy(sd[p + ".conv_res.1.weight"]).cuda()[:, :, 0]
+            res = x2[:, ::bp.conv_stride] @ w.t() + torch.from_numpy(sd[p + ".conv_res.1.bias"]).cuda()
+        else:
+            res = x2
+        x3 = res + conv_ref
+        # ---- FFN2
+        rows3 = x3.shape[0] * x3.shape[1]
+        y = torch.empty_like(x3)
+        _lib.check(lib.effconf_ffn(h, k, 2, x3.contiguous().data_ptr(), rows3, y.data_ptr(), ws.data_ptr(), ws.numel(), st), "ffn")
+        worst[p + ".ffn2"] = _rel((2.0 * (y - x3)).cpu(), t(p + ".ffn2").cpu())
+        # ---- block output = LayerNorm(x3 + 1/2 ffn2)
+        out_ref = t(p + ".out")
+        yo = torch.empty_like(out_ref)
+        _lib.check(lib.effconf_layernorm_residual(h, k, 4, x3.contiguous().data_ptr(), t(p + ".ffn2").contiguous().data_ptr(), C.c_float(0.5), rows3,
+                                                  yo.data_ptr(), st), "layernorm_residual")
+        mx, mean = _rel(yo.cpu(), out_ref.cpu())
+        assert mx < 1e-5, (p, mx)                                           # fp32 kernel
+        x = out_ref
+    torch.cuda.synchronize()
+    print({k: ("%.4f" % v[0], "%.5f" % v[1]) for k, v in worst.items()})
+    for k, (mx, mean) in worst.items():
+        assert mx < 0.02 and mean < 0.003, (k, mx, mean)
+
+
+# ------------------------------------------------------------------ advisor, round 2: precision modes sharing one workspace
+def test_alternating_precision_modes_on_one_shape_keep_the_bf16_path_bit_identical():
+    """fp32 -> bf16 -> fp32 -> bf16 on one handle, one shape, one stream (= one workspace): the exact-mode forward lays its buffers
+    over the workspace in which the bf16 path cached its positional projections E; the second bf16 run must recompute them and be
+    bit-equal to the first (round 2: it read fp32 activations as E)."""
+    m, _ = _model("Tiny", 7, "fp32")
+    enc = m.encoder
+    mel, ln = synth.make_mel(3, 80, 100, [100, 77, 52], seed=11)
+    mel_d, ln_d = torch.from_numpy(mel).cuda(), torch.from_numpy(ln).cuda()
+    outs = []
+    for prec in ("fp32", "bf16", "fp32", "bf16", "bf16"):
+        enc.precision = prec
+        out, _, _ = enc.forward_mel(mel_d, ln_d)
+        outs.append(out.clone())
+    assert torch.equal(outs[0], outs[2])
+    assert torch.equal(outs[1], outs[3]) and torch.equal(outs[1], outs[4])
+    assert float((outs[0] - outs[1]).abs().max()) < 0.1
+
+
+# ------------------------------------------------------------------ advisor, round 2: chunk loads behind the last key row
+@pytest.mark.parametrize("name,tm", [("EfficientConformerCTCSmall", 383), ("EfficientConformerCTCSmall", 1279), ("EfficientConformerCTCMedium", 383)])
+@pytest.mark.parametrize("fill", ["255", "127"])
+def test_last_key_row_chunk_loads_do_not_read_the_workspace_slack(name, tm, fill, monkeypatch):
+    """B = 1 (the longest utterance is the last one: nothing masks its last key group) with a stage-1 grouped length that is a multiple of
+    the 64-key block (Tm = 383 -> T1 = 192 -> Tg = 64; 1279 -> 640 -> 214 is the control) and a head width that is not a multiple of 8
+    (d = 90 / 135): the 16-byte chunk that closes the last head's last key row ends in the never-written slack of the K / E buffers.
+    A workspace pre-filled with NaN patterns (255) or huge values (127) must give finite output identical to a zero-filled one."""
+    mel, ln = synth.make_mel(1, 80, tm, [tm], seed=9)
+    mel_d, ln_d = torch.from_numpy(mel).cuda(), torch.from_numpy(ln).cuda()
+    outs = {}
+    for f in ("0", fill):
+        monkeypatch.setenv("EFFCONF_POISON_WORKSPACE", f)
+        m, _ = _model(name, 3)
+        out, _, _ = m.encoder.forward_mel(mel_d, ln_d)
+        assert torch.isfinite(out).all(), (name, tm, f)
+        outs[f] = out.cpu()
+        del m
+    assert torch.equal(outs["0"], outs[fill])
+
+
+# ------------------------------------------------------------------ the benchmarked path at the benchmark's size
+def test_bench_default_workload_trimmed_ranges_on_three_streams_equal_each_range_alone():
+    """bench.py's default step - EfficientConformerCTCSmall, B = 256 LibriSpeech-shaped utterances, three trimmed row ranges on three
+    streams, CTC head per range (ModelCTC.encode_greedy) - against every range run ALONE on one stream as its own batch: encoder
+    output, lengths and greedy labels bit for bit; and a sample of each range against the oracle (the reference path on that
+    collated sub-batch) within the bf16 tolerance (0.10 max / 0.012 mean)."""
+    m, sd = _model("EfficientConformerCTCSmall", 0)
+    enc = m.encoder
+    lens = synth.libri_lengths(256, seed=1234)
+    audio = torch.from_numpy(synth.make_audio(lens, seed=1234)).cuda()
+    ln = torch.from_numpy(lens).cuda()
+    cuts = [0, 80, 160, 256]
+    pads = [int(lens[cuts[i]:cuts[i + 1]].max()) for i in range(3)]
+    enc.sub_batches, enc.sub_batch_streams, enc.trim_sub_batches = 3, 3, True
+    for _ in range(2):                                                      # twice: the second pass runs with warm caches / recycled buffers
+        out, out_len, labels, label_len = m.encode_greedy(audio, ln, range_pad=pads)
+    torch.cuda.synchronize()
+    enc.sub_batches, enc.trim_sub_batches = 1, False
+    for i in range(3):
+        lo, hi = cuts[i], cuts[i + 1]
+        alone, alone_len, _ = enc(audio[lo:hi, :pads[i]].contiguous(), ln[lo:hi].contiguous())
+        _, lab, n = m._head(alone, alone_len)
+        ti = alone.shape[1]
+        assert torch.equal(out[lo:hi, :ti], alone) and torch.equal(out_len[lo:hi], alone_len), i
+        assert float(out[lo:hi, ti:].abs().sum()) == 0.0
+        assert torch.equal(label_len[lo:hi], n) and torch.equal(labels[lo:hi, :ti], lab), i
+        # oracle on 2 utterances of the range collated with the range's LONGEST one (pad frames are live: the padded length matters)
+        rows = [lo, lo + (hi - lo) // 2, hi - 1]
+        sub = audio[rows, :pads[i]].cpu()
+        with torch.no_grad():
+            ref, ref_len = R.encoder(sub, ln[rows].cpu(), sd, enc.plan)
+        got, got_len, _ = enc(audio[rows, :pads[i]].contiguous(), ln[rows].contiguous())
+        d = (got.cpu() - ref).abs()
+        assert ref_len.tolist() == got_len.cpu().tolist() and float(d.max()) < 0.10 and float(d.mean()) < 0.012, (i, float(d.max()), float(d.mean()))
+
+
+# ------------------------------------------------------------------ hipGraph capture of a forward
+@pytest.mark.parametrize("name", ["Tiny", "EfficientConformerCTCSmall"])
+def test_forward_is_graph_capturable_and_replays_bit_identically(name):
+    """include/effconf.h promises that a forward only enqueues kernels (no allocation, synchronisation or host <-> device copy): capture
+    effconf_encoder_forward + effconf_ctc_greedy into a hipGraph on a side stream, replay it on new input contents, compare with eager."""
+    m, _ = _model(name, 5)
+    enc = m.encoder
+    lens = np.array([40000, 33000, 21000, 16000], dtype=np.int64)
+    a0 = torch.from_numpy(synth.make_audio(lens, seed=1)).cuda()
+    a1 = torch.from_numpy(synth.make_audio(lens, seed=2)).cuda()
+    ln = torch.from_numpy(lens).cuda()
+    eager = []
+    for a in (a0, a1):
+        out, out_len, _ = enc(a, ln)
+        _, lab, n = m._head(out, out_len)
+        eager.append((out.clone(), lab.clone(), n.clone()))
+    static_in = a0.clone()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        enc(static_in, ln)                                                  # warm-up on the capture stream: workspace allocation happens here
+    torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=s):
+        g_out, g_len, _ = enc(static_in, ln)
+        _, g_lab, g_n = m._head(g_out, g_len)
+    for a, (out, lab, n) in ((a1, eager[1]), (a0, eager[0]), (a1, eager[1])):
+        static_in.copy_(a)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(g_out, out) and torch.equal(g_lab, lab) and torch.equal(g_n, n)
+    # an eager forward after the replays (same stream key as the warm-up) still agrees: the capture did not leave a stale cache tag
+    with torch.cuda.stream(s):
+        out, _, _ = enc(a0, ln)
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager[0][0])

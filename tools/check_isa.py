@@ -1,88 +1,10 @@
 #!/usr/bin/env python3
-"""ISA guard: no product kernel of libeffconf.so may contain a packed-fp32 VALU instruction with a low-lane operand swizzle.
-
-    python tools/check_isa.py [libeffconf.so]        exit code 1 if a hazardous form is found in a product kernel
-
-Measured on MI355X (profiles/r2_mel_packed_fp32_hazard.txt): v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 with an `op_sel` bit set
-(a low result lane taking the HIGH half of a 64-bit source pair) return wrong values while a bf16 MFMA of ANOTHER wave executes on
-the same SIMD.  libeffconf is therefore compiled with `-target-feature -packed-fp32-ops` (efficientconformer_amd/_build.py); this
-script extracts every gfx950 code object from the shared library (clang offload bundles in .hip_fatbin), disassembles it and checks.
-Kernels of csrc/debug.hip (victim_kernel / neighbour_kernel) and the diagnostic mel_kernel build with packed fp32 are exempt:
-they exist to reproduce the hazard."""
+"""ISA guard of libeffconf.so (no hazardous packed-fp32 forms in product kernels): thin front end of efficientconformer_amd/_isa_guard.py."""
 import os
-import re
-import struct
-import subprocess
 import sys
-import tempfile
 
-LLVM = "/opt/rocm/lib/llvm/bin"
-MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
-HAZARD = re.compile(r"v_pk_(add|mul|fma)_f32\b.*\bop_sel:\[[^\]]*1")
-PACKED = re.compile(r"v_pk_(add|mul|fma)_f32\b")
-EXEMPT = re.compile(r"victim_kernel|neighbour_kernel|mel_pk_build")
-
-
-def code_objects(lib):
-    with tempfile.TemporaryDirectory() as td:
-        fat = os.path.join(td, "fat.bin")
-        subprocess.run([os.path.join(LLVM, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, lib], check=True)
-        blob = open(fat, "rb").read()
-    pos = 0
-    while True:
-        pos = blob.find(MAGIC, pos)
-        if pos < 0:
-            return
-        n, = struct.unpack_from("<Q", blob, pos + len(MAGIC))
-        p = pos + len(MAGIC) + 8
-        for _ in range(n):
-            off, size, tl = struct.unpack_from("<QQQ", blob, p)
-            triple = blob[p + 24: p + 24 + tl].decode()
-            p += 24 + tl
-            if "gfx950" in triple and size:
-                yield blob[pos + off: pos + off + size]
-        pos += len(MAGIC)
-
-
-def scan(lib):
-    rows = {}
-    for co in code_objects(lib):
-        with tempfile.NamedTemporaryFile(suffix=".co") as f:
-            f.write(co); f.flush()
-            asm = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--mcpu=gfx950", f.name], capture_output=True, text=True, check=True).stdout
-        cur = None
-        for line in asm.splitlines():
-            m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
-            if m:
-                cur = m.group(1)
-                rows.setdefault(cur, [0, 0])
-            elif cur is not None:
-                if PACKED.search(line):
-                    rows[cur][0] += 1
-                    if HAZARD.search(line):
-                        rows[cur][1] += 1
-    return rows
-
-
-def demangle(names):
-    out = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.splitlines()
-    return dict(zip(names, out))
-
-
-def main():
-    lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "efficientconformer_amd", "libeffconf.so")
-    rows = scan(lib)
-    names = demangle(list(rows))
-    bad = 0
-    for k, (packed, hazard) in sorted(rows.items()):
-        exempt = bool(EXEMPT.search(names[k]))
-        if packed or hazard:
-            print("%-100s packed-fp32 %5d  op_sel(low) %5d%s" % (names[k][:100], packed, hazard, "  (diagnostic kernel, exempt)" if exempt else ""))
-        if hazard and not exempt:
-            bad += 1
-    print("%d kernels scanned, %d product kernels with hazardous packed-fp32 forms" % (len(rows), bad))
-    return 1 if bad else 0
-
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from efficientconformer_amd._isa_guard import main, scan, demangle, check, EXEMPT  # noqa: E402,F401
 
 if __name__ == "__main__":
     sys.exit(main())
