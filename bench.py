@@ -77,6 +77,9 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1 (nccl = RCCL over xGMI; gloo + --one-device: N ranks on ONE GPU, a test of the multi-rank path)")
     ap.add_argument("--one-device", action="store_true", help="every rank uses cuda:0 (tests on a single-GPU box; never a benchmark)")
+    ap.add_argument("--ragged", type=int, default=0, choices=[0, 1],
+                    help="1: ConformerEncoder.ragged - every utterance at its own length in one concatenated row space (no pad frames; an utterance's "
+                         "output = the reference's for that utterance alone); 0: row ranges padded to their longest utterance (round 2's workload)")
     ap.add_argument("--no-check", action="store_true",
                     help="skip the un-timed self-check of the benchmarked step (single-stream per-range rerun + oracle samples)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"],
@@ -163,8 +166,8 @@ def head(model, enc, enc_len):
     return labels, label_len
 
 
-def step(model, audio, lens, range_pad=None):
-    enc, enc_len, _ = model.encoder(audio, lens, range_pad=range_pad)
+def step(model, audio, lens, range_pad=None, **kw):
+    enc, enc_len, _ = model.encoder(audio, lens, range_pad=range_pad, **kw)
     labels, label_len = head(model, enc, enc_len)
     return enc, enc_len, labels, label_len
 
@@ -193,8 +196,33 @@ def self_check(model, sd, plan, audio, lens, lens_np, cuts, range_pad, nsub, las
     worst_max = worst_mean = 0.0
     n_oracle = flips = frames = dist = nlab = 0
     seq_equal = True
+    ragged = bool(getattr(model.encoder, "ragged", False))
+    model.encoder.ragged = False
     try:
-        for i in range(nsub):
+        if ragged:        # every sampled utterance ALONE (B = 1, rectangular path): bit-identical; the oracle on that utterance alone
+            b_all = audio.shape[0]
+            for r in sorted({0, 1, b_all // 5, 2 * b_all // 5, b_all // 2, 3 * b_all // 5, 4 * b_all // 5, b_all - 2, b_all - 1}):
+                li = int(lens_np[r])
+                alone, alone_len, _ = model.encoder(audio[r:r + 1, :li].contiguous(), lens[r:r + 1].contiguous())
+                _, lab, n = model._head(alone, alone_len)
+                ti = alone.shape[1]
+                bit_ok = bit_ok and int(enc_len[r]) == ti and torch.equal(enc[r, :ti], alone[0]) and float(enc[r, ti:].abs().sum()) == 0.0 and \
+                    int(label_len[r]) == int(n[0]) and torch.equal(labels[r, :ti], lab[0, :ti])
+                with torch.no_grad():
+                    ref, ref_len = R.encoder(audio[r:r + 1, :li].cpu(), lens[r:r + 1].cpu(), osd, plan)
+                    ref_logits = R.ctc_logits(ref, osd)
+                    want = R.ctc_greedy(ref_logits, ref_len)
+                got = enc[r:r + 1, :ref.shape[1]].cpu()
+                d = (got - ref).abs()
+                worst_max, worst_mean = max(worst_max, float(d.max())), max(worst_mean, float(d.mean()))
+                n_oracle += 1
+                am = R.ctc_logits(got, osd).argmax(-1)
+                t = int(ref_len[0])
+                flips += int((am[0, :t] != ref_logits[0, :t].argmax(-1)).sum()); frames += t
+                mine = labels[r, :int(label_len[r])].cpu().tolist()
+                dist += edit_distance(mine, want[0]); nlab += len(want[0])
+                seq_equal = seq_equal and mine == want[0]
+        for i in range(0 if ragged else nsub):
             lo, hi = cuts[i], cuts[i + 1]
             ni = range_pad[i] if range_pad else audio.shape[1]
             alone, alone_len, _ = model.encoder(audio[lo:hi, :ni].contiguous(), lens[lo:hi].contiguous())
@@ -220,8 +248,10 @@ def self_check(model, sd, plan, audio, lens, lens_np, cuts, range_pad, nsub, las
                 seq_equal = seq_equal and mine == want[j]
     finally:
         model.encoder.sub_batches, model.encoder.trim_sub_batches = saved
+        model.encoder.ragged = ragged
     ok = bit_ok and finite and worst_max <= tol_max and worst_mean <= tol_mean and (args.precision == "bf16" or seq_equal)
-    return {"ok": bool(ok), "finite": finite, "bit_identical_to_each_range_run_alone_on_one_stream": bool(bit_ok),
+    return {"ok": bool(ok), "finite": finite,
+            ("bit_identical_to_each_sampled_utterance_run_alone" if ragged else "bit_identical_to_each_range_run_alone_on_one_stream"): bool(bit_ok),
             "oracle_utterances": n_oracle, "max_abs_err_vs_oracle": worst_max, "mean_abs_err_vs_oracle": worst_mean,
             "tolerance": {"max": tol_max, "mean": tol_mean},
             "argmax_flips_vs_oracle": flips, "frames_compared": frames, "label_edit_distance_vs_oracle": dist, "oracle_labels": nlab,
@@ -418,7 +448,8 @@ def main():
     model.encoder.sub_batch_streams = max(args.streams, 1)
     # Row ranges padded to their own longest utterance (ConformerEncoder.trim_sub_batches): the batch is length-sorted, so range i
     # of every rank is padded to the longest utterance any rank holds in range i (known from the seeds: no exchange, equal shapes)
-    model.encoder.trim_sub_batches = not args.no_trim and nsub > 1 and args.workload == "libri"
+    model.encoder.ragged = bool(args.ragged)
+    model.encoder.trim_sub_batches = not args.ragged and not args.no_trim and nsub > 1 and args.workload == "libri"
     range_pad = None
     cuts = [args.batch * i // nsub for i in range(nsub + 1)]
     if args.batch >= 32 * nsub:      # ConformerEncoder's own default boundaries (multiples of 16 rows)
@@ -443,6 +474,11 @@ def main():
         model.encoder.set_option("fuse_subsample", args.subsample)
     if args.wide_gemm >= 0:
         model.encoder.set_option("wide_gemm", args.wide_gemm)
+    if args.ragged and world > 1 and nsub > 1:
+        model.encoder.sub_batch_bounds = cuts[1:-1]             # every rank must cut the SAME row ranges: the per-range collectives are fixed-size
+    hkw = {"x_len_host": lens_np} if args.ragged else {}       # ragged batches size their grids from the lengths on the host
+    if args.ragged:
+        padded_frames = valid_frames                            # no pad frames exist (an utterance's rows are only rounded up to the group size)
     sharded = head_stream = None
     if world > 1:
         from efficientconformer_amd.dist import ShardedEncoder
@@ -453,10 +489,10 @@ def main():
     def full_step():
         if world == 1:
             if isinstance(model, Transducer):
-                enc, enc_len, _ = model.encoder(audio, lens, range_pad=range_pad)
+                enc, enc_len, _ = model.encoder(audio, lens, range_pad=range_pad, **hkw)
                 last["labels"] = head(model, enc, enc_len)
             else:      # fc + argmax + collapse of every row range on that range's stream (ModelCTC.encode_greedy)
-                enc, enc_len, labels, label_len = model.encode_greedy(audio, lens, range_pad=range_pad)
+                enc, enc_len, labels, label_len = model.encode_greedy(audio, lens, range_pad=range_pad, **hkw)
                 last["labels"] = (labels, label_len)
             last["enc"] = (enc, enc_len)
             return
@@ -464,7 +500,7 @@ def main():
         if args.gather == "outputs":
             # encoder on this rank's utterances; per-row-range all-gather on the comm stream (dist.py); the head consumes the
             # gathered chunks on its own stream, so the next step's encoder is not queued behind the collectives
-            g = sharded.encode_shard(audio, lens, args.batch * world, range_pad=range_pad)
+            g = sharded.encode_shard(audio, lens, args.batch * world, range_pad=range_pad, **hkw)
             head_stream.wait_stream(cur)
             with torch.cuda.stream(head_stream):
                 res = []
@@ -473,7 +509,7 @@ def main():
                     res.append(head(model, ch.out if ch.out.dtype == torch.float32 else ch.out.float(), ch.out_len))
             last["labels"] = res
         else:
-            enc, enc_len, _ = model.encoder(audio, lens, range_pad=range_pad)
+            enc, enc_len, _ = model.encoder(audio, lens, range_pad=range_pad, **hkw)
             labels, label_len = head(model, enc, enc_len)
             head_stream.wait_stream(cur)
             with torch.cuda.stream(head_stream):
@@ -527,10 +563,13 @@ def main():
                                   "step_ms": {"p10": pct(0.10), "median": pct(0.50), "p90": pct(0.90), "note": "HIP events between steps on the caller's stream (rank 0); "
                                               "ms_per_step / value are wall clock over all steps"},
                                   "padded_fraction": 1.0 - all_valid / all_padded,
-                                  "_padding": ("each of the %d row ranges zero-padded to ITS longest utterance (length bucketing inside the forward)" % nsub) if range_pad
+                                  "_padding": "ragged: every utterance at its own length in one concatenated row space per row range (no pad frames; outputs = the "
+                                              "reference's for each utterance alone)" if args.ragged else
+                                              ("each of the %d row ranges zero-padded to ITS longest utterance (length bucketing inside the forward)" % nsub) if range_pad
                                               else "zero-padded to the batch's longest utterance",
                                   "row_ranges": ("%d row ranges per GPU (rows %s), each padded to ITS longest utterance %s samples (length bucketing inside "
                                                  "the forward; --no-trim pads all to the batch maximum as in round 1)" % (nsub, cuts, range_pad)) if range_pad
+                                                else ("%d ragged row range(s) per GPU, cut for equal valid frames" % nsub) if args.ragged
                                                 else "%d row range(s) per GPU padded to the batch maximum" % nsub})
         if isinstance(model, Transducer):
             result["config"]["workload"] += " (RNN-T greedy token ids, synthetic blank bias %.1f)" % RNNT_BLANK_BIAS
@@ -564,6 +603,9 @@ def main():
 
         def serial_steps(n):
             for _ in range(n):
+                if args.ragged:          # the whole ragged batch as ONE range on one stream: every launch alone on the chip
+                    step(model, audio, lens, **hkw)
+                    continue
                 for i in range(nsub):
                     lo, hi = cuts[i], cuts[i + 1]
                     step(model, audio[lo:hi, :range_pad[i]].contiguous() if range_pad else audio[lo:hi], lens[lo:hi])
@@ -580,11 +622,11 @@ def main():
         dom_name = max(PROF_CLASSES, key=lambda c: per[c]["ms_per_step"])
         flight = None
         if nsub > 1:
-            step(model, audio, lens, range_pad)
+            step(model, audio, lens, range_pad, **hkw)
             torch.cuda.synchronize()
             _lib.check(lib.effconf_profile_enable(h, 1), "profile_enable")
             for _ in range(nprof):
-                step(model, audio, lens, range_pad)
+                step(model, audio, lens, range_pad, **hkw)
             flight = read_classes()[dom_name]
         _lib.check(lib.effconf_profile_enable(h, 0), "profile_enable")
         for cname, c in per.items():      # every class against its own bound
@@ -606,7 +648,7 @@ def main():
             dec_ms = e0.elapsed_time(e1) / nprof
             e0.record()
             for _ in range(nprof):
-                model.encoder(audio, lens, range_pad=range_pad)
+                model.encoder(audio, lens, range_pad=range_pad, **hkw)
             e1.record()
             torch.cuda.synchronize()
             enc_ms = e0.elapsed_time(e1) / nprof

@@ -483,6 +483,22 @@ __global__ void attn_pad_rows_nat_kernel(GemmParams p, int B) {
     }
 }
 
+// ragged batch, natural layout: utterance b owns rows [off[b], off[b + 1]) (its frames padded to a multiple of G); rows len[b] .. are the
+// chunk padding of attentions.py:107-138, 671-675: Q = 0 -> Q + u = u, K = V = 0
+__global__ void attn_pad_rows_ragged_kernel(bf16_t* qu, bf16_t* kh, bf16_t* vt, const float* __restrict__ u, int D, int G,
+                                            const int* __restrict__ off, const int* __restrict__ len, int n) {
+    const int total = n * (G - 1) * D;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int nn = idx % D, rest = idx / D;
+        const int j = rest % (G - 1), b = rest / (G - 1);
+        const int row = off[b] + len[b] + j;
+        if (row < off[b + 1]) {
+            const size_t i1 = (size_t)row * D + nn;
+            qu[i1] = f2bf(u[nn]); kh[i1] = 0; vt[i1] = 0;
+        }
+    }
+}
+
 template <int DP, int NWV>
 int launch_dp_w(const AttnParams& p, hipStream_t s) {
     using SM = AttnSmem<DP, NWV>;
@@ -538,6 +554,13 @@ int launch_attn_pad_rows_nat(const GemmParams& p, int B, hipStream_t s) {
     if (npad <= 0 || B <= 0) return 0;
     const int total = B * npad * p.D;
     hipLaunchKernelGGL(attn_pad_rows_nat_kernel, dim3((total + 255) / 256), dim3(256), 0, s, p, B);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_attn_pad_rows_ragged(bf16_t* qu, bf16_t* kh, bf16_t* vt, const float* u, int D, int G, const RaggedRows& rg, hipStream_t s) {
+    if (G <= 1 || rg.n <= 0) return 0;
+    const int total = rg.n * (G - 1) * D;
+    hipLaunchKernelGGL(attn_pad_rows_ragged_kernel, dim3((total + 255) / 256), dim3(256), 0, s, qu, kh, vt, u, D, G, rg.off, rg.len, rg.n);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -70,36 +70,45 @@ __global__ __launch_bounds__(NWV * 64, (QT == 1 && NWV == 4 && DP <= 96) ? 2 : 1
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, g = lane >> 4;
-    const int qtiles = (p.Tg + BI - 1) / BI;
+    int qtiles = (p.Tg + BI - 1) / BI;
     // utterance b on XCD b % 8: all heads / query tiles of an utterance share one L2, and a length-sorted batch spreads evenly over
     // the XCDs.  Any B: the utterances in the order (0, 8, 16, .. | 1, 9, .. | ..) form a list that is cut into the 8 contiguous,
     // equally long chunks of logical ids xcd_remap hands the XCDs (with B % 8 != 0 a chunk border falls inside an utterance: 7
     // utterances are shared by two L2s).  Round 2 applied this only for B % 8 == 0: B = 85 ran 16 % slower per utterance than 80.
     int id = xcd_remap(blockIdx.x, gridDim.x);
+    // Ragged batch (p.rag_off != null, natural layout only): utterance b has its own frame count T = lens[b] (every frame valid), its
+    // own grouped length Tg and number of query tiles; the workgroups of the launch are laid out utterance by utterance in the SAME
+    // permuted order as below (p.rag_wg: prefix sums of heads x query tiles in that order), its rows start at row rag_off[b] of the
+    // concatenated Q / K / V / output row space, and its positional rows are the LAST 2 Tg - 1 rows of the table built for the longest
+    // utterance (R[m] = sinusoid(Tp - 1 - G/2 - m): a shorter sequence's table is the longer one's, shifted by Tg_max - Tg grouped rows).
+    int Tg = p.Tg, T = p.T, qt_wg, h, b;
     {
-        const int per_b = p.H * qtiles, u = id / per_b, q8 = p.B >> 3, r8 = p.B & 7;
+        const int per_b = p.H * qtiles, q8 = p.B >> 3, r8 = p.B & 7;
+        const int u = p.rag_off ? ragged_find(p.rag_wg, p.B, id) : id / per_b;
         int x, j;
         if (u < r8 * (q8 + 1)) { x = u / (q8 + 1); j = u - x * (q8 + 1); }
         else { const int u2 = u - r8 * (q8 + 1); x = u2 / q8; j = u2 - x * q8; x += r8; }
-        id = (x + 8 * j) * per_b + (id - u * per_b);
+        b = x + 8 * j;
+        int local = id - (p.rag_off ? p.rag_wg[u] : u * per_b);
+        if (p.rag_off) { T = p.lens[b]; Tg = (T + p.G - 1) / p.G; qtiles = (Tg + BI - 1) / BI; }
+        qt_wg = local % qtiles; h = local / qtiles;
     }
-    const int qt_wg = id % qtiles; id /= qtiles;
-    const int h = id % p.H; const int b = id / p.H;
     const int i0 = qt_wg * BI, iw0 = i0 + wave * 16 * QT;
-    const size_t qoff = (size_t)b * p.q_bstride + (size_t)h * p.q_hstride;
+    const size_t orow0 = p.rag_off ? (size_t)p.rag_off[b] : (size_t)b * p.T;          // first row of the utterance in the un-grouped output
+    const size_t qoff = (p.rag_off ? orow0 * p.D : (size_t)b * p.q_bstride) + (size_t)h * p.q_hstride;
     const bf16_t* Qu = p.qu + qoff;
     const bf16_t* Kh = p.kh + qoff;
     const bf16_t* Vh = p.vt + qoff;
-    const bf16_t* Eh = p.eh + (size_t)h * p.e_hstride;
     const int RS = p.q_rowstride, ERS = p.e_rowstride;
-    const int erows = 2 * p.Tg - 1;
+    const bf16_t* Eh = p.eh + (size_t)h * p.e_hstride + (p.rag_off ? (size_t)(p.rag_tgmax - Tg) * ERS : 0);
+    const int erows = 2 * Tg - 1;
     const int dceil = (p.d + 7) & ~7;
     const bool ragged_d = dceil != p.d;
 
     int nkeys = (p.lens[b] + p.G - 1) / p.G;
-    nkeys = nkeys < p.Tg ? nkeys : p.Tg;
+    nkeys = nkeys < Tg ? nkeys : Tg;
     const bool all_masked = nkeys < 1;                          // empty utterance: uniform softmax over all key groups (attention.hip)
-    nkeys = all_masked ? p.Tg : nkeys;
+    nkeys = all_masked ? Tg : nkeys;
 
     // ---- the wave's two query tiles: B operands of S^T = K Q^T (Q + u) and of the positional product (Q + v = (Q + u) + (v - u))
     bf16x8 qu[QT][KS], qv[QT][KS];
@@ -107,7 +116,7 @@ __global__ __launch_bounds__(NWV * 64, (QT == 1 && NWV == 4 && DP <= 96) ? 2 : 1
         const float* dv = p.dvu + (size_t)h * p.dvu_ld;
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
-            const int i = iw0 + 16 * t + c, ic = i < p.Tg ? i : p.Tg - 1;
+            const int i = iw0 + 16 * t + c, ic = i < Tg ? i : Tg - 1;
             uint4 ra[KS];
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
@@ -118,7 +127,7 @@ __global__ __launch_bounds__(NWV * 64, (QT == 1 && NWV == 4 && DP <= 96) ? 2 : 1
             for (int ks = 0; ks < KS; ++ks) {
                 const int x = ks * 32 + g * 8;
                 const float4 da = *reinterpret_cast<const float4*>(dv + x), db = *reinterpret_cast<const float4*>(dv + x + 4);
-                const int valid = i < p.Tg ? p.d - x : 0;
+                const int valid = i < Tg ? p.d - x : 0;
                 const uint4 m = mask_chunk(ra[ks], valid);
                 qu[t][ks] = as_bf16x8(m);
                 const uint4 w = make_uint4(pack_bf2(__uint_as_float(m.x << 16) + da.x, __uint_as_float(m.x & 0xFFFF0000u) + da.y),
@@ -130,7 +139,7 @@ __global__ __launch_bounds__(NWV * 64, (QT == 1 && NWV == 4 && DP <= 96) ? 2 : 1
         }
     }
     // ---- first positional band of the workgroup: absolute E rows R0 .. R0 + BI + 62
-    const int R0 = p.Tg - 1 - i0 - (BI - 1);
+    const int R0 = Tg - 1 - i0 - (BI - 1);
     {
         constexpr int NB = ((BI + 63) * CPR + NTHR - 1) / NTHR;
         uint4 fb[NB];
@@ -195,7 +204,7 @@ __global__ __launch_bounds__(NWV * 64, (QT == 1 && NWV == 4 && DP <= 96) ? 2 : 1
         // is not a multiple of 8 (d = 90 / 135 / 42) the chunk that closes a head span reads dceil - d elements of the NEXT span; behind
         // the last key row of the last head of the last utterance that is the never-written slack of the buffer (NaN patterns times the
         // queries' zero pad columns = NaN), so the block holding row Tg - 1 takes the masked tail path then.
-        if (jn + BJ <= p.Tg - (ragged_d ? 1 : 0)) {
+        if (jn + BJ <= Tg - (ragged_d ? 1 : 0)) {
             const char* kb = reinterpret_cast<const char*>(Kh + (size_t)jn * RS);
             const char* vb = reinterpret_cast<const char*>(Vh + (size_t)jn * RS);
 #pragma unroll
@@ -204,7 +213,7 @@ __global__ __launch_bounds__(NWV * 64, (QT == 1 && NWV == 4 && DP <= 96) ? 2 : 1
 #pragma unroll
             for (int n = 0; n < NK; ++n) {
                 const int kr = chunk_row(n), j = jn + kr;
-                const size_t o = (size_t)(j < p.Tg ? j : p.Tg - 1) * RS * 2 + (koffs[n] - (uint32_t)(kr * RS) * 2u);
+                const size_t o = (size_t)(j < Tg ? j : Tg - 1) * RS * 2 + (koffs[n] - (uint32_t)(kr * RS) * 2u);
                 st_.lk[n] = tail_mask(ld16b(reinterpret_cast<const char*>(Kh) + o), n); st_.lv[n] = tail_mask(ld16b(reinterpret_cast<const char*>(Vh) + o), n);
             }
         }
@@ -405,7 +414,7 @@ __global__ __launch_bounds__(NWV * 64, (QT == 1 && NWV == 4 && DP <= 96) ? 2 : 1
         l_tot += __shfl_xor(l_tot, 32);
         const float inv = 1.0f / l_tot;
         const int i = iw0 + 16 * t + c;
-        if (i >= p.Tg) continue;
+        if (i >= Tg) continue;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             const int x0 = dt * 16 + g * 4;
@@ -414,12 +423,12 @@ __global__ __launch_bounds__(NWV * 64, (QT == 1 && NWV == 4 && DP <= 96) ? 2 : 1
             while (n0 >= p.D) { n0 -= p.D; ++toff; }
             const int t0 = i * p.G + toff;
             if (x0 + 3 < p.d && n0 + 3 < p.D && (n0 & 1) == 0) {
-                if (t0 < p.T) {
+                if (t0 < T || p.rag_off) {          // ragged rows: the group-padding rows T .. Tp - 1 exist in the output and are kept zero
                     typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
                     u32x2_a4 w;
-                    w[0] = pack_bf2(acc[t][dt][0] * inv, acc[t][dt][1] * inv);
-                    w[1] = pack_bf2(acc[t][dt][2] * inv, acc[t][dt][3] * inv);
-                    *reinterpret_cast<u32x2_a4*>(p.out + ((size_t)b * p.T + t0) * p.ldo + n0) = w;
+                    w[0] = t0 < T ? pack_bf2(acc[t][dt][0] * inv, acc[t][dt][1] * inv) : 0u;
+                    w[1] = t0 < T ? pack_bf2(acc[t][dt][2] * inv, acc[t][dt][3] * inv) : 0u;
+                    *reinterpret_cast<u32x2_a4*>(p.out + (orow0 + t0) * p.ldo + n0) = w;
                 }
             } else {
 #pragma unroll
@@ -429,7 +438,7 @@ __global__ __launch_bounds__(NWV * 64, (QT == 1 && NWV == 4 && DP <= 96) ? 2 : 1
                     int n = h * p.d + x, tf = 0;
                     while (n >= p.D) { n -= p.D; ++tf; }
                     const int tt = i * p.G + tf;
-                    if (tt < p.T) p.out[((size_t)b * p.T + tt) * p.ldo + n] = f2bf(acc[t][dt][r] * inv);
+                    if (tt < T || p.rag_off) p.out[(orow0 + tt) * p.ldo + n] = tt < T ? f2bf(acc[t][dt][r] * inv) : (bf16_t)0;
                 }
             }
         }
@@ -443,7 +452,9 @@ int launch2(const AttnParams& p, hipStream_t s) {
     static LdsAttr attr;
     ensure_dynamic_lds(reinterpret_cast<const void*>(&relpos_attention2_kernel<DP, NWV, QT>), SM::TOTAL, attr);
     const int qtiles = (p.Tg + SM::BI - 1) / SM::BI;
-    hipLaunchKernelGGL((relpos_attention2_kernel<DP, NWV, QT>), dim3(p.B * p.H * qtiles), dim3(NWV * 64), SM::TOTAL, s, p);
+    const int nwg = p.rag_off ? p.rag_nwg : p.B * p.H * qtiles;       // ragged: sum over the utterances of heads x query tiles (host total)
+    if (nwg <= 0) return 0;
+    hipLaunchKernelGGL((relpos_attention2_kernel<DP, NWV, QT>), dim3(nwg), dim3(NWV * 64), SM::TOTAL, s, p);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -456,6 +467,7 @@ bool relpos_attention2_supported(int dpad) { return dpad == 32 || dpad == 64 || 
 int launch_relpos_attention2(const AttnParams& p, int waves, hipStream_t s) {
     if (p.B <= 0 || p.Tg <= 0) return 0;
     if (p.dpad < p.d || p.q_rowstride != p.e_rowstride) return -2;
+    if (p.rag_off && (waves != 1 || !p.rag_wg || p.q_rowstride != p.G * p.D)) return -2;      // ragged: natural layout, 64-query workgroups
 #define ATT2_CASE(DPV) case DPV: return waves == 1 ? launch2<DPV, 4, 1>(p, s) : launch2<DPV, 2, 2>(p, s);
     switch (p.dpad) {
         ATT2_CASE(32) ATT2_CASE(64) ATT2_CASE(96) ATT2_CASE(128)

@@ -64,5 +64,16 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + idx;
 }
 
+// Ragged batches: utterance b owns the rows [off[b], off[b + 1]) of a concatenated row space (off has n + 1 entries, non-decreasing).
+// Largest b in [0, n) with off[b] <= m  (m < off[n]); ~log2(n) L1-resident loads.
+__device__ __forceinline__ int ragged_find(const int* __restrict__ off, int n, int m) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (off[mid] <= m) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
 static inline int ec_round_up(int x, int m) { return (x + m - 1) / m * m; }
 static inline int ec_cdiv(int a, int b) { return (a + b - 1) / b; }

@@ -90,7 +90,8 @@ typedef float dwf2 __attribute__((ext_vector_type(2)));
 
 template <int KSZ, int STRIDE>
 __global__ __launch_bounds__(256) void dwconv_kernel(const bf16_t* __restrict__ g, int T, int To, int C, int ld,
-                                                     const float* __restrict__ w_kc, const float* __restrict__ bias, bf16_t* out) {
+                                                     const float* __restrict__ w_kc, const float* __restrict__ bias, bf16_t* out,
+                                                     RaggedConv rc) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ROWS = (DW_TT - 1) * STRIDE + KSZ;
     constexpr int TROWS = (DW_NT - 1) * STRIDE + KSZ;                       // input rows one thread consumes
@@ -99,7 +100,16 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const bf16_t* __restrict__ 
     const int ttiles = (To + DW_TT - 1) / DW_TT;
     int id = blockIdx.x;
     const int ct = id % ctiles; id /= ctiles;
-    const int tt = id % ttiles; const int b = id / ttiles;
+    int tt, b, Top = To;                                                    // Top: output rows of the utterance including its group padding
+    size_t grow0, orow0;                                                    // first input / output row of the utterance
+    if (rc.tile_off) {
+        // ragged batch: utterance b has its own T / To ("same" zero padding at ITS ends), its rows start at in_off[b] / out_off[b] of the
+        // concatenated row spaces; rc.tile_off = prefix sums of the utterances' time tiles.  Output rows To .. Top - 1 pad the utterance
+        // to a multiple of the NEXT stage's attention group size and are written as zeros.
+        b = ragged_find(rc.tile_off, rc.n, id); tt = id - rc.tile_off[b];
+        T = rc.in_len[b]; To = rc.out_len[b];
+        grow0 = (size_t)rc.in_off[b]; orow0 = (size_t)rc.out_off[b]; Top = rc.out_off[b + 1] - rc.out_off[b];
+    } else { tt = id % ttiles; b = id / ttiles; grow0 = (size_t)b * T; orow0 = (size_t)b * To; }
     const int c0 = ct * DW_CC, to0 = tt * DW_TT;
     constexpr int HALF = (KSZ - 1) / 2;
     const int tin0 = to0 * STRIDE - HALF;
@@ -120,7 +130,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const bf16_t* __restrict__ 
     }
     {   // all loads of the tile first (one memory latency instead of one per pass), then the LDS writes
         constexpr int NL = (ROWS * (DW_CC / 8) + 255) / 256;
-        const bf16_t* gb = g + (size_t)b * T * ld;                          // uniform base; one utterance is < 2^31 elements
+        const bf16_t* gb = g + grow0 * ld;                                  // uniform base; one utterance is < 2^31 elements
         uint4 v[NL];
 #pragma unroll
         for (int n = 0; n < NL; ++n) {
@@ -154,23 +164,26 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const bf16_t* __restrict__ 
         }
     }
     if (c < ld) {   // ld is even, so the pair is inside the row; channels >= C have zero taps and bias: swish(0) = 0 keeps the pad columns zero
-        bf16_t* ob = out + (size_t)b * To * ld;
+        bf16_t* ob = out + orow0 * ld;
 #pragma unroll
         for (int o = 0; o < DW_NT; ++o) {
             const int to = to0 + tg * DW_NT + o;
-            if (to < To) *reinterpret_cast<uint32_t*>(ob + (unsigned)(to * ld + c)) = pack_bf2(swishf_(acc[o].x), swishf_(acc[o].y));
+            if (to < Top) *reinterpret_cast<uint32_t*>(ob + (unsigned)(to * ld + c)) = to < To ? pack_bf2(swishf_(acc[o].x), swishf_(acc[o].y)) : 0u;
         }
     }
 }
 
 template <int KSZ, int STRIDE>
-int launch_dw_t(const bf16_t* g, int B, int T, int To, int C, int ld, const float* w_kc, const float* bias, bf16_t* out, hipStream_t s) {
+int launch_dw_t(const bf16_t* g, int B, int T, int To, int C, int ld, const float* w_kc, const float* bias, bf16_t* out, hipStream_t s,
+                const RaggedConv& rc) {
     const int ctiles = (C + DW_CC - 1) / DW_CC, ttiles = (To + DW_TT - 1) / DW_TT;
+    const int nwg = rc.tile_off ? rc.tiles * ctiles : B * ttiles * ctiles;
+    if (nwg <= 0) return 0;
     constexpr int ROWS = (DW_TT - 1) * STRIDE + KSZ;
     const size_t lds = (size_t)ROWS * DW_PITCH;
     static LdsAttr attr;
     ensure_dynamic_lds(reinterpret_cast<const void*>(&dwconv_kernel<KSZ, STRIDE>), (int)lds, attr);
-    hipLaunchKernelGGL((dwconv_kernel<KSZ, STRIDE>), dim3(B * ttiles * ctiles), dim3(256), lds, s, g, T, To, C, ld, w_kc, bias, out);
+    hipLaunchKernelGGL((dwconv_kernel<KSZ, STRIDE>), dim3(nwg), dim3(256), lds, s, g, T, To, C, ld, w_kc, bias, out, rc);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -187,15 +200,17 @@ int launch_subsample_conv(const float* mel, int B, int F, int Tm, int T1, const 
 }
 
 int launch_dwconv(const bf16_t* g, int B, int T, int To, int C, int ld, const float* w_kc, const float* bias,
-                  int ksize, int stride, bf16_t* out, hipStream_t s) {
+                  int ksize, int stride, bf16_t* out, hipStream_t s, const RaggedConv* rcp) {
     if (B <= 0 || To <= 0) return 0;
     if (ld % 8 || ld < C) return -2;
+    RaggedConv rc{};
+    if (rcp) rc = *rcp;
     // taps are fully unrolled per (kernel size, stride); the shipped configs use k = 15 (Efficient Conformer) and 31 (Conformer)
-    if (ksize == 15 && stride == 1) return launch_dw_t<15, 1>(g, B, T, To, C, ld, w_kc, bias, out, s);
-    if (ksize == 15 && stride == 2) return launch_dw_t<15, 2>(g, B, T, To, C, ld, w_kc, bias, out, s);
-    if (ksize == 31 && stride == 1) return launch_dw_t<31, 1>(g, B, T, To, C, ld, w_kc, bias, out, s);
-    if (ksize == 31 && stride == 2) return launch_dw_t<31, 2>(g, B, T, To, C, ld, w_kc, bias, out, s);
-    if (ksize == 7 && stride == 1) return launch_dw_t<7, 1>(g, B, T, To, C, ld, w_kc, bias, out, s);
-    if (ksize == 7 && stride == 2) return launch_dw_t<7, 2>(g, B, T, To, C, ld, w_kc, bias, out, s);
+    if (ksize == 15 && stride == 1) return launch_dw_t<15, 1>(g, B, T, To, C, ld, w_kc, bias, out, s, rc);
+    if (ksize == 15 && stride == 2) return launch_dw_t<15, 2>(g, B, T, To, C, ld, w_kc, bias, out, s, rc);
+    if (ksize == 31 && stride == 1) return launch_dw_t<31, 1>(g, B, T, To, C, ld, w_kc, bias, out, s, rc);
+    if (ksize == 31 && stride == 2) return launch_dw_t<31, 2>(g, B, T, To, C, ld, w_kc, bias, out, s, rc);
+    if (ksize == 7 && stride == 1) return launch_dw_t<7, 1>(g, B, T, To, C, ld, w_kc, bias, out, s, rc);
+    if (ksize == 7 && stride == 2) return launch_dw_t<7, 2>(g, B, T, To, C, ld, w_kc, bias, out, s, rc);
     return -3;
 }

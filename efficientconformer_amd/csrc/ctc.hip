@@ -30,6 +30,55 @@ __global__ void lengths_kernel(const int64_t* __restrict__ x_len, int B, int fro
 }
 
 
+// Ragged batches (see kernels.h): lengths of every stage, then the prefix sums the ragged kernels index with.  One workgroup: thread b
+// computes utterance b's lengths, then thread k scans position k (a few hundred serial adds per thread; launched once per forward).
+__global__ __launch_bounds__(256) void lengths_ragged_kernel(const int64_t* __restrict__ x_len, int B, int from_audio, int hop, int sub_layers,
+                                                             const int* __restrict__ block_stride, const int* __restrict__ group,
+                                                             const int* __restrict__ heads, int n_blocks, int* stage_lens, int* mel_len,
+                                                             int* row_off, int* wg_off, int* tile_off, int64_t* out_len) {
+    auto fdiv = [](long long a, long long d) { long long q = a / d; return (a % d != 0 && ((a < 0) != (d < 0))) ? q - 1 : q; };
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        long long l = x_len[b];
+        if (from_audio) l = fdiv(l, hop) + 1;
+        mel_len[b] = (int)l;
+        for (int i = 0; i < sub_layers; ++i) l = fdiv(l - 1, 2) + 1;
+        stage_lens[b] = (int)l;
+        for (int k = 0; k < n_blocks; ++k) {
+            const int s = block_stride[k];
+            if (s > 1) l = fdiv(l - 1, s) + 1;
+            stage_lens[(size_t)(k + 1) * B + b] = (int)l;
+        }
+        if (out_len) out_len[b] = l;
+    }
+    __syncthreads();
+    const int q8 = B >> 3, r8 = B & 7;
+    for (int k = threadIdx.x; k <= n_blocks; k += blockDim.x) {
+        const int G = k < n_blocks ? group[k] : 1;
+        const int* len = stage_lens + (size_t)k * B;
+        int* ro = row_off + (size_t)k * (B + 1);
+        int acc = 0;
+        for (int b = 0; b < B; ++b) { ro[b] = acc; acc += (len[b] + G - 1) / G * G; }
+        ro[B] = acc;
+        if (k == n_blocks) continue;
+        int* wo = wg_off + (size_t)k * (B + 1);
+        acc = 0;
+        for (int u = 0; u < B; ++u) {                        // list position u <-> utterance x + 8 j (the attention kernels' order)
+            int x, j;
+            if (u < r8 * (q8 + 1)) { x = u / (q8 + 1); j = u - x * (q8 + 1); }
+            else { const int u2 = u - r8 * (q8 + 1); x = u2 / q8; j = u2 - x * q8; x += r8; }
+            const int tg = (len[x + 8 * j] + G - 1) / G;
+            wo[u] = acc; acc += heads[k] * ((tg + 63) / 64);
+        }
+        wo[B] = acc;
+        const int Gn = k + 1 < n_blocks ? group[k + 1] : 1;   // block k's output rows are padded for block k + 1's attention
+        const int* lo = stage_lens + (size_t)(k + 1) * B;
+        int* to = tile_off + (size_t)k * (B + 1);
+        acc = 0;
+        for (int b = 0; b < B; ++b) { to[b] = acc; acc += ((lo[b] + Gn - 1) / Gn * Gn + 127) / 128; }
+        to[B] = acc;
+    }
+}
+
 // One workgroup = CTC_ROWS frames x the whole vocabulary (thread = vocabulary column).  Every workgroup reads all of fc^T from L2, so
 // the rows per workgroup set the L2 traffic (8 rows: 3200 workgroups x 245 KB = 0.8 GB per launch, the whole 150 us of the first
 // version); the frame tile sits in LDS and is read as float4 broadcasts along k (one LDS read per 4 FMAs).
@@ -203,6 +252,16 @@ __global__ __launch_bounds__(64) void ctc_collapse_kernel(const int* __restrict_
 }
 
 }  // namespace
+
+int launch_lengths_ragged(const int64_t* x_len, int B, int from_audio, int hop, int sub_layers, const int* block_stride, const int* group,
+                          const int* heads, int n_blocks, int* stage_lens, int* mel_len, int* row_off, int* wg_off, int* tile_off,
+                          int64_t* out_len, hipStream_t s) {
+    if (B <= 0) return 0;
+    if (B > 4096) return -2;
+    hipLaunchKernelGGL(lengths_ragged_kernel, dim3(1), dim3(256), 0, s, x_len, B, from_audio, hop, sub_layers, block_stride, group, heads,
+                       n_blocks, stage_lens, mel_len, row_off, wg_off, tile_off, out_len);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
 
 int launch_lengths(const int64_t* x_len, int B, int from_audio, int hop, int sub_layers, const int* block_stride,
                    int n_blocks, int* stage_lens, int64_t* out_len, hipStream_t s) {

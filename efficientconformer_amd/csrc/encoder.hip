@@ -83,6 +83,7 @@ struct EcEncoder {
     std::vector<BlockW> bw;
     const float *fc_wt = nullptr, *fc_b = nullptr;
     const int* block_stride = nullptr;
+    const int *block_group = nullptr, *block_heads = nullptr;     // ragged batches: attention group size / heads per block (device)
     MelTables mel{};
     // trace
     char* trace_arena = nullptr; size_t trace_bytes = 0, trace_used = 0;
@@ -91,17 +92,17 @@ struct EcEncoder {
     // untouched between forwards (opt-in), the 15-18 small E projections are skipped for an unchanged T
     // One tag per workspace: callers that alternate workspaces (one per stream) keep every one of them warm.
     bool e_cache_on = false;
-    struct ECacheTag { const void* ws; int batch, tm; };
+    struct ECacheTag { const void* ws; int batch, tm; size_t layout; };   // layout: offset of the first E buffer (ragged batches: it moves with the row totals)
     std::vector<ECacheTag> e_cache;          // most recently used last; at most E_CACHE_MAX entries
     static constexpr size_t E_CACHE_MAX = 16;
-    bool e_cache_hit(const void* ws, int batch, int tm) const {   // the workspace layout depends on (batch, tm)
-        for (const ECacheTag& t : e_cache) if (t.ws == ws) return t.batch == batch && t.tm == tm;
+    bool e_cache_hit(const void* ws, int batch, int tm, size_t layout) const {   // the workspace layout depends on (batch, tm) [+ the row totals]
+        for (const ECacheTag& t : e_cache) if (t.ws == ws) return t.batch == batch && t.tm == tm && t.layout == layout;
         return false;
     }
-    void e_cache_put(const void* ws, int batch, int tm) {
+    void e_cache_put(const void* ws, int batch, int tm, size_t layout) {
         e_cache_drop(ws);
         if (e_cache.size() >= E_CACHE_MAX) e_cache.erase(e_cache.begin());
-        e_cache.push_back({ws, batch, tm});
+        e_cache.push_back({ws, batch, tm, layout});
     }
     void e_cache_drop(const void* ws) {
         for (size_t i = 0; i < e_cache.size(); ++i) if (e_cache[i].ws == ws) { e_cache.erase(e_cache.begin() + i); break; }
@@ -297,8 +298,15 @@ bool build_mel_tables(EcEncoder* e, std::string* err) {
 
 // ------------------------------------------------------------------ shapes + workspace layout
 struct Shapes {
-    int B, Tm, T1;
-    std::vector<int> Tin, Tout;   // frames entering / leaving each block
+    int B, Tm, T1;                 // Tm / T1: mel frames / frames after the subsampling (of the LONGEST utterance when ragged)
+    std::vector<int> Tin, Tout;    // frames entering / leaving each block (longest utterance when ragged)
+    // rows of the residual stream entering / leaving each block and of the Q / K / V buffers: B * T (B * Tp for Q / K / V), or - ragged -
+    // the sum over the utterances of their frames rounded up to the block's attention group size
+    std::vector<long long> Min, Mout, Mq;
+    bool ragged = false;
+    std::vector<int> wgs, tiles;   // ragged: attention workgroups (heads x 64-query tiles) and depthwise-conv tiles (128 frames) per block
+    std::vector<double> tg2;       // ragged: sum over the utterances of (grouped length)^2 per block (attention flop accounting)
+    long long Mfinal = 0;          // ragged: rows of the encoder output (sum of the utterances' output frames)
 };
 
 Shapes make_shapes(const EcEncoder* e, int B, int Tm) {
@@ -308,8 +316,40 @@ Shapes make_shapes(const EcEncoder* e, int B, int Tm) {
     s.T1 = t;
     for (const EcBlock& b : e->blocks) {
         s.Tin.push_back(t);
+        s.Min.push_back((long long)B * t);
+        s.Mq.push_back((long long)B * ec_round_up(t, b.group_size));
         if (b.conv_stride > 1) t = (t - 1) / b.conv_stride + 1;
         s.Tout.push_back(t);
+        s.Mout.push_back((long long)B * t);
+    }
+    return s;
+}
+
+// ragged batch: `tm[b]` mel frames of every utterance (host).  The same length chain as lengths_ragged_kernel (floor divisions of positive
+// numbers), accumulated into the totals the host needs for grids and the workspace.
+Shapes make_shapes_ragged(const EcEncoder* e, const std::vector<int>& tm) {
+    const int B = (int)tm.size(), nb = (int)e->blocks.size();
+    int tmax = 0;
+    for (int v : tm) tmax = std::max(tmax, v);
+    Shapes s = make_shapes(e, B, tmax);
+    s.ragged = true;
+    s.Min.assign(nb, 0); s.Mout.assign(nb, 0); s.Mq.assign(nb, 0); s.wgs.assign(nb, 0); s.tiles.assign(nb, 0); s.tg2.assign(nb, 0.0);
+    for (int b = 0; b < B; ++b) {
+        int t = tm[b];
+        for (int i = 0; i < e->cfg.sub_layers; ++i) t = (t - 1) / 2 + 1;
+        for (int k = 0; k < nb; ++k) {
+            const EcBlock& bk = e->blocks[k];
+            const int G = bk.group_size, Gn = k + 1 < nb ? e->blocks[k + 1].group_size : 1;
+            const int tp = ec_round_up(t, G);
+            s.Min[k] += tp; s.Mq[k] += tp;
+            s.wgs[k] += bk.num_heads * ec_cdiv(tp / G, 64);
+            s.tg2[k] += (double)(tp / G) * (tp / G);
+            if (bk.conv_stride > 1) t = (t - 1) / bk.conv_stride + 1;
+            const int top = ec_round_up(t, Gn);
+            s.Mout[k] += top;
+            s.tiles[k] += ec_cdiv(top, 128);
+        }
+        s.Mfinal += t;
     }
     return s;
 }
@@ -317,6 +357,7 @@ Shapes make_shapes(const EcEncoder* e, int B, int Tm) {
 struct Workspace {
     size_t total = 0;
     size_t mel, sub, sub1, x0, x1, a, hbuf, qu, kh, vt, eh, o, gbuf, cbuf, xs, lens, preds;
+    size_t mel_len = 0, row_off = 0, wg_off = 0, tile_off = 0;     // ragged descriptors (ints)
     std::vector<size_t> eh_blk;   // per-block E (kept across forwards for the cache)
 };
 
@@ -331,23 +372,26 @@ Workspace make_workspace(const EcEncoder* e, const Shapes& s, bool from_audio) {
     std::vector<size_t> esz;
     for (size_t k = 0; k < e->blocks.size(); ++k) {
         const EcBlock& b = e->blocks[k];
-        const size_t T = s.Tin[k], To = s.Tout[k], D = b.dim_model, De = b.dim_expand;
-        const size_t Tp = ec_round_up((int)T, b.group_size), Tg = Tp / b.group_size, Tgp = ec_round_up((int)Tg, 8);
+        const size_t T = s.Tin[k], D = b.dim_model, De = b.dim_expand;
+        const size_t Tp = ec_round_up((int)T, b.group_size), Tg = Tp / b.group_size;
         const size_t d = (size_t)b.group_size * D / b.num_heads, dpad = ec_round_up((int)d, 32);
-        mx = std::max(mx, std::max(B * T * D, B * To * De) * 4);
-        ma = std::max(ma, std::max(B * T * ld8(D), B * To * ld8(De)) * 2);
-        mh = std::max(mh, std::max(B * T * D, B * To * De) * b.ff_ratio * 2);
-        mq = std::max(mq, B * b.num_heads * Tg * dpad * 2 + 512);     // + slack: 16-byte chunk loads may run past a row's head span
-        mvt = std::max(mvt, B * b.num_heads * Tg * dpad * 2 + 512);
+        const size_t Mi = (size_t)s.Min[k], Mo = (size_t)s.Mout[k], Mqk = (size_t)s.Mq[k];     // rows in, rows out, Q / K / V rows
+        mx = std::max(mx, std::max(Mi * D, Mo * De) * 4);
+        ma = std::max(ma, std::max(Mi * ld8(D), Mo * ld8(De)) * 2);
+        mh = std::max(mh, std::max(Mi * D, Mo * De) * b.ff_ratio * 2);
+        // Q / K / V: natural layout Mq rows x D; the head-major test layout needs B * H * Tg * dpad (rectangular batches only)
+        const size_t qkv = std::max(Mqk * D, s.ragged ? (size_t)0 : B * b.num_heads * Tg * dpad);
+        mq = std::max(mq, qkv * 2 + 512);     // + slack: 16-byte chunk loads may run past a row's head span
+        mvt = std::max(mvt, qkv * 2 + 512);
         me = std::max(me, (size_t)b.num_heads * (2 * Tg - 1) * dpad * 2);
         esz.push_back((size_t)b.num_heads * (2 * Tg - 1) * dpad * 2 + 512);
-        mg = std::max(mg, B * T * ld8(De) * 2);
-        mc = std::max(mc, B * To * ld8(De) * 2);
+        mg = std::max(mg, Mi * ld8(De) * 2);
+        mc = std::max(mc, Mo * ld8(De) * 2);
     }
     w.mel = take(from_audio ? B * e->cfg.n_mels * s.Tm * 4 : 0);
     const int C = e->cfg.sub_filters[e->cfg.sub_layers - 1];
     int F = e->cfg.n_mels; for (int i = 0; i < e->cfg.sub_layers; ++i) F /= 2;
-    w.sub = take(B * s.T1 * C * F * 2);
+    w.sub = take(s.ragged ? 0 : B * s.T1 * C * F * 2);      // scratch of the unfused front ends (ragged batches run sublinear2.hip only)
     {   // two-layer subsampler: channel-last layer-1 activation [B][F/2][T after layer 1][Cp]
         const size_t tl1 = (s.Tm - 1) / 2 + 1;
         w.sub1 = take(e->cfg.sub_layers == 2 ? B * (e->cfg.n_mels / 2) * tl1 * ec_round_up(e->cfg.sub_filters[0], 64) * 2 : 0);
@@ -357,6 +401,13 @@ Workspace make_workspace(const EcEncoder* e, const Shapes& s, bool from_audio) {
     w.qu = take(mq); w.kh = take(mq); w.vt = take(mvt); w.eh = take(me);
     w.o = take(ma); w.gbuf = take(mg); w.cbuf = take(mc); w.xs = take(ma);
     w.lens = take((e->blocks.size() + 1) * B * 4);
+    if (s.ragged) {
+        const size_t nbk = e->blocks.size();
+        w.mel_len = take(B * 4);
+        w.row_off = take((nbk + 1) * (B + 1) * 4);
+        w.wg_off = take(nbk * (B + 1) * 4);
+        w.tile_off = take(nbk * (B + 1) * 4);
+    }
     for (size_t k = 0; k < esz.size(); ++k) w.eh_blk.push_back(take(esz[k]));
     w.preds = take(0);
     w.total = off;
@@ -502,20 +553,46 @@ int run_subsample_linear(EcEncoder* e, hipStream_t st, const float* mel, int B, 
     return 0;
 }
 
+// Ragged batches (s.ragged): every utterance runs at its own length in one concatenated row space (kernels.h: RaggedRows) - the row-local
+// kernels (chains, GEMMs, LayerNorms) just see M rows; the frame-mixing ones (subsampling, attention, depthwise conv, conv_res decimation)
+// index utterances through the descriptor arrays lengths_ragged_kernel leaves in the workspace.  out: (B, out_frames, D_last), zero filled
+// behind every utterance's own last frame.
 int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from_audio, const Shapes& s, const Workspace& w,
-                 char* ws, float* out, int64_t* out_len, hipStream_t st) {
+                 char* ws, float* out, int64_t* out_len, hipStream_t st, int out_frames = 0) {
     const EcConfig& c = e->cfg;
     const int B = s.B, nb = (int)e->blocks.size();
+    const bool rg = s.ragged;
     e->trace.clear(); e->trace_used = 0;
     int* lens = reinterpret_cast<int*>(ws + w.lens);
-    { PROF(PC_MISC, 0, 0); EC_TRY(launch_lengths(in_len, B, from_audio, c.hop_length, c.sub_layers, e->block_stride, nb, lens, out_len, st)); }
+    const int *mel_len = nullptr, *row_off = nullptr, *wg_off = nullptr, *tile_off = nullptr;
+    if (rg) {
+        int* ml = reinterpret_cast<int*>(ws + w.mel_len); int* ro = reinterpret_cast<int*>(ws + w.row_off);
+        int* wo = reinterpret_cast<int*>(ws + w.wg_off); int* to = reinterpret_cast<int*>(ws + w.tile_off);
+        PROF(PC_MISC, 0, 0);
+        EC_TRY(launch_lengths_ragged(in_len, B, from_audio, c.hop_length, c.sub_layers, e->block_stride, e->block_group, e->block_heads, nb, lens, ml,
+                                     ro, wo, to, out_len, st));
+        mel_len = ml; row_off = ro; wg_off = wo; tile_off = to;
+    } else {
+        PROF(PC_MISC, 0, 0); EC_TRY(launch_lengths(in_len, B, from_audio, c.hop_length, c.sub_layers, e->block_stride, nb, lens, out_len, st));
+    }
     if (from_audio) trace_add(e, st, "mel", mel, (int64_t)B * c.n_mels, s.Tm, s.Tm, 0);
+    auto rows_at = [&](int k) { RaggedRows r{}; r.off = row_off + (size_t)k * (B + 1); r.len = lens + (size_t)k * B; r.n = B;
+                                r.rows = (int)(k < nb ? s.Min[k] : s.Mfinal); r.tmax = k < nb ? s.Tin[k] : s.Tout[nb - 1]; return r; };
 
     // ---- Conv2dSubsampling (modules.py:232-249) + transpose + Linear (encoders.py:113-116)
     float* x = reinterpret_cast<float*>(ws + w.x0);
     float* xalt = reinterpret_cast<float*>(ws + w.x1);
-    EC_TRY(run_subsample_linear(e, st, mel, B, s.Tm, s.T1, reinterpret_cast<bf16_t*>(ws + w.sub), reinterpret_cast<bf16_t*>(ws + w.sub1), x));
-    trace_add(e, st, "linear", x, (int64_t)B * s.T1, e->lin.N, e->lin.N, 0);
+    if (rg) {
+        if (!(c.sub_layers == 1 && e->fuse_subsample == 2 && e->lin_rs))
+            return fail("ragged batches need the sublinear2.hip front end (one subsampling layer, filters and first width <= 192, option fuse_subsample = 2)");
+        const int C0 = c.sub_filters[0], Ksub = C0 * (c.n_mels / 2);
+        const RaggedRows r0 = rows_at(0);
+        PROF(PC_SUBCONV, 2.0 * 9 * (double)s.Min[0] * Ksub + 2.0 * (double)s.Min[0] * Ksub * e->lin.N, (double)B * c.n_mels * s.Tm * 4 + (double)s.Min[0] * e->lin.N * 4);
+        EC_TRY(launch_sublinear2(mel, B, c.n_mels, s.Tm, s.T1, e->conv_tab, e->lin_rs, e->lin.bias, C0, e->lin.N, x, e->lin.N, st, &r0, mel_len));
+    } else {
+        EC_TRY(run_subsample_linear(e, st, mel, B, s.Tm, s.T1, reinterpret_cast<bf16_t*>(ws + w.sub), reinterpret_cast<bf16_t*>(ws + w.sub1), x));
+    }
+    trace_add(e, st, "linear", x, s.Min[0], e->lin.N, e->lin.N, 0);
 
     bf16_t* a = reinterpret_cast<bf16_t*>(ws + w.a);
     bf16_t* hbuf = reinterpret_cast<bf16_t*>(ws + w.hbuf);
@@ -529,14 +606,14 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
     // recomputes them) and the workspace must not be tagged warm (an eager forward before the first replay would read E nobody wrote)
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     const bool capturing = hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
-    const bool e_cached = !capturing && e->e_cache_on && e->e_cache_hit(ws, B, s.Tm);
+    const bool e_cached = !capturing && e->e_cache_on && e->e_cache_hit(ws, B, s.Tm, w.eh_blk[0]);
     if (!e_cached) e->e_cache_drop(ws);       // re-tagged only after every projection of this forward was enqueued
 
     for (int k = 0; k < nb; ++k) {
         const EcBlock& b = e->blocks[k];
         const BlockW& W = e->bw[k];
-        const int T = s.Tin[k], To = s.Tout[k], D = b.dim_model, De = b.dim_expand;
-        const int M = B * T, Mo = B * To;
+        const int T = s.Tin[k], To = s.Tout[k], D = b.dim_model, De = b.dim_expand;      // ragged: the LONGEST utterance's frames
+        const int M = (int)s.Min[k], Mo = (int)s.Mout[k];
         const int G = b.group_size, H = b.num_heads;
         const int Tp = ec_round_up(T, G), Tg = Tp / G, Tgp = ec_round_up(Tg, 8);
         const int d = G * D / H, dpad = ec_round_up(d, 32);
@@ -546,13 +623,17 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
         // fallback (a scatter epilogue of 2-byte stores, 9 % of Medium's step) is kept behind the option "head_major_odd" for tests.
         const bool head_major_odd = e->head_major_odd;
         const bool nat = (d % 2) == 0 || !head_major_odd;
+        if (rg && !nat) return fail("ragged batches use the natural Q / K / V layout (option head_major_odd = 0)");
+        // rows (b, t) -> Q / K / V rows b * Tp + t; a ragged batch keeps every utterance's rows group-padded in the residual stream itself,
+        // so the map is the identity: ONE "utterance" of M rows
+        const int qT = rg ? M : T, qTp = rg ? M : Tp;
         const bool chain_head = e->fuse_chain && W.chain_in && nat && chain_head_supported(D);          // FFN1 + QKV of this block as a fused chain
         const bool chain_b = e->fuse_chain && W.chain_in;                      // out-proj + LN + pointwise-1/GLU
         const bool chain_tail = e->fuse_chain && W.chain_out && chain_tail_supported(De);                  // pointwise-2 + FFN2 + block norm (+ next block's head)
         GemmParams p{};
         p.A = a; p.lda = ld8(D); p.W = W.qkv.w; p.ldw = W.qkv.ldw; p.bias = W.qkv.bias;
         p.M = M; p.N = 3 * D; p.K = D;
-        p.T = T; p.G = G; p.H = H; p.D = D; p.d = d; p.dpad = dpad; p.Tg = Tg; p.Tgp = Tgp;
+        p.T = qT; p.G = rg ? 1 : G; p.H = H; p.D = D; p.d = d; p.dpad = dpad; p.Tg = rg ? M : Tg; p.Tgp = Tgp;
         p.qu = reinterpret_cast<bf16_t*>(ws + w.qu);
         p.kh = reinterpret_cast<bf16_t*>(ws + w.kh); p.vt = reinterpret_cast<bf16_t*>(ws + w.vt);
         p.u = W.u; p.v = W.v; p.rs_variant = e->rs_variant;
@@ -561,7 +642,7 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
         } else if (chain_head) {
             ChainParams cp{};
             cp.variant = e->chain_variant;
-            fill_chain_head(cp, W, D, F1c(b), T, Tp, p);
+            fill_chain_head(cp, W, D, F1c(b), qT, qTp, p);
             cp.M = M; cp.X = x; cp.ldx = D; cp.Y = x; cp.ldy = D; cp.consts = W.cc_head;
             PROF(PC_GEMM_FFN, 2.0 * M * (double)D * (2.0 * D * b.ff_ratio + 3.0 * D), (double)M * D * 16 + 22.0 * D * D);
             EC_TRY(launch_chain(cp, CHAIN_A_HEAD, st));
@@ -587,7 +668,9 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
 
         // ---- x += MHSA(LN(x))   (blocks.py:125-126; attentions.py:549-718)
         {
-            { PROF(PC_MISC, 0, 0); EC_TRY(nat ? launch_attn_pad_rows_nat(p, B, st) : launch_attn_pad_rows(p, B, st)); }
+            { PROF(PC_MISC, 0, 0);
+              if (rg) EC_TRY(launch_attn_pad_rows_ragged(p.qu, p.kh, p.vt, W.u, D, G, rows_at(k), st));
+              else EC_TRY(nat ? launch_attn_pad_rows_nat(p, B, st) : launch_attn_pad_rows(p, B, st)); }
             // positional embeddings E = pos_layer(R) (attentions.py:588 / 678): input independent, tiny (2Tp-G rows)
             GemmParams pe{};
             const int erows = 2 * Tp - G;
@@ -609,7 +692,12 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
             else { ap.q_bstride = (long long)H * Tg * dpad; ap.q_hstride = (long long)Tg * dpad; ap.q_rowstride = dpad;
                    ap.e_hstride = (long long)(2 * Tg - 1) * dpad; ap.e_rowstride = dpad; }
             ap.out = o; ap.ldo = ld8(D); ap.scale = 1.0f / std::sqrt((float)d); ap.force_waves = e->attn_waves;
-            { PROF(PC_ATTENTION, 2.0 * B * H * (double)Tg * Tg * d * 3.0, (double)M * D * 2 * 5);
+            if (rg) {
+                if (!relpos_attention2_supported(dpad)) return fail("ragged batches need attention2.hip (padded head width <= 160)");
+                ap.rag_off = row_off + (size_t)k * (B + 1); ap.rag_wg = wg_off + (size_t)k * (B + 1); ap.rag_nwg = s.wgs[k]; ap.rag_tgmax = Tg;
+            }
+            { PROF(PC_ATTENTION, 2.0 * H * (rg ? s.tg2[k] : (double)B * Tg * Tg) * d * 3.0, (double)M * D * 2 * 5);
+              if (rg) EC_TRY(launch_relpos_attention2(ap, 1, st)); else
               // attention2.hip reads the natural layout only (its column masks assume the next head's finite data behind a head span); the
               // head-major test layout of odd head widths (EFFCONF_HEAD_MAJOR_ODD) stays on attention.hip
               if (e->attention_v2 && nat && relpos_attention2_supported(dpad)) EC_TRY(launch_relpos_attention2(ap, e->attention_v2, st));
@@ -622,7 +710,7 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
                 cp.g0 = ChainGemm{W.c_outp.w, W.c_outp.ldw, W.c_outp.bias, 0};
                 cp.ln[0] = ChainLn{W.ln_conv.g, W.ln_conv.b};
                 cp.g1 = ChainGemm{W.c_pw1.w, W.c_pw1.ldw, W.c_pw1.bias, W.c_pw1_chunks};
-                cp.glu = gbuf; cp.ldg = ld8(De); cp.Ng = De; cp.T = T; cp.Tp = Tp; cp.consts = W.cc_b;
+                cp.glu = gbuf; cp.ldg = ld8(De); cp.Ng = De; cp.T = qT; cp.Tp = qTp; cp.consts = W.cc_b;
                 PROF(PC_GEMM_OTHER, 2.0 * M * (double)D * (D + 2.0 * De), (double)M * D * 10 + (double)M * De * 2 + 2.0 * D * (D + 2.0 * De));
                 EC_TRY(launch_chain(cp, CHAIN_B, st));
             } else {
@@ -639,17 +727,20 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
             { PROF(PC_LAYERNORM, 0, (double)M * D * 6); EC_TRY(launch_layernorm(x, M, D, W.ln_conv.g, W.ln_conv.b, nullptr, a, ld8(D), nullptr, nullptr, st)); }
             EC_TRY(run_rs_or_tiled(e, PC_GEMM_OTHER, st, a, ld8(D), M, W.pw1, 2, EPI_GLU_BF16, gbuf, ld8(De)));
         }
-        { PROF(PC_DWCONV, 2.0 * Mo * (double)De * b.kernel_size, (double)M * De * 2 + (double)Mo * De * 2); EC_TRY(launch_dwconv(gbuf, B, T, To, De, ld8(De), W.dw_w, W.dw_b, b.kernel_size, b.conv_stride, cbuf, st)); }
+        RaggedConv rc{};
+        if (rg) { rc.in_off = row_off + (size_t)k * (B + 1); rc.in_len = lens + (size_t)k * B; rc.out_off = row_off + (size_t)(k + 1) * (B + 1);
+                  rc.out_len = lens + (size_t)(k + 1) * B; rc.tile_off = tile_off + (size_t)k * (B + 1); rc.tiles = s.tiles[k]; rc.n = B; rc.out_rows = Mo; }
+        { PROF(PC_DWCONV, 2.0 * Mo * (double)De * b.kernel_size, (double)M * De * 2 + (double)Mo * De * 2); EC_TRY(launch_dwconv(gbuf, B, T, To, De, ld8(De), W.dw_w, W.dw_b, b.kernel_size, b.conv_stride, cbuf, st, rg ? &rc : nullptr)); }
         snprintf(nm, sizeof(nm), "blocks.%d.dw", k); trace_add(e, st, nm, cbuf, Mo, De, ld8(De), 1);
         if (D != De) {   // 1x1 strided conv on frames 0, s, 2s, ...  (blocks.py:106-110)
-            { PROF(PC_MISC, 0, (double)Mo * D * 6); EC_TRY(launch_cast_rows(x, D, T, b.conv_stride, To, B, xs, ld8(D), st)); }
+            { PROF(PC_MISC, 0, (double)Mo * D * 6); EC_TRY(launch_cast_rows(x, D, T, b.conv_stride, To, B, xs, ld8(D), st, rg ? &rc : nullptr)); }
             EC_TRY(run_rs_or_tiled(e, PC_GEMM_OTHER, st, xs, ld8(D), Mo, W.res, 1, EPI_F32, xalt, De));
             std::swap(x, xalt);
         } else if (b.conv_stride > 1) {
             return fail("strided block without expansion is not native (no shipped config uses it)");
         }
         const bool last = (k == nb - 1);
-        float* xo = last ? out : x;
+        float* xo = (last && !rg) ? out : x;        // ragged: the last block writes its rows in place; emit_rows pads them into `out` below
         if (chain_tail) {
             bool next_head = false;
             if (!last) {
@@ -666,7 +757,8 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
             double fl = 2.0 * Mo * (double)De * (De + 2.0 * De * b.ff_ratio), by = (double)Mo * De * 10 + 2.0 * De * De * (1 + 2.0 * b.ff_ratio);
             if (next_head) {
                 const EcBlock& nbk = e->blocks[k + 1];
-                const int Tn = s.Tin[k + 1], Gn = nbk.group_size, Tpn = ec_round_up(Tn, Gn);
+                const int Gn = nbk.group_size;
+                const int Tn = rg ? Mo : s.Tin[k + 1], Tpn = rg ? Mo : ec_round_up(Tn, Gn);
                 GemmParams pn{};
                 pn.qu = reinterpret_cast<bf16_t*>(ws + w.qu);
                 pn.kh = reinterpret_cast<bf16_t*>(ws + w.kh); pn.vt = reinterpret_cast<bf16_t*>(ws + w.vt);
@@ -697,7 +789,12 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
         have_a = !last;
         snprintf(nm, sizeof(nm), "blocks.%d.out", k); trace_add(e, st, nm, xo, Mo, De, De, 0);
     }
-    if (!capturing) e->e_cache_put(ws, B, s.Tm);
+    if (!capturing) e->e_cache_put(ws, B, s.Tm, w.eh_blk[0]);
+    if (rg) {
+        const RaggedRows rl = rows_at(nb);
+        PROF(PC_MISC, 0, (double)s.Mfinal * e->blocks.back().dim_expand * 4 + (double)B * out_frames * e->blocks.back().dim_expand * 4);
+        EC_TRY(launch_emit_rows(x, e->blocks.back().dim_expand, rl.off, rl.len, B, out_frames, out, st));
+    }
     return 0;
 }
 
@@ -1155,6 +1252,11 @@ int effconf_encoder_finalize(EcEncoder* e) {
         }
     }
     e->block_stride = upload(e, strides);
+    {
+        std::vector<int> gs, hs;
+        for (const EcBlock& b : e->blocks) { gs.push_back(b.group_size); hs.push_back(b.num_heads); }
+        e->block_group = upload(e, gs); e->block_heads = upload(e, hs);
+    }
     if (c.vocab_size > 0) {
         const HostTensor *w = find(e, "fc.weight"), *b = find(e, "fc.bias");
         const int D = e->blocks.back().dim_expand, V = c.vocab_size;
@@ -1252,6 +1354,51 @@ int effconf_encoder_forward(EcEncoder* e, const float* audio, const int64_t* x_l
     { PROF(PC_MEL, 0, (double)batch * n_samples * 4 + (double)batch * e->cfg.n_mels * Tm * 4); EC_TRY(launch_mel(audio, batch, n_samples, e->mel, e->cfg.n_fft, e->cfg.hop_length, e->cfg.n_mels, Tm,
                       e->cfg.normalize, e->cfg.mean, e->cfg.std, mel, st)); }
     return forward_core(e, mel, x_len, 1, s, w, ws, out, out_len, st);
+}
+
+// ---- ragged batches: every utterance at its own length (the reference's result for that utterance ALONE: no pad frames exist)
+static bool ragged_host_lengths(const EcEncoder* e, const int64_t* host_len, int32_t batch, int32_t n, int32_t from_audio, std::vector<int>* tm) {
+    tm->resize(batch);
+    for (int b = 0; b < batch; ++b) {
+        const int64_t l = host_len[b];
+        if (l > n || (from_audio ? l <= e->cfg.n_fft / 2 : l < 1)) return false;
+        (*tm)[b] = from_audio ? (int)(l / e->cfg.hop_length + 1) : (int)l;
+    }
+    return true;
+}
+
+size_t effconf_encoder_workspace_bytes_ragged(const EcEncoder* e, const int64_t* x_len_host, int32_t batch, int32_t n, int32_t from_audio) {
+    if (!e || !x_len_host || batch <= 0 || n <= 0) return 0;
+    std::vector<int> tm;
+    if (!ragged_host_lengths(e, x_len_host, batch, n, from_audio, &tm)) return 0;
+    const Shapes s = make_shapes_ragged(e, tm);
+    Shapes full = s; full.Tm = from_audio ? n / e->cfg.hop_length + 1 : n;      // the mel image keeps the input's row pitch
+    return make_workspace(e, full, from_audio != 0).total;
+}
+
+int effconf_encoder_forward_ragged(EcEncoder* e, const float* x, const int64_t* x_len, const int64_t* x_len_host, int32_t batch, int32_t n,
+                                   int32_t from_audio, float* out, int32_t out_frames, int64_t* out_len, void* workspace, size_t workspace_bytes,
+                                   void* stream) {
+    if (!e || !e->finalized) return fail("encoder not finalized");
+    if (e->exact_on) return fail("ragged batches run on the bf16 path (precision = fp32 keeps rectangular batches)");
+    if (!x || !x_len || !x_len_host || !out || !workspace || batch <= 0 || n <= 0 || out_frames <= 0) return fail("bad argument");
+    std::vector<int> tm;
+    if (!ragged_host_lengths(e, x_len_host, batch, n, from_audio, &tm)) return fail("ragged lengths out of range (audio: n_fft / 2 < len <= n; mel: 1 <= len <= n)");
+    Shapes s = make_shapes_ragged(e, tm);
+    if (s.Tout.back() > out_frames) return fail("out_frames smaller than the longest utterance's output");
+    s.Tm = from_audio ? n / e->cfg.hop_length + 1 : n;        // pitch of the mel image = the input's row pitch (every utterance masks at its own length)
+    const Workspace w = make_workspace(e, s, from_audio != 0);
+    if (workspace_bytes < w.total) return fail("workspace too small");
+    char* ws = reinterpret_cast<char*>(workspace);
+    hipStream_t st = (hipStream_t)stream;
+    const float* mel = x;
+    if (from_audio) {
+        float* m = reinterpret_cast<float*>(ws + w.mel);
+        PROF(PC_MEL, 0, (double)batch * n * 4 + (double)batch * e->cfg.n_mels * s.Tm * 4);
+        EC_TRY(launch_mel(x, batch, n, e->mel, e->cfg.n_fft, e->cfg.hop_length, e->cfg.n_mels, s.Tm, e->cfg.normalize, e->cfg.mean, e->cfg.std, m, st, x_len));
+        mel = m;
+    }
+    return forward_core(e, mel, x_len, from_audio, s, w, ws, out, out_len, st, out_frames);
 }
 
 int effconf_mel_frontend(EcEncoder* e, const float* audio, int32_t batch, int32_t n_samples, float* mel, void* stream) {

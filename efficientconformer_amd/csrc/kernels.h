@@ -3,6 +3,25 @@
 #pragma once
 #include "common.h"
 
+// ---------------------------------------------------------------- ragged batches
+// Every utterance at its own length in ONE concatenated row space (no pad frames: the reference's result for that utterance alone).
+// Descriptor of the rows at one position of the network: device arrays in the workspace (lengths_ragged_kernel fills them) + host totals.
+struct RaggedRows {
+    const int* off;    // dev [n + 1]: first row of every utterance; an utterance's rows are padded to a multiple of the attention group size
+    const int* len;    // dev [n]: valid frames per utterance
+    int n;             // utterances
+    int rows;          // off[n]
+    int tmax;          // longest utterance (frames)
+};
+
+// ragged batch view of a frame-mixing kernel with a stride (depthwise conv, conv_res decimation): per-utterance lengths and first rows on
+// the input and on the output side (dev arrays), the prefix sums of the utterances' 128-frame output tiles and their host total
+struct RaggedConv {
+    const int *in_off, *in_len, *out_off, *out_len;   // [n + 1], [n], [n + 1], [n]
+    const int* tile_off; int tiles;                   // [n + 1] prefix of ceil(padded output rows / 128); tile_off[n]
+    int n, out_rows;                                  // utterances; out_off[n]
+};
+
 // ---------------------------------------------------------------- GEMM  (gemm.hip)
 // C[m, n] = sum_k A[m, k] * W[n, k] + bias[n]   (A bf16 row-major, W bf16 "Linear weight" layout [N][K])
 // W must be packed by pack_weight_bf16(): [round_up(N,128)][round_up(K,64)] zero padded; bias [round_up(N,128)].
@@ -106,7 +125,9 @@ int launch_layernorm(const float* x, int M, int D, const float* gamma, const flo
 int launch_layernorm_residual(const float* x, const float* r, float alpha, int M, int D, const float* gamma, const float* beta, float* y, hipStream_t s);
 // out[m][:] = bf16(x[src_row(m)][:])   (strided frame decimation + cast for conv_res, blocks.py:106-110)
 int launch_cast_rows(const float* x, int D, int rows_per_batch, int stride, int out_rows_per_batch, int batch,
-                     bf16_t* out, int ld_out, hipStream_t s);
+                     bf16_t* out, int ld_out, hipStream_t s, const RaggedConv* rc = nullptr);
+// ragged rows -> the caller's (B, t_out, D) fp32 output, zero filled behind every utterance's own last frame
+int launch_emit_rows(const float* x, int D, const int* off, const int* len, int batch, int t_out, float* out, hipStream_t s);
 
 // ---------------------------------------------------------------- attention  (attention.hip)
 struct AttnParams {
@@ -121,6 +142,11 @@ struct AttnParams {
     bf16_t* out; int ldo;                   // [B*T][ldo] un-grouped attention output (rows t >= T dropped)
     float scale;                            // 1/sqrt(d)
     int force_waves;                        // attention.hip only (option "attn_waves"): 8 = one 128-query workgroup per CU where LDS allows
+    // ragged batch (attention2.hip, natural layout): rag_off [B + 1] first row of every utterance in the Q / K / V / out row space (rows
+    // padded to the group size per utterance), lens[b] = its frames (all valid), rag_wg [B + 1] prefix sums of H x ceil(Tg_b / 64)
+    // workgroups in the kernel's utterance order (0, 8, 16, .. | 1, 9, ..), rag_nwg their total, rag_tgmax = Tg of the longest utterance
+    // (`eh` holds the positional rows for THAT length); T / Tg are then upper bounds only
+    const int *rag_off, *rag_wg; int rag_nwg, rag_tgmax;
 };
 int launch_relpos_attention(const AttnParams& p, hipStream_t s);
 // second generation (attention2.hip): 32 queries per wave, transposing LDS reads for V; waves = 2 (64-query workgroups) or 4
@@ -129,6 +155,7 @@ int launch_relpos_attention2(const AttnParams& p, int waves, hipStream_t s);
 // rows t in [T, Tp) of the grouped view: Qu=u, Qv=v, K=V=0  (attentions.py:107-138, 671-675)
 int launch_attn_pad_rows(const GemmParams& p, int B, hipStream_t s);       // head-major buffers
 int launch_attn_pad_rows_nat(const GemmParams& p, int B, hipStream_t s);   // natural [B*Tp][D] buffers
+int launch_attn_pad_rows_ragged(bf16_t* qu, bf16_t* kh, bf16_t* vt, const float* u, int D, int G, const RaggedRows& rg, hipStream_t s);
 
 // ---------------------------------------------------------------- convolutions  (conv.hip)
 // mel (B, F, Tm) f32 -> (B*T1, C*F/2) bf16, feature index c*(F/2)+f; 3x3 s2 p1 conv (Cin=1) + folded BN + Swish
@@ -140,8 +167,9 @@ int launch_sublinear_fused(const float* mel, int B, int F, int Tm, int T1, const
                            const bf16_t* W, int ldw, const float* bias, int N, float* out, int ldc, hipStream_t s);
 // second generation (sublinear2.hip): row-stationary, the 3x3 conv on the MFMA pipe.  groups = 32-channel groups (0: shape not supported)
 int sublinear2_groups(int F, int C, int N);
+// rg != null: ragged rows (rag_tm: dev [n] mel frames per utterance; Tm stays the pitch of the mel image; pad rows are written as zeros)
 int launch_sublinear2(const float* mel, int B, int F, int Tm, int T1, const float* ctab, const bf16_t* Wp, const float* bias, int C, int N,
-                      float* out, int ldc, hipStream_t s);
+                      float* out, int ldc, hipStream_t s, const RaggedRows* rg = nullptr, const int* rag_tm = nullptr);
 // two-layer subsampling (conv2.hip): layer 1 channel-last, layer 2 implicit GEMM
 int launch_subsample_conv_cl(const float* mel, int B, int F, int Tm, int T1, const float* w9, const float* bias, int C, int Cp,
                              bf16_t* out, hipStream_t s);
@@ -149,7 +177,7 @@ int launch_conv2_igemm(const bf16_t* act1, int B, int F1, int T1, int Cp, const 
                        int N, int F2, int T2, bf16_t* out, hipStream_t s);
 // g (B, T, ld) bf16 -> (B, To, ld) bf16: depthwise conv k taps ("same" zero pad), stride s, folded BN, Swish
 int launch_dwconv(const bf16_t* g, int B, int T, int To, int C, int ld, const float* w_kc, const float* bias,
-                  int ksize, int stride, bf16_t* out, hipStream_t s);
+                  int ksize, int stride, bf16_t* out, hipStream_t s, const RaggedConv* rc = nullptr);
 
 // ---------------------------------------------------------------- fp32-operand "exact" mode  (exact.hip)
 struct ExGemmParams {              // C = epi(A W^T + bias), everything fp32 (v_mfma_f32_32x32x2_f32)
@@ -187,8 +215,10 @@ struct MelTables {                 // device tables built once per encoder
     const float* fb_weight;        // packed non-zero triangular weights
     int fb_nnz;                    // number of packed weights
 };
+// ragged_len != null (dev i64 [B], samples): every row at its own length (reflect padding at its own ends, len / hop + 1 frames); L and
+// Tm stay the row pitches of `audio` and of the mel image
 int launch_mel(const float* audio, int B, int L, const MelTables& t, int n_fft, int hop, int n_mels, int Tm,
-               int normalize, float mean, float std, float* mel, hipStream_t s);
+               int normalize, float mean, float std, float* mel, hipStream_t s, const int64_t* ragged_len = nullptr);
 // diagnostics (tools/mel_repro.py): kernel variant (mel.hip), unused dynamic LDS per workgroup, counters dbg[8]
 int launch_mel_debug(int variant, int extra_lds, const float* audio, int B, int L, const MelTables& t, int n_fft, int hop, int n_mels,
                      int Tm, int normalize, float mean, float std, float* mel, unsigned int* dbg, hipStream_t s);
@@ -203,6 +233,16 @@ int launch_mel_debug_pk(int variant, int extra_lds, const float* audio, int B, i
 // stage lengths: mel frames -> per-stage frame counts (int32), final int64 out_len
 int launch_lengths(const int64_t* x_len, int B, int from_audio, int hop, int sub_layers, const int* block_stride,
                    int n_blocks, int* stage_lens /*[n_blocks+1][B]*/, int64_t* out_len, hipStream_t s);
+// ragged batches: the same lengths plus, per block position k = 0 .. n_blocks (position n_blocks = the encoder output):
+//   mel_len [B]                 mel frames per utterance
+//   row_off [k][B + 1]          prefix sums of the utterances' rows, every utterance padded to a multiple of group[k] (group[n_blocks] = 1)
+//   wg_off  [k][B + 1] (k < n_blocks)  prefix sums of heads[k] x ceil(ceil(len / group[k]) / 64) attention workgroups in the attention kernels'
+//                               utterance order (0, 8, 16, .. | 1, 9, ..)
+//   tile_off[k][B + 1] (k < n_blocks)  prefix sums of ceil(padded output rows of block k / 128) depthwise-conv tiles
+// One workgroup; B <= 4096.
+int launch_lengths_ragged(const int64_t* x_len, int B, int from_audio, int hop, int sub_layers, const int* block_stride, const int* group,
+                          const int* heads, int n_blocks, int* stage_lens, int* mel_len, int* row_off, int* wg_off, int* tile_off,
+                          int64_t* out_len, hipStream_t s);
 // logits = x W^T + b in fp32 (Wt is [D][V]), argmax per frame (first max), optional logits out
 int launch_ctc_argmax(const float* x, int M, int D, const float* Wt, const float* bias, int V,
                       int* preds, float* logits_or_null, hipStream_t s, int use_mfma = 1);   // use_mfma: fp32-MFMA kernel where the frame tile fits LDS

@@ -85,7 +85,8 @@ __device__ __forceinline__ float2 reread(const float2* p) {           // a secon
 template <int V>
 __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ audio, int L, MelTables tb, int hop,
                                                   int n_mels, int Tm, int normalize, float mean, float inv_std,
-                                                  float* __restrict__ mel, unsigned int* __restrict__ dbg) {
+                                                  float* __restrict__ mel, unsigned int* __restrict__ dbg,
+                                                  const int64_t* __restrict__ rag_len = nullptr) {
     constexpr int CAN = (V & 1) ? 512 : 0;                       // canary words on each side of the exchange buffers
     constexpr int O_SBUF = CAN * 4, O_POST = O_SBUF + 4 * 2 * 8 * P1 * 8, O_STW = O_POST + CAN * 4, O_SWIN = O_STW + NFFT * 8,
                   O_SOUT = O_SWIN + NFFT * 4, O_SFW = O_SOUT + MAX_MELS * (FRAMES_PER_BLOCK + 1) * 4, O_END = O_SFW + MAX_FBW * 4;
@@ -105,6 +106,11 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ audi
     auto neq = [](float2 a, float2 b) { return (__float_as_uint(a.x) != __float_as_uint(b.x)) | (__float_as_uint(a.y) != __float_as_uint(b.y)); };
     const int tiles = (Tm + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK;
     const int b = blockIdx.x / tiles, t0 = (blockIdx.x % tiles) * FRAMES_PER_BLOCK;
+    // ragged batch (rag_len != null): the utterance runs at ITS OWN length Lb - reflect padding at its own ends, Lb / hop + 1 frames -
+    // exactly what the reference computes for it alone; the row pitch of audio and of the mel image stay L and Tm
+    const int Lb = rag_len ? (int)rag_len[b] : L;
+    const int Tmb = rag_len ? Lb / hop + 1 : Tm;
+    if (t0 >= Tmb) return;                                       // workgroup-uniform: a tile past the utterance's last frame
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool fw_lds = tb.fb_nnz <= MAX_FBW;
     {   // tables -> LDS: every global load of the set-up is issued before the first wait (the rolled copy loops paid one memory
@@ -140,8 +146,8 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ audi
         for (int j = 0; j < 8; ++j) {
             const int n = lane + 64 * j;
             int sa = ta * hop - NFFT / 2 + n, sb = sa + hop;
-            sa = sa < 0 ? -sa : sa; sa = sa >= L ? 2 * (L - 1) - sa : sa; sa = sa < 0 ? 0 : (sa >= L ? L - 1 : sa);
-            sb = sb < 0 ? -sb : sb; sb = sb >= L ? 2 * (L - 1) - sb : sb; sb = sb < 0 ? 0 : (sb >= L ? L - 1 : sb);
+            sa = sa < 0 ? -sa : sa; sa = sa >= Lb ? 2 * (Lb - 1) - sa : sa; sa = sa < 0 ? 0 : (sa >= Lb ? Lb - 1 : sa);
+            sb = sb < 0 ? -sb : sb; sb = sb >= Lb ? 2 * (Lb - 1) - sb : sb; sb = sb < 0 ? 0 : (sb >= Lb ? Lb - 1 : sb);
             xa[j] = a[sa]; xb[j] = a[sb];
         }
     };
@@ -155,7 +161,7 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ audi
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float w = swin[lane + 64 * j];
-            v[j] = make_float2(ta < Tm ? nxa[j] * w : 0.f, tbb < Tm ? nxb[j] * w : 0.f);
+            v[j] = make_float2(ta < Tmb ? nxa[j] * w : 0.f, tbb < Tmb ? nxb[j] * w : 0.f);
         }
         if (it + 1 < FRAMES_PER_BLOCK / 8) gather(ta + 2, nxa, nxb);
         // ---- step 1: lane = 8*n2 + n3 holds x[64*n1 + lane]; DFT over n1, twiddle W64^{n2 k1}
@@ -259,7 +265,7 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ audi
     // ---- coalesced store: rows of FRAMES_PER_BLOCK consecutive frames
     for (int i = tid; i < n_mels * FRAMES_PER_BLOCK; i += 256) {
         const int m = i / FRAMES_PER_BLOCK, fl = i - m * FRAMES_PER_BLOCK;
-        if (t0 + fl < Tm) mel[((size_t)b * n_mels + m) * Tm + t0 + fl] = sout[m][fl];
+        if (t0 + fl < Tmb) mel[((size_t)b * n_mels + m) * Tm + t0 + fl] = sout[m][fl];
     }
     if constexpr ((V & 1) != 0) {
         const unsigned int* c0 = reinterpret_cast<const unsigned int*>(lds), *c1 = reinterpret_cast<const unsigned int*>(lds + O_POST);
@@ -277,12 +283,12 @@ using namespace mel_pk_build;
 #endif
 
 int launch_mel(const float* audio, int B, int L, const MelTables& t, int n_fft, int hop, int n_mels, int Tm,
-               int normalize, float mean, float std, float* mel, hipStream_t s) {
+               int normalize, float mean, float std, float* mel, hipStream_t s, const int64_t* ragged_len) {
     if (B <= 0) return 0;
     if (n_fft != NFFT || n_mels > MAX_MELS || L <= n_fft / 2) return -2;
     const int tiles = (Tm + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK;
     hipLaunchKernelGGL(mel_kernel<0>, dim3(B * tiles), dim3(256), 0, s, audio, L, t, hop, n_mels, Tm, normalize, mean,
-                       1.0f / std, mel, (unsigned int*)nullptr);
+                       1.0f / std, mel, (unsigned int*)nullptr, ragged_len);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -296,7 +302,7 @@ int launch_mel_debug(int variant, int extra_lds, const float* audio, int B, int 
 #endif
     const int tiles = (Tm + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK;
 #define MEL_DBG_CASE(VV) case VV: { static LdsAttr attr; ensure_dynamic_lds(reinterpret_cast<const void*>(&mel_kernel<VV>), extra_lds, attr); \
-        hipLaunchKernelGGL(mel_kernel<VV>, dim3(B * tiles), dim3(256), extra_lds, s, audio, L, t, hop, n_mels, Tm, normalize, mean, 1.0f / std, mel, dbg); break; }
+        hipLaunchKernelGGL(mel_kernel<VV>, dim3(B * tiles), dim3(256), extra_lds, s, audio, L, t, hop, n_mels, Tm, normalize, mean, 1.0f / std, mel, dbg, (const int64_t*)nullptr); break; }
     switch (variant) {
         MEL_DBG_CASE(0) MEL_DBG_CASE(1) MEL_DBG_CASE(2) MEL_DBG_CASE(3) MEL_DBG_CASE(4) MEL_DBG_CASE(5) MEL_DBG_CASE(6) MEL_DBG_CASE(7)
         default: return -2;

@@ -85,20 +85,46 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 }
 
 __global__ __launch_bounds__(256) void cast_rows_kernel(const float* __restrict__ x, int D, int rows_per_batch, int stride,
-                                                        int out_rows_per_batch, int total_out_rows, bf16_t* out, int ld_out) {
+                                                        int out_rows_per_batch, int total_out_rows, bf16_t* out, int ld_out, RaggedConv rc) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= total_out_rows) return;
-    const int b = row / out_rows_per_batch, r = row - b * out_rows_per_batch;
-    const float* xr = x + ((size_t)b * rows_per_batch + (size_t)r * stride) * D;
+    size_t src;
+    bool valid = true;
+    if (rc.out_off) {        // ragged batch: output row -> (utterance, frame); rows behind the utterance's last frame (group padding) are zeros
+        const int b = ragged_find(rc.out_off, rc.n, row), r = row - rc.out_off[b];
+        valid = r < rc.out_len[b];
+        src = (size_t)rc.in_off[b] + (size_t)(valid ? r : 0) * stride;
+    } else {
+        const int b = row / out_rows_per_batch, r = row - b * out_rows_per_batch;
+        src = (size_t)b * rows_per_batch + (size_t)r * stride;
+    }
+    const float* xr = x + src * D;
     bf16_t* o = out + (size_t)row * ld_out;
     for (int c = lane * 4; c < ld_out; c += 256) {
         uint2 w = make_uint2(0u, 0u);
-        if (c < D) {
+        if (c < D && valid) {
             const float4 v = *reinterpret_cast<const float4*>(xr + c);
             w = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
         }
         *reinterpret_cast<uint2*>(o + c) = w;
+    }
+}
+
+// ragged rows [off[b], off[b] + len[b]) of x -> out[b][0 .. len[b]), zeros up to t_out: one wave per output row
+__global__ __launch_bounds__(256) void emit_rows_kernel(const float* __restrict__ x, int D, const int* __restrict__ off, const int* __restrict__ len,
+                                                        int batch, int t_out, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= batch * t_out) return;
+    const int b = row / t_out, t = row - b * t_out;
+    const bool valid = t < len[b];
+    const float* xr = x + ((size_t)off[b] + (valid ? t : 0)) * D;
+    float* o = out + (size_t)row * D;
+    for (int c = lane * 4; c < D; c += 256) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid) v = *reinterpret_cast<const float4*>(xr + c);
+        *reinterpret_cast<float4*>(o + c) = v;
     }
 }
 
@@ -163,11 +189,20 @@ int launch_layernorm(const float* x, int M, int D, const float* gamma, const flo
 }
 
 int launch_cast_rows(const float* x, int D, int rows_per_batch, int stride, int out_rows_per_batch, int batch,
-                     bf16_t* out, int ld_out, hipStream_t s) {
-    const int total = out_rows_per_batch * batch;
+                     bf16_t* out, int ld_out, hipStream_t s, const RaggedConv* rcp) {
+    RaggedConv rc{};
+    if (rcp) rc = *rcp;
+    const int total = rcp ? rc.out_rows : out_rows_per_batch * batch;
     if (total <= 0) return 0;
     if (D % 4 || ld_out % 4) return -2;
     hipLaunchKernelGGL(cast_rows_kernel, dim3((total + 3) / 4), dim3(256), 0, s, x, D, rows_per_batch, stride,
-                       out_rows_per_batch, total, out, ld_out);
+                       out_rows_per_batch, total, out, ld_out, rc);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_emit_rows(const float* x, int D, const int* off, const int* len, int batch, int t_out, float* out, hipStream_t s) {
+    if (batch <= 0 || t_out <= 0) return 0;
+    if (D % 4) return -2;
+    hipLaunchKernelGGL(emit_rows_kernel, dim3((batch * t_out + 3) / 4), dim3(256), 0, s, x, D, off, len, batch, t_out, out);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

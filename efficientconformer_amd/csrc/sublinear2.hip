@@ -55,7 +55,8 @@ __device__ __forceinline__ uint32_t split_hi(float x) { return __float_as_uint(x
 template <int CG, int NT, int NBUF, int NW>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void sublinear2_kernel(const float* __restrict__ mel, int F, int Tm, int T1, int M,
                                                             const float* __restrict__ ctab /*[CG*32][16]*/, const bf16_t* __restrict__ Wp,
-                                                            const float* __restrict__ bias, int N, float* __restrict__ out, int ldc) {
+                                                            const float* __restrict__ bias, int N, float* __restrict__ out, int ldc,
+                                                            const int* __restrict__ rag_off, const int* __restrict__ rag_t1, const int* __restrict__ rag_tm, int rag_n) {
     constexpr int KSF = 2 * CG, P1 = 2 * KSF;                    // k-steps and 16-byte pieces per weight row of one f
     constexpr int SLAB = NT * CH * P1 * 16;                      // bytes of one f's weight slab
     constexpr int NDMA = NT * CH * P1 / 64, PER = NDMA / NW;     // wave-DMAs per slab
@@ -107,11 +108,20 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void sublinear2_kernel(co
     //      into VGPRs were tried first and broke as soon as the allocator moved one of those registers (AGPR / scratch copies taken before
     //      the data had landed: NaNs on Medium) - and the queue stays countable: per iteration 6 row pieces, then the slab's PER pieces.
     const int m = m_base + lr, mc = m < M ? m : M - 1;
-    const int b = mc / T1, t = mc - b * T1;
+    // rectangular batch: row m = (b, t) of B x T1.  Ragged batch (rag_off != null): utterance b owns rows [rag_off[b], rag_off[b + 1]) of
+    // the concatenated row space, has rag_t1[b] frames after the subsampling (rows past them pad the utterance to a multiple of the
+    // attention group size: written as zeros) and rag_tm[b] mel frames (the conv's zero padding starts THERE); Tm stays the row pitch.
+    int b, t, tmb = Tm;
+    bool pad_row = false;
+    if (rag_off) {
+        b = ragged_find(rag_off, rag_n, mc); t = mc - rag_off[b]; tmb = rag_tm[b];
+        pad_row = t >= rag_t1[b];
+        t = pad_row ? 0 : t;
+    } else { b = mc / T1; t = mc - b * T1; }
     const float* melb = mel + (size_t)b * F * Tm;
     int col[3]; bool cok[3];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) { const int tc = 2 * t - 1 + j; cok[j] = tc >= 0 && tc < Tm; col[j] = tc < 0 ? 0 : (tc < Tm ? tc : Tm - 1); }
+    for (int j = 0; j < 3; ++j) { const int tc = 2 * t - 1 + j; cok[j] = tc >= 0 && tc < tmb; col[j] = tc < 0 ? 0 : (tc < tmb ? tc : tmb - 1); }
     auto row_ptr = [&](int fr) { return melb + (size_t)(fr < 0 ? 0 : (fr < F ? fr : F - 1)) * Tm; };
     auto mask_row = [&](int fr, float (&r)[3]) __attribute__((always_inline)) {     // zero outside the image (conv padding 1)
         const bool ok = fr >= 0 && fr < F;
@@ -227,20 +237,22 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void sublinear2_kernel(co
             const int n = nt * 32 + q * 8 + half * 4;
             const float4 bz = *reinterpret_cast<const float4*>(bias + n);          // bias is padded to a multiple of 128
             xc[nt][4 * q + 0] += bz.x; xc[nt][4 * q + 1] += bz.y; xc[nt][4 * q + 2] += bz.z; xc[nt][4 * q + 3] += bz.w;
+            if (pad_row) { xc[nt][4 * q + 0] = 0.f; xc[nt][4 * q + 1] = 0.f; xc[nt][4 * q + 2] = 0.f; xc[nt][4 * q + 3] = 0.f; }
         }
     store_rows<NT>(reinterpret_cast<char*>(out), (size_t)ldc * 4, N, m_base, M, smem + wave * STG_BYTES, lane, xc);
 }
 
 template <int CG, int NT, int NBUF, int NW>
 int launch2(const float* mel, int B, int F, int Tm, int T1, const float* ctab, const bf16_t* Wp, const float* bias, int N, float* out, int ldc,
-            hipStream_t s) {
+            hipStream_t s, const RaggedRows* rg, const int* rag_tm) {
     constexpr int P1 = 4 * CG, SLAB = NT * CH * P1 * 16;
-    const int M = B * T1;
+    const int M = rg ? rg->rows : B * T1;
     const int lds = NBUF * SLAB + NW * 2 * 6 * 256 > NW * STG_BYTES ? NBUF * SLAB + NW * 2 * 6 * 256 : NW * STG_BYTES;
     if (lds > 160 * 1024) return -4;
     static LdsAttr attr;
     ensure_dynamic_lds(reinterpret_cast<const void*>(&sublinear2_kernel<CG, NT, NBUF, NW>), lds, attr);
-    hipLaunchKernelGGL((sublinear2_kernel<CG, NT, NBUF, NW>), dim3((M + NW * 32 - 1) / (NW * 32)), dim3(NW * 64), lds, s, mel, F, Tm, T1, M, ctab, Wp, bias, N, out, ldc);
+    hipLaunchKernelGGL((sublinear2_kernel<CG, NT, NBUF, NW>), dim3((M + NW * 32 - 1) / (NW * 32)), dim3(NW * 64), lds, s, mel, F, Tm, T1, M, ctab, Wp, bias, N, out, ldc,
+                       rg ? rg->off : nullptr, rg ? rg->len : nullptr, rag_tm, rg ? rg->n : 0);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -258,11 +270,12 @@ int sublinear2_groups(int F, int C, int N) {
 
 // ctab: [32 * groups][16] fp32 (9 folded taps, folded bias, zeros); Wp: [F/2][32 * NT rows][32 * groups] bf16, K-permuted per 16 (encoder.hip)
 int launch_sublinear2(const float* mel, int B, int F, int Tm, int T1, const float* ctab, const bf16_t* Wp, const float* bias, int C, int N,
-                      float* out, int ldc, hipStream_t s) {
+                      float* out, int ldc, hipStream_t s, const RaggedRows* rg, const int* rag_tm) {
     if (B <= 0 || T1 <= 0) return 0;
+    if (rg && (!rag_tm || rg->rows <= 0)) return rg->rows <= 0 ? 0 : -2;
     switch (sublinear2_groups(F, C, N)) {
-        case 4: return launch2<4, 4, 3, 8>(mel, B, F, Tm, T1, ctab, Wp, bias, N, out, ldc, s);
-        case 6: return launch2<6, 6, 2, 4>(mel, B, F, Tm, T1, ctab, Wp, bias, N, out, ldc, s);
+        case 4: return launch2<4, 4, 3, 8>(mel, B, F, Tm, T1, ctab, Wp, bias, N, out, ldc, s, rg, rag_tm);
+        case 6: return launch2<6, 6, 2, 4>(mel, B, F, Tm, T1, ctab, Wp, bias, N, out, ldc, s, rg, rag_tm);
     }
     return -2;
 }

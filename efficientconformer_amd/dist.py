@@ -157,7 +157,7 @@ class ShardedEncoder:
             chunks.append(GatheredChunk(lo, hi, g, gl, rows, keep, None, None))
 
     # ------------------------------------------------------------------ entry points
-    def encode_shard(self, xs: torch.Tensor, ls: torch.Tensor, global_batch: Optional[int] = None, range_pad=None) -> Gathered:
+    def encode_shard(self, xs: torch.Tensor, ls: torch.Tensor, global_batch: Optional[int] = None, range_pad=None, x_len_host=None) -> Gathered:
         """This rank's rows (already selected; the same number of rows on every rank) -> gathered chunks of the global batch.
         `range_pad`: padded length per row range for `ConformerEncoder.trim_sub_batches` - the SAME list on every rank (the maximum
         over the ranks' shards), so that every rank launches identical shapes and the collectives stay fixed-size."""
@@ -166,6 +166,8 @@ class ShardedEncoder:
         chunks: List[GatheredChunk] = []
         if self._hooked:
             kw = {"range_pad": range_pad} if range_pad is not None else {}
+            if x_len_host is not None:
+                kw["x_len_host"] = x_len_host
             self.encoder(xs, ls, range_hook=lambda lo, hi, out, out_len: self._gather_range(lo, hi, out, out_len, gb, chunks), **kw)
         else:
             out, out_len = self.encoder(xs, ls)[:2]

@@ -115,6 +115,11 @@ class ConformerEncoder(nn.Module):
         # the whole batch; outputs beyond a range's own T_out are zero-filled.  Needs the lengths on the host (`x_len_host`, or one
         # device sync) or explicit `range_pad` lengths.
         self.trim_sub_batches = False
+        # Ragged batches (opt-in; bench.py's default since round 3): every utterance runs at ITS OWN length in one concatenated row space -
+        # no pad frames exist, so an utterance's output is the reference's output for that utterance ALONE (batch size 1), whatever else is
+        # in the batch (the reference's batched output differs from that by its pad-frame leakage).  With `sub_batches` > 1
+        # the row ranges are cut for equal valid frames.  Needs the lengths on the host (`x_len_host`, or one device sync).
+        self.ragged = False
         self.sub_batch_bounds = None       # optional row boundaries of the ranges (nsub - 1 increasing indices); default: equal row counts
         self._sub_streams: Dict[tuple, torch.cuda.Stream] = {}
         self.eval()
@@ -239,12 +244,13 @@ class ConformerEncoder(nn.Module):
             pass
 
     # ------------------------------------------------------------------ forward
-    def _workspace(self, batch: int, n: int, from_audio: bool, device) -> torch.Tensor:
+    def _workspace(self, batch: int, n: int, from_audio: bool, device, nbytes: Optional[int] = None) -> torch.Tensor:
         # one workspace per (device, stream, entry point), grown to the largest forward seen: forwards enqueued on different streams may
         # overlap on the GPU, forwards on one stream are ordered and share the buffer.  (Keyed by shape, real variable-length traffic
         # went through a fresh allocation - and a reset of every positional-embedding cache - on nearly every forward.)
         key = (str(device), torch.cuda.current_stream(device).cuda_stream, bool(from_audio))
-        nbytes = _lib.load().effconf_encoder_workspace_bytes(self._handle, batch, n, int(from_audio))
+        if nbytes is None:
+            nbytes = _lib.load().effconf_encoder_workspace_bytes(self._handle, batch, n, int(from_audio))
         ws = self._ws.get(key)
         if ws is None or ws.numel() < nbytes:
             ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
@@ -304,7 +310,25 @@ class ConformerEncoder(nn.Module):
 
         nsub = self.sub_batches if self.sub_batches is not None else (2 if batch >= self.sub_batch_min else 1)
         nsub = max(1, min(int(nsub), batch))
-        if self.sub_batch_bounds is not None and nsub > 1:      # explicit row boundaries (e.g. equal padded work per range)
+        host_lens = None
+        if self.ragged:
+            if self._exact:
+                raise RuntimeError("ragged batches run on the bf16 path (precision = 'fp32' keeps rectangular batches)")
+            hl = x_len_host if x_len_host is not None else lens.cpu()          # without host lengths: one device sync
+            host_lens = np.ascontiguousarray(np.asarray(hl.cpu() if torch.is_tensor(hl) else hl, dtype=np.int64))
+            if host_lens.shape != (batch,):
+                raise ValueError("x_len_host needs one length per utterance")
+        if self.ragged and nsub > 1 and self.sub_batch_bounds is None:
+            # equal VALID frames per row range (the work of a ragged range), boundaries at multiples of 8 rows
+            csum = np.concatenate([[0], np.cumsum(host_lens)])
+            cuts = [0]
+            for i in range(1, nsub):
+                c = int(np.searchsorted(csum, csum[-1] * i / nsub))
+                c = max(cuts[-1] + 1, min(batch - (nsub - i), (c + 4) // 8 * 8 if batch >= 16 * nsub else c))
+                cuts.append(c)
+            cuts.append(batch)
+            ranges = [(cuts[i], cuts[i + 1]) for i in range(nsub)]
+        elif self.sub_batch_bounds is not None and nsub > 1:      # explicit row boundaries (e.g. equal padded work per range)
             cuts = [0] + [int(b) for b in self.sub_batch_bounds] + [batch]
             if len(cuts) != nsub + 1 or any(cuts[i] >= cuts[i + 1] for i in range(nsub)):
                 raise ValueError("sub_batch_bounds must be %d increasing row indices inside (0, %d)" % (nsub - 1, batch))
@@ -318,7 +342,18 @@ class ConformerEncoder(nn.Module):
             if batch >= 32 * nsub:
                 cuts = [c - c % 16 for c in cuts[:-1]] + [batch]
             ranges = [(cuts[i], cuts[i + 1]) for i in range(nsub)]
-        pads = self._range_pads(ranges, n, from_audio, lens, lens_given, x_len_host, range_pad)
+        pads = None if self.ragged else self._range_pads(ranges, n, from_audio, lens, lens_given, x_len_host, range_pad)
+        fn_ragged = lib.effconf_encoder_forward_ragged
+
+        def launch_ragged(lo: int, hi: int):
+            hp = host_lens[lo:hi]
+            hptr = hp.ctypes.data_as(C.c_void_p)
+            nbytes = lib.effconf_encoder_workspace_bytes_ragged(self._handle, hptr, hi - lo, n, int(from_audio))
+            if nbytes == 0:
+                raise _lib.EffconfError("ragged batch: a length is out of range (audio: n_fft / 2 < len <= row length)")
+            ws = self._workspace(hi - lo, n, from_audio, x.device, nbytes)
+            _lib.check(fn_ragged(self._handle, x[lo:].data_ptr(), lens[lo:].data_ptr(), hptr, hi - lo, n, int(from_audio), out[lo:].data_ptr(), t_out,
+                                 out_len[lo:].data_ptr(), ws.data_ptr(), ws.numel(), torch.cuda.current_stream(x.device).cuda_stream), "encoder_forward_ragged")
 
         def launch_trimmed(lo: int, hi: int, ni: int):
             # the rows as their own batch, padded to ni <= n: what the reference computes when these utterances are collated alone
@@ -333,11 +368,11 @@ class ConformerEncoder(nn.Module):
                 out[lo:hi, ti:] = 0
 
         if nsub == 1:
-            launch(0, batch)
+            (launch_ragged if self.ragged else launch)(0, batch)
             if range_hook is not None:
                 range_hook(0, batch, out, out_len)
         else:
-            if from_audio and pads is None:
+            if from_audio and pads is None and not self.ragged:
                 # the whole batch's mel on the caller's stream (see __init__), then forward_mel per row range
                 tm = n // self.plan.hop_length + 1
                 mel = torch.empty(batch, self.plan.n_mels, tm, dtype=torch.float32, device=x.device)
@@ -360,7 +395,9 @@ class ConformerEncoder(nn.Module):
                     st.wait_stream(cur)                  # inputs (and anything queued before this forward) are ready
                 lo, hi = ranges[i]
                 with torch.cuda.stream(st):
-                    if pads is None:
+                    if self.ragged:
+                        launch_ragged(lo, hi)
+                    elif pads is None:
                         launch(lo, hi)
                     else:
                         launch_trimmed(lo, hi, pads[i])

@@ -94,6 +94,19 @@ int effconf_encoder_forward(EcEncoder* enc, const float* audio, const int64_t* x
 int effconf_encoder_forward_mel(EcEncoder* enc, const float* mel, const int64_t* mel_len, int32_t batch, int32_t n_frames,
                                 float* out, int64_t* out_len, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Ragged batch: the same forward with every utterance at ITS OWN length - no pad frames exist, so utterance b's output is what the
+ * reference computes for that utterance alone (batch size 1; the reference's batched output differs from it by the pad-frame leakage of
+ * SURVEY.md 8a), independent of what else is in the batch.  All utterances share one concatenated row space and one set of launches.
+ *   x          dev f32 (batch, n) audio rows or (batch, n_mels, n) mel (from_audio = 0); n = the row pitch (content behind x_len unused)
+ *   x_len      dev i64 (batch); x_len_host: the same lengths on the HOST (grids and the workspace are sized from them)
+ *   out        dev f32 (batch, out_frames, D_last): utterance b's T_out(b) frames, zeros behind them; out_frames >= the longest T_out
+ * Workspace: effconf_encoder_workspace_bytes_ragged(enc, x_len_host, batch, n, from_audio).  Needs the sublinear2.hip front end (one
+ * subsampling layer, <= 192 filters and <= 192-wide first stage) and head widths <= 160 (attention2.hip); bf16 path only. */
+size_t effconf_encoder_workspace_bytes_ragged(const EcEncoder* enc, const int64_t* x_len_host, int32_t batch, int32_t n, int32_t from_audio);
+int effconf_encoder_forward_ragged(EcEncoder* enc, const float* x, const int64_t* x_len, const int64_t* x_len_host, int32_t batch, int32_t n,
+                                   int32_t from_audio, float* out, int32_t out_frames, int64_t* out_len, void* workspace,
+                                   size_t workspace_bytes, void* stream);
+
 /* AudioPreprocessing.forward alone (reference modules.py:87-106): audio -> (batch, n_mels, n//hop+1). */
 int effconf_mel_frontend(EcEncoder* enc, const float* audio, int32_t batch, int32_t n_samples, float* mel, void* stream);
 

@@ -207,3 +207,85 @@ def test_forward_is_graph_capturable_and_replays_bit_identically(name):
         out, _, _ = enc(a0, ln)
     torch.cuda.synchronize()
     assert torch.equal(out, eager[0][0])
+
+
+# ------------------------------------------------------------------ ragged batches
+def _ragged_vs_alone(m, sd, audio, lens, nsub, from_mel=False, oracle=True):
+    enc = m.encoder
+    ln = torch.from_numpy(lens).cuda()
+    x = audio.cuda()
+    enc.ragged, enc.sub_batches, enc.trim_sub_batches = True, nsub, False
+    fwd = enc.forward_mel if from_mel else enc
+    out, out_len, _ = fwd(x, ln, x_len_host=lens)
+    out2, _, _ = fwd(x, ln)                                             # lengths fetched from the device; second pass: warm caches
+    assert torch.equal(out, out2)
+    enc.ragged, enc.sub_batches = False, 1
+    for b in range(len(lens)):
+        li = int(lens[b])
+        xb = (x[b:b + 1, :, :li] if from_mel else x[b:b + 1, :li]).contiguous()
+        alone, alone_len, _ = fwd(xb, ln[b:b + 1].contiguous())
+        tb = int(alone_len[0])
+        assert int(out_len[b]) == tb and alone.shape[1] == tb
+        assert torch.equal(out[b, :tb], alone[0]), (b, float((out[b, :tb] - alone[0]).abs().max()))
+        assert float(out[b, tb:].abs().sum()) == 0.0
+        if oracle:
+            with torch.no_grad():
+                ref, ref_len = (R.encoder_from_mel(xb.cpu(), ln[b:b + 1].cpu(), sd, enc.plan) if from_mel else R.encoder(xb.cpu(), ln[b:b + 1].cpu(), sd, enc.plan))
+            d = (alone.cpu() - ref).abs()
+            assert ref_len.tolist() == [tb] and float(d.max()) < 0.10 and float(d.mean()) < 0.012, (b, float(d.max()), float(d.mean()))
+    return out, out_len
+
+
+@pytest.mark.parametrize("nsub", [1, 2, 3])
+def test_ragged_batch_equals_every_utterance_run_alone_tiny(nsub):
+    """ConformerEncoder.ragged: every utterance at its own length in one concatenated row space - its output must be, bit for bit, the
+    encoder's output for that utterance ALONE (B = 1, the rectangular path) and within the bf16 tolerance of the oracle (the reference
+    on that utterance alone); lengths with T % 3 = 0, 1, 2 in the grouped stage, one- and multi-range forwards."""
+    m, sd = _model("Tiny", 7)
+    lens = np.array([48000, 47840, 41000, 37000, 30160, 22000, 12000, 9000, 3000], dtype=np.int64)
+    audio = torch.from_numpy(synth.make_audio(lens, seed=4))
+    _ragged_vs_alone(m, sd, audio, lens, nsub)
+
+
+@pytest.mark.parametrize("name", ["EfficientConformerCTCSmall", "EfficientConformerCTCMedium"])
+def test_ragged_batch_equals_every_utterance_run_alone_shipped_configs(name):
+    m, sd = _model(name, 3)
+    lens = np.array([70000, 52345, 33000, 20000, 8000], dtype=np.int64)
+    audio = torch.from_numpy(synth.make_audio(lens, seed=6))
+    _ragged_vs_alone(m, sd, audio, lens, 2, oracle=(name == "EfficientConformerCTCSmall"))
+
+
+def test_ragged_batch_from_mel_and_greedy_labels():
+    """The mel entry point (the parity boundary) in ragged mode, and ModelCTC.encode_greedy on ragged ranges = the head on the joined output."""
+    m, sd = _model("Tiny", 7)
+    lens = np.array([100, 93, 77, 52, 31, 9], dtype=np.int64)
+    mel, _ = synth.make_mel(6, 80, 100, lens.tolist(), seed=21)
+    _ragged_vs_alone(m, sd, torch.from_numpy(mel), lens, 2, from_mel=True)
+    enc = m.encoder
+    enc.ragged, enc.sub_batches = True, 2
+    ln = torch.from_numpy(lens).cuda()
+    out, out_len, labels, label_len = m.encode_greedy(torch.from_numpy(mel).cuda(), ln, from_mel=True, x_len_host=lens)
+    _, lab, n = m._head(out, out_len)
+    assert torch.equal(labels, lab) and torch.equal(label_len, n)
+
+
+def test_ragged_bench_size_batch_vs_utterances_alone():
+    """B = 256 LibriSpeech-shaped utterances on three streams (bench.py's default): sampled utterances bit-identical to running them alone."""
+    m, sd = _model("EfficientConformerCTCSmall", 0)
+    enc = m.encoder
+    lens = synth.libri_lengths(256, seed=1234)
+    audio = torch.from_numpy(synth.make_audio(lens, seed=1234)).cuda()
+    ln = torch.from_numpy(lens).cuda()
+    enc.ragged, enc.sub_batches, enc.sub_batch_streams = True, 3, 3
+    for _ in range(2):
+        out, out_len, labels, label_len = m.encode_greedy(audio, ln, x_len_host=lens)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+    enc.ragged, enc.sub_batches = False, 1
+    for b in (0, 1, 79, 80, 127, 128, 200, 255):
+        li = int(lens[b])
+        alone, alone_len, _ = enc(audio[b:b + 1, :li].contiguous(), ln[b:b + 1].contiguous())
+        tb = int(alone_len[0])
+        assert int(out_len[b]) == tb and torch.equal(out[b, :tb], alone[0]) and float(out[b, tb:].abs().sum()) == 0.0, b
+        _, lab, n = m._head(alone, alone_len)
+        assert int(label_len[b]) == int(n[0]) and torch.equal(labels[b, :tb], lab[0, :tb])
