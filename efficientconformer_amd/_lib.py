@@ -10,7 +10,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libeffconf.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class EcBlock(C.Structure):
@@ -22,7 +22,8 @@ class EcConfig(C.Structure):
     _fields_ = [("n_mels", C.c_int32), ("sample_rate", C.c_int32), ("n_fft", C.c_int32), ("win_length", C.c_int32),
                 ("hop_length", C.c_int32), ("normalize", C.c_int32), ("mean", C.c_float), ("std", C.c_float),
                 ("sub_layers", C.c_int32), ("sub_filters", C.c_int32 * 4), ("num_blocks", C.c_int32),
-                ("blocks", C.POINTER(EcBlock)), ("vocab_size", C.c_int32)]
+                ("blocks", C.POINTER(EcBlock)), ("vocab_size", C.c_int32),
+                ("causal", C.c_int32), ("left_context", C.c_int32), ("right_context", C.c_int32)]
 
 
 class EcRnntConfig(C.Structure):

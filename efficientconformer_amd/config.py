@@ -11,6 +11,12 @@ restates that *rule* (not the code) once, so that the Python host, the C-ABI
       att_group_size               <- stage n_gt(strided_blocks)
       max_pos_encoding             <- max_pos // stride**n_gt(strided_blocks)
       conv_stride                  <- conv_stride[stage] if b in strided_blocks else 1
+    streaming / causal (encoders.py:68, 94; attentions.py:1377-1403, 506; layers.py:94-101; blocks.py:83):
+      left_context  L (default max_pos_encoding), right_context R (default max_pos_encoding; 0 when causal), in frames AFTER the
+      subsampling: key j of query i is masked iff j - i > R or j - i < -L; the mask is sliced `::s` after every strided block, so
+      block b compares mask_stride * (j - i), mask_stride = product of the strides of the blocks before b (and `::G` inside grouped
+      attention: att_group_size * mask_stride * (j' - i') for grouped positions);
+      causal: relative table of T (not 2T - 1) positions, depthwise conv pre-padded (k - 1, 0) instead of ((k-1)/2, (k-1)/2)
 
 Only the values shipped configs reach are implemented natively; anything else
 raises NotImplementedError (reference raises a bare Exception for unknown
@@ -44,6 +50,7 @@ class BlockPlan:
     group_size: int
     max_pos: int
     conv_stride: int
+    mask_stride: int = 1      # product of the conv strides of the blocks before this one (the streaming mask is sliced ::s after each)
 
     @property
     def dim_head(self) -> int:
@@ -68,6 +75,9 @@ class EncoderPlan:
     sub_layers: int
     sub_filters: List[int]
     dim_in: int               # subsampling_filters[-1] * n_mels // 2**layers
+    causal: bool = False      # encoders.py:94: causal rel-pos table + causal depthwise padding + right_context 0
+    left_context: int = 1 << 30    # frames after the subsampling; >= any sequence length = unlimited (the shipped configs: max_pos_encoding)
+    right_context: int = 1 << 30
     blocks: List[BlockPlan] = field(default_factory=list)
 
     @property
@@ -107,8 +117,6 @@ def build_plan(params: dict) -> EncoderPlan:
         raise NotImplementedError("absolute positional encodings (relative_pos_enc=false) not native")
     if p.get("linear_att", False) or p.get("att_kernel_size", None) is not None:
         raise NotImplementedError("linear / local attention variants not native")
-    if p.get("causal", False) or "left_context" in p or "right_context" in p:
-        raise NotImplementedError("causal / streaming contexts not native")
     if p.get("subsampling_norm", "batch") != "batch" or p.get("subsampling_act", "swish") != "swish":
         raise NotImplementedError("subsampling norm/act other than batch/swish not native")
     if int(p.get("subsampling_kernel_size", 3)) != 3:
@@ -127,6 +135,13 @@ def build_plan(params: dict) -> EncoderPlan:
         mean=float(p.get("mean", 0.0)), std=float(p.get("std", 1.0)),
         sub_layers=layers, sub_filters=filters,
         dim_in=filters[-1] * int(p["n_mels"]) // 2 ** layers)
+    # StreamingMask(left_context, right_context) of encoders.py:68
+    plan.causal = bool(p.get("causal", False))
+    plan.left_context = int(p.get("left_context", p["max_pos_encoding"]))
+    plan.right_context = 0 if plan.causal else int(p.get("right_context", p["max_pos_encoding"]))
+    if plan.left_context < 0 or plan.right_context < 0:
+        raise Exception("left_context / right_context must be >= 0")
+    mask_stride = 1
     for b in range(int(p["num_blocks"])):
         n_gt_e = sum(1 for e in expand if b > e)
         n_ge_e = sum(1 for e in expand if b >= e)
@@ -150,7 +165,8 @@ def build_plan(params: dict) -> EncoderPlan:
             dim_ffn1=d_model * int(p["ff_ratio"]), dim_ffn2=d_exp * int(p["ff_ratio"]),
             num_heads=heads, kernel_size=int(_stage(p["kernel_size"], n_ge_e)),
             group_size=g, max_pos=int(p["max_pos_encoding"]) // stride ** n_gt_s,
-            conv_stride=int(cs)))
+            conv_stride=int(cs), mask_stride=mask_stride))
+        mask_stride *= int(cs)
     return plan
 
 

@@ -22,6 +22,8 @@ namespace {
 constexpr int BJ = 64;          // keys per block
 constexpr int SKEW_LD = 84;     // floats per query row of a skew buffer
 constexpr float RESCALE_T = 4.0f;   // deferred accumulator rescale: threshold on the growth of a row maximum, log2 units
+constexpr float NEG_BIG = -1.0e30f;  // masked score / initial row maximum: finite, so that (max - max) never becomes inf - inf; whatever a row
+                                     // accumulates while its maximum still is NEG_BIG is wiped by the first real score (alpha = exp2(-huge) = 0)
 
 __device__ __forceinline__ uint4 ld16(const bf16_t* p) {       // 16-byte global load from a 2-byte aligned address (natural layout, odd d)
     typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(2)));
@@ -101,14 +103,27 @@ __global__ __launch_bounds__(NWV * 64, (QT == 1 && NWV == 4 && DP <= 96) ? 2 : 1
     const bf16_t* Vh = p.vt + qoff;
     const int RS = p.q_rowstride, ERS = p.e_rowstride;
     const bf16_t* Eh = p.eh + (size_t)h * p.e_hstride + (p.rag_off ? (size_t)(p.rag_tgmax - Tg) * ERS : 0);
-    const int erows = 2 * Tg - 1;
+    const int erows = p.causal ? Tg : 2 * Tg - 1;                  // causal tables hold the Tg rows of the non-negative distances only
     const int dceil = (p.d + 7) & ~7;
     const bool ragged_d = dceil != p.d;
 
-    int nkeys = (p.lens[b] + p.G - 1) / p.G;
-    nkeys = nkeys < Tg ? nkeys : Tg;
-    const bool all_masked = nkeys < 1;                          // empty utterance: uniform softmax over all key groups (attention.hip)
-    nkeys = all_masked ? Tg : nkeys;
+    // Visible keys of query i (reference attentions.py:1377-1403, sliced ::s and ::G on the way here): j < nkv (key-padding mask) and
+    // -band_l <= j - i <= band_r (streaming contexts in grouped positions of this stage; INT_MAX / 2 = unlimited).  A query whose band lies
+    // entirely in the padding (i - band_l >= nkv; every query of an empty utterance) sees -1e9 on EVERY key in the reference: a uniform
+    // softmax over all Tg key groups ("dead" rows: scores forced to 0).  A workgroup visits the key blocks its 64 queries can see - all
+    // of them when it holds a dead row.
+    int nkv = (p.lens[b] + p.G - 1) / p.G;
+    nkv = nkv < Tg ? nkv : Tg;
+    const int band_l = p.band_l < Tg ? p.band_l : Tg, band_r = p.band_r < Tg ? p.band_r : Tg;
+    const bool banded = band_l < Tg || band_r < Tg;
+    const bool tile_dead = i0 + BI - 1 - band_l >= nkv;           // (nkv == 0: every row)
+    int kbeg = 0, nkeys = nkv;
+    if (tile_dead) nkeys = Tg;
+    else if (banded) {
+        kbeg = i0 - band_l; kbeg = kbeg < 0 ? 0 : kbeg & ~(BJ - 1);
+        const int ke = i0 + BI + band_r;
+        nkeys = ke < nkv ? ke : nkv;
+    }
 
     // ---- the wave's two query tiles: B operands of S^T = K Q^T (Q + u) and of the positional product (Q + v = (Q + u) + (v - u))
     bf16x8 qu[QT][KS], qv[QT][KS];
@@ -139,7 +154,7 @@ __global__ __launch_bounds__(NWV * 64, (QT == 1 && NWV == 4 && DP <= 96) ? 2 : 1
         }
     }
     // ---- first positional band of the workgroup: absolute E rows R0 .. R0 + BI + 62
-    const int R0 = Tg - 1 - i0 - (BI - 1);
+    const int R0 = Tg - 1 - i0 - (BI - 1) + kbeg;                 // absolute E row of band row 0 of the FIRST visited key block
     {
         constexpr int NB = ((BI + 63) * CPR + NTHR - 1) / NTHR;
         uint4 fb[NB];
@@ -164,7 +179,7 @@ __global__ __launch_bounds__(NWV * 64, (QT == 1 && NWV == 4 && DP <= 96) ? 2 : 1
     float m_run[QT], l_run[QT];
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
-        m_run[t] = -INFINITY; l_run[t] = 0.f;
+        m_run[t] = NEG_BIG; l_run[t] = 0.f;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) acc[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -217,8 +232,8 @@ __global__ __launch_bounds__(NWV * 64, (QT == 1 && NWV == 4 && DP <= 96) ? 2 : 1
                 st_.lk[n] = tail_mask(ld16b(reinterpret_cast<const char*>(Kh) + o), n); st_.lv[n] = tail_mask(ld16b(reinterpret_cast<const char*>(Vh) + o), n);
             }
         }
-        if (jn > 0) {
-            const int rnew = R0 + jn + BI - 1;                   // first new absolute E row of the block
+        if (jn > kbeg) {
+            const int rnew = R0 + (jn - kbeg) + BI - 1;          // first new absolute E row of the block
             if (rnew >= 0 && rnew + 63 < erows - (ragged_d ? 1 : 0)) {      // the batch holding the table's last row: masked path (see above)
                 const char* eb = reinterpret_cast<const char*>(Eh + (size_t)rnew * ERS);
 #pragma unroll
@@ -256,7 +271,7 @@ __global__ __launch_bounds__(NWV * 64, (QT == 1 && NWV == 4 && DP <= 96) ? 2 : 1
             if (FULL || tid + NTHR * n < BJ * CPR) {
                 *reinterpret_cast<uint4*>(sK + ldk[n]) = st_.lk[n];
                 *reinterpret_cast<uint4*>(sV + ldv[n]) = st_.lv[n];
-                if (j0 > 0) *reinterpret_cast<uint4*>(sE + lde[par][n]) = st_.le[n];
+                if (j0 > kbeg) *reinterpret_cast<uint4*>(sE + lde[par][n]) = st_.le[n];
             }
         }
         __syncthreads();
@@ -317,25 +332,32 @@ __global__ __launch_bounds__(NWV * 64, (QT == 1 && NWV == 4 && DP <= 96) ? 2 : 1
                     const int jl = jt * 16 + g * 4 + r;
                     st[t][jt][r] += skew[jl + 15 - c];
                 }
-            if (all_masked) {                                  // empty utterance: all scores equal (attention.hip) -> uniform softmax over every key group
+            // masks only where the (query tile, key block) pair is not fully visible (wave-uniform test): padding tail or band edge
+            const int iq0 = iw0 + 16 * t;
+            if (j0 + BJ > nkv || (banded && (j0 - (iq0 + 15) < -band_l || j0 + BJ - 1 - iq0 > band_r))) {
+                const int iq = iq0 + c;
 #pragma unroll
                 for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) st[t][jt][r] = 0.f;
+                    for (int r = 0; r < 4; ++r) {
+                        const int j = j0 + jt * 16 + g * 4 + r, dj = j - iq;
+                        st[t][jt][r] = (j < nkv && dj <= band_r && dj >= -band_l) ? st[t][jt][r] : NEG_BIG;
+                    }
             }
-            if (j0 + BJ > nkeys) {
+            if (tile_dead) {                                   // rows that see no key at all: every score equal -> uniform softmax over all key groups
+                const bool dead = iq0 + c - band_l >= nkv;
 #pragma unroll
                 for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) st[t][jt][r] = (j0 + jt * 16 + g * 4 + r < nkeys) ? st[t][jt][r] : -INFINITY;
+                    for (int r = 0; r < 4; ++r) st[t][jt][r] = dead ? (j0 + jt * 16 + g * 4 + r < Tg ? 0.f : NEG_BIG) : st[t][jt][r];
             }
 #pragma unroll
             for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) mloc = fmaxf(mloc, st[t][jt][r]);
             mloc = fmaxf(mloc, __shfl_xor(mloc, 16));
-            mloc = fmaxf(mloc, __shfl_xor(mloc, 32));             // finite: key j0 of every visited block is unmasked
-            if (!__all((mloc - m_run[t]) * scale2 <= RESCALE_T)) {   // m_run = -inf in the first block: always taken there
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32));             // finite (masked scores are NEG_BIG, never -inf)
+            if (!__all((mloc - m_run[t]) * scale2 <= RESCALE_T)) {   // m_run = NEG_BIG until the row's first visible key: taken there
                 const float m_new = fmaxf(m_run[t], mloc);
                 const float alpha = __builtin_amdgcn_exp2f((m_run[t] - m_new) * scale2);
                 l_run[t] *= alpha;
@@ -383,10 +405,10 @@ __global__ __launch_bounds__(NWV * 64, (QT == 1 && NWV == 4 && DP <= 96) ? 2 : 1
     // two staging sets (loads two key blocks ahead) while they fit the register file; one set (one block ahead) for the widest heads
     // of the 2-wave workgroup, whose threads stage twice as many chunks
     constexpr bool TWO_SETS = !(NWV == 2 && DP >= 96);
-    issue_loads(sa, 0);
+    issue_loads(sa, kbeg);
     if constexpr (TWO_SETS) {
-        if (BJ < nkeys) issue_loads(sb, BJ);
-        for (int jb = 0; jb < nkeys; jb += 2 * BJ)
+        if (kbeg + BJ < nkeys) issue_loads(sb, kbeg + BJ);
+        for (int jb = kbeg; jb < nkeys; jb += 2 * BJ)
 #pragma unroll
         for (int half2 = 0; half2 < 2; ++half2) {
             const int j0 = jb + half2 * BJ;
@@ -396,7 +418,7 @@ __global__ __launch_bounds__(NWV * 64, (QT == 1 && NWV == 4 && DP <= 96) ? 2 : 1
             compute_block(j0, half2);
         }
     } else {
-        for (int jb = 0; jb < nkeys; jb += 2 * BJ)
+        for (int jb = kbeg; jb < nkeys; jb += 2 * BJ)
 #pragma unroll
         for (int half2 = 0; half2 < 2; ++half2) {
             const int j0 = jb + half2 * BJ;

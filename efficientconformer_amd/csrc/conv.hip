@@ -91,7 +91,7 @@ typedef float dwf2 __attribute__((ext_vector_type(2)));
 template <int KSZ, int STRIDE>
 __global__ __launch_bounds__(256) void dwconv_kernel(const bf16_t* __restrict__ g, int T, int To, int C, int ld,
                                                      const float* __restrict__ w_kc, const float* __restrict__ bias, bf16_t* out,
-                                                     RaggedConv rc) {
+                                                     RaggedConv rc, int causal) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ROWS = (DW_TT - 1) * STRIDE + KSZ;
     constexpr int TROWS = (DW_NT - 1) * STRIDE + KSZ;                       // input rows one thread consumes
@@ -111,8 +111,8 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const bf16_t* __restrict__ 
         grow0 = (size_t)rc.in_off[b]; orow0 = (size_t)rc.out_off[b]; Top = rc.out_off[b + 1] - rc.out_off[b];
     } else { tt = id % ttiles; b = id / ttiles; grow0 = (size_t)b * T; orow0 = (size_t)b * To; }
     const int c0 = ct * DW_CC, to0 = tt * DW_TT;
-    constexpr int HALF = (KSZ - 1) / 2;
-    const int tin0 = to0 * STRIDE - HALF;
+    // zero pre-padding of reference layers.py:97-101: "same" = ((k - 1) / 2 on both sides), "causal" = (k - 1, 0)
+    const int tin0 = to0 * STRIDE - (causal ? KSZ - 1 : (KSZ - 1) / 2);
     const int tid = threadIdx.x;
     const int cp = tid & 31, tg = tid >> 5;
     const int c = c0 + 2 * cp;                                              // this thread's channel pair
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const bf16_t* __restrict__ 
 
 template <int KSZ, int STRIDE>
 int launch_dw_t(const bf16_t* g, int B, int T, int To, int C, int ld, const float* w_kc, const float* bias, bf16_t* out, hipStream_t s,
-                const RaggedConv& rc) {
+                const RaggedConv& rc, int causal) {
     const int ctiles = (C + DW_CC - 1) / DW_CC, ttiles = (To + DW_TT - 1) / DW_TT;
     const int nwg = rc.tile_off ? rc.tiles * ctiles : B * ttiles * ctiles;
     if (nwg <= 0) return 0;
@@ -183,7 +183,7 @@ int launch_dw_t(const bf16_t* g, int B, int T, int To, int C, int ld, const floa
     const size_t lds = (size_t)ROWS * DW_PITCH;
     static LdsAttr attr;
     ensure_dynamic_lds(reinterpret_cast<const void*>(&dwconv_kernel<KSZ, STRIDE>), (int)lds, attr);
-    hipLaunchKernelGGL((dwconv_kernel<KSZ, STRIDE>), dim3(nwg), dim3(256), lds, s, g, T, To, C, ld, w_kc, bias, out, rc);
+    hipLaunchKernelGGL((dwconv_kernel<KSZ, STRIDE>), dim3(nwg), dim3(256), lds, s, g, T, To, C, ld, w_kc, bias, out, rc, causal);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -200,17 +200,17 @@ int launch_subsample_conv(const float* mel, int B, int F, int Tm, int T1, const 
 }
 
 int launch_dwconv(const bf16_t* g, int B, int T, int To, int C, int ld, const float* w_kc, const float* bias,
-                  int ksize, int stride, bf16_t* out, hipStream_t s, const RaggedConv* rcp) {
+                  int ksize, int stride, bf16_t* out, hipStream_t s, const RaggedConv* rcp, int causal) {
     if (B <= 0 || To <= 0) return 0;
     if (ld % 8 || ld < C) return -2;
     RaggedConv rc{};
     if (rcp) rc = *rcp;
     // taps are fully unrolled per (kernel size, stride); the shipped configs use k = 15 (Efficient Conformer) and 31 (Conformer)
-    if (ksize == 15 && stride == 1) return launch_dw_t<15, 1>(g, B, T, To, C, ld, w_kc, bias, out, s, rc);
-    if (ksize == 15 && stride == 2) return launch_dw_t<15, 2>(g, B, T, To, C, ld, w_kc, bias, out, s, rc);
-    if (ksize == 31 && stride == 1) return launch_dw_t<31, 1>(g, B, T, To, C, ld, w_kc, bias, out, s, rc);
-    if (ksize == 31 && stride == 2) return launch_dw_t<31, 2>(g, B, T, To, C, ld, w_kc, bias, out, s, rc);
-    if (ksize == 7 && stride == 1) return launch_dw_t<7, 1>(g, B, T, To, C, ld, w_kc, bias, out, s, rc);
-    if (ksize == 7 && stride == 2) return launch_dw_t<7, 2>(g, B, T, To, C, ld, w_kc, bias, out, s, rc);
+    if (ksize == 15 && stride == 1) return launch_dw_t<15, 1>(g, B, T, To, C, ld, w_kc, bias, out, s, rc, causal);
+    if (ksize == 15 && stride == 2) return launch_dw_t<15, 2>(g, B, T, To, C, ld, w_kc, bias, out, s, rc, causal);
+    if (ksize == 31 && stride == 1) return launch_dw_t<31, 1>(g, B, T, To, C, ld, w_kc, bias, out, s, rc, causal);
+    if (ksize == 31 && stride == 2) return launch_dw_t<31, 2>(g, B, T, To, C, ld, w_kc, bias, out, s, rc, causal);
+    if (ksize == 7 && stride == 1) return launch_dw_t<7, 1>(g, B, T, To, C, ld, w_kc, bias, out, s, rc, causal);
+    if (ksize == 7 && stride == 2) return launch_dw_t<7, 2>(g, B, T, To, C, ld, w_kc, bias, out, s, rc, causal);
     return -3;
 }

@@ -609,6 +609,7 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
     const bool e_cached = !capturing && e->e_cache_on && e->e_cache_hit(ws, B, s.Tm, w.eh_blk[0]);
     if (!e_cached) e->e_cache_drop(ws);       // re-tagged only after every projection of this forward was enqueued
 
+    int mask_stride = 1;                       // product of the strides of the blocks before block k
     for (int k = 0; k < nb; ++k) {
         const EcBlock& b = e->blocks[k];
         const BlockW& W = e->bw[k];
@@ -673,11 +674,12 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
               else EC_TRY(nat ? launch_attn_pad_rows_nat(p, B, st) : launch_attn_pad_rows(p, B, st)); }
             // positional embeddings E = pos_layer(R) (attentions.py:588 / 678): input independent, tiny (2Tp-G rows)
             GemmParams pe{};
-            const int erows = 2 * Tp - G;
-            pe.A = W.pos_table + (size_t)(b.max_pos - Tp + G / 2) * ld8(D); pe.lda = ld8(D);
+            // relative tables: R[m] = sinusoid(Tp - 1 - G/2 - m), m < 2 Tp - G; causal: R[m] = sinusoid(Tp - 1 - m), m < Tp (attentions.py:1243-1251, 1296-1309)
+            const int erows = c.causal ? Tp : 2 * Tp - G;
+            pe.A = W.pos_table + (size_t)(b.max_pos - Tp + (c.causal ? 0 : G / 2)) * ld8(D); pe.lda = ld8(D);
             pe.W = W.pos.w; pe.ldw = W.pos.ldw; pe.bias = W.pos.bias;
             pe.M = erows; pe.N = D; pe.K = D;
-            pe.T = erows; pe.G = G; pe.H = H; pe.D = D; pe.d = d; pe.dpad = dpad; pe.Tg = 2 * Tg - 1; pe.Tgp = 0;
+            pe.T = erows; pe.G = G; pe.H = H; pe.D = D; pe.d = d; pe.dpad = dpad; pe.Tg = c.causal ? Tg : 2 * Tg - 1; pe.Tgp = 0;
             pe.kh = reinterpret_cast<bf16_t*>(ws + w.eh_blk[k]);
             pe.C = pe.kh; pe.ldc = D;
             if (Tp > b.max_pos) return fail("sequence longer than max_pos_encoding");
@@ -692,12 +694,20 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
             else { ap.q_bstride = (long long)H * Tg * dpad; ap.q_hstride = (long long)Tg * dpad; ap.q_rowstride = dpad;
                    ap.e_hstride = (long long)(2 * Tg - 1) * dpad; ap.e_rowstride = dpad; }
             ap.out = o; ap.ldo = ld8(D); ap.scale = 1.0f / std::sqrt((float)d); ap.force_waves = e->attn_waves;
+            // streaming mask of this block: built after the subsampling, sliced ::stride after every strided block before this one and ::G in
+            // grouped attention (encoders.py:132-136, attentions.py:698): grouped positions compare (mask_stride * G) * (j - i) with the contexts
+            const long long unit = (long long)mask_stride * G;
+            ap.band_l = (int)std::min<long long>(c.left_context / unit, 1 << 30); ap.band_r = (int)std::min<long long>(c.right_context / unit, 1 << 30);
+            ap.causal = c.causal;
+            const bool streaming = c.causal || ap.band_l < Tg || ap.band_r < Tg;
+            if (streaming && !(nat && relpos_attention2_supported(dpad) && e->attention_v2))
+                return fail("streaming contexts / causal attention run on attention2.hip (natural layout, padded head width <= 160, option attention_v2 != 0)");
             if (rg) {
                 if (!relpos_attention2_supported(dpad)) return fail("ragged batches need attention2.hip (padded head width <= 160)");
                 ap.rag_off = row_off + (size_t)k * (B + 1); ap.rag_wg = wg_off + (size_t)k * (B + 1); ap.rag_nwg = s.wgs[k]; ap.rag_tgmax = Tg;
             }
             { PROF(PC_ATTENTION, 2.0 * H * (rg ? s.tg2[k] : (double)B * Tg * Tg) * d * 3.0, (double)M * D * 2 * 5);
-              if (rg) EC_TRY(launch_relpos_attention2(ap, 1, st)); else
+              if (rg || streaming) EC_TRY(launch_relpos_attention2(ap, 1, st)); else
               // attention2.hip reads the natural layout only (its column masks assume the next head's finite data behind a head span); the
               // head-major test layout of odd head widths (EFFCONF_HEAD_MAJOR_ODD) stays on attention.hip
               if (e->attention_v2 && nat && relpos_attention2_supported(dpad)) EC_TRY(launch_relpos_attention2(ap, e->attention_v2, st));
@@ -730,7 +740,8 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
         RaggedConv rc{};
         if (rg) { rc.in_off = row_off + (size_t)k * (B + 1); rc.in_len = lens + (size_t)k * B; rc.out_off = row_off + (size_t)(k + 1) * (B + 1);
                   rc.out_len = lens + (size_t)(k + 1) * B; rc.tile_off = tile_off + (size_t)k * (B + 1); rc.tiles = s.tiles[k]; rc.n = B; rc.out_rows = Mo; }
-        { PROF(PC_DWCONV, 2.0 * Mo * (double)De * b.kernel_size, (double)M * De * 2 + (double)Mo * De * 2); EC_TRY(launch_dwconv(gbuf, B, T, To, De, ld8(De), W.dw_w, W.dw_b, b.kernel_size, b.conv_stride, cbuf, st, rg ? &rc : nullptr)); }
+        { PROF(PC_DWCONV, 2.0 * Mo * (double)De * b.kernel_size, (double)M * De * 2 + (double)Mo * De * 2); EC_TRY(launch_dwconv(gbuf, B, T, To, De, ld8(De), W.dw_w, W.dw_b, b.kernel_size, b.conv_stride, cbuf, st, rg ? &rc : nullptr, c.causal)); }
+        mask_stride *= b.conv_stride;
         snprintf(nm, sizeof(nm), "blocks.%d.dw", k); trace_add(e, st, nm, cbuf, Mo, De, ld8(De), 1);
         if (D != De) {   // 1x1 strided conv on frames 0, s, 2s, ...  (blocks.py:106-110)
             { PROF(PC_MISC, 0, (double)Mo * D * 6); EC_TRY(launch_cast_rows(x, D, T, b.conv_stride, To, B, xs, ld8(D), st, rg ? &rc : nullptr)); }
@@ -853,6 +864,10 @@ int forward_core_exact(EcEncoder* e, const float* mel, const int64_t* in_len, in
                        char* ws, float* out, int64_t* out_len, hipStream_t st) {
     const EcConfig& c = e->cfg;
     const int B = s.B, nb = (int)e->blocks.size();
+    if (c.causal || c.left_context < (1 << 30) / 2 || c.right_context < (1 << 30) / 2) {
+        int tmax = 0; for (int t : s.Tin) tmax = std::max(tmax, t);
+        if (c.causal || c.left_context < tmax || c.right_context < tmax) return fail("the fp32-operand mode has no streaming contexts / causal kernels (bf16 path only)");
+    }
     e->trace.clear(); e->trace_used = 0;
     // this forward lays its own buffers over the caller's workspace: a positional-embedding cache the bf16 path left there is gone
     // (fp32 -> bf16 -> fp32 -> bf16 on one workspace otherwise ends with attention reading fp32 activations as E)
@@ -962,6 +977,7 @@ EcEncoder* effconf_encoder_create(const EcConfig* cfg) {
             fail("unsupported block hyper-parameters at block " + std::to_string(i)); return nullptr;
         }
     }
+    if (cfg->left_context < 0 || cfg->right_context < 0) { fail("left_context / right_context must be >= 0"); return nullptr; }
     EcEncoder* e = new EcEncoder();
     e->cfg = *cfg;
     e->blocks.assign(cfg->blocks, cfg->blocks + cfg->num_blocks);
@@ -1435,6 +1451,7 @@ int effconf_relpos_attention(const uint16_t* qu, const uint16_t* k, const uint16
     ap.B = batch; ap.H = heads; ap.T = frames; ap.G = group; ap.D = dim; ap.d = d; ap.dpad = dpad; ap.Tg = Tg; ap.Tgp = ec_round_up(Tg, 8);
     ap.q_bstride = (long long)Tp * dim; ap.q_hstride = d; ap.q_rowstride = group * dim; ap.e_hstride = d; ap.e_rowstride = group * dim;
     ap.out = out; ap.ldo = ld_out; ap.scale = 1.0f / std::sqrt((float)d);
+    ap.band_l = ap.band_r = 1 << 30;          // full context (the streaming variants are tested end to end against the reference goldens)
     if (variant == 0) { EC_TRY(launch_relpos_attention(ap, (hipStream_t)stream)); return 0; }
     if ((variant != 1 && variant != 2) || !relpos_attention2_supported(dpad)) return fail("attention variant not available for this head width");
     EC_TRY(launch_relpos_attention2(ap, variant, (hipStream_t)stream));
@@ -1505,7 +1522,7 @@ int effconf_conv_module(EcEncoder* e, int32_t block, const float* x, int32_t bat
         EC_TRY(run_rs_or_tiled(e, PC_GEMM_OTHER, st, a, ld8(D), M, W.pw1, 2, EPI_GLU_BF16, gbuf, ld8(De)));
     }
     // depthwise conv + BatchNorm + Swish (modules.py:516-518), pointwise-2 (modules.py:519)
-    EC_TRY(launch_dwconv(gbuf, batch, T, To, De, ld8(De), W.dw_w, W.dw_b, b.kernel_size, b.conv_stride, cbuf, st));
+    EC_TRY(launch_dwconv(gbuf, batch, T, To, De, ld8(De), W.dw_w, W.dw_b, b.kernel_size, b.conv_stride, cbuf, st, nullptr, e->cfg.causal));
     return run_rs_or_tiled(e, PC_GEMM_OTHER, st, cbuf, ld8(De), Mo, W.pw2, 1, EPI_F32, y, De);
 }
 

@@ -147,6 +147,9 @@ struct AttnParams {
     // workgroups in the kernel's utterance order (0, 8, 16, .. | 1, 9, ..), rag_nwg their total, rag_tgmax = Tg of the longest utterance
     // (`eh` holds the positional rows for THAT length); T / Tg are then upper bounds only
     const int *rag_off, *rag_wg; int rag_nwg, rag_tgmax;
+    // streaming contexts / causal (attention2.hip): key j of query i (grouped positions) is visible iff -band_l <= j - i <= band_r
+    // (>= Tg: unlimited); causal: `eh` holds the Tg rows of the non-negative distances only (index Tg - 1 + j - i, j <= i)
+    int band_l, band_r, causal;
 };
 int launch_relpos_attention(const AttnParams& p, hipStream_t s);
 // second generation (attention2.hip): 32 queries per wave, transposing LDS reads for V; waves = 2 (64-query workgroups) or 4
@@ -177,7 +180,7 @@ int launch_conv2_igemm(const bf16_t* act1, int B, int F1, int T1, int Cp, const 
                        int N, int F2, int T2, bf16_t* out, hipStream_t s);
 // g (B, T, ld) bf16 -> (B, To, ld) bf16: depthwise conv k taps ("same" zero pad), stride s, folded BN, Swish
 int launch_dwconv(const bf16_t* g, int B, int T, int To, int C, int ld, const float* w_kc, const float* bias,
-                  int ksize, int stride, bf16_t* out, hipStream_t s, const RaggedConv* rc = nullptr);
+                  int ksize, int stride, bf16_t* out, hipStream_t s, const RaggedConv* rc = nullptr, int causal = 0);   // causal: pre-padding (k - 1, 0)
 
 // ---------------------------------------------------------------- fp32-operand "exact" mode  (exact.hip)
 struct ExGemmParams {              // C = epi(A W^T + bias), everything fp32 (v_mfma_f32_32x32x2_f32)

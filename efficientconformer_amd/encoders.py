@@ -199,6 +199,7 @@ class ConformerEncoder(nn.Module):
         cfg.num_blocks = len(plan.blocks)
         cfg.blocks = C.cast(blocks, C.POINTER(_lib.EcBlock))
         cfg.vocab_size = self._head.out_features if self._head is not None else 0
+        cfg.causal, cfg.left_context, cfg.right_context = int(plan.causal), min(plan.left_context, 1 << 30), min(plan.right_context, 1 << 30)
         return cfg, blocks
 
     def _ensure_packed(self):

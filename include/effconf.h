@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define EFFCONF_ABI_VERSION 1
+#define EFFCONF_ABI_VERSION 2      /* 2: EcConfig gained causal / left_context / right_context */
 
 /* Per-block hyper-parameters, already resolved from the per-stage lists exactly as
  * ConformerEncoder.__init__ does (reference encoders.py:80-95). */
@@ -50,6 +50,11 @@ typedef struct EcConfig {
     int32_t num_blocks;
     const EcBlock* blocks;
     int32_t vocab_size;                                          /* >0: CTC head `fc` present  */
+    /* streaming / causal (encoders.py:68, 94): contexts in frames AFTER the subsampling, as StreamingMask gets them - key j of query i
+     * masked iff j - i > right_context or j - i < -left_context; >= 2^30 = unlimited (the shipped configs pass max_pos_encoding);
+     * causal = 1: causal relative tables (attentions.py:506, 1243-1247), depthwise convs pre-padded (k - 1, 0) (layers.py:97-101), and
+     * the caller passes right_context = 0 (encoders.py:68).  bf16 path, attention2.hip head widths (<= 160 padded) only. */
+    int32_t causal, left_context, right_context;
 } EcConfig;
 
 typedef struct EcEncoder EcEncoder;

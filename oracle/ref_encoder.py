@@ -122,10 +122,25 @@ def rel_sinusoid_rows(tp: int, dim: int, group: int) -> torch.Tensor:
     return r
 
 
+def rel_sinusoid_rows_causal(tp: int, dim: int) -> torch.Tensor:
+    """causal tables: R[m] = sinusoid(p = Tp-1-m), m in [0, Tp)  (attentions.py:1243-1247 / 1296-1300: the slice [max_len - T, max_len))"""
+    pos = torch.arange(tp - 1, -1, -1, dtype=torch.float).unsqueeze(1)
+    angles = pos / 10000 ** (2 * torch.arange(0, dim // 2, dtype=torch.float).unsqueeze(0) / dim)
+    r = torch.zeros(pos.shape[0], dim)
+    r[:, 0::2] = angles.sin()
+    r[:, 1::2] = angles.cos()
+    return r
+
+
 def relpos_attention(x: torch.Tensor, lens: Optional[torch.Tensor], sd, prefix: str, heads: int, group: int,
-                     return_probs: bool = False):
+                     return_probs: bool = False, causal: bool = False, left: Optional[int] = None, right: Optional[int] = None,
+                     mask_stride: int = 1):
     """x: (B, T, D) *already pre-normed*; lens: valid frames per utterance at this stage.
-    Closed form: S[b,h,i,j] = (Qu_i.K_j + Qv_i.E[Tg-1+j-i]) / sqrt(d)."""
+    Closed form: S[b,h,i,j] = (Qu_i.K_j + Qv_i.E[Tg-1+j-i]) / sqrt(d).
+    Streaming contexts (attentions.py:1377-1403, sliced ::s at encoders.py:132-136 and ::G at attentions.py:698): grouped key j is masked
+    for grouped query i iff mask_stride * G * (j - i) > right or < -left.  causal (attentions.py:506-529, 1243-1247): E has Tg rows and the
+    relative-to-absolute shift is the Music-Transformer skew; entries right of the diagonal are whatever the skew wraps in - the causal
+    mask (right = 0) covers them."""
     bsz, t, dim = x.shape
     m = prefix + ".mhsa."
     q = F.linear(x, _t(sd, m + "query_layer.weight"), _t(sd, m + "query_layer.bias"))
@@ -139,43 +154,63 @@ def relpos_attention(x: torch.Tensor, lens: Optional[torch.Tensor], sd, prefix: 
     qv = q + _t(sd, m + "v")
     tg = tp // group
     d = group * dim // heads                               # attentions.py:643
-    e = F.linear(rel_sinusoid_rows(tp, dim, group), _t(sd, m + "pos_layer.weight"), _t(sd, m + "pos_layer.bias"))
+    rows = rel_sinusoid_rows_causal(tp, dim) if causal else rel_sinusoid_rows(tp, dim, group)
+    e = F.linear(rows, _t(sd, m + "pos_layer.weight"), _t(sd, m + "pos_layer.bias"))
 
     def split(z, rows):                                    # (B, rows*G, D) -> (B, H, rows, d): a pure view + transpose
         return z.reshape(z.shape[0], rows, heads, d).transpose(1, 2)
     qu, qv, k, v = split(qu, tg), split(qv, tg), split(k, tg), split(v, tg)
-    e = split(e.unsqueeze(0), 2 * tg - 1)[0]               # (H, 2Tg-1, d)
+    e = split(e.unsqueeze(0), tg if causal else 2 * tg - 1)[0]               # (H, 2Tg-1, d); causal: (H, Tg, d)
     s_k = qu @ k.transpose(2, 3)                           # (B, H, Tg, Tg)
-    s_rel = qv @ e.transpose(1, 2)                         # (B, H, Tg, 2Tg-1)
+    s_rel = qv @ e.transpose(1, 2)                         # (B, H, Tg, 2Tg-1); causal: (B, H, Tg, Tg)
     i = torch.arange(tg).unsqueeze(1)
     j = torch.arange(tg).unsqueeze(0)
-    idx = (tg - 1 + j - i).expand(bsz, heads, tg, tg)      # rel_to_abs == this gather (attentions.py:483-547)
-    s = (s_k + torch.gather(s_rel, 3, idx)) / d ** 0.5     # scale by grouped d, attentions.py:692
+    if causal:      # attentions.py:506-529: pad one column left, flatten, pad the start, reshape (1 + Tg, Tg), drop the first row
+        z = F.pad(s_rel, (1, 0)).reshape(bsz, heads, -1)
+        z = F.pad(z, (0, 0)).reshape(bsz, heads, 1 + tg, tg)[:, :, 1:]       # seq_length2 - seq_length1 = 0 start padding
+        s = (s_k + z) / d ** 0.5
+    else:
+        idx = (tg - 1 + j - i).expand(bsz, heads, tg, tg)      # rel_to_abs == this gather (attentions.py:483-547)
+        s = (s_k + torch.gather(s_rel, 3, idx)) / d ** 0.5     # scale by grouped d, attentions.py:692
+    if left is not None or right is not None:                  # streaming mask, on the positions the slicing keeps
+        pos = torch.arange(tg) * (mask_stride * group)
+        delta = pos.unsqueeze(0) - pos.unsqueeze(1)            # [i][j] = pos_j - pos_i
+        band = torch.zeros(tg, tg)
+        if right is not None:
+            band = torch.maximum(band, (delta > right).float())
+        if left is not None:
+            band = torch.maximum(band, (delta < -left).float())
+    else:
+        band = None
     if lens is not None:
         # key group j masked iff its first frame G*j >= lens[b] (mask[:, :, ::G, ::G], attentions.py:698;
         # chunk padding is masked too, attentions.py:128-131); additive -1e9 as in the reference (:701)
-        masked = (torch.arange(tg).unsqueeze(0) * group >= lens.unsqueeze(1)).float()
-        s = s + masked[:, None, None, :] * -1e9
-    elif pad:
-        masked = (torch.arange(tg) * group >= t).float()
-        s = s + masked[None, None, None, :] * -1e9
+        masked = (torch.arange(tg).unsqueeze(0) * group >= lens.unsqueeze(1)).float()[:, None, None, :]
+        if band is not None:
+            masked = torch.maximum(masked, band[None, None])   # streaming_mask.maximum(padding_mask), attentions.py:1399
+        s = s + masked * -1e9
+    elif pad or band is not None:
+        masked = (torch.arange(tg) * group >= t).float()[None, None, None, :]
+        if band is not None:
+            masked = torch.maximum(masked, band[None, None])
+        s = s + masked * -1e9
     p = s.softmax(dim=-1)
     o = (p @ v).transpose(1, 2).reshape(bsz, tp, dim)[:, :t]      # un-group, drop chunk padding (:710-713)
     o = F.linear(o, _t(sd, m + "output_layer.weight"), _t(sd, m + "output_layer.bias"))
     return (o, p) if return_probs else o
 
 
-def mhsa_module(x, lens, sd, prefix, heads, group):
+def mhsa_module(x, lens, sd, prefix, heads, group, **ctx):
     d = x.shape[-1]
     h = F.layer_norm(x, (d,), _t(sd, prefix + ".norm.weight"), _t(sd, prefix + ".norm.bias"), LN_EPS)  # modules.py:475
-    return relpos_attention(h, lens, sd, prefix, heads, group)
+    return relpos_attention(h, lens, sd, prefix, heads, group, **ctx)
 
 
 # --------------------------------------------------------------------------
 # a7  convolution module  (modules.py:511-525; layers.py:122-136; activations.py:28-29, 37-39)
 # --------------------------------------------------------------------------
 
-def conv_module(x: torch.Tensor, sd, prefix: str, kernel: int, stride: int) -> torch.Tensor:
+def conv_module(x: torch.Tensor, sd, prefix: str, kernel: int, stride: int, causal: bool = False) -> torch.Tensor:
     d = x.shape[-1]
     p = prefix + ".layers"
     h = F.layer_norm(x, (d,), _t(sd, p + ".0.weight"), _t(sd, p + ".0.bias"), LN_EPS)
@@ -183,7 +218,7 @@ def conv_module(x: torch.Tensor, sd, prefix: str, kernel: int, stride: int) -> t
     a, g = h.chunk(2, dim=-1)                                                         # GLU over channels
     h = (a * torch.sigmoid(g)).transpose(1, 2)                                        # (B, De, T)
     half = (kernel - 1) // 2
-    h = F.pad(h, (half, half))                                                        # "same" pre-padding, layers.py:100
+    h = F.pad(h, (kernel - 1, 0) if causal else (half, half))                         # "causal" / "same" pre-padding, layers.py:97-101
     h = F.conv1d(h, _t(sd, p + ".4.weight"), _t(sd, p + ".4.bias"), stride=stride, groups=h.shape[1])
     h = F.batch_norm(h, _t(sd, p + ".5.running_mean"), _t(sd, p + ".5.running_var"),
                      _t(sd, p + ".5.weight"), _t(sd, p + ".5.bias"), False, 0.0, BN_EPS)
@@ -195,17 +230,20 @@ def conv_module(x: torch.Tensor, sd, prefix: str, kernel: int, stride: int) -> t
 # a8  Conformer block  (blocks.py:119-137; residual paths blocks.py:99-114)
 # --------------------------------------------------------------------------
 
-def conformer_block(x, lens, sd, bp, trace: Optional[dict] = None):
+def conformer_block(x, lens, sd, bp, trace: Optional[dict] = None, plan=None):
     """bp: efficientconformer_amd.config.BlockPlan.  Returns x_out (B, To, De).
     ``trace`` (optional) receives the four module outputs the reference's forward hooks see."""
     p = "blocks.%d" % bp.index
     f1 = ffn(x, sd, p + ".feed_forward_module1")
     x = x + 0.5 * f1
     x_ffn1 = x
-    att = mhsa_module(x, lens, sd, p + ".multi_head_self_attention_module", bp.num_heads, bp.group_size)
+    ctx = {}
+    if plan is not None and (plan.causal or plan.left_context < (1 << 30) or plan.right_context < (1 << 30)):
+        ctx = dict(causal=plan.causal, left=plan.left_context, right=plan.right_context, mask_stride=bp.mask_stride)
+    att = mhsa_module(x, lens, sd, p + ".multi_head_self_attention_module", bp.num_heads, bp.group_size, **ctx)
     x = x + att                                                   # att_res is Identity (att_stride == 1)
     x_mhsa = x
-    c = conv_module(x, sd, p + ".convolution_module", bp.kernel_size, bp.conv_stride)
+    c = conv_module(x, sd, p + ".convolution_module", bp.kernel_size, bp.conv_stride, causal=bool(plan is not None and plan.causal))
     if bp.transition:       # 1x1 strided conv on frames 0, s, 2s, ...   blocks.py:106-110
         res = F.linear(x[:, ::bp.conv_stride], _t(sd, p + ".conv_res.1.weight")[:, :, 0], _t(sd, p + ".conv_res.1.bias"))
     elif bp.conv_stride > 1:  # MaxPool1d(kernel 1, stride s) == frame decimation   blocks.py:110-114
@@ -236,7 +274,7 @@ def encoder_from_mel(mel: torch.Tensor, mel_len: Optional[torch.Tensor], sd, pla
     if trace is not None:
         trace["linear"] = x
     for bp in plan.blocks:
-        x = conformer_block(x, lens, sd, bp, trace)
+        x = conformer_block(x, lens, sd, bp, trace, plan)
         if bp.conv_stride > 1 and lens is not None:
             lens = torch.div(lens - 1, bp.conv_stride, rounding_mode="floor") + 1     # encoders.py:139
     return x, lens

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), "libeffconf.so does not export %s" % name
     assert sorted(_lib.SIGNATURES) == declared, "ctypes binding out of sync with include/effconf.h"
-    assert _lib.load().effconf_abi_version() == 1
+    assert _lib.load().effconf_abi_version() == _lib.ABI_VERSION == 2
 
 
 def test_create_rejects_bad_config_and_reports_error():
@@ -74,10 +74,16 @@ def test_block_plan_rule():
 
 def test_unsupported_configs_raise():
     p = named_config("EfficientConformerCTCSmall")["encoder_params"]
-    for k, v in (("subsampling_module", "VGG"), ("relative_pos_enc", False), ("causal", True), ("linear_att", True)):
+    for k, v in (("subsampling_module", "VGG"), ("relative_pos_enc", False), ("linear_att", True)):
         q = dict(p); q[k] = v
         with pytest.raises(NotImplementedError):
             build_plan(q)
+    # streaming / causal contexts are native since round 3 (encoders.py:68, 94): the plan carries them, block b's mask stride included
+    q = dict(p, causal=True, left_context=64)
+    plan = build_plan(q)
+    assert plan.causal and plan.left_context == 64 and plan.right_context == 0
+    assert [b.mask_stride for b in plan.blocks] == [1] * 5 + [2] * 5 + [4] * 5
+    assert build_plan(p).right_context == p["max_pos_encoding"] and not build_plan(p).causal
     q = dict(p); q["subsampling_module"] = "Nope"
     with pytest.raises(Exception):
         build_plan(q)

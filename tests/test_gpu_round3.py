@@ -289,3 +289,72 @@ def test_ragged_bench_size_batch_vs_utterances_alone():
         assert int(out_len[b]) == tb and torch.equal(out[b, :tb], alone[0]) and float(out[b, tb:].abs().sum()) == 0.0, b
         _, lab, n = m._head(alone, alone_len)
         assert int(label_len[b]) == int(n[0]) and torch.equal(labels[b, :tb], lab[0, :tb])
+
+
+# ------------------------------------------------------------------ streaming contexts / causal (SURVEY.md 8f-4 tail)
+def _stream_model(gname, g):
+    small = "small" in gname
+    cfg = named_config("EfficientConformerCTCSmall" if small else "Tiny")
+    extra = {k[4:]: (bool(g[k]) if k == "cfg/causal" else int(g[k])) for k in g.files if k.startswith("cfg/")}
+    cfg["encoder_params"] = dict(cfg["encoder_params"], **extra)
+    m = ModelCTC.from_config(cfg)
+    sd = synth.make_state_dict(m.encoder.plan, int(g["weight_seed"]), cfg["tokenizer_params"]["vocab_size"], prefix="encoder.")
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    osd = {k[len("encoder."):] if k.startswith("encoder.") else k: v for k, v in sd.items()}
+    return m.cuda(), osd, small
+
+
+_STREAM = sorted(f for f in os.listdir(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")) if f.startswith("stream_"))
+
+
+@pytest.mark.parametrize("gname", _STREAM)
+def test_streaming_and_causal_vs_reference_goldens(golden_dir, gname):
+    """`causal` and finite `left_context` / `right_context` (reference encoders.py:68, 94; attentions.py:1377-1403, 506, 1243-1247;
+    layers.py:97-101): band-masked attention with key-block skipping, causal relative tables, causal depthwise padding - against the
+    reference encoder run with those settings (tools/make_goldens.py --only-streaming).  bf16 tolerance 0.10 max / 0.012 mean; every
+    frame counts (pad frames included: their fully masked rows follow the reference's uniform softmax)."""
+    g = np.load(os.path.join(golden_dir, gname))
+    m, sd, small = _stream_model(gname, g)
+    lens = g["mel_len"].tolist()
+    mel, ln = synth.make_mel(len(lens), 80, max(lens), lens, seed=int(g["mel_seed"]))
+    out, out_len, _ = m.encoder.forward_mel(torch.from_numpy(mel).cuda(), torch.from_numpy(ln).cuda())
+    assert out_len.cpu().tolist() == g["out_len"].tolist()
+    ref = torch.from_numpy(g["out_rows"] if small else g["out"])
+    got = out.cpu()[:, ::4] if small else out.cpu()
+    d = (got - ref).abs()
+    print("%s: max %.4f mean %.5f" % (gname, float(d.max()), float(d.mean())))
+    assert float(d.max()) < 0.10 and float(d.mean()) < 0.012
+    if small:
+        logits, _, _ = m._head(out, out_len, want_logits=True)
+        am = logits.argmax(-1).cpu().numpy()
+        valid = np.arange(am.shape[1])[None, :] < g["out_len"][:, None]
+        safe = (g["margin"] > 0.15) & valid
+        assert safe.sum() > 20 and np.array_equal(am[safe], g["argmax"][safe])
+    again, _, _ = m.encoder.forward_mel(torch.from_numpy(mel).cuda(), torch.from_numpy(ln).cuda())
+    assert torch.equal(again, out)
+
+
+@pytest.mark.parametrize("extra", [dict(causal=True), dict(left_context=20, right_context=4), dict(causal=True, left_context=6)])
+def test_streaming_ragged_batch_equals_utterances_alone_and_the_oracle(extra):
+    cfg = named_config("Tiny")
+    cfg["encoder_params"] = dict(cfg["encoder_params"], **extra)
+    m = ModelCTC.from_config(cfg)
+    sd = synth.make_state_dict(m.encoder.plan, 7, cfg["tokenizer_params"]["vocab_size"], prefix="encoder.")
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    osd = {k[len("encoder."):] if k.startswith("encoder.") else k: v for k, v in sd.items()}
+    lens = np.array([48000, 41000, 30160, 22000, 12000, 3000], dtype=np.int64)
+    audio = torch.from_numpy(synth.make_audio(lens, seed=4))
+    _ragged_vs_alone(m.cuda(), osd, audio, lens, 2)
+
+
+def test_exact_mode_rejects_streaming_contexts():
+    cfg = named_config("Tiny")
+    cfg["encoder_params"] = dict(cfg["encoder_params"], causal=True)
+    m = ModelCTC.from_config(cfg)
+    sd = synth.make_state_dict(m.encoder.plan, 7, cfg["tokenizer_params"]["vocab_size"], prefix="encoder.")
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m.encoder.precision = "fp32"
+    m = m.cuda()
+    mel, ln = synth.make_mel(2, 80, 100, [100, 77], seed=1)
+    with pytest.raises(_lib.EffconfError, match="streaming|causal"):
+        m.encoder.forward_mel(torch.from_numpy(mel).cuda(), torch.from_numpy(ln).cuda())

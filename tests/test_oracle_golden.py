@@ -146,3 +146,26 @@ def test_rnnt_greedy_oracle_matches_reference_tokens(golden_dir, name):
             else:                          # greedy decoding is causal in the frame index: a prefix of frames gives a prefix of tokens
                 assert t == want[:len(t)], (tag, b)
                 assert tag != "rand" or len(t) == 5 * int(f_len[b]), (tag, b)
+
+
+_GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("gname", sorted(f for f in os.listdir(_GOLDEN_DIR) if f.startswith("stream_")))
+def test_oracle_streaming_and_causal_vs_reference(gname):
+    """Streaming contexts / causal attention + causal depthwise padding (reference encoders.py:68, 94; attentions.py:1377-1403, 506, 1243-1247;
+    layers.py:97-101): the oracle against the reference encoder run with `causal` / finite `left_context` / `right_context`."""
+    g = np.load(os.path.join(_GOLDEN_DIR, gname))
+    small = "small" in gname
+    cfg = named_config("EfficientConformerCTCSmall" if small else "Tiny")
+    ep = dict(cfg["encoder_params"], **{k[4:]: (bool(g[k]) if k == "cfg/causal" else int(g[k])) for k in g.files if k.startswith("cfg/")})
+    plan = build_plan(ep)
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(plan, int(g["weight_seed"]), cfg["tokenizer_params"]["vocab_size"]).items()}
+    lens = g["mel_len"].tolist()
+    mel, ln = synth.make_mel(len(lens), 80, max(lens), lens, seed=int(g["mel_seed"]))
+    with torch.no_grad():
+        out, out_len = R.encoder_from_mel(torch.from_numpy(mel), torch.from_numpy(ln), sd, plan)
+    assert out_len.tolist() == g["out_len"].tolist()
+    ref = torch.from_numpy(g["out_rows"] if small else g["out"])
+    got = out[:, ::4] if small else out
+    assert float((got - ref).abs().max()) < 2e-5

@@ -82,9 +82,11 @@ def to_torch(sd):
     return {k: torch.from_numpy(v.copy()) for k, v in sd.items()}
 
 
-def run_encoder(enc_mod, name, mel, lens, seed, hooks=False):
-    """Reference ConformerEncoder driven from mel (encoders.py:107-140) + fc head."""
+def run_encoder(enc_mod, name, mel, lens, seed, hooks=False, extra=None):
+    """Reference ConformerEncoder driven from mel (encoders.py:107-140) + fc head.  extra: encoder_params overrides (causal / contexts)."""
     cfg = named_config(name)
+    if extra:
+        cfg["encoder_params"] = dict(cfg["encoder_params"], **extra)
     plan = build_plan(cfg["encoder_params"])
     vocab = cfg["tokenizer_params"]["vocab_size"]
     sd = synth.make_state_dict(plan, seed, vocab)
@@ -174,13 +176,38 @@ def rnnt_goldens(enc_mod):
         save("rnnt_" + name, **arrs)
 
 
+STREAMING = (("causal", dict(causal=True)), ("ctx_l20_r4", dict(left_context=20, right_context=4)),
+             ("causal_l12", dict(causal=True, left_context=12)), ("ctx_l3_r0", dict(left_context=3, right_context=0)))
+
+
+def streaming_goldens(enc_mod):
+    """Streaming / causal contexts (reference encoders.py:68, 94; attentions.py:1377-1403, 506; layers.py:94-101): the reference encoder
+    with `causal` and finite `left_context` / `right_context`, tiny config (both sequence lengths) and EfficientConformerCTCSmall."""
+    for tag, extra in STREAMING:
+        for tm, lens in ((47, [47, 40, 23]), (100, [100, 77, 52])):
+            mel, ln = synth.make_mel(3, 80, tm, lens, seed=4321 + tm)
+            plan, x, out_len, logits, atts, _ = run_encoder(enc_mod, "Tiny", mel, ln, seed=7, extra=extra)
+            lab, offs = pack_labels(greedy_reference(logits, out_len))
+            save("stream_tiny_%s_T%d" % (tag, tm), mel_seed=np.int64(4321 + tm), weight_seed=np.int64(7), mel_len=ln, out=x.numpy(),
+                 out_len=out_len.numpy(), labels=lab, label_offsets=offs, **{"cfg/" + k: np.int64(v) for k, v in extra.items()})
+    for tag, extra in (("causal", dict(causal=True)), ("ctx_l64_r16", dict(left_context=64, right_context=16))):
+        mel, ln = synth.make_mel(2, 80, 601, [601, 433], seed=4321)
+        plan, x, out_len, logits, atts, _ = run_encoder(enc_mod, "EfficientConformerCTCSmall", mel, ln, seed=0, extra=extra)
+        save("stream_small_%s" % tag, mel_seed=np.int64(4321), weight_seed=np.int64(0), mel_len=ln, out_rows=x[:, ::4].numpy(),
+             out_len=out_len.numpy(), argmax=logits.argmax(-1).numpy().astype(np.int16), margin=margins(logits),
+             **{"cfg/" + k: np.int64(v) for k, v in extra.items()})
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     enc_mod, att_mod = import_reference()
     if "--only-rnnt" in sys.argv:
         return rnnt_goldens(enc_mod)
+    if "--only-streaming" in sys.argv:
+        return streaming_goldens(enc_mod)
     rnnt_goldens(enc_mod)
+    streaming_goldens(enc_mod)
 
     # ---- 1. tiny config: every module output, two sequence lengths (T1 % 3 == 0 and != 0)
     for tm, lens in ((47, [47, 40, 23]), (100, [100, 77, 52])):
