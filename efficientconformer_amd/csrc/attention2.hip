@@ -116,7 +116,7 @@ __global__ __launch_bounds__(NWV * 64, (QT == 1 && NWV == 4 && DP <= 96) ? 2 : 1
     nkv = nkv < Tg ? nkv : Tg;
     const int band_l = p.band_l < Tg ? p.band_l : Tg, band_r = p.band_r < Tg ? p.band_r : Tg;
     const bool banded = band_l < Tg || band_r < Tg;
-    const bool tile_dead = i0 + BI - 1 - band_l >= nkv;           // (nkv == 0: every row)
+    const bool tile_dead = nkv < 1 || i0 + BI - 1 - band_l >= nkv;    // empty utterance: every row
     int kbeg = 0, nkeys = nkv;
     if (tile_dead) nkeys = Tg;
     else if (banded) {
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(NWV * 64, (QT == 1 && NWV == 4 && DP <= 96) ? 2 : 1
                     }
             }
             if (tile_dead) {                                   // rows that see no key at all: every score equal -> uniform softmax over all key groups
-                const bool dead = iq0 + c - band_l >= nkv;
+                const bool dead = nkv < 1 || iq0 + c - band_l >= nkv;
 #pragma unroll
                 for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
