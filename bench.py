@@ -77,9 +77,10 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1 (nccl = RCCL over xGMI; gloo + --one-device: N ranks on ONE GPU, a test of the multi-rank path)")
     ap.add_argument("--one-device", action="store_true", help="every rank uses cuda:0 (tests on a single-GPU box; never a benchmark)")
-    ap.add_argument("--ragged", type=int, default=0, choices=[0, 1],
+    ap.add_argument("--ragged", type=int, default=-1, choices=[-1, 0, 1],
                     help="1: ConformerEncoder.ragged - every utterance at its own length in one concatenated row space (no pad frames; an utterance's "
-                         "output = the reference's for that utterance alone); 0: row ranges padded to their longest utterance (round 2's workload)")
+                         "output = the reference's for that utterance alone); 0: row ranges padded to their longest utterance (round 2's workload); "
+                         "-1 (default): 1 where the model supports it (one-layer subsampler, bf16 path, libri workload)")
     ap.add_argument("--no-check", action="store_true",
                     help="skip the un-timed self-check of the benchmarked step (single-stream per-range rerun + oracle samples)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"],
@@ -433,6 +434,8 @@ def main():
             dist.init_process_group("gloo")
 
     cfg, model, sd = build_model(args.model)
+    if args.ragged < 0:
+        args.ragged = int(model.encoder.plan.sub_layers == 1 and args.precision == "bf16" and args.workload == "libri" and not args.no_trim)
     model.encoder.precision = args.precision
     model = model.to(dev)
     plan = model.encoder.plan

@@ -15,7 +15,7 @@ constexpr int SUB_TT = 8;     // output frames per workgroup
 
 __global__ __launch_bounds__(256) void subsample_conv_kernel(const float* __restrict__ mel, int F, int Tm, int T1,
                                                              const float* __restrict__ w9, const float* __restrict__ bias,
-                                                             int C, bf16_t* out, int ldo) {
+                                                             int C, bf16_t* out, int ldo, const int* __restrict__ rag_tm) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TW = 2 * SUB_TT + 1;                 // input frames needed: 2t-1 .. 2t+1
     float* sm = reinterpret_cast<float*>(smem);        // [F + 1][TW + 1]  row 0 = frequency -1 (zero pad)
@@ -24,10 +24,11 @@ __global__ __launch_bounds__(256) void subsample_conv_kernel(const float* __rest
     const int b = blockIdx.x / tiles, t0 = (blockIdx.x % tiles) * SUB_TT;
     const int tid = threadIdx.x;
     const int F2 = F / 2;
+    const int tmb = rag_tm ? rag_tm[b] : Tm;          // ragged batch: the conv's zero padding starts at the utterance's own last mel frame
     for (int i = tid; i < (F + 1) * TW; i += 256) {
         const int fr = i / TW, tc = i - fr * TW;
         const int f = fr - 1, t = 2 * t0 - 1 + tc;
-        const bool ok = f >= 0 && t >= 0 && t < Tm;
+        const bool ok = f >= 0 && t >= 0 && t < tmb;
         const float v = mel[((size_t)b * F + (f < 0 ? 0 : f)) * Tm + (t < 0 ? 0 : (t < Tm ? t : Tm - 1))];   // clamped, unconditional
         sm[fr * (TW + 1) + tc] = ok ? v : 0.f;
     }
@@ -190,12 +191,12 @@ int launch_dw_t(const bf16_t* g, int B, int T, int To, int C, int ld, const floa
 }  // namespace
 
 int launch_subsample_conv(const float* mel, int B, int F, int Tm, int T1, const float* w9, const float* bias, int C,
-                          bf16_t* out, int ldo, hipStream_t s) {
+                          bf16_t* out, int ldo, hipStream_t s, const int* rag_tm) {
     if (B <= 0 || T1 <= 0) return 0;
     if (F % 4 || (C * (F / 2)) % 2) return -2;
     const int tiles = (T1 + SUB_TT - 1) / SUB_TT;
     const size_t lds = ((size_t)(F + 1) * (2 * SUB_TT + 2) + (size_t)C * 10) * sizeof(float);
-    hipLaunchKernelGGL(subsample_conv_kernel, dim3(B * tiles), dim3(256), lds, s, mel, F, Tm, T1, w9, bias, C, out, ldo);
+    hipLaunchKernelGGL(subsample_conv_kernel, dim3(B * tiles), dim3(256), lds, s, mel, F, Tm, T1, w9, bias, C, out, ldo, rag_tm);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

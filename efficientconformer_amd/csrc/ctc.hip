@@ -30,8 +30,15 @@ __global__ void lengths_kernel(const int64_t* __restrict__ x_len, int B, int fro
 }
 
 
-// Ragged batches (see kernels.h): lengths of every stage, then the prefix sums the ragged kernels index with.  One workgroup: thread b
-// computes utterance b's lengths, then thread k scans position k (a few hundred serial adds per thread; launched once per forward).
+// Ragged batches (see kernels.h): lengths of every stage, then the prefix sums the ragged kernels index with.  One workgroup of four
+// waves: thread b computes utterance b's lengths; then every (position, array) pair is one wave-parallel exclusive scan (64 utterances per
+// step, __shfl_up ladder) - a serial scan per thread cost ~0.1 ms of dependent global accesses at the head of every forward.
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(v, o); if (lane >= o) v += t; }
+    return v;
+}
+
 __global__ __launch_bounds__(256) void lengths_ragged_kernel(const int64_t* __restrict__ x_len, int B, int from_audio, int hop, int sub_layers,
                                                              const int* __restrict__ block_stride, const int* __restrict__ group,
                                                              const int* __restrict__ heads, int n_blocks, int* stage_lens, int* mel_len,
@@ -50,32 +57,40 @@ __global__ __launch_bounds__(256) void lengths_ragged_kernel(const int64_t* __re
         }
         if (out_len) out_len[b] = l;
     }
+    __threadfence_block();
     __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
     const int q8 = B >> 3, r8 = B & 7;
-    for (int k = threadIdx.x; k <= n_blocks; k += blockDim.x) {
+    // job = 3 * k + a: a = 0 row offsets of position k (k <= n_blocks), 1 attention workgroups of block k, 2 depthwise-conv tiles of block k
+    for (int job = wave; job < 3 * (n_blocks + 1); job += nwave) {
+        const int k = job / 3, a = job - 3 * k;
+        if (k == n_blocks && a != 0) continue;
         const int G = k < n_blocks ? group[k] : 1;
         const int* len = stage_lens + (size_t)k * B;
-        int* ro = row_off + (size_t)k * (B + 1);
-        int acc = 0;
-        for (int b = 0; b < B; ++b) { ro[b] = acc; acc += (len[b] + G - 1) / G * G; }
-        ro[B] = acc;
-        if (k == n_blocks) continue;
-        int* wo = wg_off + (size_t)k * (B + 1);
-        acc = 0;
-        for (int u = 0; u < B; ++u) {                        // list position u <-> utterance x + 8 j (the attention kernels' order)
-            int x, j;
-            if (u < r8 * (q8 + 1)) { x = u / (q8 + 1); j = u - x * (q8 + 1); }
-            else { const int u2 = u - r8 * (q8 + 1); x = u2 / q8; j = u2 - x * q8; x += r8; }
-            const int tg = (len[x + 8 * j] + G - 1) / G;
-            wo[u] = acc; acc += heads[k] * ((tg + 63) / 64);
+        int* dst = (a == 0 ? row_off + (size_t)k * (B + 1) : (a == 1 ? wg_off : tile_off) + (size_t)k * (B + 1));
+        int carry = 0;
+        for (int base = 0; base < B; base += 64) {
+            const int u = base + lane;
+            int v = 0;
+            if (u < B) {
+                if (a == 0) v = (len[u] + G - 1) / G * G;
+                else if (a == 1) {                               // list position u <-> utterance x + 8 j (the attention kernels' order)
+                    int x, j;
+                    if (u < r8 * (q8 + 1)) { x = u / (q8 + 1); j = u - x * (q8 + 1); }
+                    else { const int u2 = u - r8 * (q8 + 1); x = u2 / q8; j = u2 - x * q8; x += r8; }
+                    const int tg = (len[x + 8 * j] + G - 1) / G;
+                    v = heads[k] * ((tg + 63) / 64);
+                } else {                                         // block k's output rows are padded for block k + 1's attention
+                    const int Gn = k + 1 < n_blocks ? group[k + 1] : 1;
+                    const int lo = stage_lens[(size_t)(k + 1) * B + u];
+                    v = ((lo + Gn - 1) / Gn * Gn + 127) / 128;
+                }
+            }
+            const int inc = wave_incl_scan(v, lane);
+            if (u < B) dst[u] = carry + inc - v;
+            carry += __shfl(inc, 63);
         }
-        wo[B] = acc;
-        const int Gn = k + 1 < n_blocks ? group[k + 1] : 1;   // block k's output rows are padded for block k + 1's attention
-        const int* lo = stage_lens + (size_t)(k + 1) * B;
-        int* to = tile_off + (size_t)k * (B + 1);
-        acc = 0;
-        for (int b = 0; b < B; ++b) { to[b] = acc; acc += ((lo[b] + Gn - 1) / Gn * Gn + 127) / 128; }
-        to[B] = acc;
+        if (lane == 0) dst[B] = carry;
     }
 }
 

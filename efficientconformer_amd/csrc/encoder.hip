@@ -358,6 +358,7 @@ struct Workspace {
     size_t total = 0;
     size_t mel, sub, sub1, x0, x1, a, hbuf, qu, kh, vt, eh, o, gbuf, cbuf, xs, lens, preds;
     size_t mel_len = 0, row_off = 0, wg_off = 0, tile_off = 0;     // ragged descriptors (ints)
+    size_t xrect = 0;                                              // ragged + unfused front end: rectangular Linear output before the gather
     std::vector<size_t> eh_blk;   // per-block E (kept across forwards for the cache)
 };
 
@@ -391,7 +392,10 @@ Workspace make_workspace(const EcEncoder* e, const Shapes& s, bool from_audio) {
     w.mel = take(from_audio ? B * e->cfg.n_mels * s.Tm * 4 : 0);
     const int C = e->cfg.sub_filters[e->cfg.sub_layers - 1];
     int F = e->cfg.n_mels; for (int i = 0; i < e->cfg.sub_layers; ++i) F /= 2;
-    w.sub = take(s.ragged ? 0 : B * s.T1 * C * F * 2);      // scratch of the unfused front ends (ragged batches run sublinear2.hip only)
+    const bool rag_unfused = s.ragged && !(e->fuse_subsample == 2 && e->lin_rs);        // (s.Tm = the input's row pitch in ragged batches)
+    const size_t T1r = s.ragged ? (size_t)(s.Tm - 1) / 2 + 1 : (size_t)s.T1;
+    w.sub = take(s.ragged && !rag_unfused ? 0 : B * T1r * C * F * 2);      // scratch of the unfused front ends
+    w.xrect = take(rag_unfused ? B * T1r * e->blocks[0].dim_model * 4 : 0);
     {   // two-layer subsampler: channel-last layer-1 activation [B][F/2][T after layer 1][Cp]
         const size_t tl1 = (s.Tm - 1) / 2 + 1;
         w.sub1 = take(e->cfg.sub_layers == 2 ? B * (e->cfg.n_mels / 2) * tl1 * ec_round_up(e->cfg.sub_filters[0], 64) * 2 : 0);
@@ -583,12 +587,24 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
     float* x = reinterpret_cast<float*>(ws + w.x0);
     float* xalt = reinterpret_cast<float*>(ws + w.x1);
     if (rg) {
-        if (!(c.sub_layers == 1 && e->fuse_subsample == 2 && e->lin_rs))
-            return fail("ragged batches need the sublinear2.hip front end (one subsampling layer, filters and first width <= 192, option fuse_subsample = 2)");
+        if (c.sub_layers != 1) return fail("ragged batches need a one-layer Conv2dSubsampling (the EfficientConformer configurations)");
         const int C0 = c.sub_filters[0], Ksub = C0 * (c.n_mels / 2);
         const RaggedRows r0 = rows_at(0);
-        PROF(PC_SUBCONV, 2.0 * 9 * (double)s.Min[0] * Ksub + 2.0 * (double)s.Min[0] * Ksub * e->lin.N, (double)B * c.n_mels * s.Tm * 4 + (double)s.Min[0] * e->lin.N * 4);
-        EC_TRY(launch_sublinear2(mel, B, c.n_mels, s.Tm, s.T1, e->conv_tab, e->lin_rs, e->lin.bias, C0, e->lin.N, x, e->lin.N, st, &r0, mel_len));
+        if (e->fuse_subsample == 2 && e->lin_rs) {        // sublinear2.hip indexes the ragged rows itself
+            PROF(PC_SUBCONV, 2.0 * 9 * (double)s.Min[0] * Ksub + 2.0 * (double)s.Min[0] * Ksub * e->lin.N, (double)B * c.n_mels * s.Tm * 4 + (double)s.Min[0] * e->lin.N * 4);
+            EC_TRY(launch_sublinear2(mel, B, c.n_mels, s.Tm, s.T1, e->conv_tab, e->lin_rs, e->lin.bias, C0, e->lin.N, x, e->lin.N, st, &r0, mel_len));
+        } else {
+            // wide front ends (Large: 360 filters): conv (zero padding at every utterance's own last mel frame) + Linear on the RECTANGULAR
+            // (B, T1 of the longest) rows, then the valid rows are gathered into the ragged row space (pad rows are computed and dropped:
+            // the subsampler is a few percent of the step)
+            bf16_t* sub = reinterpret_cast<bf16_t*>(ws + w.sub);
+            float* xrect = reinterpret_cast<float*>(ws + w.xrect);
+            const int T1r = (s.Tm - 1) / 2 + 1;            // rows per utterance of the rectangular image (pitch of the input)
+            { PROF(PC_SUBCONV, 2.0 * 9 * B * T1r * (double)Ksub, (double)B * c.n_mels * s.Tm * 4 + (double)B * T1r * Ksub * 2);
+              EC_TRY(launch_subsample_conv(mel, B, c.n_mels, s.Tm, T1r, e->sub_w9, e->sub_b, C0, sub, Ksub, st, mel_len)); }
+            EC_TRY(run_gemm(e, PC_GEMM_OTHER, st, sub, Ksub, B * T1r, e->lin, EPI_F32, xrect, e->lin.N));
+            { PROF(PC_MISC, 0, (double)s.Min[0] * e->lin.N * 8); EC_TRY(launch_gather_rows(xrect, e->lin.N, T1r, r0, x, st)); }
+        }
     } else {
         EC_TRY(run_subsample_linear(e, st, mel, B, s.Tm, s.T1, reinterpret_cast<bf16_t*>(ws + w.sub), reinterpret_cast<bf16_t*>(ws + w.sub1), x));
     }

@@ -162,8 +162,11 @@ int launch_attn_pad_rows_ragged(bf16_t* qu, bf16_t* kh, bf16_t* vt, const float*
 
 // ---------------------------------------------------------------- convolutions  (conv.hip)
 // mel (B, F, Tm) f32 -> (B*T1, C*F/2) bf16, feature index c*(F/2)+f; 3x3 s2 p1 conv (Cin=1) + folded BN + Swish
+// rag_tm != null (dev [B]): per-utterance mel frames (the zero padding starts there); rows stay rectangular (b, t < T1)
 int launch_subsample_conv(const float* mel, int B, int F, int Tm, int T1, const float* w9, const float* bias, int C,
-                          bf16_t* out, int ldo, hipStream_t s);
+                          bf16_t* out, int ldo, hipStream_t s, const int* rag_tm = nullptr);
+// rectangular fp32 rows (b, t) of B x t_pitch -> the ragged row space (row off[b] + t for t < len[b]; group-padding rows = zeros)
+int launch_gather_rows(const float* x, int D, int t_pitch, const RaggedRows& rg, float* out, hipStream_t s);
 // fused subsampling conv + Linear (sublinear.hip): mel (B, F, Tm) -> out fp32 (B*T1, N); W packed in (f-chunk, channel, f) K order
 bool sublinear_fused_supported(int F, int N);
 int launch_sublinear_fused(const float* mel, int B, int F, int Tm, int T1, const float* w9, const float* cbias, int C,

@@ -128,6 +128,22 @@ __global__ __launch_bounds__(256) void emit_rows_kernel(const float* __restrict_
     }
 }
 
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ x, int D, int t_pitch, const int* __restrict__ off,
+                                                          const int* __restrict__ len, int n, int rows, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int b = ragged_find(off, n, row), t = row - off[b];
+    const bool valid = t < len[b];
+    const float* xr = x + ((size_t)b * t_pitch + (valid ? t : 0)) * D;
+    float* o = out + (size_t)row * D;
+    for (int c = lane * 4; c < D; c += 256) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid) v = *reinterpret_cast<const float4*>(xr + c);
+        *reinterpret_cast<float4*>(o + c) = v;
+    }
+}
+
 // y = LayerNorm(x + alpha * r): the residual + norm glue of ConformerBlock.forward as ONE unit-testable kernel (per-kernel C ABI
 // entry effconf_layernorm_residual; the forward itself keeps this inside the chain / GEMM epilogues).  One wave per row.
 __global__ __launch_bounds__(256) void layernorm_residual_kernel(const float* __restrict__ x, const float* __restrict__ r, float alpha, int M, int D,
@@ -197,6 +213,13 @@ int launch_cast_rows(const float* x, int D, int rows_per_batch, int stride, int 
     if (D % 4 || ld_out % 4) return -2;
     hipLaunchKernelGGL(cast_rows_kernel, dim3((total + 3) / 4), dim3(256), 0, s, x, D, rows_per_batch, stride,
                        out_rows_per_batch, total, out, ld_out, rc);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_gather_rows(const float* x, int D, int t_pitch, const RaggedRows& rg, float* out, hipStream_t s) {
+    if (rg.rows <= 0) return 0;
+    if (D % 4) return -2;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((rg.rows + 3) / 4), dim3(256), 0, s, x, D, t_pitch, rg.off, rg.len, rg.n, rg.rows, out);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -247,7 +247,8 @@ def test_ragged_batch_equals_every_utterance_run_alone_tiny(nsub):
     _ragged_vs_alone(m, sd, audio, lens, nsub)
 
 
-@pytest.mark.parametrize("name", ["EfficientConformerCTCSmall", "EfficientConformerCTCMedium"])
+@pytest.mark.parametrize("name", ["EfficientConformerCTCSmall", "EfficientConformerCTCMedium", "EfficientConformerCTCLarge",
+                                  "EfficientConformerTransducerSmall", "EfficientConformerTransducerLarge"])
 def test_ragged_batch_equals_every_utterance_run_alone_shipped_configs(name):
     m, sd = _model(name, 3)
     lens = np.array([70000, 52345, 33000, 20000, 8000], dtype=np.int64)
@@ -358,3 +359,12 @@ def test_exact_mode_rejects_streaming_contexts():
     mel, ln = synth.make_mel(2, 80, 100, [100, 77], seed=1)
     with pytest.raises(_lib.EffconfError, match="streaming|causal"):
         m.encoder.forward_mel(torch.from_numpy(mel).cuda(), torch.from_numpy(ln).cuda())
+
+
+def test_ragged_rejects_the_two_layer_subsampler():
+    m, _ = _model("ConformerCTCSmall", 1)
+    m.encoder.ragged = True
+    lens = np.array([30000, 20000], dtype=np.int64)
+    audio = torch.from_numpy(synth.make_audio(lens, seed=1)).cuda()
+    with pytest.raises(_lib.EffconfError, match="one-layer"):
+        m.encoder(audio, torch.from_numpy(lens).cuda(), x_len_host=lens)

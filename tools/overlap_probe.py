@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One-GPU stand-in for the multi-GPU step (north_star: "RCCL all-gather of encoder outputs before CTC, overlapped with the last encoder
-stage on a side HIP stream"): the default bench step (EfficientConformerCTCSmall, B = 256, three trimmed row ranges on three streams)
+stage on a side HIP stream"): the default bench step (EfficientConformerCTCSmall, B = 256, three ragged row ranges on three streams)
 with `dist.ShardedEncoder`'s exact stream protocol - a `range_hook` that records an event on the range's stream, a comm stream that waits
 for it - where the collective itself is replaced by device-to-device copies of the SAME BYTES an 8-rank all-gather makes this rank
 receive (7 x the range's rows, fp32 wire by default), followed by the CTC head on the "gathered" chunk on a head stream.
@@ -38,7 +38,7 @@ def main():
     lens = torch.from_numpy(lens_np).to(dev)
     cuts = [0, 80, 160, 256]
     pads = [int(lens_np[cuts[i]:cuts[i + 1]].max()) for i in range(3)]
-    enc.sub_batches, enc.sub_batch_streams, enc.trim_sub_batches, enc.stagger_ranges = 3, 3, True, True
+    enc.sub_batches, enc.sub_batch_streams, enc.ragged, enc.stagger_ranges = 3, 3, True, True        # bench.py's default step
     comm, head = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
     wire = torch.float32 if args.wire == "fp32" else torch.bfloat16
     bufs = {}
@@ -63,7 +63,7 @@ def main():
                 ev = torch.cuda.Event()
                 ev.record(comm)
             chunks.append((lo, hi, g, out_len, ev))
-        enc(audio, lens, range_hook=hook, range_pad=pads)
+        enc(audio, lens, range_hook=hook, x_len_host=lens_np)
         head.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(head):
             for lo, hi, g, out_len, ev in chunks:
