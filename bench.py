@@ -74,6 +74,7 @@ def parse():
                     help="attention kernel: 0 attention.hip, 1 / 2 attention2.hip variants (-1: the library's default = 1)")
     ap.add_argument("--wide-gemm", type=int, default=-1, choices=[-1, 0, 1, 2, 3],
                     help="tiled GEMM layers: 0 tile by shape, 1 gemm.hip only, 2 / 3 gemm256.hip 256x256 / 256x128 wherever it applies (-1: default = 0)")
+    ap.add_argument("--opt", action="append", default=[], help="library option name=value (effconf_encoder_set_option), repeatable (tuning)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1 (nccl = RCCL over xGMI; gloo + --one-device: N ranks on ONE GPU, a test of the multi-rank path)")
     ap.add_argument("--one-device", action="store_true", help="every rank uses cuda:0 (tests on a single-GPU box; never a benchmark)")
@@ -477,6 +478,9 @@ def main():
         model.encoder.set_option("fuse_subsample", args.subsample)
     if args.wide_gemm >= 0:
         model.encoder.set_option("wide_gemm", args.wide_gemm)
+    for opt in args.opt:                                      # tuning: any library option, e.g. --opt chain_max_dim=192
+        k, v = opt.split("=")
+        model.encoder.set_option(k, int(v))
     if args.ragged and world > 1 and nsub > 1:
         model.encoder.sub_batch_bounds = cuts[1:-1]             # every rank must cut the SAME row ranges: the per-range collectives are fixed-size
     hkw = {"x_len_host": lens_np} if args.ragged else {}       # ragged batches size their grids from the lengths on the host

@@ -60,7 +60,7 @@ struct Attn2Smem {
     static constexpr int TOTAL = K_BYTES + V_BYTES + E_BYTES + S_BYTES;
 };
 
-template <int DP, int NWV, int QT>
+template <int DP, int NWV, int QT, int SETS = 0>      // SETS: staging register sets (0 = by shape, 1 = loads one key block ahead, 2 = two ahead)
 __global__ __launch_bounds__(NWV * 64, (QT == 1 && NWV == 4 && DP <= 96) ? 2 : 1) void relpos_attention2_kernel(const AttnParams p) {
     using SM = Attn2Smem<DP, NWV, QT>;
     constexpr int KS = DP / 32, DT = DP / 16, BI = SM::BI, NTHR = NWV * 64, CPR = DP / 8, ERING = SM::ERING;
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(NWV * 64, (QT == 1 && NWV == 4 && DP <= 96) ? 2 : 1
 
     // two staging sets (loads two key blocks ahead) while they fit the register file; one set (one block ahead) for the widest heads
     // of the 2-wave workgroup, whose threads stage twice as many chunks
-    constexpr bool TWO_SETS = !(NWV == 2 && DP >= 96);
+    constexpr bool TWO_SETS = SETS == 2 || (SETS == 0 && !(NWV == 2 && DP >= 96));
     issue_loads(sa, kbeg);
     if constexpr (TWO_SETS) {
         if (kbeg + BJ < nkeys) issue_loads(sb, kbeg + BJ);
@@ -467,16 +467,16 @@ __global__ __launch_bounds__(NWV * 64, (QT == 1 && NWV == 4 && DP <= 96) ? 2 : 1
     }
 }
 
-template <int DP, int NWV, int QT>
+template <int DP, int NWV, int QT, int SETS = 0>
 int launch2(const AttnParams& p, hipStream_t s) {
     using SM = Attn2Smem<DP, NWV, QT>;
     static_assert(SM::TOTAL <= 160 * 1024, "LDS");
     static LdsAttr attr;
-    ensure_dynamic_lds(reinterpret_cast<const void*>(&relpos_attention2_kernel<DP, NWV, QT>), SM::TOTAL, attr);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(&relpos_attention2_kernel<DP, NWV, QT, SETS>), SM::TOTAL, attr);
     const int qtiles = (p.Tg + SM::BI - 1) / SM::BI;
     const int nwg = p.rag_off ? p.rag_nwg : p.B * p.H * qtiles;       // ragged: sum over the utterances of heads x query tiles (host total)
     if (nwg <= 0) return 0;
-    hipLaunchKernelGGL((relpos_attention2_kernel<DP, NWV, QT>), dim3(nwg), dim3(NWV * 64), SM::TOTAL, s, p);
+    hipLaunchKernelGGL((relpos_attention2_kernel<DP, NWV, QT, SETS>), dim3(nwg), dim3(NWV * 64), SM::TOTAL, s, p);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -491,6 +491,10 @@ int launch_relpos_attention2(const AttnParams& p, int waves, hipStream_t s) {
     if (p.dpad < p.d || p.q_rowstride != p.e_rowstride) return -2;
     if (p.rag_off && (waves != 1 || !p.rag_wg || p.q_rowstride != p.G * p.D)) return -2;      // ragged: natural layout, 64-query workgroups
 #define ATT2_CASE(DPV) case DPV: return waves == 1 ? launch2<DPV, 4, 1>(p, s) : launch2<DPV, 2, 2>(p, s);
+    // head width 96 (EfficientConformer Small stage 1): with two staging sets the kernel needs 9 registers more than two waves per SIMD allow
+    // and reloads loop-invariant addresses from scratch inside the key loop; ONE set (loads one key block ahead) fits: attention class
+    // 1.625 -> 1.555 ms per step (option attn_waves = 2 restores the two sets for comparison)
+    if (waves == 1 && p.dpad == 96 && p.force_waves != 2) return launch2<96, 4, 1, 1>(p, s);
     switch (p.dpad) {
         ATT2_CASE(32) ATT2_CASE(64) ATT2_CASE(96) ATT2_CASE(128)
         case 160: return launch2<160, 4, 1>(p, s);       // d = 135 (Medium / Large stage 1): one wave per SIMD either way; the 32-query variant spills

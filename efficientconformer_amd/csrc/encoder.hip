@@ -77,6 +77,8 @@ struct EcEncoder {
     int attention_v2 = 1;                    // 0: attention.hip; 1 (default) / 2: attention2.hip variants where they support the head width (padded <= 160)
     // tuning / test options that used to be process-global environment switches (effconf_encoder_set_option)
     int chain_variant = 0, chain_full_max = 192, attn_waves = 4, rs_variant = 0, ffn_variant = 0;
+    int chain_max_dim = 256;                 // fused chains only for stage widths <= this (tuning: wider stages on the per-GEMM / tiled kernels)
+    int tiled_min_k = 256;                   // with wide_gemm >= 2: layers with K > this leave the row-stationary kernels for LayerNorm + tiled GEMMs
     bool head_major_odd = false;             // odd grouped head widths on the head-major Q/K/V layout (tests; the default reads the natural layout unaligned)
     // two-layer subsampler (plain Conformer configs): layer-2 implicit-GEMM weight [N][9*Cp] (tap, c_in), folded bias, Cp
     const bf16_t* sub2_w = nullptr; const float* sub2_b = nullptr; int sub2_cp = 0;
@@ -480,10 +482,12 @@ void fill_chain_head(ChainParams& cp, const BlockW& W, int D, int Fp, int T, int
     cp.qu = q.qu; cp.kh = q.kh; cp.vt = q.vt; cp.u = W.u; cp.v = W.v; cp.T = T; cp.Tp = Tp;
 }
 
+bool prefer_tiled(const EcEncoder* e, int M, int N, int K);
+
 int run_ffn(EcEncoder* e, hipStream_t st, const bf16_t* a, int M, int D, const PackedLinear& L1, const PackedLinear& L2,
             const bf16_t* w2p, float* x, bf16_t* hbuf, const LNp* ln = nullptr) {
     const int F = L1.N;
-    if (ffn_fused_supported(D)) {
+    if (ffn_fused_supported(D) && !(prefer_tiled(e, M, F, D) && !ln)) {
         PROF(PC_GEMM_FFN, 4.0 * M * (double)D * F, (double)M * D * 10 + 4.0 * D * F);
         FfnParams p{};
         p.A = a; p.lda = ld8(D); p.X = x; p.ldx = D; p.Y = x; p.ldy = D;
@@ -504,7 +508,7 @@ int run_ffn(EcEncoder* e, hipStream_t st, const bf16_t* a, int M, int D, const P
 // (the two paths round differently; tools/robustness_sweep.py) - the gemm.hip / gemm256.hip choice does not (bit-identical kernels).
 bool prefer_tiled(const EcEncoder* e, int M, int N, int K) {
     (void)M; (void)N;
-    return e->wide_gemm >= 2 && K > 256 && K % 8 == 0;
+    return e->wide_gemm >= 2 && K > e->tiled_min_k && K % 8 == 0;
 }
 
 // row-stationary single GEMM when K <= 384, else the tiled kernel
@@ -644,9 +648,9 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
         // rows (b, t) -> Q / K / V rows b * Tp + t; a ragged batch keeps every utterance's rows group-padded in the residual stream itself,
         // so the map is the identity: ONE "utterance" of M rows
         const int qT = rg ? M : T, qTp = rg ? M : Tp;
-        const bool chain_head = e->fuse_chain && W.chain_in && nat && chain_head_supported(D);          // FFN1 + QKV of this block as a fused chain
-        const bool chain_b = e->fuse_chain && W.chain_in;                      // out-proj + LN + pointwise-1/GLU
-        const bool chain_tail = e->fuse_chain && W.chain_out && chain_tail_supported(De);                  // pointwise-2 + FFN2 + block norm (+ next block's head)
+        const bool chain_head = e->fuse_chain && W.chain_in && nat && chain_head_supported(D) && D <= e->chain_max_dim;          // FFN1 + QKV of this block as a fused chain
+        const bool chain_b = e->fuse_chain && W.chain_in && D <= e->chain_max_dim;                      // out-proj + LN + pointwise-1/GLU
+        const bool chain_tail = e->fuse_chain && W.chain_out && chain_tail_supported(De) && De <= e->chain_max_dim;                  // pointwise-2 + FFN2 + block norm (+ next block's head)
         GemmParams p{};
         p.A = a; p.lda = ld8(D); p.W = W.qkv.w; p.ldw = W.qkv.ldw; p.bias = W.qkv.bias;
         p.M = M; p.N = 3 * D; p.K = D;
@@ -772,7 +776,7 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
             bool next_head = false;
             if (!last) {
                 const EcBlock& nbk = e->blocks[k + 1];
-                next_head = W.cc_full && e->bw[k + 1].chain_in && chain_full_supported(De, e->chain_full_max) && (((nbk.group_size * nbk.dim_model / nbk.num_heads) % 2) == 0 || !head_major_odd) && nbk.dim_model == De;
+                next_head = W.cc_full && nbk.dim_model <= e->chain_max_dim && e->bw[k + 1].chain_in && chain_full_supported(De, e->chain_full_max) && (((nbk.group_size * nbk.dim_model / nbk.num_heads) % 2) == 0 || !head_major_odd) && nbk.dim_model == De;
             }
             ChainParams cp{};
             cp.variant = e->chain_variant;
@@ -804,7 +808,7 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
         snprintf(nm, sizeof(nm), "blocks.%d.x_conv", k); trace_add(e, st, nm, x, Mo, De, De, 0);
 
         // ---- x += 1/2 FFN2(x); x = LN(x)   (blocks.py:132-135)
-        if (ffn_fused_supported(De)) {
+        if (ffn_fused_supported(De) && !prefer_tiled(e, Mo, De * b.ff_ratio, De)) {
             EC_TRY(run_ffn(e, st, a, Mo, De, W.ffn2_a, W.ffn2_b, W.ffn2_bp, x, hbuf, &W.ln_ffn2));
         } else {
             { PROF(PC_LAYERNORM, 0, (double)Mo * De * 6); EC_TRY(launch_layernorm(x, Mo, De, W.ln_ffn2.g, W.ln_ffn2.b, nullptr, a, ld8(De), nullptr, nullptr, st)); }
@@ -1610,8 +1614,10 @@ int effconf_encoder_set_option(EcEncoder* e, const char* name, int32_t value) {
     // former EFFCONF_* environment switches (process-global statics): per-handle options now
     if (!strcmp(name, "chain_variant")) { if (value != 0 && value != 1) return fail("chain_variant: 0 (8-wave chain workgroups) or 1 (4-wave, two per CU, at 65..128-wide stages)"); e->chain_variant = value; return 0; }
     if (!strcmp(name, "chain_full_max")) { if (value < 0 || value > 256) return fail("chain_full_max: widest stage (0..256) that runs chain A as ONE kernel"); e->chain_full_max = value; return 0; }   // widening takes effect at the next finalize (the combined constant blocks are built there)
-    if (!strcmp(name, "attn_waves")) { if (value != 4 && value != 8) return fail("attn_waves: 4 or 8 (attention.hip workgroup size)"); e->attn_waves = value; return 0; }
+    if (!strcmp(name, "attn_waves")) { if (value != 4 && value != 8 && value != 2) return fail("attn_waves: 4 or 8 (attention.hip workgroup size); 2: attention2.hip with two staging sets at head width 96 (tuning)"); e->attn_waves = value; return 0; }
     if (!strcmp(name, "rs_variant")) { if (value != 0 && value != 1) return fail("rs_variant: 0 or 1 (8-wave row-stationary GEMM workgroups)"); e->rs_variant = value; return 0; }
+    if (!strcmp(name, "chain_max_dim")) { e->chain_max_dim = value; return 0; }
+    if (!strcmp(name, "tiled_min_k")) { e->tiled_min_k = value; return 0; }
     if (!strcmp(name, "ffn_variant")) { if (value < 0 || value > 2) return fail("ffn_variant: 0, 1 or 2 (fused-FFN workgroup shapes)"); e->ffn_variant = value; return 0; }
     if (!strcmp(name, "head_major_odd")) { e->head_major_odd = value != 0; return 0; }
     if (!strcmp(name, "cache_pos_embeddings")) { e->e_cache_on = value != 0; e->e_cache.clear(); return 0; }
