@@ -486,11 +486,10 @@ def main():
     hkw = {"x_len_host": lens_np} if args.ragged else {}       # ragged batches size their grids from the lengths on the host
     if args.ragged:
         padded_frames = valid_frames                            # no pad frames exist (an utterance's rows are only rounded up to the group size)
-    sharded = head_stream = None
+    sharded = None
     if world > 1:
         from efficientconformer_amd.dist import ShardedEncoder
         sharded = ShardedEncoder(model.encoder, wire_dtype=torch.bfloat16 if args.wire == "bf16" else None)
-        head_stream = torch.cuda.Stream(device=dev)
     last = {}
 
     def full_step():
@@ -503,33 +502,24 @@ def main():
                 last["labels"] = (labels, label_len)
             last["enc"] = (enc, enc_len)
             return
-        cur = torch.cuda.current_stream(dev)
         if args.gather == "outputs":
-            # encoder on this rank's utterances; per-row-range all-gather on the comm stream (dist.py); the head consumes the
-            # gathered chunks on its own stream, so the next step's encoder is not queued behind the collectives
-            g = sharded.encode_shard(audio, lens, args.batch * world, range_pad=range_pad, **hkw)
-            head_stream.wait_stream(cur)
-            with torch.cuda.stream(head_stream):
-                res = []
-                for ch in g.chunks:
-                    ch.wait(head_stream)
-                    res.append(head(model, ch.out if ch.out.dtype == torch.float32 else ch.out.float(), ch.out_len))
+            # encoder on this rank's utterances; per-row-range all-gather issued from each range's stream (dist.py); the head consumes
+            # the gathered chunk on that same stream (no extra streams: see dist.py on the four-stream budget)
+            res = []
+            sharded.encode_shard(audio, lens, args.batch * world, range_pad=range_pad,
+                                 consumer=lambda ch: res.append(head(model, ch.out if ch.out.dtype == torch.float32 else ch.out.float(), ch.out_len)), **hkw)
             last["labels"] = res
         else:
-            enc, enc_len, _ = model.encoder(audio, lens, range_pad=range_pad, **hkw)
-            labels, label_len = head(model, enc, enc_len)
-            head_stream.wait_stream(cur)
-            with torch.cuda.stream(head_stream):
-                gl = labels.new_empty((world,) + tuple(labels.shape)); gn = label_len.new_empty((world,) + tuple(label_len.shape))
-                labels.record_stream(head_stream); label_len.record_stream(head_stream)
-                from efficientconformer_amd.dist import _all_gather
-                _all_gather(gl, labels)
-                _all_gather(gn, label_len)
+            # the head per row range on that range's stream, then ONE small collective of the label ids on the caller's stream
+            enc, enc_len, labels, label_len = model.encode_greedy(audio, lens, range_pad=range_pad, **hkw)
+            gl = labels.new_empty((world,) + tuple(labels.shape)); gn = label_len.new_empty((world,) + tuple(label_len.shape))
+            from efficientconformer_amd.dist import _all_gather
+            _all_gather(gl, labels)
+            _all_gather(gn, label_len)
             last["labels"] = (gl, gn)
 
     def drain():
-        if head_stream is not None:
-            torch.cuda.current_stream(dev).wait_stream(head_stream)
+        pass
 
     for _ in range(args.warmup):
         full_step()

@@ -10,10 +10,13 @@ output depends only on its own row and on the padded length (pad frames are live
   * every shard has ceil(B / world) rows (a short shard is filled with a copy of its last row), so all ranks
     launch identical shapes and every collective is one fixed-size all_gather_into_tensor (the RCCL fast path);
   * the encoder outputs are all-gathered PER SUB-BATCH ROW RANGE (`backend="nccl"` is RCCL over xGMI on ROCm):
-    `ConformerEncoder.forward(..., range_hook=...)` calls back as soon as a row range's last kernel is enqueued,
-    the collective of that range waits for an event on the range's stream and runs on a side ("comm") stream —
-    range 0 (higher stream priority) is on the wire while the later ranges are still in their last stage, and the
-    last range's collective overlaps the consumer's work on the earlier chunks;
+    `ConformerEncoder.forward(..., range_hook=...)` calls back as soon as a row range's last kernel is enqueued, with
+    that range's HIP stream current, and the collective is issued right there: the process group runs it on ITS OWN
+    side stream behind the range's kernels, the other ranges' streams keep computing under it, and the range's stream
+    (and whatever the consumer enqueues on it) continues once the chunk has arrived.  No further stream is created:
+    on the MI355X more than four concurrently active HIP streams per process stop overlapping (a 5.5 ms step became
+    7.4 ms with an extra comm + head stream; tools/overlap_probe.py), so the budget is: caller's stream + two side
+    streams for the ranges + the process group's;
   * consumers (CTC head, RNN-T decode) work chunk by chunk on the gathered tensors (`Gathered.chunks`), or call
     `Gathered.assemble()` for one (B, T, D) tensor in global order;
   * weights are replicated (<= 251 MB bf16), there is no other data-path collective.
@@ -108,18 +111,15 @@ class ShardedEncoder:
 
     def __init__(self, encoder: Callable, group=None, wire_dtype: Optional[torch.dtype] = None):
         self.encoder, self.group, self.wire_dtype = encoder, group, wire_dtype
-        self._comm: Optional["torch.cuda.Stream"] = None
         self._maps = {}
         fwd = getattr(encoder, "forward", encoder)
         try:
             self._hooked = "range_hook" in inspect.signature(fwd).parameters
         except (TypeError, ValueError):
             self._hooked = False
-        if self._hooked and hasattr(encoder, "stagger_ranges"):
-            encoder.stagger_ranges = True
 
     # ------------------------------------------------------------------ collective of one row range
-    def _gather_range(self, lo: int, hi: int, out: torch.Tensor, out_len: torch.Tensor, global_batch: int, chunks: list):
+    def _gather_range(self, lo: int, hi: int, out: torch.Tensor, out_len: torch.Tensor, global_batch: int, chunks: list, consumer=None):
         world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
         n = hi - lo
         # row map of the gathered chunk, built ON the output's device and cached per (lo, hi, world, global batch): a pageable
@@ -132,35 +132,38 @@ class ShardedEncoder:
         rows, keep = self._maps[key]
         if out.is_cuda:
             dev = out.device
-            if self._comm is None:
-                self._comm = torch.cuda.Stream(device=dev)
-            done = torch.cuda.Event()
-            done.record(torch.cuda.current_stream(dev))          # the range's stream: its last kernel is enqueued
-            self._comm.wait_event(done)
-            with torch.cuda.stream(self._comm):
-                wire = out[lo:hi] if self.wire_dtype is None else out[lo:hi].to(self.wire_dtype)
-                wl = out_len[lo:hi]
-                out.record_stream(self._comm); out_len.record_stream(self._comm)   # read here, owned by the caller's stream
-                g = wire.new_empty((world * n,) + tuple(wire.shape[1:]))
-                gl = wl.new_empty(world * n)
-                _all_gather(g, wire.contiguous(), self.group)
-                _all_gather(gl, wl.contiguous(), self.group)
-                ev = torch.cuda.Event()
-                ev.record(self._comm)
-            chunks.append(GatheredChunk(lo, hi, g, gl, rows, keep, ev, self._comm))
+            # issued on the range's own stream (current): RCCL's process-group stream waits for this stream's kernels, the other ranges
+            # compute under the transfer, this stream resumes when the chunk is there
+            wire = out[lo:hi] if self.wire_dtype is None else out[lo:hi].to(self.wire_dtype)
+            wl = out_len[lo:hi]
+            g = wire.new_empty((world * n,) + tuple(wire.shape[1:]))
+            gl = wl.new_empty(world * n)
+            _all_gather(g, wire.contiguous(), self.group)
+            _all_gather(gl, wl.contiguous(), self.group)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            ch = GatheredChunk(lo, hi, g, gl, rows, keep, ev, torch.cuda.current_stream(dev))
+            chunks.append(ch)
+            if consumer is not None:
+                consumer(ch)                              # e.g. the CTC head on the gathered chunk, on this range's stream
         else:
             wire = out[lo:hi] if self.wire_dtype is None else out[lo:hi].to(self.wire_dtype)
             g = wire.new_empty((world * n,) + tuple(wire.shape[1:]))
             gl = out_len.new_empty(world * n)
             dist.all_gather_into_tensor(g, wire.contiguous(), group=self.group)
             dist.all_gather_into_tensor(gl, out_len[lo:hi].contiguous(), group=self.group)
-            chunks.append(GatheredChunk(lo, hi, g, gl, rows, keep, None, None))
+            ch = GatheredChunk(lo, hi, g, gl, rows, keep, None, None)
+            chunks.append(ch)
+            if consumer is not None:
+                consumer(ch)
 
     # ------------------------------------------------------------------ entry points
-    def encode_shard(self, xs: torch.Tensor, ls: torch.Tensor, global_batch: Optional[int] = None, range_pad=None, x_len_host=None) -> Gathered:
+    def encode_shard(self, xs: torch.Tensor, ls: torch.Tensor, global_batch: Optional[int] = None, range_pad=None, x_len_host=None,
+                     consumer: Optional[Callable] = None) -> Gathered:
         """This rank's rows (already selected; the same number of rows on every rank) -> gathered chunks of the global batch.
         `range_pad`: padded length per row range for `ConformerEncoder.trim_sub_batches` - the SAME list on every rank (the maximum
-        over the ranks' shards), so that every rank launches identical shapes and the collectives stay fixed-size."""
+        over the ranks' shards), so that every rank launches identical shapes and the collectives stay fixed-size.
+        `consumer(chunk)`: called right after a range's collective was issued, with that range's stream current (the CTC head of bench.py)."""
         world = dist.get_world_size(self.group)
         gb = global_batch if global_batch is not None else xs.shape[0] * world
         chunks: List[GatheredChunk] = []
@@ -168,10 +171,10 @@ class ShardedEncoder:
             kw = {"range_pad": range_pad} if range_pad is not None else {}
             if x_len_host is not None:
                 kw["x_len_host"] = x_len_host
-            self.encoder(xs, ls, range_hook=lambda lo, hi, out, out_len: self._gather_range(lo, hi, out, out_len, gb, chunks), **kw)
+            self.encoder(xs, ls, range_hook=lambda lo, hi, out, out_len: self._gather_range(lo, hi, out, out_len, gb, chunks, consumer), **kw)
         else:
             out, out_len = self.encoder(xs, ls)[:2]
-            self._gather_range(0, out.shape[0], out, out_len, gb, chunks)
+            self._gather_range(0, out.shape[0], out, out_len, gb, chunks, consumer)
         return Gathered(chunks, gb)
 
     def __call__(self, x: torch.Tensor, x_len: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:

@@ -122,6 +122,7 @@ class ConformerEncoder(nn.Module):
         self.ragged = False
         self.sub_batch_bounds = None       # optional row boundaries of the ranges (nsub - 1 increasing indices); default: equal row counts
         self._sub_streams: Dict[tuple, torch.cuda.Stream] = {}
+        self.caller_stream_slot = True     # stream slot 0 of the row ranges = the caller's stream (False: every range on a side stream, as round 2)
         self.eval()
 
     # ------------------------------------------------------------------ weights
@@ -384,16 +385,30 @@ class ConformerEncoder(nn.Module):
             cur = torch.cuda.current_stream(x.device)
             streams = []
             smax = nsub if not self.sub_batch_streams else max(1, min(int(self.sub_batch_streams), nsub))
-            for i in range(nsub):
-                # earlier row ranges get the higher priority: range 0 leaves the last stage first, so a `range_hook`
-                # consumer (the all-gather of dist.ShardedEncoder) overlaps with the later ranges' last stage
-                prio = -1 if (i == 0 and self.stagger_ranges) else 0
-                key = (str(x.device), i % smax, prio)        # the priority is part of the key: `stagger_ranges` may change after the first forward
-                if key not in self._sub_streams:
-                    self._sub_streams[key] = torch.cuda.Stream(device=x.device, priority=prio)
-                st = self._sub_streams[key]
-                if i < smax:
-                    st.wait_stream(cur)                  # inputs (and anything queued before this forward) are ready
+            # Stream slot 0 IS the caller's stream; slots 1 .. smax - 1 are side streams that fork from an event recorded before anything of
+            # this forward is enqueued.  (Measured on the MI355X: with more than four HIP streams active in the process the ranges stop
+            # overlapping - three side streams + the caller's idle stream + ONE more (a collective's stream, a consumer's stream) turned a
+            # 5.5 ms step into 7.4 ms, `GPU_MAX_HW_QUEUES` notwithstanding - so the forward itself uses smax streams, not smax + 1, and leaves
+            # room for the process group's own stream.)  The side streams are enqueued first: they run while the host enqueues the rest.
+            fork = torch.cuda.Event()
+            fork.record(cur)
+            order = [i for i in range(nsub) if i % smax != 0] + [i for i in range(nsub) if i % smax == 0]
+            if self.caller_stream_slot is False:
+                order = list(range(nsub))
+            for i in order:
+                slot = i % smax
+                if slot == 0 and self.caller_stream_slot is not False:
+                    st = cur
+                else:
+                    # earlier row ranges get the higher priority (opt-in `stagger_ranges`): range 0 leaves the last stage first
+                    prio = -1 if (i == 0 and self.stagger_ranges) else 0
+                    key = (str(x.device), slot, prio)        # the priority is part of the key: `stagger_ranges` may change after the first forward
+                    if key not in self._sub_streams:
+                        self._sub_streams[key] = torch.cuda.Stream(device=x.device, priority=prio)
+                    st = self._sub_streams[key]
+                    if st not in streams:
+                        st.wait_event(fork)              # inputs (and anything queued before this forward) are ready
+                        streams.append(st)
                 lo, hi = ranges[i]
                 with torch.cuda.stream(st):
                     if self.ragged:
@@ -402,11 +417,10 @@ class ConformerEncoder(nn.Module):
                         launch(lo, hi)
                     else:
                         launch_trimmed(lo, hi, pads[i])
-                    x.record_stream(st); lens.record_stream(st); out.record_stream(st); out_len.record_stream(st)
+                    if st is not cur:
+                        x.record_stream(st); lens.record_stream(st); out.record_stream(st); out_len.record_stream(st)
                     if range_hook is not None:
                         range_hook(lo, hi, out, out_len)     # called with the range's stream current: rows [lo, hi) of `out` are enqueued
-                if i < smax:
-                    streams.append(st)
             for st in streams:
                 cur.wait_stream(st)                      # joined: the caller continues on its own stream
         return out, (out_len if lens_given else None), [None] * len(self.plan.blocks)
