@@ -674,8 +674,10 @@ def main():
                                              "mfma_frac_of_serial_kernel_time": tot_gf / max(tot_ms, 1e-9) / PEAK_BF16_TFLOPS,
                                              "note": "mfma_frac = algorithmic flop of one step / wall step time / 2.5 PF (padded frames: the work the kernels do)"},
                               "note": "dominant class = most time per step; HIP events around every launch of the class on the launch stream, %d extra "
-                                      "steps after the timed region (the step's %d row ranges one after the other on one stream, so launches do not "
-                                      "overlap); kernel_classes lists every class against its own bound" % (nprof, nsub)}
+                                      "steps after the timed region (%s, so launches do not "
+                                      "overlap); kernel_classes lists every class against its own bound"
+                                      % (nprof, "the whole ragged batch as one row range on one stream" if args.ragged else
+                                         "the step's %d row ranges one after the other on one stream" % nsub)}
         if flight:
             result["roofline"]["in_flight"] = {"event_bracket_ms": flight["ms_per_step"] / max(flight["launches_per_step"], 1),
                                                "note": "event pairs around the same launches with the %d row ranges in flight on %d streams, as in the timed "
