@@ -626,7 +626,9 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
     // recomputes them) and the workspace must not be tagged warm (an eager forward before the first replay would read E nobody wrote)
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     const bool capturing = hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
-    const bool e_cached = !capturing && e->e_cache_on && e->e_cache_hit(ws, B, s.Tm, w.eh_blk[0]);
+    // E of block k depends on the frame count entering it (the LONGEST utterance's in a ragged batch, where s.Tm is only the input's row pitch)
+    const int e_tag = rg ? -(s.Tin[0] + 1) : s.Tm;
+    const bool e_cached = !capturing && e->e_cache_on && e->e_cache_hit(ws, B, e_tag, w.eh_blk[0]);
     if (!e_cached) e->e_cache_drop(ws);       // re-tagged only after every projection of this forward was enqueued
 
     int mask_stride = 1;                       // product of the strides of the blocks before block k
@@ -820,7 +822,7 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
         have_a = !last;
         snprintf(nm, sizeof(nm), "blocks.%d.out", k); trace_add(e, st, nm, xo, Mo, De, De, 0);
     }
-    if (!capturing) e->e_cache_put(ws, B, s.Tm, w.eh_blk[0]);
+    if (!capturing) e->e_cache_put(ws, B, e_tag, w.eh_blk[0]);
     if (rg) {
         const RaggedRows rl = rows_at(nb);
         PROF(PC_MISC, 0, (double)s.Mfinal * e->blocks.back().dim_expand * 4 + (double)B * out_frames * e->blocks.back().dim_expand * 4);

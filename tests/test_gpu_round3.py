@@ -242,7 +242,7 @@ def test_ragged_batch_equals_every_utterance_run_alone_tiny(nsub):
     encoder's output for that utterance ALONE (B = 1, the rectangular path) and within the bf16 tolerance of the oracle (the reference
     on that utterance alone); lengths with T % 3 = 0, 1, 2 in the grouped stage, one- and multi-range forwards."""
     m, sd = _model("Tiny", 7)
-    lens = np.array([48000, 47840, 41000, 37000, 30160, 22000, 12000, 9000, 3000], dtype=np.int64)
+    lens = np.array([48000, 47840, 41000, 37000, 30160, 22000, 12000, 9000, 3000, 640, 300], dtype=np.int64)     # down to 2 mel frames
     audio = torch.from_numpy(synth.make_audio(lens, seed=4))
     _ragged_vs_alone(m, sd, audio, lens, nsub)
 
@@ -368,3 +368,25 @@ def test_ragged_rejects_the_two_layer_subsampler():
     audio = torch.from_numpy(synth.make_audio(lens, seed=1)).cuda()
     with pytest.raises(_lib.EffconfError, match="one-layer"):
         m.encoder(audio, torch.from_numpy(lens).cuda(), x_len_host=lens)
+
+
+def test_ragged_positional_cache_follows_the_longest_utterance():
+    """Two ragged batches with the same batch size, row pitch and row TOTALS but different longest utterances: the cached positional
+    projections (built for the longest utterance) must not be reused across them."""
+    m, sd = _model("Tiny", 7)
+    enc = m.encoder
+    enc.ragged = True
+    n = 48000
+    la = np.array([48000, 16000], dtype=np.int64)
+    lb = np.array([32000, 32000], dtype=np.int64)        # same total frames, shorter longest utterance
+    audio = torch.from_numpy(synth.make_audio(np.array([n, n], dtype=np.int64), seed=8)).cuda()
+    outs = {}
+    for tag, l in (("a", la), ("b", lb), ("a2", la), ("b2", lb)):
+        o, _, _ = enc(audio, torch.from_numpy(l).cuda(), x_len_host=l)
+        outs[tag] = o.clone()
+    assert torch.equal(outs["a"], outs["a2"]) and torch.equal(outs["b"], outs["b2"])
+    enc.ragged = False
+    for tag, l in (("a", la), ("b", lb)):
+        for b in range(2):
+            alone, al, _ = enc(audio[b:b + 1, :int(l[b])].contiguous(), torch.from_numpy(l[b:b + 1]).cuda())
+            assert torch.equal(outs[tag][b, :int(al[0])], alone[0]), (tag, b)
