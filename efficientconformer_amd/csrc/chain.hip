@@ -208,7 +208,7 @@ __device__ __forceinline__ void load_a(const char* ab, size_t pitch, int row_byt
     }
 }
 
-// PROF (tuning only, EFFCONF_CHAIN_PHASES=1, KS = 8 full chain): s_memtime per phase of the FFN stages -
+// PROF (tuning only, EFFCONF_CHAIN_PHASES=81 | 162 | 163: KS = 8 full chain, KS = 16 head / tail): s_memtime per phase of the FFN stages -
 // 0 advance (DMA wait + barrier + refill), 1 GEMM1, 2 Swish, 3 GEMM2, 4 everything else, 5 waves
 template <int KS, int NW, int NBUF, int KIND, bool PROF = false>
 __global__ __launch_bounds__(NW * 64, (NW == 4 && KS <= 8) ? 2 : 1) void chain_kernel(const ChainDev cd, unsigned long long* prof = nullptr) {
@@ -605,7 +605,7 @@ void chain_prof_dump() {
     static const char* names[9] = {"ffn advance", "ffn gemm1", "ffn swish", "ffn gemm2", "norms+misc", "prologue", "g0 stage", "store_x", "qkv stage"};
     unsigned long long tot = 0;
     for (int i = 0; i < 9; ++i) tot += h[i];
-    fprintf(stderr, "[chain phases] KS=8 full chain: waves %llu, cycles/wave %.0f\n", h[9], (double)tot / h[9]);
+    fprintf(stderr, "[chain phases] %s: waves %llu, cycles/wave %.0f\n", getenv("EFFCONF_CHAIN_PHASES"), h[9], (double)tot / h[9]);
     for (int i = 0; i < 9; ++i) fprintf(stderr, "[chain phases]   %-12s %10.0f cyc/wave  %5.1f%%\n", names[i], (double)h[i] / h[9], 100.0 * h[i] / tot);
 }
 
@@ -666,8 +666,9 @@ int launch_chain_t(const ChainParams& p, hipStream_t s) {
     static LdsAttr attr;
     ensure_dynamic_lds(reinterpret_cast<const void*>(&chain_kernel<KS, NW, NBUF, KIND, false>), lds, attr);
     const int rows_per_wg = NW * 32;
-    if constexpr (KS == 8 && KIND == CHAIN_A_FULL) {
-        static const bool prof = getenv("EFFCONF_CHAIN_PHASES") != nullptr;
+    if constexpr ((KS == 8 && KIND == CHAIN_A_FULL) || (KS == 16 && (KIND == CHAIN_A_HEAD || KIND == CHAIN_A_TAIL))) {
+        // EFFCONF_CHAIN_PHASES = "<KS><kind>": 81 = the KS = 8 full chain, 162 / 163 = the KS = 16 head / tail (one instance per process)
+        static const bool prof = getenv("EFFCONF_CHAIN_PHASES") != nullptr && atoi(getenv("EFFCONF_CHAIN_PHASES")) == KS * 10 + KIND;
         if (prof) {
             if (!g_chain_prof) {
                 if (hipMalloc(&g_chain_prof, 128) != hipSuccess || hipMemset(g_chain_prof, 0, 128) != hipSuccess) return -1;
