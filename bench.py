@@ -159,10 +159,10 @@ def balanced_cuts(frames_desc, nsub):
 
 
 def head(model, enc, enc_len):
-    if isinstance(model, Transducer):        # RNN-T greedy (transducer.py:139-186); <= 128 utterances per call: the cluster decode's automatic range
+    if isinstance(model, Transducer):        # RNN-T greedy (transducer.py:139-186); <= 256 utterances per call: the cluster decode's automatic range
         out = None
-        for i in range(0, enc.shape[0], 128):
-            out = model.decode_encoded(enc[i:i + 128].contiguous(), enc_len[i:i + 128].contiguous())
+        for i in range(0, enc.shape[0], 256):
+            out = model.decode_encoded(enc[i:i + 256].contiguous(), enc_len[i:i + 256].contiguous())
         return out
     _, labels, label_len = model._head(enc, enc_len)                 # fc + argmax + CTC collapse (model_ctc.py:90-133)
     return labels, label_len

@@ -168,6 +168,152 @@ __global__ __launch_bounds__(64) void ex_attention_kernel(ExAttnParams p) {
     }
 }
 
+// The same arithmetic, tiled: a workgroup (XQT / 4 waves) owns XQT = 32 (16 when LDS is short) grouped query rows of one (utterance, head) and walks the keys in blocks of
+// 64.  The one-wave-per-row kernel above re-reads every K / E / V row from L2 for every query row (3.6 TFLOP/s: 100 of the 131 ms of an exact
+// step); here a key block's K rows, the XQT + 63 rows of E its (query, key) pairs touch and later its V rows are staged once in LDS and shared
+// by its rows.  Lane <-> key in the score phase (each lane 4 query rows: K fragment read once, E fragment per row at row offset
+// lane - r, Q + u / Q + v rows as broadcast reads), lane <-> output column in the P V phase.  Every sum runs in the order of the kernel above
+// (x ascending for the dot products, j ascending for P V, the same per-lane partial maxima / sums and butterflies for the softmax), and the
+// zero pad columns only add fmaf(0, 0, s) = s: the two kernels agree BIT FOR BIT (tests/test_gpu_round3.py compares them).
+constexpr int XKB = 64;
+
+// global rows -> LDS rows of pitch P (zero pad columns): one thread per 4-column group, rows strided over the workgroup; 8-byte loads
+// when the head spans are 8-byte aligned (even head width)
+template <class F>
+__device__ __forceinline__ void ex_stage_rows(float* dst, int nrows, int P, int d, int r0, int c, int rstep, bool vec2, F rowptr) {
+    if (r0 >= rstep) return;                          // tail threads that do not fill a whole row group
+    for (int r = r0; r < nrows; r += rstep) {
+        const float* src = rowptr(r) + c;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (vec2) {
+            if (c < d) { const float2 a = *reinterpret_cast<const float2*>(src); v.x = a.x; v.y = a.y; }
+            if (c + 2 < d) { const float2 b = *reinterpret_cast<const float2*>(src + 2); v.z = b.x; v.w = b.y; }
+        } else {
+            if (c < d) v.x = src[0];
+            if (c + 1 < d) v.y = src[1];
+            if (c + 2 < d) v.z = src[2];
+            if (c + 3 < d) v.w = src[3];
+        }
+        *reinterpret_cast<float4*>(dst + r * P + c) = v;
+    }
+}
+
+template <int XQT>
+__global__ __launch_bounds__(XQT * 16) void ex_attention2_kernel(ExAttnParams p, int P, int TgP) {
+    constexpr int NTH = XQT * 16;                     // 4 query rows per wave
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* sq = sm;                                   // [2][XQT][P]: Q + u | Q + v, pad columns zero
+    float* sk = sq + 2 * XQT * P;                     // [XKB][P]: K block (score phase), V block (P V phase)
+    float* se = sk + XKB * P;                         // [XKB + XQT - 1][P]: E rows Tg - 1 + (jb - i0) - (XQT - 1) + w
+    float* sc = se + (XKB + XQT - 1) * P;             // [XQT][TgP]: scores, then probabilities
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i0 = blockIdx.x * XQT, h = blockIdx.y, b = blockIdx.z;
+    const int d = p.d, Tg = p.Tg;
+    const size_t hb = (size_t)h * d;
+    for (int idx = tid; idx < XQT * P; idx += NTH) {
+        const int r = idx / P, x = idx - r * P;
+        const int i = i0 + r < Tg ? i0 + r : Tg - 1;
+        float a = 0.f, c = 0.f;
+        if (x < d) {
+            const int n = (int)((hb + x) % p.D);
+            const float q = p.q[((size_t)b * p.Tp + (size_t)p.G * i) * p.D + hb + x];
+            a = q + p.u[n]; c = q + p.vb[n];
+        }
+        sq[idx] = a; sq[XQT * P + idx] = c;
+    }
+    const int len = p.lens[b];
+    const float rs = sqrtf((float)d);
+    const int tpr = P >> 2, sr0 = tid / tpr, scol = (tid - sr0 * tpr) * 4, srstep = NTH / tpr;      // staging: this thread's row phase / columns
+    const bool vec2 = (d & 1) == 0;
+    const size_t gd = (size_t)p.G * p.D;
+    const float* kbase = p.k + (size_t)b * p.Tp * p.D + hb;
+    const float* vbase = p.v + (size_t)b * p.Tp * p.D + hb;
+    const float* ebase = p.e + hb;
+    for (int jb = 0; jb < Tg; jb += XKB) {
+        __syncthreads();                              // the previous block's readers are done (first pass: sq complete)
+        ex_stage_rows(sk, XKB, P, d, sr0, scol, srstep, vec2, [&](int r) { const int j = jb + r < Tg ? jb + r : Tg - 1; return kbase + gd * j; });
+        ex_stage_rows(se, XKB + XQT - 1, P, d, sr0, scol, srstep, vec2, [&](int w) {
+            int rel = Tg - 1 + jb - i0 - (XQT - 1) + w;
+            rel = rel < 0 ? 0 : (rel > 2 * Tg - 2 ? 2 * Tg - 2 : rel);       // rows no valid (i, j) pair touches
+            return ebase + gd * rel; });
+        __syncthreads();
+        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+        const float* kr = sk + lane * P;
+        const float* er = se + (lane + XQT - 1 - 4 * wave) * P;             // row of (i0 + 4 wave, jb + lane); next query row: one row up
+        const float* qa = sq + 4 * wave * P;
+        for (int x = 0; x < P; x += 4) {
+            const float4 kq = *reinterpret_cast<const float4*>(kr + x);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const float4 a = *reinterpret_cast<const float4*>(qa + rr * P + x), c = *reinterpret_cast<const float4*>(qa + (XQT + rr) * P + x);
+                const float4 eq = *reinterpret_cast<const float4*>(er - rr * P + x);
+                s1[rr] = fmaf(a.x, kq.x, s1[rr]); s1[rr] = fmaf(a.y, kq.y, s1[rr]); s1[rr] = fmaf(a.z, kq.z, s1[rr]); s1[rr] = fmaf(a.w, kq.w, s1[rr]);
+                s2[rr] = fmaf(c.x, eq.x, s2[rr]); s2[rr] = fmaf(c.y, eq.y, s2[rr]); s2[rr] = fmaf(c.z, eq.z, s2[rr]); s2[rr] = fmaf(c.w, eq.w, s2[rr]);
+            }
+        }
+        const int j = jb + lane;
+        if (j < Tg) {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                float s = (s1[rr] + s2[rr]) / rs;
+                if (p.G * j >= len) s += -1e9f;                             // attentions.py:698-701 (additive mask, as the reference)
+                sc[(4 * wave + rr) * TgP + j] = s;
+            }
+        }
+    }
+    __syncthreads();
+    // softmax of this wave's 4 rows (the partial maxima / sums of the kernel above: lane l owns keys l, l + 64, ...)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        float* row = sc + (4 * wave + rr) * TgP;
+        float mx = -INFINITY;
+        for (int j = lane; j < Tg; j += 64) mx = fmaxf(mx, row[j]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        float sum = 0.f;
+        for (int j = lane; j < Tg; j += 64) { const float e = expf(row[j] - mx); row[j] = e; sum += e; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        for (int j = lane; j < TgP; j += 64) row[j] = j < Tg ? row[j] / sum : 0.f;
+    }
+    // P V: lane <-> output columns lane, lane + 64, lane + 128
+    float acc[4][3];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) { acc[rr][0] = 0.f; acc[rr][1] = 0.f; acc[rr][2] = 0.f; }
+    for (int jb = 0; jb < Tg; jb += XKB) {
+        __syncthreads();
+        ex_stage_rows(sk, XKB, P, d, sr0, scol, srstep, vec2, [&](int r) { const int j = jb + r < Tg ? jb + r : Tg - 1; return vbase + gd * j; });
+        __syncthreads();
+        int nj = Tg - jb < XKB ? Tg - jb : XKB;
+        nj = (nj + 3) & ~3;                           // probabilities of the pad keys are zero, their V rows finite: fmaf(0, v, acc) = acc
+        const bool c1 = lane + 64 < P, c2 = lane + 128 < P;
+        for (int jj = 0; jj < nj; jj += 4) {
+            float v0[4], v1[4], v2[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float* vr = sk + (jj + t) * P;
+                v0[t] = vr[lane]; v1[t] = c1 ? vr[lane + 64] : 0.f; v2[t] = c2 ? vr[lane + 128] : 0.f;
+            }
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const float4 pr = *reinterpret_cast<const float4*>(sc + (4 * wave + rr) * TgP + jb + jj);
+                acc[rr][0] = fmaf(pr.x, v0[0], acc[rr][0]); acc[rr][0] = fmaf(pr.y, v0[1], acc[rr][0]); acc[rr][0] = fmaf(pr.z, v0[2], acc[rr][0]); acc[rr][0] = fmaf(pr.w, v0[3], acc[rr][0]);
+                acc[rr][1] = fmaf(pr.x, v1[0], acc[rr][1]); acc[rr][1] = fmaf(pr.y, v1[1], acc[rr][1]); acc[rr][1] = fmaf(pr.z, v1[2], acc[rr][1]); acc[rr][1] = fmaf(pr.w, v1[3], acc[rr][1]);
+                acc[rr][2] = fmaf(pr.x, v2[0], acc[rr][2]); acc[rr][2] = fmaf(pr.y, v2[1], acc[rr][2]); acc[rr][2] = fmaf(pr.z, v2[2], acc[rr][2]); acc[rr][2] = fmaf(pr.w, v2[3], acc[rr][2]);
+            }
+        }
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int i = i0 + 4 * wave + rr;
+        if (i >= Tg) continue;
+        float* orow = p.out + ((size_t)b * p.Tp + (size_t)p.G * i) * p.D + hb;
+        if (lane < d) orow[lane] = acc[rr][0];
+        if (lane + 64 < d) orow[lane + 64] = acc[rr][1];
+        if (lane + 128 < d) orow[lane + 128] = acc[rr][2];
+    }
+}
+
 inline int grid_for(long long total) { long long g = (total + 255) / 256; return (int)(g < 1 ? 1 : (g > 65535 ? 65535 : g)); }
 
 }  // namespace
@@ -198,6 +344,23 @@ int launch_ex_dwconv(const float* g, int B, int T, int To, int C, const float* w
 }
 
 int launch_ex_attention(const ExAttnParams& p, hipStream_t s) {
+    if (p.variant != 1 && p.d <= 192) {                // tiled kernel unless its LDS image does not fit (very long utterances at wide heads)
+        int P = (p.d + 3) / 4 * 4;
+        if (((P / 4) & 1) == 0) P += 4;                // P / 4 odd: the 16-byte reads of 16 consecutive rows fall into 16 different bank groups
+        const int TgP = (p.Tg + 3) / 4 * 4;
+        auto lds_for = [&](int qt) { return ((size_t)(2 * qt + XKB + XKB + qt - 1) * P + (size_t)qt * TgP) * 4; };
+        static LdsAttr attr32, attr16;
+        if (p.variant != 2 && lds_for(32) <= 160 * 1024) {               // 8 waves: two per SIMD (variant 2: the 16-row shape, for tests)
+            ensure_dynamic_lds(reinterpret_cast<const void*>(&ex_attention2_kernel<32>), (int)lds_for(32), attr32);
+            hipLaunchKernelGGL(ex_attention2_kernel<32>, dim3((p.Tg + 31) / 32, p.H, p.B), dim3(512), lds_for(32), s, p, P, TgP);
+            return hipGetLastError() == hipSuccess ? 0 : -1;
+        }
+        if (lds_for(16) <= 160 * 1024) {
+            ensure_dynamic_lds(reinterpret_cast<const void*>(&ex_attention2_kernel<16>), (int)lds_for(16), attr16);
+            hipLaunchKernelGGL(ex_attention2_kernel<16>, dim3((p.Tg + 15) / 16, p.H, p.B), dim3(256), lds_for(16), s, p, P, TgP);
+            return hipGetLastError() == hipSuccess ? 0 : -1;
+        }
+    }
     const size_t lds = (size_t)(2 * p.d + p.Tg) * 4;
     if (lds > 64 * 1024) return -2;
     hipLaunchKernelGGL(ex_attention_kernel, dim3(p.Tg, p.H, p.B), dim3(64), lds, s, p);

@@ -208,6 +208,7 @@ struct ExAttnParams {              // natural-layout fp32 Q, K, V [B*Tp][D], E [
     const int* lens;
     int B, H, T, Tp, G, D, d, Tg;
     float* out;
+    int variant;                   // 0: tiled kernel (default), 2: its 16-row shape, 1: one wave per query row (round 2's kernel); all agree bit for bit
 };
 int launch_ex_attention(const ExAttnParams& p, hipStream_t s);
 

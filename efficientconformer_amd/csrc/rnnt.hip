@@ -29,6 +29,7 @@
 #include <map>
 #include <string>
 #include <vector>
+#include <type_traits>
 
 int ec_fail(const char* msg);
 
@@ -127,6 +128,7 @@ struct RnntDev {
     const float4* wd4;       // [H/4][J]
     const float* bd;         // [J]
     const float4* wj4;       // [J/4][V]
+    const float4 *whh16, *wd16, *wj16;   // the same three in the MFMA order: [K/16][4][N] (kperm16), null if K % 16
     const float* bj;         // [V]
     int H, J, V, max_consec;
 };
@@ -255,8 +257,10 @@ __global__ __launch_bounds__(NT) void rnnt_greedy_kernel(RnntDev w, const float*
 // weights a round streams from L2 are read ONCE per cluster instead of once per utterance, and the per-step latency of an
 // utterance drops from "10.7 MB through one CU" to "1.3 MB through each of CW CUs" plus three cluster barriers
 // (counter in global memory: agent-scope release / acquire, bounded spin).  State machines (token, frame, counters) are
-// replicated: every workgroup takes the same decisions from the same exchanged argmax candidates.  The arithmetic (k order
-// of every dot product, libm tanhf / expf) is that of rnnt_greedy_kernel, so both produce identical tokens.
+// replicated: every workgroup takes the same decisions from the same exchanged argmax candidates.  The three mat-vec phases run on
+// the fp32 matrix pipe (mfma_rows16 below) with the k order of every dot product ascending as in rnnt_greedy_kernel, the rest (libm
+// tanhf / expf, the decisions) is that kernel's code: both produce identical tokens (tests: the reference's goldens and 165 k tokens
+// of tools/rnnt_diag.py).  Round 3, per round of a 256-utterance decode: 206 k -> 112 k cycles (140 -> 46 ms per decode).
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int CW = 8;          // workgroups per cluster
 constexpr int CU = 8;          // utterances per cluster
@@ -269,7 +273,7 @@ struct ClusterArgs {
     const float* fe; const int64_t* lens; int T, B;
     int* tokens; int* counts; int max_tok;
     float* xh; float* xgd; float* xav; int* xai; unsigned* cnt; int* status;     // exchange buffers (per cluster), barrier counters
-    int ncl;
+    int ncl, by_slice;
 };
 
 // Exchange data and the barrier counter are accessed with relaxed agent-scope atomics (sc1 loads / stores served at the coherent
@@ -297,6 +301,68 @@ __device__ __forceinline__ bool cluster_sync(unsigned* cnt, unsigned& epoch, int
     return __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
 }
 
+// ---- the three mat-vec phases on the fp32 matrix pipe -----------------------------------------------------------------------------------
+// A round multiplies a slice of a weight matrix with the CU = 8 (joint: CU * CKF = 16) state vectors of the cluster's utterances.  As VALU
+// code that is 32 FMAs + 8 broadcast LDS reads per weight float4 and thread: the phases were issue-bound (s_memtime: 71k + 37k + 77k of a
+// round's 206k cycles; the three cluster barriers 1.5k each).  v_mfma_f32_16x16x4_f32 takes 16 weight rows x 4 k (A) against 4 k x 16 state
+// vectors (B): one weight float4 and one state float4 per lane feed four MFMAs (4096 MACs).  The k order of every dot product stays
+// ASCENDING: lane group g = lane / 16 is k-slot g of an MFMA, so the float4 a lane loads for 16-block q must hold k = 16q + g, 16q + 4 + g,
+// 16q + 8 + g, 16q + 12 + g (MFMA c of the block then covers k = 16q + 4c .. 16q + 4c + 3) - the weights get a second image in that order
+// (kperm16) and the state vectors sit in LDS with k permuted the same way (kperm).
+__host__ __device__ __forceinline__ int kperm(int k) { return (k & ~15) | ((k & 3) << 2) | ((k >> 2) & 3); }
+constexpr int CMB = 4;          // 16-blocks of weight loads in flight per tile and lane (8 when a wave owns at most two tiles and K allows)
+
+template <int NTL, int CMB>
+__device__ __forceinline__ void mfma_rows16_t(const float4* __restrict__ W16, int N, int K16, const int (&nrow)[NTL], const float* xs_lane, f32x4 (&acc)[NTL]) {
+    const int g = (threadIdx.x & 63) >> 4;
+    const size_t bs = (size_t)4 * N;                    // float4s per 16-block: [g][n]
+    const float4* wp[NTL];
+    float4 wn[NTL][CMB];
+#pragma unroll
+    for (int i = 0; i < NTL; ++i) {
+        wp[i] = W16 + (size_t)g * N + nrow[i];
+#pragma unroll
+        for (int b = 0; b < CMB; ++b) wn[i][b] = wp[i][b * bs];
+    }
+    for (int q0 = 0; q0 < K16; q0 += CMB) {
+        float4 wv[NTL][CMB];
+#pragma unroll
+        for (int i = 0; i < NTL; ++i)
+#pragma unroll
+            for (int b = 0; b < CMB; ++b) wv[i][b] = wn[i][b];
+        const int qn = q0 + CMB < K16 ? q0 + CMB : q0;                      // last pass: harmless re-load
+#pragma unroll
+        for (int i = 0; i < NTL; ++i)
+#pragma unroll
+            for (int b = 0; b < CMB; ++b) wn[i][b] = wp[i][(size_t)(qn + b) * bs];
+#pragma unroll
+        for (int b = 0; b < CMB; ++b) {
+            const float4 x = *reinterpret_cast<const float4*>(xs_lane + 16 * (q0 + b));
+#pragma unroll
+            for (int i = 0; i < NTL; ++i) {
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[i][b].x, x.x, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[i][b].y, x.y, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[i][b].z, x.z, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[i][b].w, x.w, acc[i], 0, 0, 0);
+            }
+        }
+    }
+}
+
+template <int NTL>
+__device__ __forceinline__ void mfma_rows16(const float4* __restrict__ W16, int N, int K16, const int (&nrow)[NTL], const float* xs_lane, f32x4 (&acc)[NTL]) {
+    if (NTL <= 2 && (K16 & 7) == 0) mfma_rows16_t<NTL, 8>(W16, N, K16, nrow, xs_lane, acc);
+    else mfma_rows16_t<NTL, 4>(W16, N, K16, nrow, xs_lane, acc);
+}
+
+// exchange buffers -> registers, three 16-byte loads per lane in flight (sc1: served at the coherent level, as xload; plain loads instead of
+// atomics so that they pipeline - the relaxed atomic loads were issued one at a time, 13k cycles per round for two 20 KB reloads).  The
+// cluster barrier in front orders them against the producers' stores.
+__device__ __forceinline__ void xload3(const float* p0, const float* p1, const float* p2, float4& a, float4& b, float4& c) {
+    asm volatile("global_load_dwordx4 %0, %3, off sc1\n\tglobal_load_dwordx4 %1, %4, off sc1\n\tglobal_load_dwordx4 %2, %5, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(c) : "v"(p0), "v"(p1), "v"(p2) : "memory");
+}
+
 __global__ __launch_bounds__(CNT) void rnnt_cluster_kernel(const ClusterArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const RnntDev& w = a.w;
@@ -311,7 +377,10 @@ __global__ __launch_bounds__(CNT) void rnnt_cluster_kernel(const ClusterArgs a) 
     int* sredi = reinterpret_cast<int*>(sred + CU * CKF * 8);
     __shared__ int s_y[CU], s_step[CU], s_consec[CU], s_ntok[CU], s_need[CU], s_T[CU], s_pred[CU * CKF];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int cl = blockIdx.x % a.ncl, wg = blockIdx.x / a.ncl;      // cluster members are a.ncl apart: same XCD when ncl % 8 == 0
+    // workgroup -> (cluster, slice).  by_slice: consecutive workgroups are the CW = 8 slices of one cluster, i.e. slice k of EVERY cluster
+    // runs on XCD k (workgroups are dealt to the 8 XCDs round-robin) and that XCD's L2 only ever holds slice k of the weights (1.3 of the
+    // 10.7 MB: resident); otherwise the members of a cluster share an XCD (ncl % 8 == 0) and its L2 sees all 10.7 MB per round.
+    const int cl = a.by_slice ? blockIdx.x / CW : blockIdx.x % a.ncl, wg = a.by_slice ? blockIdx.x % CW : blockIdx.x / a.ncl;
     const int u0 = cl * CU;
     float* xh = a.xh + (size_t)cl * CU * H;
     float* xgd = a.xgd + (size_t)cl * CU * J;
@@ -338,39 +407,43 @@ __global__ __launch_bounds__(CNT) void rnnt_cluster_kernel(const ClusterArgs a) 
         for (int u = 0; u < CU; ++u) { const bool act = s_step[u] < s_T[u]; active |= act; dec |= act && s_need[u]; }
         if (!active) break;
         if (dec) {
-            // ---- phase 1: gates of this workgroup's units, cell update, h slice out
-            if (tid < 4 * HU) {
-                const int gate = tid / HU, unit = tid - gate * HU;
-                const int n = gate * H + wg * HU + unit;
-                float acc[CU];
+            // ---- phase 1: gates of this workgroup's units (4 HU rows of W_hh as 16-row tiles, dealt to the waves), cell update, h slice out
+            {
+                const int ntile = 4 * HU / 16;                             // HU % 4 == 0 (cluster_supported)
+                const int j = lane & 15, g = lane >> 4;
+                const float* xl = sh + (j & 7) * H + 4 * g;                // columns 8 .. 15 of B repeat the 8 utterances (results unused)
+                auto run = [&](auto ntl_c) __attribute__((always_inline)) {
+                    constexpr int NTL = decltype(ntl_c)::value;
+                    int nrow[NTL];
+                    f32x4 acc[NTL];
 #pragma unroll
-                for (int u = 0; u < CU; ++u) acc[u] = 0.f;
-                const float4* __restrict__ wp = w.whh4 + n;
-                float4 wn[CLB];
+                    for (int i = 0; i < NTL; ++i) {
+                        const int r = 16 * (wave + 8 * i) + j;             // local gate row of this lane's A operand
+                        nrow[i] = (r / HU) * H + wg * HU + r % HU;
+                        acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                    mfma_rows16<NTL>(w.whh16, 4 * H, H / 16, nrow, xl, acc);
+                    if (j < CU) {
 #pragma unroll
-                for (int i = 0; i < CLB; ++i) wn[i] = wp[(size_t)i * 4 * H];
-                for (int k0 = 0; k0 < H / 4; k0 += CLB) {                  // next batch of weight loads in flight under this batch's FMAs
-                    float4 wv[CLB];
+                        for (int i = 0; i < NTL; ++i)
 #pragma unroll
-                    for (int i = 0; i < CLB; ++i) wv[i] = wn[i];
-                    const int kn = k0 + CLB < H / 4 ? k0 + CLB : k0;       // last iteration: harmless re-load
-#pragma unroll
-                    for (int i = 0; i < CLB; ++i) wn[i] = wp[(size_t)(kn + i) * 4 * H];
-#pragma unroll
-                    for (int i = 0; i < CLB; ++i)
-#pragma unroll
-                        for (int u = 0; u < CU; ++u) {
-                            const float4 xv = *reinterpret_cast<const float4*>(sh + u * H + 4 * (k0 + i));
-                            acc[u] = fmaf(wv[i].w, xv.w, fmaf(wv[i].z, xv.z, fmaf(wv[i].y, xv.y, fmaf(wv[i].x, xv.x, acc[u]))));
-                        }
-                }
-#pragma unroll
-                for (int u = 0; u < CU; ++u) sg[u * 4 * HU + tid] = acc[u] + w.gin[(size_t)s_y[u] * 4 * H + n];
+                            for (int e = 0; e < 4; ++e) {
+                                const int r = 16 * (wave + 8 * i) + 4 * g + e;
+                                const int n = (r / HU) * H + wg * HU + r % HU;
+                                sg[j * 4 * HU + r] = acc[i][e] + w.gin[(size_t)s_y[j] * 4 * H + n];
+                            }
+                    }
+                };
+                const int mine = (ntile - wave + 7) / 8;                   // tiles wave, wave + 8, ...
+                if (mine == 1) run(std::integral_constant<int, 1>{});
+                else if (mine == 2) run(std::integral_constant<int, 2>{});
+                else if (mine == 3) run(std::integral_constant<int, 3>{});
+                else if (mine >= 4) run(std::integral_constant<int, 4>{});
             }
             __syncthreads();
             for (int i = tid; i < CU * HU; i += CNT) {
                 const int u = i / HU, unit = i - u * HU;
-                float hv = sh[u * H + wg * HU + unit];
+                float hv = sh[u * H + kperm(wg * HU + unit)];
                 if (s_need[u] && s_step[u] < s_T[u]) {
                     const float* g = sg + u * 4 * HU + unit;
                     const float ig = sigmoid_precise(g[0]), fg = sigmoid_precise(g[HU]), gg = tanhf(g[2 * HU]), og = sigmoid_precise(g[3 * HU]);
@@ -381,99 +454,111 @@ __global__ __launch_bounds__(CNT) void rnnt_cluster_kernel(const ClusterArgs a) 
                 xstore(xh + u * H + wg * HU + unit, hv);
             }
             ok = cluster_sync(cnt, epoch, a.status);
-            for (int i = tid; i < CU * H; i += CNT) sh[i] = xload(xh + i);
-            __syncthreads();
-            // ---- phase 2: this workgroup's columns of linear_decoder(h)
-            if (tid < JU * 4) {
-                const int lc = tid % JU, ug = tid / JU;                   // 4 groups of CU/4 utterances
-                const int n = wg * JU + lc;
-                float acc[CU / 4];
+            for (int i0 = tid; i0 < CU * H / 4; i0 += 3 * CNT) {         // h of every utterance, k-permuted (see mfma_rows16)
+                const int n4 = CU * H / 4, i1 = i0 + CNT, i2 = i0 + 2 * CNT;
+                float4 v[3];
+                xload3(xh + 4 * i0, xh + 4 * (i1 < n4 ? i1 : i0), xh + 4 * (i2 < n4 ? i2 : i0), v[0], v[1], v[2]);
 #pragma unroll
-                for (int q = 0; q < CU / 4; ++q) acc[q] = 0.f;
-                const float4* __restrict__ wp = w.wd4 + n;
-                float4 wn[CLB];
-#pragma unroll
-                for (int i = 0; i < CLB; ++i) wn[i] = wp[(size_t)i * J];
-                for (int k0 = 0; k0 < H / 4; k0 += CLB) {
-                    float4 wv[CLB];
-#pragma unroll
-                    for (int i = 0; i < CLB; ++i) wv[i] = wn[i];
-                    const int kn = k0 + CLB < H / 4 ? k0 + CLB : k0;
-#pragma unroll
-                    for (int i = 0; i < CLB; ++i) wn[i] = wp[(size_t)(kn + i) * J];
-#pragma unroll
-                    for (int i = 0; i < CLB; ++i)
-#pragma unroll
-                        for (int q = 0; q < CU / 4; ++q) {
-                            const float4 xv = *reinterpret_cast<const float4*>(sh + (ug * (CU / 4) + q) * H + 4 * (k0 + i));
-                            acc[q] = fmaf(wv[i].w, xv.w, fmaf(wv[i].z, xv.z, fmaf(wv[i].y, xv.y, fmaf(wv[i].x, xv.x, acc[q]))));
-                        }
+                for (int e = 0; e < 3; ++e) {
+                    const int i = 4 * (i0 + e * CNT);
+                    if (i < CU * H) {
+                        float* d = sh + (i / H) * H + kperm(i % H);           // elements i .. i + 3 sit 4 floats apart
+                        d[0] = v[e].x; d[4] = v[e].y; d[8] = v[e].z; d[12] = v[e].w;
+                    }
                 }
+            }
+            __syncthreads();
+            // ---- phase 2: this workgroup's columns of linear_decoder(h): JU rows of W_d as 16-row tiles
+            {
+                const int ntile = (JU + 15) / 16;
+                const int j = lane & 15, g = lane >> 4;
+                for (int t = wave; t < ntile; t += 8) {
+                    int nrow[1];
+                    const int lr = 16 * t + j;
+                    nrow[0] = wg * JU + (lr < JU ? lr : JU - 1);
+                    f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+                    mfma_rows16<1>(w.wd16, J, H / 16, nrow, sh + (j & 7) * H + 4 * g, acc);
+                    if (j < CU) {
+                        const int u = j;
+                        const bool upd = s_need[u] && s_step[u] < s_T[u];
 #pragma unroll
-                for (int q = 0; q < CU / 4; ++q) {
-                    const int u = ug * (CU / 4) + q;
-                    const bool upd = s_need[u] && s_step[u] < s_T[u];
-                    xstore(xgd + u * J + n, upd ? acc[q] + w.bd[n] : sgd[u * J + n]);
+                        for (int e = 0; e < 4; ++e) {
+                            const int lc = 16 * t + 4 * g + e, n = wg * JU + lc;
+                            if (lc < JU) xstore(xgd + u * J + n, upd ? acc[0][e] + w.bd[n] : sgd[u * J + n]);
+                        }
+                    }
                 }
             }
             ok = cluster_sync(cnt, epoch, a.status) && ok;
-            for (int i = tid; i < CU * J; i += CNT) sgd[i] = xload(xgd + i);
+            for (int i0 = tid; i0 < CU * J / 4; i0 += 3 * CNT) {
+                const int n4 = CU * J / 4, i1 = i0 + CNT, i2 = i0 + 2 * CNT;
+                float4 v[3];
+                xload3(xgd + 4 * i0, xgd + 4 * (i1 < n4 ? i1 : i0), xgd + 4 * (i2 < n4 ? i2 : i0), v[0], v[1], v[2]);
+                *reinterpret_cast<float4*>(sgd + 4 * i0) = v[0];
+                if (i1 < n4) *reinterpret_cast<float4*>(sgd + 4 * i1) = v[1];
+                if (i2 < n4) *reinterpret_cast<float4*>(sgd + 4 * i2) = v[2];
+            }
             __syncthreads();
         }
         // ---- phase 3: joint on CKF frames per utterance, this workgroup's slice of the vocabulary
-        for (int i = tid; i < CU * CKF * J; i += CNT) {
-            const int row = i / J, j = i - row * J, u = row / CKF, kf = row - u * CKF;
-            const int b = u0 + u < a.B ? u0 + u : a.B - 1;
-            int t = s_step[u] + kf;
-            t = t < s_T[u] ? t : (s_T[u] > 0 ? s_T[u] - 1 : 0);
-            sz[i] = tanhf(a.fe[((size_t)b * a.T + t) * J + j] + sgd[u * J + j]);
+        for (int q0 = tid; q0 < CU * CKF * J / 4; q0 += 4 * CNT) {       // four 16-byte loads of linear_encoder(f) in flight per lane
+            const int n4 = CU * CKF * J / 4, J4 = J / 4;
+            float4 fv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int q = q0 + e * CNT < n4 ? q0 + e * CNT : q0;
+                const int row = q / J4, u = row / CKF, kf = row - u * CKF;
+                const int b = u0 + u < a.B ? u0 + u : a.B - 1;
+                int t = s_step[u] + kf;
+                t = t < s_T[u] ? t : (s_T[u] > 0 ? s_T[u] - 1 : 0);
+                fv[e] = *reinterpret_cast<const float4*>(a.fe + ((size_t)b * a.T + t) * J + 4 * (q - row * J4));
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int q = q0 + e * CNT;
+                if (q < n4) {
+                    const int row = q / J4, j = 4 * (q - row * J4), u = row / CKF;
+                    const float4 gd = *reinterpret_cast<const float4*>(sgd + u * J + j);
+                    float* d = sz + row * J + kperm(j);                       // elements j .. j + 3 sit 4 floats apart
+                    d[0] = tanhf(fv[e].x + gd.x); d[4] = tanhf(fv[e].y + gd.y); d[8] = tanhf(fv[e].z + gd.z); d[12] = tanhf(fv[e].w + gd.w);
+                }
+            }
         }
         __syncthreads();
-        {
-            constexpr int RG = CNT / 128, RPG = CU * CKF / RG;          // 4 row groups of 4 rows
-            const int lc = tid & 127, rg = tid >> 7;
-            const int n = wg * VU + lc;
-            const bool colok = lc < VU && n < V;
-            const int nc = colok ? n : V - 1;
-            float acc[RPG];
+        {   // VU vocabulary rows of W_j as 16-row tiles (one per wave) against the CU * CKF = 16 joint inputs; partial argmax per wave
+            const int ntile = (VU + 15) / 16;                              // <= 8 (cluster_supported)
+            const int j = lane & 15, g = lane >> 4;
+            float bv = -INFINITY; int bi = 0x7fffffff;
+            if (wave < ntile) {
+                int nrow[1];
+                const int lr = 16 * wave + j;
+                const int nn = wg * VU + lr;
+                nrow[0] = (lr < VU && nn < V) ? nn : V - 1;
+                f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+                mfma_rows16<1>(w.wj16, V, J / 16, nrow, sz + j * J + 4 * g, acc);
 #pragma unroll
-            for (int q = 0; q < RPG; ++q) acc[q] = 0.f;
-            const float4* __restrict__ wp = w.wj4 + nc;
-            float4 wn[CLB];
-#pragma unroll
-            for (int i = 0; i < CLB; ++i) wn[i] = wp[(size_t)i * V];
-            for (int k0 = 0; k0 < J / 4; k0 += CLB) {
-                float4 wv[CLB];
-#pragma unroll
-                for (int i = 0; i < CLB; ++i) wv[i] = wn[i];
-                const int kn = k0 + CLB < J / 4 ? k0 + CLB : k0;
-#pragma unroll
-                for (int i = 0; i < CLB; ++i) wn[i] = wp[(size_t)(kn + i) * V];
-#pragma unroll
-                for (int i = 0; i < CLB; ++i)
-#pragma unroll
-                    for (int q = 0; q < RPG; ++q) {
-                        const float4 xv = *reinterpret_cast<const float4*>(sz + (rg * RPG + q) * J + 4 * (k0 + i));
-                        acc[q] = fmaf(wv[i].w, xv.w, fmaf(wv[i].z, xv.z, fmaf(wv[i].y, xv.y, fmaf(wv[i].x, xv.x, acc[q]))));
+                for (int e = 0; e < 4; ++e) {                              // rows 4 g + e of the tile, column j = (utterance, frame)
+                    const int lc = 16 * wave + 4 * g + e, n = wg * VU + lc;
+                    if (lc < VU && n < V) {
+                        const float v = acc[0][e] + w.bj[n];
+                        if (v > bv || (v == bv && n < bi)) { bv = v; bi = n; }
                     }
-            }
-            const float bz = w.bj[nc];
-#pragma unroll
-            for (int q = 0; q < RPG; ++q) {
-                float bv = colok ? acc[q] + bz : -INFINITY; int bi = colok ? n : 0x7fffffff;
-#pragma unroll
-                for (int o = 32; o >= 1; o >>= 1) {
-                    const float ov = __shfl_xor(bv, o); const int oi = __shfl_xor(bi, o);
-                    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
                 }
-                if (lane == 0) { sred[(rg * RPG + q) * 8 + (wave & 1)] = bv; sredi[(rg * RPG + q) * 8 + (wave & 1)] = bi; }
             }
+#pragma unroll
+            for (int o = 16; o <= 32; o <<= 1) {                           // the 4 lane groups hold different rows of the same column
+                const float ov = __shfl_xor(bv, o); const int oi = __shfl_xor(bi, o);
+                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            }
+            if (lane < 16) { sred[lane * 8 + wave] = bv; sredi[lane * 8 + wave] = bi; }
         }
         __syncthreads();
         if (tid < CU * CKF) {
             float bv = sred[tid * 8]; int bi = sredi[tid * 8];
-            const float ov = sred[tid * 8 + 1]; const int oi = sredi[tid * 8 + 1];
-            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            for (int q = 1; q < 8; ++q) {
+                const float ov = sred[tid * 8 + q]; const int oi = sredi[tid * 8 + q];
+                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            }
             xstore(xav + wg * CU * CKF + tid, bv); xstorei(xai + wg * CU * CKF + tid, bi);
         }
         ok = cluster_sync(cnt, epoch, a.status) && ok;
@@ -521,8 +606,9 @@ inline size_t cluster_exchange_bytes(int ncl, int H, int J) {
     return (size_t)ncl * ((size_t)CU * H * 4 + (size_t)CU * J * 4 + (size_t)CW * CU * CKF * 8 + 256) + 256;
 }
 inline bool cluster_supported(const EcRnntConfig& c) {
-    return c.dim_decoder % (4 * CW) == 0 && c.dim_joint % (4 * CW) == 0 && (c.dim_decoder / 4) % CLB == 0 && (c.dim_joint / 4) % CLB == 0 && 4 * (c.dim_decoder / CW) <= CNT && 4 * (c.dim_joint / CW) <= CNT &&
-           (c.vocab_size + CW - 1) / CW <= 128;
+    // 16-blocks of k in groups of CMB; whole 16-row tiles of gate rows; at most 4 gate tiles per wave and one vocabulary tile per wave
+    return c.dim_decoder % (16 * CMB) == 0 && c.dim_joint % (16 * CMB) == 0 && c.dim_decoder % (4 * CW) == 0 && c.dim_joint % CW == 0 &&
+           4 * (c.dim_decoder / CW) <= 16 * 8 * 4 && (c.vocab_size + CW - 1) / CW <= 128;
 }
 
 struct HostT { std::vector<int64_t> shape; std::vector<float> data; };
@@ -537,6 +623,7 @@ struct EcRnnt {
     float* we = nullptr;     // linear_encoder.weight [J][De]
     float* be = nullptr;
     bool finalized = false;
+    int cluster_by_slice = 1;   // cluster decode: workgroup -> XCD mapping (see rnnt_cluster_kernel)
     int cluster_mode = -1;   // -1 auto (cluster decode for batches >= 2*CU), 0 per-utterance kernel, 1 force cluster
 };
 
@@ -556,6 +643,16 @@ std::vector<float> kmajor4(const std::vector<float>& W, int N, int K) {
     for (int k4 = 0; k4 < K / 4; ++k4)
         for (int n = 0; n < N; ++n)
             for (int e = 0; e < 4; ++e) o[((size_t)k4 * N + n) * 4 + e] = W[(size_t)n * K + 4 * k4 + e];
+    return o;
+}
+
+// W [N][K] row-major -> float4 image [K/16][4][N]: entry (q, g, n) = W[n][16q + g], W[n][16q + 4 + g], W[n][16q + 8 + g], W[n][16q + 12 + g]
+std::vector<float> kperm16(const std::vector<float>& W, int N, int K) {
+    std::vector<float> o((size_t)N * K);
+    for (int q = 0; q < K / 16; ++q)
+        for (int g = 0; g < 4; ++g)
+            for (int n = 0; n < N; ++n)
+                for (int e = 0; e < 4; ++e) o[(((size_t)q * 4 + g) * N + n) * 4 + e] = W[(size_t)n * K + 16 * q + 4 * e + g];
     return o;
 }
 
@@ -628,6 +725,14 @@ int effconf_rnnt_finalize(EcRnnt* r) {
     r->dev.bd = (const float*)upload(r, bd->data.data(), bd->data.size() * 4);
     r->dev.wj4 = (const float4*)upload(r, wj4.data(), wj4.size() * 4);
     r->dev.bj = (const float*)upload(r, bj->data.data(), bj->data.size() * 4);
+    r->dev.whh16 = r->dev.wd16 = r->dev.wj16 = nullptr;
+    if (cluster_supported(r->cfg)) {
+        const std::vector<float> a16 = kperm16(whh->data, 4 * H, H), b16 = kperm16(wd->data, J, H), c16 = kperm16(wj->data, V, J);
+        r->dev.whh16 = (const float4*)upload(r, a16.data(), a16.size() * 4);
+        r->dev.wd16 = (const float4*)upload(r, b16.data(), b16.size() * 4);
+        r->dev.wj16 = (const float4*)upload(r, c16.data(), c16.size() * 4);
+        if (!r->dev.whh16 || !r->dev.wd16 || !r->dev.wj16) return ec_fail("device allocation / upload failed");
+    }
     r->we = (float*)upload(r, we->data.data(), we->data.size() * 4);
     r->be = (float*)upload(r, be->data.data(), be->data.size() * 4);
     if (!d_emb || !d_wih || !d_bsum || !d_gin || !r->dev.whh4 || !r->dev.wd4 || !r->dev.bd || !r->dev.wj4 || !r->dev.bj || !r->we || !r->be)
@@ -650,6 +755,7 @@ size_t effconf_rnnt_workspace_bytes(const EcRnnt* r, int32_t batch, int32_t t_ou
 int effconf_rnnt_set_option(EcRnnt* r, const char* name, int32_t value) {
     if (!r || !name) return ec_fail("null argument");
     if (!strcmp(name, "cluster_decode")) { r->cluster_mode = value; return 0; }
+    if (!strcmp(name, "cluster_by_slice")) { r->cluster_by_slice = value != 0; return 0; }
     return ec_fail("unknown option");
 }
 
@@ -671,9 +777,11 @@ int effconf_rnnt_greedy(EcRnnt* r, const float* enc_out, const int64_t* out_len,
     float* fe = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
     // linear_encoder(f) for every frame of the batch, once (joint_networks.py:82 recomputes it per decision)
     if (launch_sgemm_nt(enc_out, De, r->we, De, r->be, fe, J, batch * t_out, J, De, s) != 0) return ec_fail("linear_encoder GEMM launch failed");
-    // auto: clusters only while they need at most half of the CUs (two decodes on two streams must not starve each other's
-    // cluster-mates: a spinning workgroup keeps its CU)
-    const bool cluster = cluster_supported(r->cfg) && (r->cluster_mode == 1 || (r->cluster_mode < 0 && batch >= 2 * CU && ((batch + CU - 1) / CU) * CW <= 128));
+    // auto: clusters only while they need at most half of the CUs with the by-cluster mapping (two decodes on two streams must not starve
+    // each other's cluster-mates: a spinning workgroup keeps its CU).
+    // With the by-slice mapping a cluster is 8 CONSECUTIVE workgroups: whatever part of a launch is resident consists of whole clusters plus
+    // at most one split at the dispatch frontier, so decodes sharing the GPU cannot starve each other and a launch may use every CU.
+    const bool cluster = cluster_supported(r->cfg) && (r->cluster_mode == 1 || (r->cluster_mode < 0 && batch >= 2 * CU && ((batch + CU - 1) / CU) * CW <= (r->cluster_by_slice ? 256 : 128)));
     if (cluster) {
         const int ncl = (batch + CU - 1) / CU;
         if (ncl * CW > 256) return ec_fail("cluster decode needs every workgroup resident: batch <= 256");
@@ -681,7 +789,7 @@ int effconf_rnnt_greedy(EcRnnt* r, const float* enc_out, const int64_t* out_len,
         ex = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(ex) + 255) & ~(uintptr_t)255);
         ClusterArgs a{};
         a.w = r->dev; a.fe = fe; a.lens = out_len; a.T = t_out; a.B = batch; a.tokens = tokens; a.counts = token_len; a.max_tok = max_tokens;
-        a.ncl = ncl;
+        a.ncl = ncl; a.by_slice = r->cluster_by_slice;
         a.cnt = reinterpret_cast<unsigned*>(ex); a.status = reinterpret_cast<int*>(ex + (size_t)ncl * 256);
         char* p = ex + (size_t)ncl * 256 + 256;
         a.xh = reinterpret_cast<float*>(p); p += (size_t)ncl * CU * H * 4;

@@ -184,10 +184,13 @@ int32_t effconf_rnnt_max_tokens(const EcRnnt* r, int32_t t_out);
 /* enc_out dev f32 (batch, T_out, dim_encoder), out_len dev i64 (batch) -> tokens dev i32 (batch, max_tokens), zero-filled
  * tails (the leading start token of the reference's `y` is not included: transducer.py:179 decodes y[:, 1:]),
  * token_len dev i32 (batch). */
-/* "cluster_decode": -1 auto (default: batches of 16..128 utterances decode in clusters of 8 workgroups x 8 utterances that share the
- * weight streams), 0 one workgroup per utterance, 1 force (batch <= 256).  A cluster's workgroups synchronise through global memory
- * and must be co-resident: do not run two forced cluster decodes that together need more than the device's 256 CUs concurrently
- * (the spin is bounded: a starved cluster gives up with undefined tokens instead of hanging).  Both paths produce identical tokens. */
+/* "cluster_decode": -1 auto (default: batches of 16..256 utterances decode in clusters of 8 workgroups x 8 utterances that share the
+ * weight streams and run their three mat-vec phases on the fp32 matrix pipe), 0 one workgroup per utterance, 1 force (batch <= 256).
+ * A cluster's workgroups synchronise through global memory.  "cluster_by_slice" (default 1): a cluster is 8 CONSECUTIVE workgroups, so
+ * slice k of the weights is only ever read through XCD k's L2 and any resident part of a launch consists of whole clusters (decodes that
+ * share the GPU cannot starve each other); 0: the members of a cluster share an XCD and must all be resident - auto then stops at 128
+ * utterances.  The spin is bounded: a starved cluster gives up with undefined tokens instead of hanging.  All paths produce identical
+ * tokens. */
 int effconf_rnnt_set_option(EcRnnt* r, const char* name, int32_t value);
 int effconf_rnnt_greedy(EcRnnt* r, const float* enc_out, const int64_t* out_len, int32_t batch, int32_t t_out,
                         int32_t* tokens, int32_t* token_len, int32_t max_tokens, void* workspace, size_t workspace_bytes,
@@ -213,7 +216,7 @@ int effconf_rnnt_greedy(EcRnnt* r, const float* enc_out, const int64_t* out_len,
  * "ctc_mfma" (default 1): the CTC head (fc + argmax) on the fp32 MFMA; 0 selects the VALU kernel.  Both are k-ordered fp32 fma chains:
  *   bit-identical logits and labels.
  * "chain_variant" (0 / 1), "chain_full_max" (widest stage that runs chain A as one kernel; set before finalize to widen), "attn_waves"
- *   (4 / 8, attention.hip), "rs_variant" (0 / 1), "ffn_variant" (0 .. 2), "head_major_odd" (0 / 1): tuning / test switches of the kernel launchers that were
+ *   (4 / 8, attention.hip), "rs_variant" (0 / 1), "ffn_variant" (0 .. 2), "head_major_odd" (0 / 1), "exact_attention" (0 tiled / 2 tiled with 16-row workgroups / 1 one wave per query row; fp32 mode, bit-identical): tuning / test switches of the kernel launchers that were
  *   process-global EFFCONF_* environment variables until round 2; per handle now.  (Still read from the environment, once, as
  *   profiling / test hooks: EFFCONF_POISON_GUARDS at create, EFFCONF_{CHAIN,ATTN,FFN}_PHASES for the in-kernel phase profilers.)
  * "exact_fp32" (default 0): fp32-operand precision mode (csrc/exact.hip): every GEMM on fp32 MFMA, fp32 attention / convolutions,

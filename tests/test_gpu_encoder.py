@@ -444,8 +444,10 @@ def test_rnnt_cluster_decode_equals_per_utterance_decode(golden_dir, name, tag, 
     m.set_decode_option("cluster_decode", 0)
     ref_t, ref_n = m.decode_encoded(f, lens)
     m.set_decode_option("cluster_decode", 1)
-    got_t, got_n = m.decode_encoded(f, lens)
-    assert torch.equal(got_n, ref_n) and torch.equal(got_t, ref_t)
+    for by_slice in (0, 1):                           # workgroup -> XCD mapping: a cluster on one XCD / slice k of every cluster on XCD k
+        m.set_decode_option("cluster_by_slice", by_slice)
+        got_t, got_n = m.decode_encoded(f, lens)
+        assert torch.equal(got_n, ref_n) and torch.equal(got_t, ref_t), by_slice
     offs = g["offsets_" + tag]
     for b in range(f0.shape[0]):                      # the first copies keep the golden lengths
         want = g["tokens_" + tag][offs[b]:offs[b + 1]].tolist()

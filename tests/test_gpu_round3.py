@@ -390,3 +390,27 @@ def test_ragged_positional_cache_follows_the_longest_utterance():
         for b in range(2):
             alone, al, _ = enc(audio[b:b + 1, :int(l[b])].contiguous(), torch.from_numpy(l[b:b + 1]).cuda())
             assert torch.equal(outs[tag][b, :int(al[0])], alone[0]), (tag, b)
+
+
+# ------------------------------------------------------------------ fp32 mode: the tiled attention kernel == the one-wave-per-row kernel
+@pytest.mark.parametrize("name,tm,lens", [
+    ("Tiny", 100, [100, 77, 52, 0]),
+    ("EfficientConformerCTCSmall", 1001, [1001, 640, 333]),         # grouped heads of 90 / 42 / 60 columns, Tg = 167 / 126 / 126
+    ("EfficientConformerCTCLarge", 701, [701, 350]),                # an odd head width (135) and 3 output columns per lane
+    ("ConformerCTCLarge", 501, [501, 77]),
+])
+def test_exact_mode_tiled_attention_is_bit_identical_to_the_row_kernel(name, tm, lens):
+    """exact.hip: ex_attention2_kernel stages K / E / V blocks in LDS for 32 (16) query rows and keeps every sum in the order of
+    ex_attention_kernel (attentions.py:549-718), so the whole fp32 forward must not change by one bit - including an empty utterance
+    (all keys masked: the reference's uniform softmax) and a last query tile that is only partly valid."""
+    m, _ = _model(name, 11, "fp32")
+    mel, ln = synth.make_mel(len(lens), 80, tm, lens, seed=97)
+    mel_d, ln_d = torch.from_numpy(mel).cuda(), torch.from_numpy(ln).cuda()
+    m.encoder.set_option("exact_attention", 1)
+    ref, ref_len, _ = m.encoder.forward_mel(mel_d, ln_d)
+    for variant in (0, 2):                                          # 32-row (8 waves) and 16-row workgroups
+        m.encoder.set_option("exact_attention", variant)
+        out, out_len, _ = m.encoder.forward_mel(mel_d, ln_d)
+        assert torch.equal(out_len, ref_len)
+        assert torch.isfinite(out).all()
+        assert torch.equal(out, ref), variant
