@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Time the RNN-T greedy decode paths (per-utterance kernel vs cluster decode, both workgroup -> XCD mappings) on synthetic encoder outputs.
 
-    python tools/rnnt_diag.py [blank_bias=1.2] [batch=128]
+    [RNNT_MODES=cluster:by_slice,...] python tools/rnnt_diag.py [blank_bias=1.2] [batch=128]
 """
 import sys, os, time
 import numpy as np, torch
@@ -22,7 +22,8 @@ g = torch.Generator().manual_seed(0)
 f = torch.randn(B, T, 360, generator=g).cuda()
 lens = torch.tensor(sorted([int(x) for x in np.linspace(60, T, B)], reverse=True)).cuda()
 ref = None
-for mode, by_slice in ((0, 0), (1, 0), (1, 1)):
+modes = [tuple(int(v) for v in m.split(':')) for m in os.environ.get('RNNT_MODES', '0:0,1:0,1:1').split(',')]
+for mode, by_slice in modes:
     m.set_decode_option("cluster_decode", mode)
     m.set_decode_option("cluster_by_slice", by_slice)
     t, n = m.decode_encoded(f, lens)
