@@ -174,6 +174,45 @@ def step(model, audio, lens, range_pad=None, **kw):
     return enc, enc_len, labels, label_len
 
 
+def self_check_transducer(model, sd, plan, audio, lens, lens_np, last):
+    """Transducer configurations: the last timed step's token ids against (1) the one-workgroup-per-utterance decode kernel on the same
+    encoder output (identical), (2) the oracle's greedy loop (oracle/ref_transducer.py = transducer.py:139-186) on the same encoder
+    output for sampled utterances (identical: the head is fp32), and the encoder output of those utterances against the oracle encoder
+    run on each ALONE (bf16 tolerance)."""
+    from oracle import ref_encoder as R
+    from oracle import ref_transducer as RT
+    enc, enc_len = last["enc"]
+    tok, tok_len = last["labels"]
+    torch.cuda.synchronize()
+    osd = {k[len("encoder."):] if k.startswith("encoder.") else k: torch.from_numpy(v) for k, v in sd.items()}
+    model.set_decode_option("cluster_decode", 0)
+    try:
+        ref_tok, ref_n = model.decode_encoded(enc, enc_len)
+    finally:
+        model.set_decode_option("cluster_decode", -1)
+    same_kernel = bool(torch.equal(ref_n, tok_len) and torch.equal(ref_tok, tok))
+    b_all = enc.shape[0]
+    rows = sorted({0, b_all // 3, 2 * b_all // 3, b_all - 1})
+    want, margins = RT.greedy_decode(osd, enc[rows].cpu(), enc_len[rows].cpu(), model.max_consec_dec_step, with_margins=True)
+    got = [tok[r, :int(tok_len[r])].cpu().tolist() for r in rows]
+    seq_equal = got == want
+    worst_max = worst_mean = 0.0
+    for r in rows[1:3]:
+        li = int(lens_np[r])
+        with torch.no_grad():
+            ref, ref_len = R.encoder(audio[r:r + 1, :li].cpu(), lens[r:r + 1].cpu(), osd, plan)
+        d = (enc[r:r + 1, :ref.shape[1]].cpu() - ref).abs()
+        worst_max, worst_mean = max(worst_max, float(d.max())), max(worst_mean, float(d.mean()))
+    finite = bool(torch.isfinite(enc).all())
+    ok = same_kernel and seq_equal and finite and worst_max <= 0.10 and worst_mean <= 0.012
+    return {"ok": bool(ok), "finite": finite, "tokens_identical_to_the_per_utterance_decode_kernel": same_kernel,
+            "oracle_utterances": len(rows), "token_sequences_identical_to_oracle_greedy_on_the_same_encoder_output": bool(seq_equal),
+            "oracle_tokens": int(sum(len(w) for w in want)), "smallest_top2_logit_margin": float(min(margins)),
+            "encoder_max_abs_err_vs_oracle": worst_max, "encoder_mean_abs_err_vs_oracle": worst_mean, "tolerance": {"max": 0.10, "mean": 0.012},
+            "note": "token ids of the last timed step (cluster decode); oracle = oracle/ref_transducer.py greedy loop on this step's encoder "
+                    "output rows, oracle/ref_encoder.py on two sampled utterances alone"}
+
+
 def edit_distance(a, b):
     prev = list(range(len(b) + 1))
     for i, x in enumerate(a, 1):
@@ -574,8 +613,11 @@ def main():
     # ---- self-check of the benchmarked step (un-timed): the step's outputs against (1) every row range run ALONE on one stream
     #      (bit-identical) and (2) the oracle = the reference path on sampled utterances of each range, collated with the range's
     #      longest utterance (pad frames are live), within the bf16 tolerance of tests/test_gpu_encoder.py
-    if rank == 0 and world == 1 and not args.no_check and not isinstance(model, Transducer):
-        result["check"] = self_check(model, sd, plan, audio, lens, lens_np, cuts, range_pad, nsub, last, args)
+    if rank == 0 and world == 1 and not args.no_check:
+        if isinstance(model, Transducer):
+            result["check"] = self_check_transducer(model, sd, plan, audio, lens, lens_np, last)
+        else:
+            result["check"] = self_check(model, sd, plan, audio, lens, lens_np, cuts, range_pad, nsub, last, args)
 
     # ---- roofline leg: the same steps again with every launch bracketed by HIP events on the launch stream
     if rank == 0 and not args.no_roofline:
