@@ -47,6 +47,7 @@ SIGNATURES = {
     "effconf_encoder_workspace_bytes_ragged": (_SZ, [_P, _P, _I32, _I32, _I32]),
     "effconf_encoder_forward_ragged": (C.c_int, [_P, _F32P, _I64P, _P, _I32, _I32, _I32, _F32P, _I32, _I64P, _P, _SZ, _P]),
     "effconf_mel_frontend": (C.c_int, [_P, _F32P, _I32, _I32, _F32P, _P]),
+    "effconf_host_pack_rows": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int64), _I32, C.c_void_p, C.c_int64, _I32, _I32]),
     "effconf_ctc_greedy": (C.c_int, [_P, _F32P, _I64P, _I32, _I32, _P, _P, _F32P, _P, _SZ, _P]),
     "effconf_rnnt_create": (_P, [C.POINTER(EcRnntConfig)]),
     "effconf_rnnt_destroy": (None, [_P]),

@@ -3,8 +3,9 @@
 * ``collate_fn_pad`` — the reference's collate (utils/preprocessing.py:27-45): sort by length descending, zero-pad.
 * ``bucket_batches`` — length-bucketed batch plan: utterances sorted by length, cut into batches bounded by a number of
   utterances and by padded samples, so that padding waste (and the pad-frame work of the encoder) stays small.
-* ``FrontDoor`` — runs a model over a list of waveforms: every batch is assembled in a pinned host buffer, copied to the device
-  on a side stream while the previous batch is being encoded (double buffering), results returned in the caller's order.
+* ``FrontDoor`` — runs a model over a list of waveforms: every batch is packed by worker threads into one of two persistent pinned
+  host buffers and copied to the device on a side stream while the previous batch is being encoded; result ids come back through
+  asynchronous downloads; results are returned in the caller's order.
 
 The encoder's results for an utterance depend on the padded length of its batch (pad frames are live in the reference,
 SURVEY.md section 8a); the plan is therefore deterministic for a given list of lengths.
@@ -13,7 +14,13 @@ from __future__ import annotations
 
 from typing import Callable, Iterable, List, Optional, Sequence, Tuple
 
+import ctypes as C
+import time
+from concurrent.futures import ThreadPoolExecutor
+
 import torch
+
+from . import _lib
 
 
 def collate_fn_pad(batch):
@@ -52,42 +59,119 @@ def bucket_batches(lengths: Sequence[int], max_batch: int = 128, max_padded_samp
 
 
 class FrontDoor:
-    """Encode / decode a list of host waveforms with H2D copies overlapped with compute.
+    """Encode / decode a list of host waveforms with packing, H2D copies and result downloads overlapped with compute.
 
-    ``fn(audio (B, L) device tensor, lengths (B,) device tensor) -> list of per-utterance results`` is typically
-    ``model.greedy_labels`` (``ModelCTC``) or ``model.greedy_tokens`` (``Transducer``)."""
+    Two kinds of per-batch function:
 
-    def __init__(self, fn: Callable, device, max_batch: int = 128, max_padded_samples: Optional[int] = None):
-        self.fn, self.device = fn, torch.device(device)
+    * ``fn(audio (B, L) device tensor, lengths (B,) device tensor) -> list of per-utterance results`` - typically
+      ``model.greedy_labels`` (``ModelCTC``) or ``model.greedy_tokens`` (``Transducer``).  It returns host lists, i.e. it synchronises
+      once per batch; packing and the H2D copy of the next batch still overlap its GPU work.
+    * ``device_fn(audio, lengths) -> (ids (B, N) int32 device tensor, counts (B,) int32 device tensor)`` - e.g.
+      ``lambda x, n: model.encode_greedy(x, n)[2:]`` or ``lambda x, n: model.decode_encoded(*model.encoder(x, n)[:2])``.  Nothing
+      synchronises inside the loop: the id tensors are downloaded asynchronously into pinned memory and turned into lists after the last
+      batch, so the host packs batch k + 1 while the GPU still encodes batch k.
+
+    The staging buffers are two pinned host buffers, allocated once and grown on demand (``tensor.pin_memory()`` per batch costs more
+    than the batch's compute); rows are packed by ``workers`` native threads (``effconf_host_pack_rows``; a 256-utterance batch is 190 MB against
+    5.6 ms of GPU work).  ``zero_pad = False`` skips zeroing the pad samples - for ragged batches, whose kernels never read them
+    (``ConformerEncoder.ragged``); with the rectangular path the pad samples are live and must be zero."""
+
+    def __init__(self, fn: Optional[Callable] = None, device="cuda", max_batch: int = 128, max_padded_samples: Optional[int] = None,
+                 device_fn: Optional[Callable] = None, workers: int = 8, zero_pad: bool = True):
+        if (fn is None) == (device_fn is None):
+            raise ValueError("FrontDoor needs exactly one of fn / device_fn")
+        self.fn, self.device_fn, self.device = fn, device_fn, torch.device(device)
         self.max_batch, self.max_padded_samples = max_batch, max_padded_samples
+        self.zero_pad = zero_pad
         self.copy_stream = torch.cuda.Stream(device=self.device)
+        self._host = [None, None]                 # pinned fp32 staging, one per slot
+        self._hlen = [None, None]
+        self._free = [None, None]                 # event: the slot's last H2D copy has finished
+        self._workers = max(1, workers)
+        self._results: dict = {}
+        self._stager = ThreadPoolExecutor(max_workers=1)
+        self.stats: dict = {}                     # host seconds per piece of the last run() (pack, h2d_issue, launch, results)
 
-    def _stage(self, waves: Sequence[torch.Tensor], idx: List[int]):
+    def _stage(self, waves: Sequence[torch.Tensor], idx: List[int], slot: int):
+        t0 = time.perf_counter()
+        if self.device.index is not None:
+            torch.cuda.set_device(self.device)    # runs on the helper thread: the current device is per thread
         lens = [int(waves[i].numel()) for i in idx]
-        host = torch.zeros(len(idx), max(lens), dtype=torch.float32).pin_memory()
+        b, width = len(idx), max(max(lens), 1)
+        if self._free[slot] is not None:
+            self._free[slot].synchronize()        # the copy that last read this slot (two batches ago) is long done
+        if self._host[slot] is None or self._host[slot].numel() < b * width:
+            self._host[slot] = torch.empty(max(b * width, 1 << 20), dtype=torch.float32).pin_memory()
+        if self._hlen[slot] is None or self._hlen[slot].numel() < b:
+            self._hlen[slot] = torch.empty(max(b, 256), dtype=torch.int64).pin_memory()
+        host = self._host[slot][:b * width].view(b, width)
+        hlen = self._hlen[slot][:b]
+        hlen.copy_(torch.tensor(lens, dtype=torch.int64))
+        # native multi-threaded pack (csrc/hostpack.hip): per-row interpreter overhead and the GIL held 8 numpy threads at ~7 GB/s
+        rows = []
         for r, i in enumerate(idx):
-            host[r, :lens[r]] = waves[i].reshape(-1)
-        hlen = torch.tensor(lens, dtype=torch.int64).pin_memory()
+            w = waves[i].reshape(-1)
+            if w.dtype != torch.float32 or not w.is_contiguous() or w.requires_grad or w.is_cuda:
+                w = w.detach().to("cpu", torch.float32).contiguous()
+            rows.append(w)                        # keeps converted rows alive across the call
+        lib = _lib.load()
+        ptrs = (C.c_void_p * b)(*[w.data_ptr() for w in rows])
+        _lib.check(lib.effconf_host_pack_rows(ptrs, C.cast(hlen.data_ptr(), C.POINTER(C.c_int64)), b, host.data_ptr(), width,
+                                              1 if self.zero_pad else 0, self._workers), "host_pack_rows")
+        t1 = time.perf_counter()
         with torch.cuda.stream(self.copy_stream):
-            dev = host.to(self.device, non_blocking=True)
-            dlen = hlen.to(self.device, non_blocking=True)
+            dev = torch.empty(b, width, dtype=torch.float32, device=self.device)
+            dlen = torch.empty(b, dtype=torch.int64, device=self.device)
+            dev.copy_(host, non_blocking=True)
+            dlen.copy_(hlen, non_blocking=True)
             ready = torch.cuda.Event()
             ready.record(self.copy_stream)
-        return dev, dlen, ready, (host, hlen)
+        self._free[slot] = ready
+        t2 = time.perf_counter()
+        self.stats["pack"] = self.stats.get("pack", 0.0) + t1 - t0
+        self.stats["h2d_issue"] = self.stats.get("h2d_issue", 0.0) + t2 - t1
+        return dev, dlen, ready
+
+    def _result_buffer(self, key: int, n: int, dtype) -> torch.Tensor:
+        # pinned download buffers, kept across runs (pin_memory() per batch costs 0.5 - 40 ms)
+        buf = self._results.get(key)
+        if buf is None or buf.dtype != dtype or buf.numel() < n:
+            buf = torch.empty(max(n, 1), dtype=dtype).pin_memory()
+            self._results[key] = buf
+        return buf[:n]
 
     def run(self, waves: Sequence[torch.Tensor]) -> list:
         plan = bucket_batches([int(w.numel()) for w in waves], self.max_batch, self.max_padded_samples)
         out: list = [None] * len(waves)
-        staged = self._stage(waves, plan[0]) if plan else None
+        self.stats = {}
+        pending = []                              # device_fn: (idx, pinned ids, pinned counts) per batch
+        # batch k + 1 is packed and copied by a helper thread WHILE this thread enqueues batch k's ~400 kernels (5 ms of host time per
+        # 256-utterance batch against 6 ms on the GPU: staging on the same thread made the host the bottleneck)
+        nxt_job = self._stager.submit(self._stage, waves, plan[0], 0) if plan else None
+        cur = torch.cuda.current_stream(self.device)
         for k, idx in enumerate(plan):
-            dev, dlen, ready, keep = staged
-            nxt = self._stage(waves, plan[k + 1]) if k + 1 < len(plan) else None       # copy of batch k+1 overlaps compute of k
-            torch.cuda.current_stream(self.device).wait_event(ready)
-            res = self.fn(dev, dlen)
+            dev, dlen, ready = nxt_job.result()
+            nxt_job = self._stager.submit(self._stage, waves, plan[k + 1], (k + 1) & 1) if k + 1 < len(plan) else None
+            cur.wait_event(ready)
+            if self.device_fn is not None:
+                ids, counts = self.device_fn(dev, dlen)                      # asynchronous
+                h_ids = self._result_buffer(2 * k, ids.numel(), ids.dtype).view(ids.shape)
+                h_n = self._result_buffer(2 * k + 1, counts.numel(), counts.dtype).view(counts.shape)
+                h_ids.copy_(ids, non_blocking=True)
+                h_n.copy_(counts, non_blocking=True)
+                pending.append((idx, h_ids, h_n))
             # both were allocated on the copy stream and are consumed on the caller's stream
-            dev.record_stream(torch.cuda.current_stream(self.device))
-            dlen.record_stream(torch.cuda.current_stream(self.device))
-            for r, i in enumerate(idx):
-                out[i] = res[r]
-            staged = nxt
+            dev.record_stream(cur)
+            dlen.record_stream(cur)
+            if self.device_fn is None:
+                res = self.fn(dev, dlen)
+                for r, i in enumerate(idx):
+                    out[i] = res[r]
+        if pending:
+            cur.synchronize()
+            for idx, h_ids, h_n in pending:
+                n = h_n.tolist()
+                rows = h_ids.tolist()
+                for r, i in enumerate(idx):
+                    out[i] = rows[r][:n[r]]
         return out

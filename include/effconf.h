@@ -261,6 +261,13 @@ int effconf_debug_gemm(const uint16_t* a, int32_t lda, const uint16_t* w, int32_
  * 3 v_log/v_exp_f32, 4 v_mul/v_add_f32, 5 integer, 6 wave-local LDS exchange); out dev f32 (blocks * 256 * 16). */
 int effconf_debug_victim(int32_t kind, int32_t blocks, int32_t iters, float* out, void* stream);
 
+/* ---- host helper of the batching front door (reference: utils/preprocessing.py:33-45, collate_fn_pad zero-pads a sorted batch) -------
+ * Copies n host rows src[i][0 .. len[i]) to dst + i * pitch (floats) on `threads` host threads, zero-filling dst[i][len[i] .. pitch) when
+ * zero_pad != 0 (ragged batches never read the pad samples: pass 0).  dst is typically pinned memory, so that ONE H2D copy follows.  No
+ * device work, no stream; returns when the copy is complete. */
+int effconf_host_pack_rows(const float* const* src, const int64_t* len, int32_t n, float* dst, int64_t pitch, int32_t zero_pad,
+                           int32_t threads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -325,3 +325,30 @@ def test_every_shipped_config_has_a_name_and_a_plan(name):
     p2 = build_plan(theirs)
     assert [(b.dim_model, b.dim_expand, b.num_heads, b.kernel_size, b.group_size, b.conv_stride, b.max_pos) for b in plan.blocks] == \
            [(b.dim_model, b.dim_expand, b.num_heads, b.kernel_size, b.group_size, b.conv_stride, b.max_pos) for b in p2.blocks]
+
+
+def test_host_pack_rows_is_the_reference_collate():
+    """effconf_host_pack_rows (the front door's native packer) == pad_sequence of the reference's collate_fn_pad
+    (utils/preprocessing.py:33-45) for every thread count, with and without zero-fill, incl. empty rows; bad arguments are errors."""
+    import ctypes as C
+
+    from efficientconformer_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(3)
+    lens = [5000, 4096, 4095, 17, 1, 0, 0]
+    rows = [torch.randn(n, generator=g) for n in lens]
+    want = torch.nn.utils.rnn.pad_sequence(rows, batch_first=True, padding_value=0)
+    n, pitch = len(rows), want.shape[1]
+    ptrs = (C.c_void_p * n)(*[r.data_ptr() for r in rows])
+    ln = torch.tensor(lens, dtype=torch.int64)
+    lp = C.cast(ln.data_ptr(), C.POINTER(C.c_int64))
+    for threads in (1, 2, 3, 8, 64):
+        dst = torch.full((n, pitch), 7.0)
+        assert lib.effconf_host_pack_rows(ptrs, lp, n, dst.data_ptr(), pitch, 1, threads) == 0
+        assert torch.equal(dst, want)
+        dst = torch.full((n, pitch), 7.0)
+        assert lib.effconf_host_pack_rows(ptrs, lp, n, dst.data_ptr(), pitch, 0, threads) == 0
+        for r in range(n):
+            assert torch.equal(dst[r, :lens[r]], rows[r]) and bool((dst[r, lens[r]:] == 7.0).all())
+    assert lib.effconf_host_pack_rows(ptrs, lp, n, dst.data_ptr(), 4999, 1, 2) != 0          # a row longer than the pitch
+    assert lib.effconf_host_pack_rows(ptrs, lp, 0, None, 0, 1, 2) == 0

@@ -414,3 +414,24 @@ def test_exact_mode_tiled_attention_is_bit_identical_to_the_row_kernel(name, tm,
         assert torch.equal(out_len, ref_len)
         assert torch.isfinite(out).all()
         assert torch.equal(out, ref), variant
+
+
+# ------------------------------------------------------------------ batching front door: asynchronous path, ragged batches without zero-fill
+def test_front_door_device_fn_path_with_stale_pad_samples_equals_the_list_path():
+    """FrontDoor(device_fn=...) (no synchronisation inside the loop, ids downloaded asynchronously) must return what the list-returning
+    path returns; with ragged batches and zero_pad = False the pad samples of the reused pinned staging buffer hold the PREVIOUS run's
+    audio (here: 100x louder) and must not reach any output (utils/preprocessing.py:33-45 zero-pads; a ragged batch never reads them)."""
+    from efficientconformer_amd import FrontDoor
+    m, _ = _model("Tiny", 5)
+    m.encoder.ragged = True
+    g = torch.Generator().manual_seed(11)
+    lens = [16000, 15999, 9000, 8000, 7777, 4000, 3999, 1600, 801, 800, 400, 16000, 12000]
+    waves = [0.1 * torch.randn(n, generator=g) for n in lens]
+    loud = [10.0 * torch.randn(16000, generator=g) for _ in lens]
+    want = FrontDoor(m.greedy_labels, "cuda", max_batch=4).run(waves)
+    door = FrontDoor(device_fn=lambda x, n: m.encode_greedy(x, n)[2:], device="cuda", max_batch=4, workers=3, zero_pad=False)
+    door.run(loud)                                   # fills both staging buffers to the brim
+    got = door.run(waves)
+    assert got == want
+    assert door.run(waves) == want                   # and again on the reused buffers
+    assert sum(len(x) for x in want) > 0

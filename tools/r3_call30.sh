@@ -1,0 +1,2 @@
+#!/bin/bash
+mkdir -p gpurun_out; ( timeout 600 python tools/front_door_bench.py 1024 256; timeout 900 python tools/front_door_bench.py 4096 256 ) 2>&1 | grep -v amdgpu.ids > gpurun_out/c30.log; cat gpurun_out/c30.log
