@@ -15,9 +15,11 @@ from __future__ import annotations
 from typing import Callable, Iterable, List, Optional, Sequence, Tuple
 
 import ctypes as C
+import inspect
 import time
 from concurrent.futures import ThreadPoolExecutor
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -67,7 +69,8 @@ class FrontDoor:
       ``model.greedy_labels`` (``ModelCTC``) or ``model.greedy_tokens`` (``Transducer``).  It returns host lists, i.e. it synchronises
       once per batch; packing and the H2D copy of the next batch still overlap its GPU work.
     * ``device_fn(audio, lengths) -> (ids (B, N) int32 device tensor, counts (B,) int32 device tensor)`` - e.g.
-      ``lambda x, n: model.encode_greedy(x, n)[2:]`` or ``lambda x, n: model.decode_encoded(*model.encoder(x, n)[:2])``.  Nothing
+      ``lambda x, n, host_n: model.encode_greedy(x, n, x_len_host=host_n)[2:]`` (the optional third argument is the batch's lengths as
+      a host array) or ``lambda x, n: model.decode_encoded(*model.encoder(x, n)[:2])``.  Nothing
       synchronises inside the loop: the id tensors are downloaded asynchronously into pinned memory and turned into lists after the last
       batch, so the host packs batch k + 1 while the GPU still encodes batch k.
 
@@ -90,6 +93,12 @@ class FrontDoor:
         self._workers = max(1, workers)
         self._results: dict = {}
         self._stager = ThreadPoolExecutor(max_workers=1)
+        self._host_lengths = False
+        if device_fn is not None:
+            try:
+                self._host_lengths = len(inspect.signature(device_fn).parameters) >= 3
+            except (TypeError, ValueError):
+                pass
         self.stats: dict = {}                     # host seconds per piece of the last run() (pack, h2d_issue, launch, results)
 
     def _stage(self, waves: Sequence[torch.Tensor], idx: List[int], slot: int):
@@ -130,7 +139,7 @@ class FrontDoor:
         t2 = time.perf_counter()
         self.stats["pack"] = self.stats.get("pack", 0.0) + t1 - t0
         self.stats["h2d_issue"] = self.stats.get("h2d_issue", 0.0) + t2 - t1
-        return dev, dlen, ready
+        return dev, dlen, ready, np.asarray(lens, dtype=np.int64)
 
     def _result_buffer(self, key: int, n: int, dtype) -> torch.Tensor:
         # pinned download buffers, kept across runs (pin_memory() per batch costs 0.5 - 40 ms)
@@ -150,11 +159,13 @@ class FrontDoor:
         nxt_job = self._stager.submit(self._stage, waves, plan[0], 0) if plan else None
         cur = torch.cuda.current_stream(self.device)
         for k, idx in enumerate(plan):
-            dev, dlen, ready = nxt_job.result()
+            dev, dlen, ready, hl = nxt_job.result()
             nxt_job = self._stager.submit(self._stage, waves, plan[k + 1], (k + 1) & 1) if k + 1 < len(plan) else None
             cur.wait_event(ready)
             if self.device_fn is not None:
-                ids, counts = self.device_fn(dev, dlen)                      # asynchronous
+                # asynchronous; a three-argument device_fn also gets the lengths as a host array (ragged batches size their grids from
+                # them: without it the encoder reads them back from the device - one synchronisation per batch)
+                ids, counts = self.device_fn(dev, dlen, hl) if self._host_lengths else self.device_fn(dev, dlen)
                 h_ids = self._result_buffer(2 * k, ids.numel(), ids.dtype).view(ids.shape)
                 h_n = self._result_buffer(2 * k + 1, counts.numel(), counts.dtype).view(counts.shape)
                 h_ids.copy_(ids, non_blocking=True)

@@ -429,7 +429,7 @@ def test_front_door_device_fn_path_with_stale_pad_samples_equals_the_list_path()
     waves = [0.1 * torch.randn(n, generator=g) for n in lens]
     loud = [10.0 * torch.randn(16000, generator=g) for _ in lens]
     want = FrontDoor(m.greedy_labels, "cuda", max_batch=4).run(waves)
-    door = FrontDoor(device_fn=lambda x, n: m.encode_greedy(x, n)[2:], device="cuda", max_batch=4, workers=3, zero_pad=False)
+    door = FrontDoor(device_fn=lambda x, n, hl: m.encode_greedy(x, n, x_len_host=hl)[2:], device="cuda", max_batch=4, workers=3, zero_pad=False)
     door.run(loud)                                   # fills both staging buffers to the brim
     got = door.run(waves)
     assert got == want

@@ -41,13 +41,14 @@ for idx in plan:
     for r, i in enumerate(idx):
         x[r, :n[r]] = waves[i]
     dev.append((x.cuda(), torch.tensor(n).cuda()))
-for x, l in dev[:1]:
-    m.encode_greedy(x, l)
+hls = [l.cpu().numpy() for _, l in dev]
+for (x, l), hl in list(zip(dev, hls))[:1]:
+    m.encode_greedy(x, l, x_len_host=hl)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(3):
-    for x, l in dev:
-        m.encode_greedy(x, l)
+    for (x, l), hl in zip(dev, hls):
+        m.encode_greedy(x, l, x_len_host=hl)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / 3
 print("device-resident (encoder + CTC head, %d batches): %.1f ms -> %.1f M frames/s" % (len(dev), dt * 1e3, frames / dt / 1e6))
@@ -72,5 +73,5 @@ def timed(name, door):
 a = timed("front door, fn = model.greedy_labels (one sync per batch), 8 packing threads", FrontDoor(m.greedy_labels, "cuda", max_batch=max_batch, zero_pad=False))
 for w in (1, 4, 8, 16):
     b = timed("front door, device_fn = encode_greedy (no sync inside the loop), %d packing threads" % w,
-              FrontDoor(device_fn=lambda x, n: m.encode_greedy(x, n)[2:], device="cuda", max_batch=max_batch, workers=w, zero_pad=False))
+              FrontDoor(device_fn=lambda x, n, hl: m.encode_greedy(x, n, x_len_host=hl)[2:], device="cuda", max_batch=max_batch, workers=w, zero_pad=False))
     assert a == b

@@ -21,7 +21,7 @@ def wrap(obj, name, key):
     def g(*a, **k):
         t0 = time.perf_counter(); r = f(*a, **k); T[key] = T.get(key, 0.0) + time.perf_counter() - t0; return r
     setattr(obj, name, g)
-door = FrontDoor(device_fn=lambda x, n: m.encode_greedy(x, n)[2:], device="cuda", max_batch=256, workers=8, zero_pad=False)
+door = FrontDoor(device_fn=lambda x, n, hl: m.encode_greedy(x, n, x_len_host=hl)[2:], device="cuda", max_batch=256, workers=8, zero_pad=False)
 door.run(waves); torch.cuda.synchronize()
 wrap(door, "_stage", "stage (pack + H2D issue)")
 wrap(door, "device_fn", "device_fn launch")
