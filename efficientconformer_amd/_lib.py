@@ -47,6 +47,8 @@ SIGNATURES = {
     "effconf_encoder_workspace_bytes_ragged": (_SZ, [_P, _P, _I32, _I32, _I32]),
     "effconf_encoder_forward_ragged": (C.c_int, [_P, _F32P, _I64P, _P, _I32, _I32, _I32, _F32P, _I32, _I64P, _P, _SZ, _P]),
     "effconf_mel_frontend": (C.c_int, [_P, _F32P, _I32, _I32, _F32P, _P]),
+    "effconf_encoder_attention_dims": (C.c_int, [_P, _I32, _I32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "effconf_encoder_set_attention_outputs": (C.c_int, [_P, C.POINTER(C.c_void_p), _I32]),
     "effconf_host_pack_rows": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int64), _I32, C.c_void_p, C.c_int64, _I32, _I32]),
     "effconf_ctc_greedy": (C.c_int, [_P, _F32P, _I64P, _I32, _I32, _P, _P, _F32P, _P, _SZ, _P]),
     "effconf_rnnt_create": (_P, [C.POINTER(EcRnntConfig)]),

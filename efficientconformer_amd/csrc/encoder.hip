@@ -79,6 +79,7 @@ struct EcEncoder {
     int chain_variant = 0, chain_full_max = 192, attn_waves = 4, rs_variant = 0, ffn_variant = 0;
     int chain_max_dim = 256;                 // fused chains only for stage widths <= this (tuning: wider stages on the per-GEMM / tiled kernels)
     int tiled_min_k = 256;                   // with wide_gemm >= 2: layers with K > this leave the row-stationary kernels for LayerNorm + tiled GEMMs
+    std::vector<float*> att_out;             // per block: device buffer [B][H][Tg][Tg] for the softmax maps of the next forward, or null
     int exact_attention = 0;                 // fp32 mode: 0 tiled attention kernel (2: its 16-row shape), 1 one wave per query row (round 2's); bit-identical
     bool head_major_odd = false;             // odd grouped head widths on the head-major Q/K/V layout (tests; the default reads the natural layout unaligned)
     // two-layer subsampler (plain Conformer configs): layer-2 implicit-GEMM weight [N][9*Cp] (tap, c_in), folded bias, Cp
@@ -735,6 +736,10 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
               // head-major test layout of odd head widths (EFFCONF_HEAD_MAJOR_ODD) stays on attention.hip
               if (e->attention_v2 && nat && relpos_attention2_supported(dpad)) EC_TRY(launch_relpos_attention2(ap, e->attention_v2, st));
               else EC_TRY(launch_relpos_attention(ap, st)); }
+            if ((int)e->att_out.size() == nb && e->att_out[k]) {       // opt-in: the reference's att_w of this block (encoders.py:129)
+                if (rg) return fail("attention maps are written for rectangular batches only");
+                EC_TRY(launch_attention_probs(ap, e->att_out[k], st));
+            }
             snprintf(nm, sizeof(nm), "blocks.%d.att_o", k); trace_add(e, st, nm, o, M, D, ld8(D), 1);
             if (chain_b) {
                 ChainParams cp{};
@@ -950,6 +955,7 @@ int forward_core_exact(EcEncoder* e, const float* mel, const int64_t* in_len, in
         ExAttnParams ap{};
         ap.q = q; ap.k = kk; ap.v = v; ap.e = eb; ap.u = W.u; ap.vb = W.v; ap.lens = lens + (size_t)k * B;
         ap.B = B; ap.H = H; ap.T = T; ap.Tp = Tp; ap.G = G; ap.D = D; ap.d = d; ap.Tg = Tg; ap.out = o; ap.variant = e->exact_attention;
+        ap.att = (int)e->att_out.size() == nb ? e->att_out[k] : nullptr;
         { PROF(PC_ATTENTION, 2.0 * B * H * (double)Tg * Tg * d * 3.0, (double)M * D * 4 * 5); EC_TRY(launch_ex_attention(ap, st)); }
         EC_TRY(xgemm(e, st, o, D, M, m + ".mhsa.output_layer", D, D, x, D, 2, x, 1.0f, T, Tp, 1));
         snprintf(nm, sizeof(nm), "blocks.%d.x_mhsa", k); trace_add(e, st, nm, x, M, D, D, 0);
@@ -1604,6 +1610,27 @@ int effconf_ctc_greedy(EcEncoder* e, const float* enc_out, const int64_t* out_le
     EC_TRY(launch_ctc_argmax(enc_out, batch * t_out, e->blocks.back().dim_expand, e->fc_wt, e->fc_b, e->cfg.vocab_size,
                              preds, logits, st, e->ctc_mfma));
     EC_TRY(launch_ctc_collapse(preds, out_len, batch, t_out, labels, label_len, st));
+    return 0;
+}
+
+/* Attention maps (reference encoders.py:126-142): maps[k] = device buffer of batch x heads[k] x tg[k] x tg[k] floats for block k, or null. */
+int effconf_encoder_attention_dims(EcEncoder* e, int32_t n, int32_t from_audio, int32_t* heads, int32_t* tg) {
+    if (!e || !e->finalized || !heads || !tg) return fail("effconf_encoder_attention_dims: null argument / encoder not finalized");
+    if (n < 0) return fail("effconf_encoder_attention_dims: negative length");
+    const Shapes s = make_shapes(e, 1, from_audio ? n / e->cfg.hop_length + 1 : n);
+    for (size_t k = 0; k < e->blocks.size(); ++k) {
+        const EcBlock& b = e->blocks[k];
+        heads[k] = b.num_heads;
+        tg[k] = ec_round_up(s.Tin[k], b.group_size) / b.group_size;
+    }
+    return 0;
+}
+
+int effconf_encoder_set_attention_outputs(EcEncoder* e, float* const* maps, int32_t n_blocks) {
+    if (!e) return fail("null encoder");
+    if (!maps || n_blocks == 0) { e->att_out.clear(); return 0; }
+    if (n_blocks != (int)e->blocks.size()) return fail("effconf_encoder_set_attention_outputs: one pointer per block (null = skip that block)");
+    e->att_out.assign(maps, maps + n_blocks);
     return 0;
 }
 

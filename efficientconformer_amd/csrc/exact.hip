@@ -160,6 +160,7 @@ __global__ __launch_bounds__(64) void ex_attention_kernel(ExAttnParams p) {
     for (int j = lane; j < p.Tg; j += 64) { const float e = expf(sc[j] - mx); sc[j] = e; sum += e; }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if (p.att) for (int j = lane; j < p.Tg; j += 64) p.att[(((size_t)b * p.H + h) * p.Tg + i) * p.Tg + j] = sc[j] / sum;
     __syncthreads();
     for (int x = lane; x < p.d; x += 64) {
         float acc = 0.f;
@@ -275,6 +276,8 @@ __global__ __launch_bounds__(XQT * 16) void ex_attention2_kernel(ExAttnParams p,
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
         for (int j = lane; j < TgP; j += 64) row[j] = j < Tg ? row[j] / sum : 0.f;
+        const int i = i0 + 4 * wave + rr;
+        if (p.att && i < Tg) for (int j = lane; j < Tg; j += 64) p.att[(((size_t)b * p.H + h) * Tg + i) * Tg + j] = row[j];
     }
     // P V: lane <-> output columns lane, lane + 64, lane + 128
     float acc[4][3];

@@ -152,6 +152,8 @@ struct AttnParams {
     int band_l, band_r, causal;
 };
 int launch_relpos_attention(const AttnParams& p, hipStream_t s);
+// opt-in side output: att [B][H][Tg][Tg] fp32 softmax maps (the reference's att_w), recomputed from the same bf16 operands; rectangular batches
+int launch_attention_probs(const AttnParams& p, float* att, hipStream_t s);
 // second generation (attention2.hip): 32 queries per wave, transposing LDS reads for V; waves = 2 (64-query workgroups) or 4
 bool relpos_attention2_supported(int dpad);
 int launch_relpos_attention2(const AttnParams& p, int waves, hipStream_t s);
@@ -208,6 +210,7 @@ struct ExAttnParams {              // natural-layout fp32 Q, K, V [B*Tp][D], E [
     const int* lens;
     int B, H, T, Tp, G, D, d, Tg;
     float* out;
+    float* att;                    // optional [B][H][Tg][Tg] softmax maps (null: not written)
     int variant;                   // 0: tiled kernel (default), 2: its 16-row shape, 1: one wave per query row (round 2's kernel); all agree bit for bit
 };
 int launch_ex_attention(const ExAttnParams& p, hipStream_t s);

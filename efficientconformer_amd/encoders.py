@@ -265,12 +265,12 @@ class ConformerEncoder(nn.Module):
         return ws
 
     def _run(self, x: torch.Tensor, x_len: Optional[torch.Tensor], from_audio: bool, range_hook: Optional[Callable] = None,
-             x_len_host=None, range_pad=None):
+             x_len_host=None, range_pad=None, return_attentions: bool = False):
         if x.is_cuda:
             # the C library allocates packed weights on, and launches on, the CURRENT device: make that the input's device
             with torch.cuda.device(x.device):
-                return self._run_on_device(x, x_len, from_audio, range_hook, x_len_host, range_pad)
-        return self._run_on_device(x, x_len, from_audio, range_hook, x_len_host, range_pad)
+                return self._run_on_device(x, x_len, from_audio, range_hook, x_len_host, range_pad, return_attentions)
+        return self._run_on_device(x, x_len, from_audio, range_hook, x_len_host, range_pad, return_attentions)
 
     def _range_pads(self, ranges, n, from_audio, lens, lens_given, x_len_host, range_pad):
         """Padded length (samples / mel frames) of every row range in trimmed mode, or None (every range keeps the batch's)."""
@@ -289,7 +289,7 @@ class ConformerEncoder(nn.Module):
         return None if all(v == n for v in pads) else pads
 
     def _run_on_device(self, x: torch.Tensor, x_len: Optional[torch.Tensor], from_audio: bool, range_hook: Optional[Callable],
-                       x_len_host=None, range_pad=None):
+                       x_len_host=None, range_pad=None, return_attentions: bool = False):
         if self.training:
             raise RuntimeError("efficientconformer_amd.ConformerEncoder is an inference path: call .eval()")
         if not x.is_cuda:
@@ -312,6 +312,18 @@ class ConformerEncoder(nn.Module):
 
         nsub = self.sub_batches if self.sub_batches is not None else (2 if batch >= self.sub_batch_min else 1)
         nsub = max(1, min(int(nsub), batch))
+        attentions = [None] * len(self.plan.blocks)
+        if return_attentions:
+            # the reference's third return value (encoders.py:126-142): one (B, H, Tg, Tg) softmax map per block, written by the library
+            # next to the forward (effconf_encoder_set_attention_outputs); the whole batch as ONE rectangular range
+            if self.ragged:
+                raise RuntimeError("return_attentions needs a rectangular batch (ConformerEncoder.ragged = False)")
+            nsub, nb = 1, len(self.plan.blocks)
+            heads, tg = (C.c_int32 * nb)(), (C.c_int32 * nb)()
+            _lib.check(lib.effconf_encoder_attention_dims(self._handle, n, int(from_audio), heads, tg), "attention_dims")
+            attentions = [torch.empty(batch, heads[k], tg[k], tg[k], dtype=torch.float32, device=x.device) for k in range(nb)]
+            _lib.check(lib.effconf_encoder_set_attention_outputs(self._handle, (C.c_void_p * nb)(*[a.data_ptr() for a in attentions]), nb),
+                       "set_attention_outputs")
         host_lens = None
         if self.ragged:
             if self._exact:
@@ -370,7 +382,11 @@ class ConformerEncoder(nn.Module):
                 out[lo:hi, ti:] = 0
 
         if nsub == 1:
-            (launch_ragged if self.ragged else launch)(0, batch)
+            try:
+                (launch_ragged if self.ragged else launch)(0, batch)
+            finally:
+                if return_attentions:
+                    _lib.check(lib.effconf_encoder_set_attention_outputs(self._handle, None, 0), "set_attention_outputs")
             if range_hook is not None:
                 range_hook(0, batch, out, out_len)
         else:
@@ -423,23 +439,25 @@ class ConformerEncoder(nn.Module):
                         range_hook(lo, hi, out, out_len)     # called with the range's stream current: rows [lo, hi) of `out` are enqueued
             for st in streams:
                 cur.wait_stream(st)                      # joined: the caller continues on its own stream
-        return out, (out_len if lens_given else None), [None] * len(self.plan.blocks)
+        return out, (out_len if lens_given else None), attentions
 
     def forward(self, x: torch.Tensor, x_len: Optional[torch.Tensor] = None, range_hook: Optional[Callable] = None,
-                x_len_host=None, range_pad=None):
+                x_len_host=None, range_pad=None, return_attentions: bool = False):
         """x: (B, L) raw 16 kHz audio, x_len: (B,) samples -> (x (B, T_out, D_last), x_len, attentions)
         (reference encoders.py:97-142).
 
         ``range_hook(lo, hi, out, out_len)`` (optional, not in the reference) is called once per sub-batch row range right after
         that range's kernels were enqueued, with the range's HIP stream current: work enqueued from the hook (an all-gather of
         ``out[lo:hi]``) starts when THAT range is done, while the other ranges are still in their last stage.
-        ``x_len_host`` (the lengths as a host sequence) / ``range_pad`` (one padded length per row range) serve ``trim_sub_batches``."""
-        return self._run(x, x_len, True, range_hook, x_len_host, range_pad)
+        ``x_len_host`` (the lengths as a host sequence) / ``range_pad`` (one padded length per row range) serve ``trim_sub_batches``.
+        ``attentions`` is a list of ``None`` per block unless ``return_attentions=True``: then the reference's per-block softmax maps
+        (B, H, Tg, Tg) (encoders.py:126-142), at the price of one extra kernel per block and a single row range."""
+        return self._run(x, x_len, True, range_hook, x_len_host, range_pad, return_attentions)
 
     def forward_mel(self, mel: torch.Tensor, mel_len: Optional[torch.Tensor] = None, range_hook: Optional[Callable] = None,
-                    x_len_host=None, range_pad=None):
+                    x_len_host=None, range_pad=None, return_attentions: bool = False):
         """Enter after AudioPreprocessing: mel (B, n_mels, Tm), lengths in frames (the parity boundary)."""
-        return self._run(mel, mel_len, False, range_hook, x_len_host, range_pad)
+        return self._run(mel, mel_len, False, range_hook, x_len_host, range_pad, return_attentions)
 
     def mel_frontend(self, x: torch.Tensor, x_len: Optional[torch.Tensor] = None):
         """AudioPreprocessing.forward (reference modules.py:87-106) on the GPU."""

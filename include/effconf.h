@@ -261,6 +261,15 @@ int effconf_debug_gemm(const uint16_t* a, int32_t lda, const uint16_t* w, int32_
  * 3 v_log/v_exp_f32, 4 v_mul/v_add_f32, 5 integer, 6 wave-local LDS exchange); out dev f32 (blocks * 256 * 16). */
 int effconf_debug_victim(int32_t kind, int32_t blocks, int32_t iters, float* out, void* stream);
 
+/* ---- attention maps: the third return value of the reference's ConformerEncoder.forward (encoders.py:126-142: att_w of every block,
+ * (batch, heads, Tg, Tg) softmax rows; no caller on the hot path reads them, so they are opt-in).  effconf_encoder_attention_dims fills
+ * heads[k] / tg[k] per block for inputs of n samples (from_audio) or mel frames; effconf_encoder_set_attention_outputs registers one device
+ * buffer of batch * heads[k] * tg[k] * tg[k] floats per block (null entries skip a block; maps = null or n_blocks = 0 clears the
+ * registration) - every following effconf_encoder_forward writes them (rectangular batches; bf16 path: recomputed in fp32 from the bf16
+ * Q / K / E operands; fp32 path: the kernel's own probabilities). */
+int effconf_encoder_attention_dims(EcEncoder* enc, int32_t n, int32_t from_audio, int32_t* heads, int32_t* tg);
+int effconf_encoder_set_attention_outputs(EcEncoder* enc, float* const* maps, int32_t n_blocks);
+
 /* ---- host helper of the batching front door (reference: utils/preprocessing.py:33-45, collate_fn_pad zero-pads a sorted batch) -------
  * Copies n host rows src[i][0 .. len[i]) to dst + i * pitch (floats) on `threads` host threads, zero-filling dst[i][len[i] .. pitch) when
  * zero_pad != 0 (ragged batches never read the pad samples: pass 0).  dst is typically pinned memory, so that ONE H2D copy follows.  No

@@ -200,10 +200,10 @@ def relpos_attention(x: torch.Tensor, lens: Optional[torch.Tensor], sd, prefix: 
     return (o, p) if return_probs else o
 
 
-def mhsa_module(x, lens, sd, prefix, heads, group, **ctx):
+def mhsa_module(x, lens, sd, prefix, heads, group, return_probs: bool = False, **ctx):
     d = x.shape[-1]
     h = F.layer_norm(x, (d,), _t(sd, prefix + ".norm.weight"), _t(sd, prefix + ".norm.bias"), LN_EPS)  # modules.py:475
-    return relpos_attention(h, lens, sd, prefix, heads, group, **ctx)
+    return relpos_attention(h, lens, sd, prefix, heads, group, return_probs=return_probs, **ctx)
 
 
 # --------------------------------------------------------------------------
@@ -240,7 +240,7 @@ def conformer_block(x, lens, sd, bp, trace: Optional[dict] = None, plan=None):
     ctx = {}
     if plan is not None and (plan.causal or plan.left_context < (1 << 30) or plan.right_context < (1 << 30)):
         ctx = dict(causal=plan.causal, left=plan.left_context, right=plan.right_context, mask_stride=bp.mask_stride)
-    att = mhsa_module(x, lens, sd, p + ".multi_head_self_attention_module", bp.num_heads, bp.group_size, **ctx)
+    att, att_w = mhsa_module(x, lens, sd, p + ".multi_head_self_attention_module", bp.num_heads, bp.group_size, return_probs=True, **ctx)
     x = x + att                                                   # att_res is Identity (att_stride == 1)
     x_mhsa = x
     c = conv_module(x, sd, p + ".convolution_module", bp.kernel_size, bp.conv_stride, causal=bool(plan is not None and plan.causal))
@@ -258,6 +258,7 @@ def conformer_block(x, lens, sd, bp, trace: Optional[dict] = None, plan=None):
     if trace is not None:
         trace[p + ".ffn1"], trace[p + ".mhsa"], trace[p + ".conv"], trace[p + ".ffn2"], trace[p + ".out"] = f1, att, c, f2, x
         trace[p + ".x_ffn1"], trace[p + ".x_mhsa"], trace[p + ".x_conv"] = x_ffn1, x_mhsa, x_conv   # residual stream
+        trace[p + ".att_w"] = att_w        # the attention map the reference's forward returns per block (blocks.py:126, encoders.py:129)
     return x
 
 

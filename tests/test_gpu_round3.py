@@ -435,3 +435,64 @@ def test_front_door_device_fn_path_with_stale_pad_samples_equals_the_list_path()
     assert got == want
     assert door.run(waves) == want                   # and again on the reused buffers
     assert sum(len(x) for x in want) > 0
+
+
+# ------------------------------------------------------------------ attention maps (the third return value of the reference's forward)
+@pytest.mark.parametrize("gname", ["tiny_T47.npz", "tiny_T100.npz"])
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_attention_maps_vs_the_reference(golden_dir, gname, precision):
+    """ConformerEncoder.forward(..., return_attentions=True) returns one (B, H, Tg, Tg) softmax map per block (reference
+    encoders.py:126-142, attentions.py:620 / 718).  First / last block against the reference's own maps (tools/make_goldens.py: atts[0],
+    atts[-1]), every block against the oracle's; rows sum to one; the forward's other outputs do not change.  bf16 path: the maps are
+    recomputed in fp32 from bf16 Q / K / E (tolerance 0.02 on probabilities); fp32 path: 2e-5."""
+    g = np.load(os.path.join(golden_dir, gname))
+    m, sd = _model("Tiny", int(g["weight_seed"]), precision)
+    b, tm = len(g["mel_len"]), int(g["mel_len"].max())
+    mel, ln = synth.make_mel(b, 80, tm, g["mel_len"].tolist(), seed=int(g["mel_seed"]))
+    mel_d, ln_d = torch.from_numpy(mel).cuda(), torch.from_numpy(ln).cuda()
+    plain, plain_len, none = m.encoder.forward_mel(mel_d, ln_d)
+    assert all(a is None for a in none)
+    out, out_len, atts = m.encoder.forward_mel(mel_d, ln_d, return_attentions=True)
+    assert torch.equal(out, plain) and torch.equal(out_len, plain_len)
+    trace = {}
+    with torch.no_grad():
+        R.encoder_from_mel(torch.from_numpy(mel), torch.from_numpy(ln), sd, m.encoder.plan, trace)
+    tol = 0.02 if precision == "bf16" else 2e-5
+    assert len(atts) == len(m.encoder.plan.blocks)
+    worst = 0.0
+    for k, a in enumerate(atts):
+        ref = trace["blocks.%d.att_w" % k]
+        assert tuple(a.shape) == tuple(ref.shape)
+        assert float((a.sum(-1) - 1.0).abs().max()) < 1e-4
+        worst = max(worst, float((a.cpu() - ref).abs().max()))
+    print("attention maps, %s, %s: max |p - p_ref| over all blocks %.2e" % (gname, precision, worst))
+    assert worst < tol
+    assert float((atts[0].cpu() - torch.from_numpy(g["att0"])).abs().max()) < tol
+    assert float((atts[-1].cpu() - torch.from_numpy(g["att_last"])).abs().max()) < tol
+    again, _, none = m.encoder.forward_mel(mel_d, ln_d)            # the registration does not outlive the call
+    assert torch.equal(again, plain) and all(a is None for a in none)
+
+
+@pytest.mark.parametrize("extra", [dict(causal=True), dict(left_context=20, right_context=4), dict(causal=True, left_context=6)])
+def test_attention_maps_with_streaming_contexts_vs_oracle(extra):
+    """The maps of a streaming / causal encoder carry the band mask (attentions.py:1377-1403: streaming_mask.maximum(padding_mask),
+    additive -1e9): masked entries are exactly zero, the rest matches the oracle; return_attentions is refused for ragged batches."""
+    cfg = named_config("Tiny")
+    cfg["encoder_params"] = dict(cfg["encoder_params"], **extra)
+    m = ModelCTC.from_config(cfg)
+    sd = synth.make_state_dict(m.encoder.plan, 7, cfg["tokenizer_params"]["vocab_size"], prefix="encoder.")
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    osd = {k[len("encoder."):] if k.startswith("encoder.") else k: v for k, v in sd.items()}
+    m = m.cuda()
+    mel, ln = synth.make_mel(3, 80, 120, [120, 77, 30], seed=9)
+    out, out_len, atts = m.encoder.forward_mel(torch.from_numpy(mel).cuda(), torch.from_numpy(ln).cuda(), return_attentions=True)
+    trace = {}
+    with torch.no_grad():
+        R.encoder_from_mel(torch.from_numpy(mel), torch.from_numpy(ln), osd, m.encoder.plan, trace)
+    for k, a in enumerate(atts):
+        ref = trace["blocks.%d.att_w" % k]
+        assert float((a.cpu() - ref).abs().max()) < 0.02, k
+        assert bool((a.cpu()[ref == 0] == 0).all())
+    m.encoder.ragged = True
+    with pytest.raises(RuntimeError, match="rectangular"):
+        m.encoder.forward_mel(torch.from_numpy(mel).cuda(), torch.from_numpy(ln).cuda(), return_attentions=True)

@@ -169,3 +169,22 @@ def test_oracle_streaming_and_causal_vs_reference(gname):
     ref = torch.from_numpy(g["out_rows"] if small else g["out"])
     got = out[:, ::4] if small else out
     assert float((got - ref).abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("gname", ["tiny_T47.npz", "tiny_T100.npz"])
+def test_oracle_attention_maps_equal_the_reference(golden_dir, gname):
+    """The third return value of ConformerEncoder.forward (encoders.py:126-142: one (B, H, Tg, Tg) softmax map per block): the oracle's maps
+    of the first and the last block against the reference's (tools/make_goldens.py stores atts[0] / atts[-1])."""
+    g = np.load(os.path.join(golden_dir, gname))
+    plan = build_plan(named_config("Tiny")["encoder_params"])
+    sd = synth.make_state_dict(plan, int(g["weight_seed"]), None)
+    sd = {k: torch.from_numpy(v) for k, v in sd.items()}
+    b, tm = len(g["mel_len"]), int(g["mel_len"].max())
+    mel, ln = synth.make_mel(b, 80, tm, g["mel_len"].tolist(), seed=int(g["mel_seed"]))
+    trace = {}
+    with torch.no_grad():
+        R.encoder_from_mel(torch.from_numpy(mel), torch.from_numpy(ln), sd, plan, trace)
+    first, last = trace["blocks.0.att_w"], trace["blocks.%d.att_w" % (len(plan.blocks) - 1)]
+    assert tuple(first.shape) == g["att0"].shape and tuple(last.shape) == g["att_last"].shape
+    assert float((first - torch.from_numpy(g["att0"])).abs().max()) < 2e-6
+    assert float((last - torch.from_numpy(g["att_last"])).abs().max()) < 2e-6
