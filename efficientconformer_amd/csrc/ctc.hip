@@ -242,6 +242,101 @@ __global__ __launch_bounds__(256) void ctc_argmax_mfma_kernel(const float* __res
     if (part == 0 && m0 + prow < M) preds[m0 + prow] = bidx;
 }
 
+// fc + argmax with SPLIT-bf16 operands on the bf16 matrix pipe (the default of the bf16 path): x = x_hi + x_lo, W = W_hi + W_lo (two bf16 each:
+// 16 significant bits), logits = x_hi W_hi + x_hi W_lo + x_lo W_hi, fp32 accumulation - relative error ~2^-16 per product, four orders below the
+// 3e-2 the bf16 encoder output already carries, at 3 bf16 MFMAs (96 cycles) per 16 k where the fp32 pipe needs 8 fp32 MFMAs (512 cycles).
+// The fp32 head was 2 % of the Small step and, with the north_star's all-gather BEFORE the head, runs on N x the frames on every rank.
+// Same tiling as the fp32 kernel (ROWS frames x 256 columns per pass, wave = 64 columns); the frame tile is split once into two bf16 LDS
+// images (row pitch 2 Kp + 16 bytes: the 16-byte fragment reads of 16 consecutive rows fall on disjoint banks), the weight halves are
+// packed at finalize as MFMA B fragments ([k / 16][column][k-half][8] bf16: a wave's load is 1 KiB contiguous).
+template <int ROWS>
+__global__ __launch_bounds__(256) void ctc_argmax_bf16x3_kernel(const float* __restrict__ x, int M, int D, int Kp, const bf16_t* __restrict__ Whi,
+                                                                const bf16_t* __restrict__ Wlo, const float* __restrict__ bias, int V, int Vp,
+                                                                int* __restrict__ preds, float* __restrict__ logits) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int RT = ROWS / 32, TPR = 256 / ROWS, CPT = 256 / TPR, LDT = 257;
+    const int pitch = Kp * 2 + 16;                                       // bytes per frame row of one half
+    char* xh = smem;                                                     // [ROWS][pitch] hi
+    char* xl = smem + ROWS * pitch;                                      // [ROWS][pitch] lo
+    float* st = reinterpret_cast<float*>(smem + 2 * ROWS * pitch);      // [ROWS][LDT] logits tile
+    const int m0 = blockIdx.x * ROWS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid * 4; i < ROWS * Kp; i += 1024) {
+        const int r = i / Kp, k = i - r * Kp;
+        const int mr = m0 + r < M ? m0 + r : M - 1;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < D) v = *reinterpret_cast<const float4*>(x + (size_t)mr * D + k);        // D % 4 == 0: a quad is valid or pad as a whole
+        const uint16_t h0 = f2bf(v.x), h1 = f2bf(v.y), h2 = f2bf(v.z), h3 = f2bf(v.w);
+        *reinterpret_cast<uint2*>(xh + r * pitch + k * 2) = make_uint2(h0 | ((uint32_t)h1 << 16), h2 | ((uint32_t)h3 << 16));
+        *reinterpret_cast<uint2*>(xl + r * pitch + k * 2) = make_uint2(pack_bf2(v.x - bf2f(h0), v.y - bf2f(h1)), pack_bf2(v.z - bf2f(h2), v.w - bf2f(h3)));
+    }
+    __syncthreads();
+    const int prow = tid / TPR, part = tid - prow * TPR;
+    float best = -INFINITY;
+    int bidx = 0x7fffffff;
+    const int kh = lane >> 5, lc = lane & 31;
+    const int nks = Kp / 16;
+    for (int v0 = 0; v0 < V; v0 += 256) {
+        f32x16 acc[RT][2];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[rt][ct][r] = 0.f;
+        const int c0 = v0 + wave * 64 + lc, c1 = c0 + 32;               // < Vp: the packed images are padded to whole 64-column groups
+        const size_t o0 = ((size_t)c0 * 2 + kh) * 8, o1 = ((size_t)c1 * 2 + kh) * 8, ks = (size_t)Vp * 16;
+        bf16x8 bh0 = *reinterpret_cast<const bf16x8*>(Whi + o0), bl0 = *reinterpret_cast<const bf16x8*>(Wlo + o0);
+        bf16x8 bh1 = *reinterpret_cast<const bf16x8*>(Whi + o1), bl1 = *reinterpret_cast<const bf16x8*>(Wlo + o1);
+        for (int s = 0; s < nks; ++s) {
+            const bf16x8 ch0 = bh0, cl0 = bl0, ch1 = bh1, cl1 = bl1;
+            const size_t nx = (size_t)(s + 1 < nks ? s + 1 : s) * ks;        // next k-step's fragments under this step's MFMAs
+            bh0 = *reinterpret_cast<const bf16x8*>(Whi + nx + o0); bl0 = *reinterpret_cast<const bf16x8*>(Wlo + nx + o0);
+            bh1 = *reinterpret_cast<const bf16x8*>(Whi + nx + o1); bl1 = *reinterpret_cast<const bf16x8*>(Wlo + nx + o1);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const int off = (rt * 32 + lc) * pitch + (16 * s + 8 * kh) * 2;
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(xh + off), al = *reinterpret_cast<const bf16x8*>(xl + off);
+                acc[rt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ch0, acc[rt][0], 0, 0, 0);
+                acc[rt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ch1, acc[rt][1], 0, 0, 0);
+                acc[rt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, cl0, acc[rt][0], 0, 0, 0);
+                acc[rt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, cl1, acc[rt][1], 0, 0, 0);
+                acc[rt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, ch0, acc[rt][0], 0, 0, 0);
+                acc[rt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, ch1, acc[rt][1], 0, 0, 0);
+            }
+        }
+        if (v0 > 0) __syncthreads();                                    // later passes: the previous logits tile was consumed
+        const float bz0 = bias[c0 < V ? c0 : V - 1], bz1 = bias[c1 < V ? c1 : V - 1];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                st[row * LDT + wave * 64 + lc] = acc[rt][0][r] + bz0;
+                st[row * LDT + wave * 64 + 32 + lc] = acc[rt][1][r] + bz1;
+            }
+        __syncthreads();
+        if (logits) {
+            for (int i = tid; i < ROWS * 256; i += 256) {
+                const int r = i >> 8, cc = i & 255;
+                if (m0 + r < M && v0 + cc < V) logits[(size_t)(m0 + r) * V + v0 + cc] = st[r * LDT + cc];
+            }
+        }
+#pragma unroll 8
+        for (int j = 0; j < CPT; ++j) {
+            const int cc = part * CPT + j;
+            const float val = st[prow * LDT + cc];
+            if (v0 + cc < V && val > best) { best = val; bidx = v0 + cc; }
+        }
+    }
+#pragma unroll
+    for (int o = 1; o < TPR; o <<= 1) {
+        const float ov = __shfl_xor(best, o); const int oi = __shfl_xor(bidx, o);
+        if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+    }
+    if (part == 0 && m0 + prow < M) preds[m0 + prow] = bidx;
+}
+
 // one wave per utterance: 64 frames per step, keep = (c != 0 && c != previous frame's c), output position = running count +
 // prefix popcount of the keep ballot
 __global__ __launch_bounds__(64) void ctc_collapse_kernel(const int* __restrict__ preds, const int64_t* __restrict__ lens, int B, int T,
@@ -296,6 +391,25 @@ int launch_ctc_mfma(const float* x, int M, int D, const float* Wt, const float* 
     ensure_dynamic_lds(reinterpret_cast<const void*>(&ctc_argmax_mfma_kernel<ROWS>), (int)lds, attr);
     hipLaunchKernelGGL((ctc_argmax_mfma_kernel<ROWS>), dim3((M + ROWS - 1) / ROWS), dim3(256), lds, s, x, M, D, Wt, bias, V, preds, logits,
                        alias ? 0 : (int)(frame / 4));
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_ctc_split(const float* x, int M, int D, const bf16_t* Whi, const bf16_t* Wlo, const float* bias, int V, int* preds, float* logits,
+                     hipStream_t s) {
+    if (M <= 0) return 0;
+    if (D % 4 || !Whi || !Wlo) return -2;
+    const int Kp = (D + 15) / 16 * 16, Vp = (V + 63) / 64 * 64;
+    auto lds_for = [&](int rows) { return (size_t)2 * rows * (Kp * 2 + 16) + (size_t)rows * 257 * 4; };
+    static LdsAttr attr64, attr32;
+    if (lds_for(64) <= 160 * 1024) {
+        ensure_dynamic_lds(reinterpret_cast<const void*>(&ctc_argmax_bf16x3_kernel<64>), (int)lds_for(64), attr64);
+        hipLaunchKernelGGL((ctc_argmax_bf16x3_kernel<64>), dim3((M + 63) / 64), dim3(256), lds_for(64), s, x, M, D, Kp, Whi, Wlo, bias, V, Vp, preds, logits);
+    } else if (lds_for(32) <= 160 * 1024) {          // wide last stages (D = 720: Large)
+        ensure_dynamic_lds(reinterpret_cast<const void*>(&ctc_argmax_bf16x3_kernel<32>), (int)lds_for(32), attr32);
+        hipLaunchKernelGGL((ctc_argmax_bf16x3_kernel<32>), dim3((M + 31) / 32), dim3(256), lds_for(32), s, x, M, D, Kp, Whi, Wlo, bias, V, Vp, preds, logits);
+    } else {
+        return -2;
+    }
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

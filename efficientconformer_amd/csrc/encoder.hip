@@ -73,7 +73,7 @@ struct EcEncoder {
     const bf16_t* lin_rs = nullptr; const float* conv_tab = nullptr;   // sublinear2.hip: Linear weight [F/2][32 NT][32 CG] (K-permuted per 16), conv taps [32 CG][16]
     int fuse_subsample = 2;                  // 0: separate conv + GEMM kernels, 1: sublinear.hip, 2: sublinear2.hip where it supports the shape (else 1)
     bool fuse_chain = true;                  // row-local chains (chain.hip) where supported
-    int ctc_mfma = 1;                        // CTC head on the fp32 MFMA (bit-identical logits); 0: the VALU kernel
+    int ctc_mfma = 2;                        // CTC head: 2 split-bf16 operands on the bf16 MFMA (bf16 path; fp32 mode falls back to 1), 1 fp32 MFMA (bit-identical to 0), 0 the VALU kernel
     int attention_v2 = 1;                    // 0: attention.hip; 1 (default) / 2: attention2.hip variants where they support the head width (padded <= 160)
     // tuning / test options that used to be process-global environment switches (effconf_encoder_set_option)
     int chain_variant = 0, chain_full_max = 192, attn_waves = 4, rs_variant = 0, ffn_variant = 0;
@@ -86,6 +86,7 @@ struct EcEncoder {
     const bf16_t* sub2_w = nullptr; const float* sub2_b = nullptr; int sub2_cp = 0;
     std::vector<BlockW> bw;
     const float *fc_wt = nullptr, *fc_b = nullptr;
+    const bf16_t *fc_hi = nullptr, *fc_lo = nullptr;      // fc.weight as split-bf16 MFMA B fragments (launch_ctc_split)
     const int* block_stride = nullptr;
     const int *block_group = nullptr, *block_heads = nullptr;     // ragged batches: attention group size / heads per block (device)
     MelTables mel{};
@@ -1310,6 +1311,18 @@ int effconf_encoder_finalize(EcEncoder* e) {
             std::vector<float> wt((size_t)D * V);
             for (int v = 0; v < V; ++v) for (int k = 0; k < D; ++k) wt[(size_t)k * V + v] = w->data[(size_t)v * D + k];
             e->fc_wt = upload(e, wt); e->fc_b = upload(e, b->data);
+            // split-bf16 images: W = hi + lo (hi = bf16(W), lo = bf16(W - hi)), fragment (k-step s, column v, k-half h) = W[v][16 s + 8 h .. + 7]
+            const int Kp = ec_round_up(D, 16), Vp = ec_round_up(V, 64);
+            std::vector<uint16_t> hi((size_t)(Kp / 16) * Vp * 16, 0), lo(hi.size(), 0);
+            for (int v = 0; v < V; ++v)
+                for (int k = 0; k < D; ++k) {
+                    const float wv = w->data[(size_t)v * D + k];
+                    const uint16_t h = h_f2bf(wv);
+                    uint32_t hb = (uint32_t)h << 16; float hf; memcpy(&hf, &hb, 4);
+                    const size_t idx = (((size_t)(k / 16) * Vp + v) * 2 + (k % 16) / 8) * 8 + k % 8;
+                    hi[idx] = h; lo[idx] = h_f2bf(wv - hf);
+                }
+            e->fc_hi = upload(e, hi); e->fc_lo = upload(e, lo);
         }
     }
     if (!build_mel_tables(e, &err)) return fail(err);
@@ -1607,8 +1620,14 @@ int effconf_ctc_greedy(EcEncoder* e, const float* enc_out, const int64_t* out_le
     if (workspace_bytes < (size_t)batch * t_out * 4) return fail("workspace too small");
     int* preds = reinterpret_cast<int*>(workspace);
     hipStream_t st = (hipStream_t)stream;
+    // bf16 path: split-bf16 operands on the bf16 matrix pipe (ctc_mfma = 2, the default); fp32-operand mode: the fp32 matrix pipe, bit-identical
+    // to the VALU kernel (the label-exact mode keeps the reference's fp32 head)
+    const int mode = e->exact_on && e->ctc_mfma == 2 ? 1 : e->ctc_mfma;
+    if (mode == 2 && e->fc_hi && launch_ctc_split(enc_out, batch * t_out, e->blocks.back().dim_expand, e->fc_hi, e->fc_lo, e->fc_b, e->cfg.vocab_size,
+                                                  preds, logits, st) == 0) {
+    } else
     EC_TRY(launch_ctc_argmax(enc_out, batch * t_out, e->blocks.back().dim_expand, e->fc_wt, e->fc_b, e->cfg.vocab_size,
-                             preds, logits, st, e->ctc_mfma));
+                             preds, logits, st, mode != 0));
     EC_TRY(launch_ctc_collapse(preds, out_len, batch, t_out, labels, label_len, st));
     return 0;
 }
@@ -1638,7 +1657,7 @@ int effconf_encoder_set_option(EcEncoder* e, const char* name, int32_t value) {
     if (!e || !name) return fail("null argument");
     if (!strcmp(name, "fuse_subsample")) { if (value < 0 || value > 2) return fail("fuse_subsample: 0, 1 or 2"); e->fuse_subsample = value; return 0; }
     if (!strcmp(name, "fuse_chain")) { e->fuse_chain = value != 0; return 0; }
-    if (!strcmp(name, "ctc_mfma")) { e->ctc_mfma = value != 0; return 0; }
+    if (!strcmp(name, "ctc_mfma")) { if (value < 0 || value > 2) return fail("ctc_mfma: 0 (VALU), 1 (fp32 MFMA) or 2 (split-bf16 MFMA)"); e->ctc_mfma = value; return 0; }
     if (!strcmp(name, "wide_gemm")) { if (value < 0 || value > 3) return fail("wide_gemm: 0 (by shape), 1 (never), 2 (256-column tile), 3 (128-column tile)"); e->wide_gemm = value; return 0; }
     if (!strcmp(name, "attention_v2")) { if (value != 0 && value != 1 && value != 2) return fail("attention_v2: 0, 1 or 2"); e->attention_v2 = value; return 0; }
     // former EFFCONF_* environment switches (process-global statics): per-handle options now

@@ -213,8 +213,9 @@ int effconf_rnnt_greedy(EcRnnt* r, const float* enc_out, const int64_t* out_len,
  *   always use attention.hip.  Results agree to fp32 summation order (variant 1's deferred rescale: to bf16 rounding of P).
  * "wide_gemm" (default 0): tile choice of the tiled GEMM layers (the widths the row-stationary kernels do not hold): 0 by shape,
  *     1 always csrc/gemm.hip (128 x 128, register staged), 2 / 3 csrc/gemm256.hip with 256 x 256 / 256 x 128 tiles wherever it applies.
- * "ctc_mfma" (default 1): the CTC head (fc + argmax) on the fp32 MFMA; 0 selects the VALU kernel.  Both are k-ordered fp32 fma chains:
- *   bit-identical logits and labels.
+ * "ctc_mfma" (default 2): the CTC head (fc + argmax).  2: split-bf16 operands on the bf16 MFMA (x_hi W_hi + x_hi W_lo + x_lo W_hi, fp32
+ *   accumulation: logits within ~2^-16 relative of the fp32 head) - bf16 path only, the fp32-operand mode runs 1; 1: the fp32 MFMA; 0: the VALU
+ *   kernel.  1 and 0 are k-ordered fp32 fma chains: bit-identical logits and labels.
  * "chain_variant" (0 / 1), "chain_full_max" (widest stage that runs chain A as one kernel; set before finalize to widen), "attn_waves"
  *   (4 / 8, attention.hip), "rs_variant" (0 / 1), "ffn_variant" (0 .. 2), "head_major_odd" (0 / 1), "exact_attention" (0 tiled / 2 tiled with 16-row workgroups / 1 one wave per query row; fp32 mode, bit-identical): tuning / test switches of the kernel launchers that were
  *   process-global EFFCONF_* environment variables until round 2; per handle now.  (Still read from the environment, once, as

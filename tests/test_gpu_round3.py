@@ -496,3 +496,50 @@ def test_attention_maps_with_streaming_contexts_vs_oracle(extra):
     m.encoder.ragged = True
     with pytest.raises(RuntimeError, match="rectangular"):
         m.encoder.forward_mel(torch.from_numpy(mel).cuda(), torch.from_numpy(ln).cuda(), return_attentions=True)
+
+
+# ------------------------------------------------------------------ CTC head with split-bf16 operands (the bf16 path's default)
+@pytest.mark.parametrize("name,vocab", [("EfficientConformerCTCSmall", 256), ("EfficientConformerCTCSmall", 1000), ("EfficientConformerCTCMedium", 256),
+                                        ("EfficientConformerCTCLarge", 256), ("Tiny", 48)])
+def test_ctc_head_split_bf16_vs_the_fp32_head(name, vocab):
+    """ctc_argmax_bf16x3_kernel (x_hi W_hi + x_hi W_lo + x_lo W_hi on the bf16 MFMA, fp32 accumulation; model_ctc.py:49, 96-99) against the
+    fp32 head: logits within 2^-15 of the operand magnitudes (measured ~1e-5 relative), argmax identical wherever the fp32 top-2 margin
+    exceeds 1e-3 - on frame counts that are no multiple of the row tile, D = 240 / 360 (not a multiple of 16) / 720, one and four column
+    passes.  The fp32-operand mode keeps the fp32 head."""
+    cfg = named_config(name)
+    m = ModelCTC(cfg["encoder_params"], {"vocab_size": vocab})
+    sd = synth.make_state_dict(m.encoder.plan, 5, vocab, prefix="encoder.")
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m = m.cuda()
+    m.encoder._ensure_packed()
+    g = torch.Generator().manual_seed(3)
+    enc = torch.randn(3, 77, m.encoder.plan.dim_out, generator=g).cuda()
+    ln = torch.tensor([77, 50, 9]).cuda()
+    m.encoder.set_option("ctc_mfma", 1)
+    l1, lab1, n1 = m._head(enc, ln, want_logits=True)
+    m.encoder.set_option("ctc_mfma", 2)
+    l2, lab2, n2 = m._head(enc, ln, want_logits=True)
+    scale = float(l1.abs().max())
+    err = float((l2 - l1).abs().max())
+    print("%s V=%d: split-bf16 head vs fp32 head: max |dlogit| %.2e (logits up to %.1f)" % (name, vocab, err, scale))
+    assert err < 3e-5 * max(scale, 1.0) * 8
+    top = l1.topk(2, dim=-1).values
+    safe = (top[..., 0] - top[..., 1]) > 1e-3
+    assert bool(safe.float().mean() > 0.9)
+    assert torch.equal(l2.argmax(-1)[safe], l1.argmax(-1)[safe])
+    _, lab3, n3 = m._head(enc, ln)                                     # without the logits output
+    assert torch.equal(lab3, lab2) and torch.equal(n3, n2)
+
+
+def test_fp32_mode_keeps_the_fp32_ctc_head():
+    """The label-exact mode (precision = "fp32") runs the fp32 head whatever ctc_mfma says: its logits equal ctc_mfma = 1's bit for bit."""
+    m, _ = _model("Tiny", 5, "fp32")
+    m.encoder._ensure_packed()
+    g = torch.Generator().manual_seed(3)
+    enc = torch.randn(3, 40, m.encoder.plan.dim_out, generator=g).cuda()
+    ln = torch.tensor([40, 33, 9]).cuda()
+    m.encoder.set_option("ctc_mfma", 1)
+    l1, lab1, _ = m._head(enc, ln, want_logits=True)
+    m.encoder.set_option("ctc_mfma", 2)
+    l2, lab2, _ = m._head(enc, ln, want_logits=True)
+    assert torch.equal(l2, l1) and torch.equal(lab2, lab1)
