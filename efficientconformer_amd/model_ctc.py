@@ -58,9 +58,9 @@ class ModelCTC(nn.Module):
         return load_checkpoint(self, path)
 
     # ---- reference ModelCTC.forward (model_ctc.py:57-68): batch = (x, y, x_len, y_len)
-    def forward(self, batch):
+    def forward(self, batch, return_attentions: bool = False):
         x, _, x_len, _ = batch
-        enc, enc_len, attentions = self.encoder(x, x_len)
+        enc, enc_len, attentions = self.encoder(x, x_len, return_attentions=return_attentions)
         logits, _, _ = self._head(enc, enc_len, want_logits=True)
         return logits, enc_len, attentions
 
