@@ -62,7 +62,9 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--gather", default="outputs", choices=["outputs", "labels"],
                     help="N > 1: all-gather the encoder outputs before the CTC head (north_star) or the label ids after it")
-    ap.add_argument("--wire", default="fp32", choices=["fp32", "bf16"], help="dtype of the gathered encoder outputs on xGMI")
+    ap.add_argument("--wire", default="auto", choices=["auto", "fp32", "bf16"],
+                    help="dtype of the gathered encoder outputs on xGMI; auto = bf16 on the bf16 path (half the bytes; the rounding, 2^-9 relative, "
+                         "is an order below the bf16 encoder's own output error), fp32 with --precision fp32")
     ap.add_argument("--balanced-split", action="store_true",
                     help="cut the row ranges for equal PADDED FRAMES per range instead of equal utterance counts (measured: no gain at B = 256)")
     ap.add_argument("--cuts", default="", help="explicit row boundaries of the ranges, e.g. 80,168 (tuning; overrides --balanced-split)")
@@ -528,6 +530,8 @@ def main():
     sharded = None
     if world > 1:
         from efficientconformer_amd.dist import ShardedEncoder
+        if args.wire == "auto":
+            args.wire = "bf16" if args.precision == "bf16" else "fp32"
         sharded = ShardedEncoder(model.encoder, wire_dtype=torch.bfloat16 if args.wire == "bf16" else None)
     last = {}
 
