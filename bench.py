@@ -477,7 +477,7 @@ def main():
 
     cfg, model, sd = build_model(args.model)
     if args.ragged < 0:
-        args.ragged = int(model.encoder.plan.sub_layers == 1 and args.precision == "bf16" and args.workload == "libri" and not args.no_trim)
+        args.ragged = int(args.precision == "bf16" and args.workload == "libri" and not args.no_trim)
     model.encoder.precision = args.precision
     model = model.to(dev)
     plan = model.encoder.plan

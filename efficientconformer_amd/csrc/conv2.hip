@@ -21,7 +21,7 @@ constexpr int CL_TT = 8;
 
 __global__ __launch_bounds__(256) void subsample_conv_cl_kernel(const float* __restrict__ mel, int F, int Tm, int T1,
                                                                 const float* __restrict__ w9, const float* __restrict__ bias,
-                                                                int C, int Cp, bf16_t* __restrict__ out) {
+                                                                int C, int Cp, bf16_t* __restrict__ out, const int* __restrict__ rag_tm) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TW = 2 * CL_TT + 1;
     float* sm = reinterpret_cast<float*>(smem);        // [F + 1][TW + 1]  row 0 = frequency -1 (zero pad)
@@ -29,11 +29,15 @@ __global__ __launch_bounds__(256) void subsample_conv_cl_kernel(const float* __r
     const int tiles = (T1 + CL_TT - 1) / CL_TT;
     const int b = blockIdx.x / tiles, t0 = (blockIdx.x % tiles) * CL_TT;
     const int tid = threadIdx.x, F1 = F / 2;
+    // ragged batch: utterance b has rag_tm[b] mel frames in rows of pitch Tm; the zero padding starts there, and its layer-1 image is zero
+    // behind its own (rag_tm[b] - 1) / 2 + 1 frames - what layer 2 sees when the utterance runs alone
+    const int Tmb = rag_tm ? rag_tm[b] : Tm;
+    const int T1b = rag_tm ? (Tmb - 1) / 2 + 1 : T1;
     for (int i = tid; i < (F + 1) * TW; i += 256) {
         const int fr = i / TW, tc = i - fr * TW;
         const int f = fr - 1, t = 2 * t0 - 1 + tc;
         const float v = mel[((size_t)b * F + (f < 0 ? 0 : f)) * Tm + (t < 0 ? 0 : (t < Tm ? t : Tm - 1))];
-        sm[fr * (TW + 1) + tc] = (f >= 0 && t >= 0 && t < Tm) ? v : 0.f;
+        sm[fr * (TW + 1) + tc] = (f >= 0 && t >= 0 && t < Tmb) ? v : 0.f;
     }
     for (int i = tid; i < Cp * 10; i += 256) {
         const int c = i / 10, j = i - c * 10;
@@ -62,7 +66,7 @@ __global__ __launch_bounds__(256) void subsample_conv_cl_kernel(const float* __r
                 for (int i = 0; i < 3; ++i)
 #pragma unroll
                     for (int j = 0; j < 3; ++j) { const float x = m[i * (TW + 1) + j]; a = __builtin_elementwise_fma(w[i * 3 + j], clf2{x, x}, a); }
-                const float r0 = ok0 ? swishf_(a.x) : 0.f, r1 = ok1 ? swishf_(a.y) : 0.f;
+                const float r0 = ok0 && t < T1b ? swishf_(a.x) : 0.f, r1 = ok1 && t < T1b ? swishf_(a.y) : 0.f;
                 *reinterpret_cast<uint32_t*>(orow + (size_t)f * T1 * Cp) = pack_bf2(r0, r1);
             }
         }
@@ -200,12 +204,12 @@ __global__ __launch_bounds__(256) void conv2_igemm_kernel(const bf16_t* __restri
 }  // namespace
 
 int launch_subsample_conv_cl(const float* mel, int B, int F, int Tm, int T1, const float* w9, const float* bias, int C, int Cp,
-                             bf16_t* out, hipStream_t s) {
+                             bf16_t* out, hipStream_t s, const int* rag_tm) {
     if (B <= 0 || T1 <= 0) return 0;
     if (F % 4 || Cp % 64 || Cp < C) return -2;
     const int tiles = (T1 + CL_TT - 1) / CL_TT;
     const size_t lds = ((size_t)(F + 1) * (2 * CL_TT + 2) + (size_t)Cp * 10) * sizeof(float);
-    hipLaunchKernelGGL(subsample_conv_cl_kernel, dim3(B * tiles), dim3(256), lds, s, mel, F, Tm, T1, w9, bias, C, Cp, out);
+    hipLaunchKernelGGL(subsample_conv_cl_kernel, dim3(B * tiles), dim3(256), lds, s, mel, F, Tm, T1, w9, bias, C, Cp, out, rag_tm);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -398,7 +398,8 @@ Workspace make_workspace(const EcEncoder* e, const Shapes& s, bool from_audio) {
     const int C = e->cfg.sub_filters[e->cfg.sub_layers - 1];
     int F = e->cfg.n_mels; for (int i = 0; i < e->cfg.sub_layers; ++i) F /= 2;
     const bool rag_unfused = s.ragged && !(e->fuse_subsample == 2 && e->lin_rs);        // (s.Tm = the input's row pitch in ragged batches)
-    const size_t T1r = s.ragged ? (size_t)(s.Tm - 1) / 2 + 1 : (size_t)s.T1;
+    size_t T1r = (size_t)s.T1;
+    if (s.ragged) { T1r = (size_t)s.Tm; for (int i = 0; i < e->cfg.sub_layers; ++i) T1r = (T1r - 1) / 2 + 1; }      // rows per utterance of the rectangular image
     w.sub = take(s.ragged && !rag_unfused ? 0 : B * T1r * C * F * 2);      // scratch of the unfused front ends
     w.xrect = take(rag_unfused ? B * T1r * e->blocks[0].dim_model * 4 : 0);
     {   // two-layer subsampler: channel-last layer-1 activation [B][F/2][T after layer 1][Cp]
@@ -594,10 +595,23 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
     float* x = reinterpret_cast<float*>(ws + w.x0);
     float* xalt = reinterpret_cast<float*>(ws + w.x1);
     if (rg) {
-        if (c.sub_layers != 1) return fail("ragged batches need a one-layer Conv2dSubsampling (the EfficientConformer configurations)");
         const int C0 = c.sub_filters[0], Ksub = C0 * (c.n_mels / 2);
         const RaggedRows r0 = rows_at(0);
-        if (e->fuse_subsample == 2 && e->lin_rs) {        // sublinear2.hip indexes the ragged rows itself
+        if (c.sub_layers == 2) {
+            // two-layer subsampler (the plain Conformer configurations): both convolutions and the Linear on the RECTANGULAR image - layer 1
+            // zero-fills every utterance's image behind its own last frame, so layer 2 sees the zero padding of the utterance run alone -
+            // then the valid rows are gathered into the ragged row space
+            bf16_t* sub = reinterpret_cast<bf16_t*>(ws + w.sub);
+            bf16_t* act1 = reinterpret_cast<bf16_t*>(ws + w.sub1);
+            float* xrect = reinterpret_cast<float*>(ws + w.xrect);
+            const int Tl1 = (s.Tm - 1) / 2 + 1, T1r = (Tl1 - 1) / 2 + 1, F1 = c.n_mels / 2, F2q = c.n_mels / 4, C1 = c.sub_filters[1];
+            { PROF(PC_SUBCONV, 2.0 * 9 * B * Tl1 * (double)C0 * F1, (double)B * c.n_mels * s.Tm * 4 + (double)B * Tl1 * F1 * e->sub2_cp * 2);
+              EC_TRY(launch_subsample_conv_cl(mel, B, c.n_mels, s.Tm, Tl1, e->sub_w9, e->sub_b, C0, e->sub2_cp, act1, st, mel_len)); }
+            { PROF(PC_GEMM_OTHER, 2.0 * 9 * (double)B * F2q * T1r * C0 * C1, (double)B * Tl1 * F1 * e->sub2_cp * 2 + (double)B * T1r * F2q * C1 * 2);
+              EC_TRY(launch_conv2_igemm(act1, B, F1, Tl1, e->sub2_cp, e->sub2_w, 9 * e->sub2_cp, e->sub2_b, C1, F2q, T1r, sub, st)); }
+            EC_TRY(run_gemm(e, PC_GEMM_OTHER, st, sub, F2q * C1, B * T1r, e->lin, EPI_F32, xrect, e->lin.N));
+            { PROF(PC_MISC, 0, (double)s.Min[0] * e->lin.N * 8); EC_TRY(launch_gather_rows(xrect, e->lin.N, T1r, r0, x, st)); }
+        } else if (e->fuse_subsample == 2 && e->lin_rs) {        // sublinear2.hip indexes the ragged rows itself
             PROF(PC_SUBCONV, 2.0 * 9 * (double)s.Min[0] * Ksub + 2.0 * (double)s.Min[0] * Ksub * e->lin.N, (double)B * c.n_mels * s.Tm * 4 + (double)s.Min[0] * e->lin.N * 4);
             EC_TRY(launch_sublinear2(mel, B, c.n_mels, s.Tm, s.T1, e->conv_tab, e->lin_rs, e->lin.bias, C0, e->lin.N, x, e->lin.N, st, &r0, mel_len));
         } else {

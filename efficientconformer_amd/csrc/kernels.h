@@ -180,7 +180,7 @@ int launch_sublinear2(const float* mel, int B, int F, int Tm, int T1, const floa
                       float* out, int ldc, hipStream_t s, const RaggedRows* rg = nullptr, const int* rag_tm = nullptr);
 // two-layer subsampling (conv2.hip): layer 1 channel-last, layer 2 implicit GEMM
 int launch_subsample_conv_cl(const float* mel, int B, int F, int Tm, int T1, const float* w9, const float* bias, int C, int Cp,
-                             bf16_t* out, hipStream_t s);
+                             bf16_t* out, hipStream_t s, const int* rag_tm = nullptr);
 int launch_conv2_igemm(const bf16_t* act1, int B, int F1, int T1, int Cp, const bf16_t* W, int ldw, const float* bias,
                        int N, int F2, int T2, bf16_t* out, hipStream_t s);
 // g (B, T, ld) bf16 -> (B, To, ld) bf16: depthwise conv k taps ("same" zero pad), stride s, folded BN, Swish

@@ -105,8 +105,10 @@ int effconf_encoder_forward_mel(EcEncoder* enc, const float* mel, const int64_t*
  *   x          dev f32 (batch, n) audio rows or (batch, n_mels, n) mel (from_audio = 0); n = the row pitch (content behind x_len unused)
  *   x_len      dev i64 (batch); x_len_host: the same lengths on the HOST (grids and the workspace are sized from them)
  *   out        dev f32 (batch, out_frames, D_last): utterance b's T_out(b) frames, zeros behind them; out_frames >= the longest T_out
- * Workspace: effconf_encoder_workspace_bytes_ragged(enc, x_len_host, batch, n, from_audio).  Needs the sublinear2.hip front end (one
- * subsampling layer, <= 192 filters and <= 192-wide first stage) and head widths <= 160 (attention2.hip); bf16 path only. */
+ * Workspace: effconf_encoder_workspace_bytes_ragged(enc, x_len_host, batch, n, from_audio).  Front ends: sublinear2.hip indexes the ragged
+ * rows itself (one subsampling layer, <= 192 filters and <= 192-wide first stage); wider one-layer and the two-layer subsamplers run on the
+ * rectangular image (zero padding at every utterance's own end) and gather the valid rows.  Needs head widths <= 160 (attention2.hip);
+ * bf16 path only. */
 size_t effconf_encoder_workspace_bytes_ragged(const EcEncoder* enc, const int64_t* x_len_host, int32_t batch, int32_t n, int32_t from_audio);
 int effconf_encoder_forward_ragged(EcEncoder* enc, const float* x, const int64_t* x_len, const int64_t* x_len_host, int32_t batch, int32_t n,
                                    int32_t from_audio, float* out, int32_t out_frames, int64_t* out_len, void* workspace,

@@ -361,13 +361,16 @@ def test_exact_mode_rejects_streaming_contexts():
         m.encoder.forward_mel(torch.from_numpy(mel).cuda(), torch.from_numpy(ln).cuda())
 
 
-def test_ragged_rejects_the_two_layer_subsampler():
-    m, _ = _model("ConformerCTCSmall", 1)
-    m.encoder.ragged = True
-    lens = np.array([30000, 20000], dtype=np.int64)
-    audio = torch.from_numpy(synth.make_audio(lens, seed=1)).cuda()
-    with pytest.raises(_lib.EffconfError, match="one-layer"):
-        m.encoder(audio, torch.from_numpy(lens).cuda(), x_len_host=lens)
+@pytest.mark.parametrize("name,nsub", [("ConformerCTCSmall", 1), ("ConformerCTCSmall", 2), ("ConformerCTCLarge", 3)])
+def test_ragged_batch_with_the_two_layer_subsampler(name, nsub):
+    """Plain Conformer configurations (two Conv2d subsampling layers, modules.py:232-249): both convolutions and the Linear run on the
+    rectangular image - layer 1 zero-fills every utterance's image behind its own last frame, which is what layer 2 sees when the
+    utterance runs alone - and the valid rows are gathered into the ragged row space.  Bit-identical to every utterance alone, within
+    tolerance of the oracle; lengths chosen so that both layers' floor divisions differ between utterances."""
+    m, sd = _model(name, 1)
+    lens = np.array([48000, 47841, 40000, 30319, 22000, 12001, 3000], dtype=np.int64)
+    audio = torch.from_numpy(synth.make_audio(lens, seed=6))
+    _ragged_vs_alone(m, sd, audio, lens, nsub, oracle=(name == "ConformerCTCSmall"))
 
 
 def test_ragged_positional_cache_follows_the_longest_utterance():
