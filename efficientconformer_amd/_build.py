@@ -49,9 +49,16 @@ def build(force: bool = False, verbose: bool = True) -> str:
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
 
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "effconf.h"),
+                                                                                       os.path.abspath(__file__)]
+    hdr_t = max(os.path.getmtime(h) for h in headers if os.path.exists(h))
+
     def compile_one(job):
         src, objname, extra = job
         obj = os.path.join(objdir, objname)
+        # incremental: an object newer than its source, every header and this script (the flags) is reused unless --force
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(hdr_t, os.path.getmtime(os.path.join(CSRC, src))):
+            return obj
         cmd = [hipcc] + FLAGS + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:

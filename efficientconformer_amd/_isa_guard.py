@@ -81,13 +81,28 @@ def scan(lib):
 
 
 def demangle(names):
+    import shutil
+    if not names:
+        return {}
+    if shutil.which("c++filt") is None:          # explicit: the exemption list matches DEMANGLED names - without c++filt match the mangled ones
+        return {n: n for n in names}
     out = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.splitlines()
+    if len(out) != len(names):
+        return {n: n for n in names}
     return dict(zip(names, out))
+
+
+MIN_KERNELS = 100      # libeffconf.so holds several hundred kernel instances; a scan that saw (almost) nothing did not scan the library
 
 
 def check(lib, out=None):
     """Scan `lib`; returns (kernels scanned, product kernels with a hazardous form); `out` (a list) receives the report lines."""
     rows = scan(lib)
+    if len(rows) < MIN_KERNELS:
+        # fail CLOSED: no gfx950 code object found (a compressed offload bundle, another bundle layout, an empty objdump) would otherwise
+        # pass the guard without a single kernel looked at
+        raise RuntimeError("ISA guard: only %d gfx950 kernels found in %s (expected >= %d): the offload bundle was not read - "
+                           "refusing to pass the library unscanned" % (len(rows), lib, MIN_KERNELS))
     names = demangle(list(rows))
     bad = 0
     for k, (packed, hazard) in sorted(rows.items()):

@@ -80,7 +80,7 @@ class FrontDoor:
     (``ConformerEncoder.ragged``); with the rectangular path the pad samples are live and must be zero."""
 
     def __init__(self, fn: Optional[Callable] = None, device="cuda", max_batch: int = 128, max_padded_samples: Optional[int] = None,
-                 device_fn: Optional[Callable] = None, workers: int = 8, zero_pad: bool = True):
+                 device_fn: Optional[Callable] = None, workers: int = 8, zero_pad: bool = True, pass_host_lengths: Optional[bool] = None):
         if (fn is None) == (device_fn is None):
             raise ValueError("FrontDoor needs exactly one of fn / device_fn")
         self.fn, self.device_fn, self.device = fn, device_fn, torch.device(device)
@@ -93,18 +93,23 @@ class FrontDoor:
         self._workers = max(1, workers)
         self._results: dict = {}
         self._stager = ThreadPoolExecutor(max_workers=1)
-        self._host_lengths = False
-        if device_fn is not None:
+        # `pass_host_lengths` (explicit): device_fn(audio, lengths, host_lengths).  None = inferred: exactly three REQUIRED positional
+        # parameters (a defaulted third argument or *args no longer receives the numpy lengths by accident)
+        self._host_lengths = bool(pass_host_lengths)
+        if device_fn is not None and pass_host_lengths is None:
             try:
-                self._host_lengths = len(inspect.signature(device_fn).parameters) >= 3
+                ps = list(inspect.signature(device_fn).parameters.values())
+                req = [q for q in ps if q.kind in (q.POSITIONAL_ONLY, q.POSITIONAL_OR_KEYWORD) and q.default is q.empty]
+                self._host_lengths = len(req) == 3 and not any(q.kind == q.VAR_POSITIONAL for q in ps)
             except (TypeError, ValueError):
                 pass
         self.stats: dict = {}                     # host seconds per piece of the last run() (pack, h2d_issue, launch, results)
 
     def _stage(self, waves: Sequence[torch.Tensor], idx: List[int], slot: int):
         t0 = time.perf_counter()
-        if self.device.index is not None:
-            torch.cuda.set_device(self.device)    # runs on the helper thread: the current device is per thread
+        # runs on the helper thread, whose current device is its own: pin_memory() below would otherwise create a context on GPU 0 in
+        # every rank of a multi-GPU job (device = "cuda" without an index resolves to the copy stream's device)
+        torch.cuda.set_device(self.copy_stream.device)
         lens = [int(waves[i].numel()) for i in idx]
         b, width = len(idx), max(max(lens), 1)
         if self._free[slot] is not None:
@@ -141,6 +146,24 @@ class FrontDoor:
         self.stats["h2d_issue"] = self.stats.get("h2d_issue", 0.0) + t2 - t1
         return dev, dlen, ready, np.asarray(lens, dtype=np.int64)
 
+    def close(self):
+        """Stop the staging thread (idempotent); the pinned buffers are released with the object."""
+        st, self._stager = self._stager, None
+        if st is not None:
+            st.shutdown(wait=True)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     def _result_buffer(self, key: int, n: int, dtype) -> torch.Tensor:
         # pinned download buffers, kept across runs (pin_memory() per batch costs 0.5 - 40 ms)
         buf = self._results.get(key)
@@ -150,6 +173,8 @@ class FrontDoor:
         return buf[:n]
 
     def run(self, waves: Sequence[torch.Tensor]) -> list:
+        if self._stager is None:
+            raise RuntimeError("FrontDoor.run after close()")
         plan = bucket_batches([int(w.numel()) for w in waves], self.max_batch, self.max_padded_samples)
         out: list = [None] * len(waves)
         self.stats = {}

@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void ctc_argmax_bf16x3_kernel(const float* __r
             for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[rt][ct][r] = 0.f;
-        const int c0 = v0 + wave * 64 + lc, c1 = c0 + 32;               // < Vp: the packed images are padded to whole 64-column groups
+        const int c0 = v0 + wave * 64 + lc, c1 = c0 + 32;               // < Vp: the packed images are padded to whole 256-column passes
         const size_t o0 = ((size_t)c0 * 2 + kh) * 8, o1 = ((size_t)c1 * 2 + kh) * 8, ks = (size_t)Vp * 16;
         bf16x8 bh0 = *reinterpret_cast<const bf16x8*>(Whi + o0), bl0 = *reinterpret_cast<const bf16x8*>(Wlo + o0);
         bf16x8 bh1 = *reinterpret_cast<const bf16x8*>(Whi + o1), bl1 = *reinterpret_cast<const bf16x8*>(Wlo + o1);
@@ -398,7 +398,7 @@ int launch_ctc_split(const float* x, int M, int D, const bf16_t* Whi, const bf16
                      hipStream_t s) {
     if (M <= 0) return 0;
     if (D % 4 || !Whi || !Wlo) return -2;
-    const int Kp = (D + 15) / 16 * 16, Vp = (V + 63) / 64 * 64;
+    const int Kp = (D + 15) / 16 * 16, Vp = (V + 255) / 256 * 256;     // = finalize's packing (encoder.hip): a pass covers 256 columns
     auto lds_for = [&](int rows) { return (size_t)2 * rows * (Kp * 2 + 16) + (size_t)rows * 257 * 4; };
     static LdsAttr attr64, attr32;
     if (lds_for(64) <= 160 * 1024) {

@@ -249,3 +249,18 @@ int launch_debug_victim(int kind, int blocks, int iters, float* out, hipStream_t
 #undef VICTIM_CASE
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
+
+// One wave that does nothing for `microseconds` (s_memrealtime: the 100 MHz constant counter): stands in for the DURATION of a transfer that
+// a single GPU cannot perform (an xGMI all-gather) in tools/overlap_probe.py, without taking CUs or HBM bandwidth from the kernels beside it.
+namespace {
+__global__ __launch_bounds__(64) void spin_kernel(long long ticks) {
+    const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+    while ((long long)__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+}  // namespace
+
+int launch_debug_spin(double microseconds, hipStream_t s) {
+    if (microseconds <= 0) return 0;
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, s, (long long)(microseconds * 100.0));
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}

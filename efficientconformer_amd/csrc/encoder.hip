@@ -1326,7 +1326,7 @@ int effconf_encoder_finalize(EcEncoder* e) {
             for (int v = 0; v < V; ++v) for (int k = 0; k < D; ++k) wt[(size_t)k * V + v] = w->data[(size_t)v * D + k];
             e->fc_wt = upload(e, wt); e->fc_b = upload(e, b->data);
             // split-bf16 images: W = hi + lo (hi = bf16(W), lo = bf16(W - hi)), fragment (k-step s, column v, k-half h) = W[v][16 s + 8 h .. + 7]
-            const int Kp = ec_round_up(D, 16), Vp = ec_round_up(V, 64);
+            const int Kp = ec_round_up(D, 16), Vp = ec_round_up(V, 256);   // whole 256-column passes of ctc_argmax_bf16x3_kernel (4 waves x 64): every wave's fragment loads stay inside the image
             std::vector<uint16_t> hi((size_t)(Kp / 16) * Vp * 16, 0), lo(hi.size(), 0);
             for (int v = 0; v < V; ++v)
                 for (int k = 0; k < D; ++k) {
@@ -1619,6 +1619,11 @@ int effconf_debug_gemm(const uint16_t* a, int32_t lda, const uint16_t* w, int32_
     p.C = c; p.ldc = ldc; p.R = r; p.ldr = ldr; p.alpha = alpha; p.wide = wide;
     if (wide >= 2 && !gemm256_supported(p, epi)) return fail("gemm256 does not take this shape / alignment");
     EC_TRY(launch_gemm(p, epi, (hipStream_t)stream));
+    return 0;
+}
+
+int effconf_debug_spin(double microseconds, void* stream) {
+    if (launch_debug_spin(microseconds, reinterpret_cast<hipStream_t>(stream)) != 0) return fail("spin launch failed");
     return 0;
 }
 

@@ -234,6 +234,7 @@ int launch_mel_debug(int variant, int extra_lds, const float* audio, int B, int 
                      int Tm, int normalize, float mean, float std, float* mel, unsigned int* dbg, hipStream_t s);
 // synthetic single-resource neighbour kernels (debug.hip)
 int launch_debug_neighbour(int kind, int blocks, int lds_bytes, int iters, float* buf, size_t n, hipStream_t s);
+int launch_debug_spin(double microseconds, hipStream_t s);
 int launch_debug_victim(int kind, int blocks, int iters, float* out, hipStream_t s);
 // mel.hip compiled a second time WITH packed-fp32 VALU instructions (diagnostics: variant bit 8 = the hazardous round-1 kernel)
 int launch_mel_debug_pk(int variant, int extra_lds, const float* audio, int B, int L, const MelTables& t, int n_fft, int hop, int n_mels,

@@ -19,6 +19,10 @@ output depends only on its own row and on the padded length (pad frames are live
     streams for the ranges + the process group's;
   * consumers (CTC head, RNN-T decode) work chunk by chunk on the gathered tensors (`Gathered.chunks`), or call
     `Gathered.assemble()` for one (B, T, D) tensor in global order;
+  * `pipelined=True` (throughput serving): a range's collective is issued asynchronously and its consumer runs ONE CALL LATER, on the same
+    range's stream right after that call's encoder kernels - so collective k is on the wire under the WHOLE encoder of call k + 1 instead
+    of the tail of call k (ranges cut for equal work finish together: one GPU measured 24 % of the collectives' time covered, tools/
+    overlap_probe.py).  Results arrive one call late; `flush()` drains the last call;
   * weights are replicated (<= 251 MB bf16), there is no other data-path collective.
 """
 from __future__ import annotations
@@ -65,12 +69,26 @@ class GatheredChunk:
     """Local rows [lo, hi) of every rank: `out` is (world * (hi - lo), T, D) in wire dtype, row r * (hi - lo) + j  <->  global row
     (lo + j) * world + r (`rows`, entries >= global_batch are shard fill and are dropped by `keep`)."""
 
-    def __init__(self, lo, hi, out, out_len, rows, keep, event, comm):
+    def __init__(self, lo, hi, out, out_len, rows, keep, event, comm, works=None):
         self.lo, self.hi, self.out, self.out_len, self.rows, self.keep = lo, hi, out, out_len, rows, keep
-        self._event, self._comm = event, comm
+        self._event, self._comm, self._works = event, comm, works
 
     def wait(self, stream: Optional["torch.cuda.Stream"] = None):
         """Make `stream` (default: the current stream) wait for this chunk's collective; keeps the buffers alive for it."""
+        if self._works:                     # asynchronous collectives (pipelined mode): Work.wait() makes the CURRENT stream wait (RCCL)
+            works, self._works = self._works, None
+            if stream is not None and self.out.is_cuda:
+                with torch.cuda.stream(stream):
+                    for w in works:
+                        w.wait()
+            else:
+                for w in works:
+                    w.wait()
+            if self.out.is_cuda:
+                st = stream or torch.cuda.current_stream(self.out.device)
+                self.out.record_stream(st)
+                self.out_len.record_stream(st)
+            return self
         if self._event is None:
             return self
         stream = stream or torch.cuda.current_stream(self.out.device)
@@ -109,9 +127,18 @@ class ShardedEncoder:
     what a consumer computes from a gathered chunk is bit-identical to what the producing rank would compute locally;
     `torch.bfloat16` halves the xGMI bytes."""
 
-    def __init__(self, encoder: Callable, group=None, wire_dtype: Optional[torch.dtype] = None):
+    def __init__(self, encoder: Callable, group=None, wire_dtype: Optional[torch.dtype] = None, pipelined: bool = False):
         self.encoder, self.group, self.wire_dtype = encoder, group, wire_dtype
+        self.pipelined = bool(pipelined)
+        self._pending = []            # pipelined: (call id, (lo, hi), chunk, consumer) of collectives whose consumer has not run yet
+        self._call = 0
         self._maps = {}
+        # Every row range ends in ONE fixed-size collective, so all ranks must cut the SAME ranges.  A ragged ConformerEncoder cuts its
+        # ranges for equal valid frames of the lengths it is handed - different on every rank (mismatched collectives: a hang or a
+        # corrupted gather).  Under this class it cuts by row count instead (rank-independent: every shard has the same number of rows),
+        # unless the caller pins explicit `sub_batch_bounds` (bench.py: frame-balanced / staggered cuts computed from lengths all ranks know).
+        if hasattr(encoder, "ragged_cut"):
+            encoder.ragged_cut = "rows"
         fwd = getattr(encoder, "forward", encoder)
         try:
             self._hooked = "range_hook" in inspect.signature(fwd).parameters
@@ -138,6 +165,21 @@ class ShardedEncoder:
             wl = out_len[lo:hi]
             g = wire.new_empty((world * n,) + tuple(wire.shape[1:]))
             gl = wl.new_empty(world * n)
+            if self.pipelined:
+                # the PREVIOUS call's chunk of this row range: its collective ran under this call's encoder kernels and is (long) done;
+                # its consumer runs here, on the range's stream, behind this call's encoder and in front of this call's collective
+                self._consume_pending((lo, hi))
+                works = None
+                if dist.get_backend(self.group) == "gloo":        # device tensors over gloo (one-GPU tests): host copies, synchronous
+                    _all_gather(g, wire.contiguous(), self.group)
+                    _all_gather(gl, wl.contiguous(), self.group)
+                else:
+                    works = [dist.all_gather_into_tensor(g, wire.contiguous(), group=self.group, async_op=True),
+                             dist.all_gather_into_tensor(gl, wl.contiguous(), group=self.group, async_op=True)]
+                ch = GatheredChunk(lo, hi, g, gl, rows, keep, None, torch.cuda.current_stream(dev), works)
+                chunks.append(ch)
+                self._pending.append((self._call, (lo, hi), ch, consumer))
+                return
             _all_gather(g, wire.contiguous(), self.group)
             _all_gather(gl, wl.contiguous(), self.group)
             ev = torch.cuda.Event()
@@ -154,8 +196,27 @@ class ShardedEncoder:
             dist.all_gather_into_tensor(gl, out_len[lo:hi].contiguous(), group=self.group)
             ch = GatheredChunk(lo, hi, g, gl, rows, keep, None, None)
             chunks.append(ch)
-            if consumer is not None:
+            if self.pipelined:                            # CPU tensors (gloo tests of the protocol): same one-call-late consumer
+                self._consume_pending((lo, hi))
+                self._pending.append((self._call, (lo, hi), ch, consumer))
+            elif consumer is not None:
                 consumer(ch)
+
+    def _consume_pending(self, key=None):
+        """Run the consumers of pending chunks on the CURRENT stream: the one of row range `key`, or (key None) all of them in issue order."""
+        keep = []
+        for call, k, ch, consumer in self._pending:
+            if key is None or k == key:
+                ch.wait()
+                if consumer is not None:
+                    consumer(ch)
+            else:
+                keep.append((call, k, ch, consumer))
+        self._pending = keep
+
+    def flush(self):
+        """Pipelined mode: consume what the last call left in flight (on the current stream).  No-op otherwise."""
+        self._consume_pending(None)
 
     # ------------------------------------------------------------------ entry points
     def encode_shard(self, xs: torch.Tensor, ls: torch.Tensor, global_batch: Optional[int] = None, range_pad=None, x_len_host=None,
@@ -163,10 +224,13 @@ class ShardedEncoder:
         """This rank's rows (already selected; the same number of rows on every rank) -> gathered chunks of the global batch.
         `range_pad`: padded length per row range for `ConformerEncoder.trim_sub_batches` - the SAME list on every rank (the maximum
         over the ranks' shards), so that every rank launches identical shapes and the collectives stay fixed-size.
-        `consumer(chunk)`: called right after a range's collective was issued, with that range's stream current (the CTC head of bench.py)."""
+        `consumer(chunk)`: called right after a range's collective was issued, with that range's stream current (the CTC head of bench.py).
+        Ragged encoders (`ConformerEncoder.ragged`): pass `x_len_host`; the row ranges are the rank-independent equal-count cut (set in the
+        constructor) or explicit `encoder.sub_batch_bounds` that are IDENTICAL on all ranks - never cuts derived from a rank's own lengths."""
         world = dist.get_world_size(self.group)
         gb = global_batch if global_batch is not None else xs.shape[0] * world
         chunks: List[GatheredChunk] = []
+        self._call += 1
         if self._hooked:
             kw = {"range_pad": range_pad} if range_pad is not None else {}
             if x_len_host is not None:
@@ -175,10 +239,20 @@ class ShardedEncoder:
         else:
             out, out_len = self.encoder(xs, ls)[:2]
             self._gather_range(0, out.shape[0], out, out_len, gb, chunks, consumer)
+        if self.pipelined and any(c < self._call for c, _, _, _ in self._pending):
+            # row ranges of an EARLIER call that this call did not revisit (the cuts changed): consume them now, on the caller's stream
+            stale = [p for p in self._pending if p[0] < self._call]
+            self._pending = [p for p in self._pending if p[0] == self._call]
+            for _, _, ch, cons in stale:
+                ch.wait()
+                if cons is not None:
+                    cons(ch)
         return Gathered(chunks, gb)
 
     def __call__(self, x: torch.Tensor, x_len: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """Global (B, L) batch (the same tensor on every rank) -> (B, T, D) outputs + lengths in global order."""
         rank, world = dist.get_rank(self.group), dist.get_world_size(self.group)
         xs, ls = shard_batch(x, x_len, rank, world, uniform=True)
-        return self.encode_shard(xs, ls, x.shape[0]).assemble()
+        g = self.encode_shard(xs, ls, x.shape[0])
+        self.flush()                       # a whole-batch call wants THIS call's outputs
+        return g.assemble()

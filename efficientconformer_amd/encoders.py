@@ -121,6 +121,14 @@ class ConformerEncoder(nn.Module):
         # the row ranges are cut for equal valid frames.  Needs the lengths on the host (`x_len_host`, or one device sync).
         self.ragged = False
         self.sub_batch_bounds = None       # optional row boundaries of the ranges (nsub - 1 increasing indices); default: equal row counts
+        # How a RAGGED batch is cut into row ranges when `sub_batch_bounds` is None: "frames" = equal valid frames per range, computed from
+        # THIS call's lengths; "rows" = the rank-independent equal-count cut of the rectangular path.  Under `dist.ShardedEncoder` every
+        # range ends in a fixed-size collective, so all ranks must cut identical ranges: it sets "rows" (or pass explicit bounds).
+        self.ragged_cut = "frames"
+        # True: a caller-supplied `x_len_host` is compared with the device lengths (one synchronisation per forward; tests / debugging).
+        # Contract otherwise: `x_len_host[b] == x_len[b]` - grids and the workspace are sized from the host copy, the kernels index with
+        # the device copy (include/effconf.h: effconf_encoder_forward_ragged).
+        self.check_host_lengths = False
         self._sub_streams: Dict[tuple, torch.cuda.Stream] = {}
         self.caller_stream_slot = True     # stream slot 0 of the row ranges = the caller's stream (False: every range on a side stream, as round 2)
         self.eval()
@@ -288,6 +296,35 @@ class ConformerEncoder(nn.Module):
         pads = [min(n, max(v, floor)) for v in pads]
         return None if all(v == n for v in pads) else pads
 
+    def row_ranges(self, batch: int, nsub: int, host_lens=None):
+        """The contiguous row ranges [(lo, hi)] a forward of `batch` utterances runs as (`sub_batches` = nsub): explicit `sub_batch_bounds`,
+        else - ragged batches with `ragged_cut == "frames"` - equal VALID frames per range from `host_lens`, else equal utterance counts."""
+        if nsub <= 1:
+            return [(0, batch)]
+        if self.ragged and self.sub_batch_bounds is None and self.ragged_cut != "rows" and host_lens is not None:
+            # equal VALID frames per row range (the work of a ragged range), boundaries at multiples of 8 rows
+            csum = np.concatenate([[0], np.cumsum(host_lens)])
+            cuts = [0]
+            for i in range(1, nsub):
+                c = int(np.searchsorted(csum, csum[-1] * i / nsub))
+                c = max(cuts[-1] + 1, min(batch - (nsub - i), (c + 4) // 8 * 8 if batch >= 16 * nsub else c))
+                cuts.append(c)
+            cuts.append(batch)
+            return [(cuts[i], cuts[i + 1]) for i in range(nsub)]
+        if self.sub_batch_bounds is not None:      # explicit row boundaries (e.g. equal padded work per range, staggered ranges)
+            cuts = [0] + [int(b) for b in self.sub_batch_bounds] + [batch]
+            if len(cuts) != nsub + 1 or any(cuts[i] >= cuts[i + 1] for i in range(nsub)):
+                raise ValueError("sub_batch_bounds must be %d increasing row indices inside (0, %d)" % (nsub - 1, batch))
+            return [(cuts[i], cuts[i + 1]) for i in range(nsub)]
+        # equal utterance counts, boundaries floored to multiples of 16 rows when the ranges are large enough: with a length-sorted
+        # batch this moves a few rows from the longest range to the shortest one (B = 256 in 3 ranges: 80 / 80 / 96 rows,
+        # +1 % over 85 / 85 / 86 on the LibriSpeech-shaped bench batch; the 4 % first measured for it was the attention kernels'
+        # XCD mapping, which only handled B % 8 == 0 - fixed in attention.hip / attention2.hip)
+        cuts = [batch * i // nsub for i in range(nsub + 1)]
+        if batch >= 32 * nsub:
+            cuts = [c - c % 16 for c in cuts[:-1]] + [batch]
+        return [(cuts[i], cuts[i + 1]) for i in range(nsub)]
+
     def _run_on_device(self, x: torch.Tensor, x_len: Optional[torch.Tensor], from_audio: bool, range_hook: Optional[Callable],
                        x_len_host=None, range_pad=None, return_attentions: bool = False):
         if self.training:
@@ -332,30 +369,10 @@ class ConformerEncoder(nn.Module):
             host_lens = np.ascontiguousarray(np.asarray(hl.cpu() if torch.is_tensor(hl) else hl, dtype=np.int64))
             if host_lens.shape != (batch,):
                 raise ValueError("x_len_host needs one length per utterance")
-        if self.ragged and nsub > 1 and self.sub_batch_bounds is None:
-            # equal VALID frames per row range (the work of a ragged range), boundaries at multiples of 8 rows
-            csum = np.concatenate([[0], np.cumsum(host_lens)])
-            cuts = [0]
-            for i in range(1, nsub):
-                c = int(np.searchsorted(csum, csum[-1] * i / nsub))
-                c = max(cuts[-1] + 1, min(batch - (nsub - i), (c + 4) // 8 * 8 if batch >= 16 * nsub else c))
-                cuts.append(c)
-            cuts.append(batch)
-            ranges = [(cuts[i], cuts[i + 1]) for i in range(nsub)]
-        elif self.sub_batch_bounds is not None and nsub > 1:      # explicit row boundaries (e.g. equal padded work per range)
-            cuts = [0] + [int(b) for b in self.sub_batch_bounds] + [batch]
-            if len(cuts) != nsub + 1 or any(cuts[i] >= cuts[i + 1] for i in range(nsub)):
-                raise ValueError("sub_batch_bounds must be %d increasing row indices inside (0, %d)" % (nsub - 1, batch))
-            ranges = [(cuts[i], cuts[i + 1]) for i in range(nsub)]
-        else:
-            # equal utterance counts, boundaries floored to multiples of 16 rows when the ranges are large enough: with a length-sorted
-            # batch this moves a few rows from the longest range to the shortest one (B = 256 in 3 ranges: 80 / 80 / 96 rows,
-            # +1 % over 85 / 85 / 86 on the LibriSpeech-shaped bench batch; the 4 % first measured for it was the attention kernels'
-            # XCD mapping, which only handled B % 8 == 0 - fixed in attention.hip / attention2.hip)
-            cuts = [batch * i // nsub for i in range(nsub + 1)]
-            if batch >= 32 * nsub:
-                cuts = [c - c % 16 for c in cuts[:-1]] + [batch]
-            ranges = [(cuts[i], cuts[i + 1]) for i in range(nsub)]
+            if x_len_host is not None and self.check_host_lengths and not np.array_equal(host_lens, lens.cpu().numpy()):
+                raise ValueError("x_len_host differs from x_len: the ragged forward sizes its grids and workspace from the host lengths "
+                                 "and indexes with the device lengths - they must be the same numbers")
+        ranges = self.row_ranges(batch, nsub, host_lens)
         pads = None if self.ragged else self._range_pads(ranges, n, from_audio, lens, lens_given, x_len_host, range_pad)
         fn_ragged = lib.effconf_encoder_forward_ragged
 

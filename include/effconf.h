@@ -104,6 +104,9 @@ int effconf_encoder_forward_mel(EcEncoder* enc, const float* mel, const int64_t*
  * SURVEY.md 8a), independent of what else is in the batch.  All utterances share one concatenated row space and one set of launches.
  *   x          dev f32 (batch, n) audio rows or (batch, n_mels, n) mel (from_audio = 0); n = the row pitch (content behind x_len unused)
  *   x_len      dev i64 (batch); x_len_host: the same lengths on the HOST (grids and the workspace are sized from them)
+ *              CONTRACT: x_len_host[b] == x_len[b] for every b.  The library cannot compare them without a synchronisation and does not:
+ *              the kernels index rows with the device copy inside grids / a workspace sized from the host copy, so a device length that
+ *              exceeds its host twin is an out-of-bounds access.  (The Python wrapper checks on request: ConformerEncoder.check_host_lengths.)
  *   out        dev f32 (batch, out_frames, D_last): utterance b's T_out(b) frames, zeros behind them; out_frames >= the longest T_out
  * Workspace: effconf_encoder_workspace_bytes_ragged(enc, x_len_host, batch, n, from_audio).  Front ends: sublinear2.hip indexes the ragged
  * rows itself (one subsampling layer, <= 192 filters and <= 192-wide first stage); wider one-layer and the two-layer subsamplers run on the
@@ -263,6 +266,8 @@ int effconf_debug_gemm(const uint16_t* a, int32_t lda, const uint16_t* w, int32_
 /* One self-contained victim: 16 chains per lane of a single instruction class (0 v_fma_f32, 1 v_pk_fma_f32, 2 v_pk_mul/add_f32,
  * 3 v_log/v_exp_f32, 4 v_mul/v_add_f32, 5 integer, 6 wave-local LDS exchange); out dev f32 (blocks * 256 * 16). */
 int effconf_debug_victim(int32_t kind, int32_t blocks, int32_t iters, float* out, void* stream);
+/* One idle wave that occupies `stream` for `microseconds` (tools/overlap_probe.py: the duration of an xGMI transfer a single GPU cannot make). */
+int effconf_debug_spin(double microseconds, void* stream);
 
 /* ---- attention maps: the third return value of the reference's ConformerEncoder.forward (encoders.py:126-142: att_w of every block,
  * (batch, heads, Tg, Tg) softmax rows; no caller on the hot path reads them, so they are opt-in).  effconf_encoder_attention_dims fills

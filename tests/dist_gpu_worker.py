@@ -1,6 +1,7 @@
 """Worker of tests/test_gpu_dist.py: launched twice by torch.distributed.run on ONE GPU (gloo process group, device tensors).
 The real HIP encoder behind dist.ShardedEncoder with two sub-batch row ranges: per-range hooks, comm stream, chunk protocol,
-record_stream - everything of the multi-GPU path except the RCCL transport.  Prints DIST_GPU_OK on success."""
+record_stream - everything of the multi-GPU path except the RCCL transport - on rectangular ranges AND on the ragged ranges that are
+the default of `bench.py --gpus N` (reference sharding: main.py:33-35, 217-220, model_ctc.py:70-75).  Prints DIST_GPU_OK on success."""
 import os
 import sys
 
@@ -47,6 +48,42 @@ def main():
                 seen[int(ch.rows[r])] = lab[r, :int(n[r])].tolist()
         want = {b: labels_full[b, :int(n_full[b])].tolist() for b in range(audio.shape[0])}
         ok = ok and len(g.chunks) == 2 and seen == want
+    # ---- the default of `bench.py --gpus N`: RAGGED row ranges (every utterance at its own length), one fixed-size collective per range
+    #      issued from the range's stream, the CTC head as the consumer of every gathered chunk.  A ragged forward is batch-invariant, so
+    #      the gathered outputs must equal the UNSHARDED ragged run bit for bit (fp32 wire), or its bf16 rounding (bf16 wire); labels from
+    #      the gathered chunks equal the head run locally on the same values.  Cuts: ShardedEncoder's rank-independent equal-count cut,
+    #      then explicit (pinned) bounds as bench.py sets them.
+    if enc.precision == "bf16":
+        enc.ragged, enc.sub_batches, enc.sub_batch_bounds = True, 1, None
+        rag, rag_len, _ = enc(audio, ln, x_len_host=lens)
+        ok = ok and torch.equal(rag_len, full_len)
+        xs, ls = shard_batch(audio, ln, rank, world, uniform=True)
+        idx = list(range(rank, audio.shape[0], world))
+        hl = lens[idx + [idx[-1]] * (xs.shape[0] - len(idx))]
+        enc.check_host_lengths = True
+        for wire in (None, torch.bfloat16):
+            want_out = rag if wire is None else rag.to(wire)
+            _, lab_w, n_w = m._head(want_out.float(), rag_len)
+            for bounds in (None, [1], [3]):
+                enc.sub_batches, enc.sub_batch_bounds = 2, bounds
+                shr = ShardedEncoder(enc, wire_dtype=wire)
+                ok = ok and enc.ragged_cut == "rows"
+                seen, outs = {}, {}
+
+                def consumer(ch):                          # runs with the range's stream current, right behind the collective
+                    _, lab, n = m._head(ch.out.float(), ch.out_len)
+                    for r in torch.nonzero(ch.keep).flatten().tolist():
+                        seen[int(ch.rows[r])] = (lab[r], n[r])
+                        outs[int(ch.rows[r])] = (ch.out[r], ch.out_len[r])
+                g = shr.encode_shard(xs, ls, audio.shape[0], x_len_host=hl, consumer=consumer)
+                torch.cuda.synchronize()
+                ok = ok and len(g.chunks) == 2 and sorted(seen) == list(range(audio.shape[0]))
+                for b in range(audio.shape[0]):
+                    o, l = outs[b]
+                    nl = int(seen[b][1])
+                    ok = ok and torch.equal(o, want_out[b]) and int(l) == int(rag_len[b]) and nl == int(n_w[b]) and \
+                        torch.equal(seen[b][0][:nl], lab_w[b, :nl])
+        enc.ragged, enc.sub_batches, enc.sub_batch_bounds, enc.check_host_lengths = False, 1, None, False
     torch.cuda.synchronize()
     flag = torch.tensor([1.0 if ok else 0.0])
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)

@@ -55,6 +55,24 @@ def _worker(rank, world, port, q):
         ok = ok and torch.equal(c.out[c.keep], full[c.rows[c.keep]])
     out3, _ = ShardedEncoder(enc, wire_dtype=torch.bfloat16)(mel, lens)
     ok = ok and out3.dtype == torch.bfloat16 and torch.equal(out3, full.to(torch.bfloat16))
+    # pipelined protocol (dist.py): a range's consumer runs ONE CALL LATER (its collective overlaps the next call's encoder); flush() drains
+    shp = ShardedEncoder(Ranged(), pipelined=True)
+    got = []
+    mel_b, lens_b = synth.make_mel(5, 80, 64, [64, 50, 44, 30, 21], seed=5)
+    mel_b, lens_b = torch.from_numpy(mel_b), torch.from_numpy(lens_b)
+    full_b, _ = enc(mel_b, lens_b)
+    xb, lb = shard_batch(mel_b, lens_b, rank, world, uniform=True)
+    shp.encode_shard(xs, ls, mel.shape[0], consumer=lambda c: got.append(("a", c)))
+    ok = ok and got == []                                       # nothing consumed yet: call 1's collectives are "in flight"
+    shp.encode_shard(xb, lb, mel.shape[0], consumer=lambda c: got.append(("b", c)))
+    ok = ok and [t for t, _ in got] == ["a", "a"]               # call 2 consumed call 1's two chunks, range by range
+    shp.flush()
+    ok = ok and [t for t, _ in got] == ["a", "a", "b", "b"]
+    for tag, c in got:
+        ref = full if tag == "a" else full_b
+        ok = ok and torch.equal(c.out[c.keep], ref[c.rows[c.keep]])
+    o4, l4 = ShardedEncoder(Ranged(), pipelined=True)(mel, lens)     # whole-batch call: flushes itself
+    ok = ok and torch.equal(o4, full) and torch.equal(l4, full_len)
     q.put((rank, bool(ok), float((out - full).abs().max())))
     dist.barrier()
     dist.destroy_process_group()

@@ -41,3 +41,4 @@ def test_bench_two_ranks_on_one_gpu(gather):
     assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-3000:])
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 32 and j["value"] > 0
+    assert j["check"]["ok"], j["check"]                      # rank 0 verifies what it holds after the last step (gathered chunks / label ids)

@@ -1,6 +1,6 @@
 """Parity of the HIP path (through the C ABI) against the oracle and the committed reference goldens.
 Runs on a real MI355X only (-m gpu).  Tolerances are for the bf16-operand / fp32-accumulate path:
-  * encoder output (LayerNorm-ed, O(1) values): max |err| <= 0.10, mean |err| <= 0.012
+  * encoder output (LayerNorm-ed, O(1) values): max |err| <= 0.06, mean |err| <= 0.010 (round 4: 1.5x the worst measured 0.039 / 0.008; was 0.10 / 0.012)
   * greedy CTC labels: identical at every frame whose reference top-2 logit margin exceeds 0.15
     (random-weight logits have tiny margins; bf16 flips only frames inside that band)
   * fp32 kernels (mel frontend, CTC head on identical input): 2e-4 abs / bit-exact labels.
@@ -17,7 +17,7 @@ from oracle import ref_encoder as R
 
 pytestmark = pytest.mark.gpu
 
-OUT_MAX, OUT_MEAN, MARGIN = 0.10, 0.012, 0.15
+OUT_MAX, OUT_MEAN, MARGIN = 0.06, 0.010, 0.15
 
 
 def _model(name, seed):

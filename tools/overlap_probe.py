@@ -31,7 +31,19 @@ def main():
     ap.add_argument("--model", default="EfficientConformerCTCSmall")
     ap.add_argument("--no-collective", action="store_true", help="bench.py's single-GPU step: no comm stream, the CTC head per range on the range's stream")
     ap.add_argument("--stagger", type=int, default=0, help="1: range 0's stream gets the higher priority (ConformerEncoder.stagger_ranges)")
+    ap.add_argument("--mode", default="sync", choices=["sync", "pipelined"],
+                    help="sync: the range's stream waits for its collective, then runs the head (dist.ShardedEncoder default); pipelined: the head of "
+                         "a chunk runs one step later, right behind that step's encoder kernels of the same range (ShardedEncoder(pipelined=True))")
+    ap.add_argument("--standin", default="spin", choices=["spin", "copies"],
+                    help="what stands in for the all-gather on the comm stream: spin = one own-slot copy + an idle wave for bytes received / --xgmi-gbs "
+                         "(the DURATION of the transfer; round 3's `copies` = world - 1 device-to-device copies run at 2 TB/s, 7x faster than xGMI)")
+    ap.add_argument("--xgmi-gbs", type=float, default=300.0, help="sustained all-gather receive bandwidth per GPU to emulate (GB/s)")
+    ap.add_argument("--range-frames", default="", help="share of the valid frames per row range in percent, e.g. 40,35,25 (default: equal)")
     args = ap.parse_args()
+    import ctypes as C
+    import numpy as np
+    from efficientconformer_amd import _lib
+    lib = _lib.load()
     dev = torch.device("cuda", 0)
     cfg = named_config(args.model)
     model = ModelCTC.from_config(cfg)
@@ -45,6 +57,15 @@ def main():
     cuts = [0, 80, 160, 256]
     pads = [int(lens_np[cuts[i]:cuts[i + 1]].max()) for i in range(3)]
     enc.sub_batches, enc.sub_batch_streams, enc.ragged, enc.stagger_ranges = 3, 3, True, bool(args.stagger)        # bench.py's default step
+    if args.range_frames:
+        fr = np.cumsum(lens_np // 160 + 1).astype(np.float64)
+        shares = [float(v) for v in args.range_frames.split(",")]
+        acc, cc = 0.0, []
+        for v in shares[:-1]:
+            acc += v / sum(shares)
+            cc.append((int(np.searchsorted(fr, acc * fr[-1])) + 4) // 8 * 8)
+        enc.sub_batch_bounds = cc
+    pending = {}
     comm = torch.cuda.Stream(device=dev)          # stands in for the process group's own stream
     wire = torch.float32 if args.wire == "fp32" else torch.bfloat16
     bufs = {}
@@ -65,26 +86,45 @@ def main():
                 ev = torch.cuda.Event(enable_timing=True); ev.record(torch.cuda.current_stream(dev))
                 rec["ranges"].append({"rows": (lo, hi), "done": done, "cs": done, "ce": ev, "head": ev})
                 return
-            comm.wait_event(done)
+            key = (lo, hi)
+            cur = torch.cuda.current_stream(dev)
+            if args.mode == "pipelined" and key in pending:      # the previous step's chunk of this range: consumed here, behind this step's encoder
+                pg, plen, pev, prec = pending.pop(key)
+                cur.wait_event(pev)
+                for r in range(args.world):                       # the head runs on the GATHERED chunk: world x the range's rows
+                    model._head(pg[r].float() if pg.dtype != torch.float32 else pg[r], plen)
+                he = torch.cuda.Event(enable_timing=True); he.record(cur)
+                prec["head"] = he
+            issue = torch.cuda.Event(); issue.record(cur)       # this step's collective is issued here (pipelined: behind the previous chunk's head)
+            comm.wait_event(issue)
             with torch.cuda.stream(comm):
                 cs = torch.cuda.Event(enable_timing=True); cs.record(comm)
                 src = out[lo:hi] if wire == torch.float32 else out[lo:hi].to(wire)
                 out.record_stream(comm)
-                key = (lo, hi)
                 if key not in bufs:
                     bufs[key] = torch.empty((args.world,) + tuple(src.shape), dtype=wire, device=dev)
                 g = bufs[key]
                 g[0].copy_(src)                                   # this rank's own slot
-                for r in range(1, args.world):                    # the bytes the other world - 1 ranks send
-                    g[r].copy_(src, non_blocking=True)
+                if args.standin == "copies":
+                    for r in range(1, args.world):                # the bytes the other world - 1 ranks send, as device-to-device copies
+                        g[r].copy_(src, non_blocking=True)
+                else:                                             # the TIME those bytes take over xGMI: an idle wave on the comm stream
+                    us = (args.world - 1) * src.numel() * src.element_size() / (args.xgmi_gbs * 1e9) * 1e6
+                    _lib.check(lib.effconf_debug_spin(C.c_double(us), comm.cuda_stream), "spin")
                 ev = torch.cuda.Event(enable_timing=True)
                 ev.record(comm)
-            # as torch.distributed does for a collective issued on this stream: the range's stream resumes when the chunk has arrived,
-            # and the consumer (CTC head on the gathered chunk) runs on it
-            torch.cuda.current_stream(dev).wait_event(ev)
-            model._head(g[0].float() if g.dtype != torch.float32 else g[0], out_len[lo:hi])
-            he = torch.cuda.Event(enable_timing=True); he.record(torch.cuda.current_stream(dev))
-            rec["ranges"].append({"rows": (lo, hi), "done": done, "cs": cs, "ce": ev, "head": he})
+            entry = {"rows": (lo, hi), "done": done, "cs": cs, "ce": ev, "head": ev}
+            rec["ranges"].append(entry)
+            if args.mode == "pipelined":
+                pending[key] = (g, out_len[lo:hi].clone(), ev, entry)
+            else:
+                # as torch.distributed does for a collective issued on this stream: the range's stream resumes when the chunk has arrived,
+                # and the consumer (CTC head on the gathered chunk: world x the range's rows) runs on it
+                cur.wait_event(ev)
+                for r in range(args.world):
+                    model._head(g[r].float() if g.dtype != torch.float32 else g[r], out_len[lo:hi])
+                he = torch.cuda.Event(enable_timing=True); he.record(cur)
+                entry["head"] = he
             chunks.append((lo, hi, g, out_len, ev))
         enc(audio, lens, range_hook=hook, x_len_host=lens_np)
         te = torch.cuda.Event(enable_timing=True); te.record(torch.cuda.current_stream(dev))      # the forward's join on the caller's stream
@@ -99,6 +139,8 @@ def main():
         step()
     torch.cuda.synchronize()
     nbytes = sum(b.numel() * b.element_size() for b in bufs.values())
+    print("# mode %s, stand-in %s%s, row ranges %s" % (args.mode, args.standin, "" if args.standin == "copies" else " (%.0f GB/s per GPU)" % args.xgmi_gbs,
+                                                       [tuple(r["rows"]) for r in log[2]["ranges"]]))
     if args.no_collective:
         bufs.update({r["rows"]: torch.empty(0) for r in log[0]["ranges"]})
     print("# overlap_probe: %d steps, stand-in collective bytes per step %.1f MB (world %d, wire %s); times in ms from the step's start (median over steps)"
@@ -118,19 +160,29 @@ def main():
     print("  join on the caller's stream      %10.3f" % med(lambda r: r["t0"].elapsed_time(r["join"])))
     nxt = [log[k]["t0"].elapsed_time(log[k + 1]["t0"]) for k in range(2, len(log) - 1)]
     print("  next step starts at              %10.3f   (= step period)" % st.median(nxt))
-    cov = []
-    for k in range(2, len(log) - 1):
-        r, n = log[k], log[k + 1]
-        last_done = max(r["t0"].elapsed_time(x["done"]) for x in r["ranges"])
-        period = r["t0"].elapsed_time(n["t0"])
-        tot = under = 0.0
+    # share of the collectives' time that lies under encoder kernels: the union over steps and row ranges of [step start, that range's last
+    # encoder kernel done] on one time axis (the first probed step's start)
+    base = log[2]["t0"]
+    busy = []
+    for r in log[2:]:
+        a = base.elapsed_time(r["t0"])
         for x in r["ranges"]:
-            a, b = r["t0"].elapsed_time(x["cs"]), r["t0"].elapsed_time(x["ce"])
+            busy.append((a, base.elapsed_time(x["done"])))
+    busy.sort()
+    merged = []
+    for a, b in busy:
+        if merged and a <= merged[-1][1]:
+            merged[-1][1] = max(merged[-1][1], b)
+        else:
+            merged.append([a, b])
+    tot = under = 0.0
+    for r in log[3:-1]:                 # interior steps: a neighbour on both sides
+        for x in r["ranges"]:
+            a, b = base.elapsed_time(x["cs"]), base.elapsed_time(x["ce"])
             tot += b - a
-            # under this step's encoder kernels: before the last range's last encoder kernel finished
-            under += max(0.0, min(b, last_done) - a)
-        cov.append(under / max(tot, 1e-9))
-    print("# share of the collectives' time that runs while encoder kernels of another row range of the same step are executing: %.0f %%" % (100 * st.median(cov)))
+            under += sum(max(0.0, min(b, hi) - max(a, lo)) for lo, hi in merged)
+    print("# collective time per step %.3f ms; share of it that runs while encoder kernels (any row range, this or the next step) are executing: %.0f %%"
+          % (tot / max(len(log) - 4, 1), 100 * under / max(tot, 1e-9)))
 
 
 if __name__ == "__main__":
