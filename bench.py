@@ -103,8 +103,9 @@ def parse():
                          "-1 (default): 1 where the model supports it (one-layer subsampler, bf16 path, libri workload)")
     ap.add_argument("--no-check", action="store_true",
                     help="skip the un-timed self-check of the benchmarked step (single-stream per-range rerun + oracle samples)")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"],
-                    help="bf16: bf16 MFMA operands / fp32 accumulate (default); fp32: the library's label-exact mode")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "split"],
+                    help="bf16: bf16 MFMA operands / fp32 accumulate (default); fp32: the library's label-exact mode on the fp32 matrix pipe; "
+                         "split: the label-exact mode on the fp16 matrix pipe (operands split into two fp16 numbers, three MFMAs per product)")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU work: build the batch plan, join the process group (gloo) and print the JSON skeleton (CPU tests)")
     return ap.parse_args()
@@ -547,9 +548,10 @@ def result_skeleton(args, world, value, ms_per_step, gb, extra_cfg):
         "value": value, "unit": "mel-frames/s (valid, 10 ms hop)",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": {"bf16": "bf16", "fp32": "f32", "split": "f16x2 (split fp32 operands, fp32 accumulate)"}[args.precision], "data": "synthetic",
         "config": dict({"workload": "%s: %s, B=%d utterances/GPU, %s lengths, audio in HBM -> encoder out + greedy labels"
-                                    % (args.model, "bf16 operands / fp32 accumulate" if args.precision == "bf16" else "fp32 operands (label-exact mode)",
+                                    % (args.model, {"bf16": "bf16 operands / fp32 accumulate", "fp32": "fp32 operands (label-exact mode)",
+                                                    "split": "fp32 tensors, every product on the fp16 matrix pipe with split operands x = h + l / 2048 (label-exact mode, 3 MFMAs per product)"}[args.precision],
                                        args.batch,
                                        ("lognormal 1.5-16 s (LibriSpeech-shaped), sorted desc; " + padding)
                                        if args.workload == "libri" else "10 s"),
@@ -804,6 +806,7 @@ def main():
                     model.encoder.sub_batch_streams = 1          # every range on the caller's stream, one after the other
                     step_greedy()
                     continue
+                model.encoder.sub_batches = 1                    # rectangular ranges: each range as its own forward
                 for i in range(nsub):
                     lo, hi = cuts[i], cuts[i + 1]
                     step(model, audio[lo:hi, :range_pad[i]].contiguous() if range_pad else audio[lo:hi], lens[lo:hi])

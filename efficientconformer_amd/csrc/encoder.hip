@@ -115,6 +115,10 @@ struct EcEncoder {
     // fp32-operand "exact" mode (exact.hip): raw fp32 state-dict tensors on the device by key, fp32 sinusoid tables,
     // per-layer BatchNorm scale / shift of the subsampling convs
     bool exact_pack = false, exact_on = false;
+    // exact_fp32 = 2: the same schedule with every GEMM / the attention products on the fp16 matrix pipe with split operands (split.hip)
+    bool exact_split = false;
+    struct SplitW { const uint16_t *hi, *lo; int ldh; };
+    std::map<std::string, SplitW> xsplit;    // Linear / 1x1 conv weights by state-dict prefix (+ the stacked "...mhsa.qkv_layer")
     std::map<std::string, const float*> xw;
     std::map<std::pair<int, int>, const float*> xtab;
     const float *xsub_scale[2] = {nullptr, nullptr}, *xsub_shift[2] = {nullptr, nullptr};
@@ -853,7 +857,7 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
 }
 
 // ------------------------------------------------------------------ fp32-operand "exact" forward (kernels: exact.hip)
-struct XWorkspace { size_t total = 0, conv1, sub, x0, x1, a, h, q, k, v, e, o, p1, g, c, lens; };
+struct XWorkspace { size_t total = 0, conv1, sub, x0, x1, a, h, q, k, v, e, o, p1, g, c, lens, scores = 0; size_t qkv_stride = 0; };
 
 XWorkspace make_xworkspace(const EcEncoder* e, const Shapes& s) {
     XWorkspace w;
@@ -882,6 +886,16 @@ XWorkspace make_xworkspace(const EcEncoder* e, const Shapes& s) {
     w.q = take(mq); w.k = take(mq); w.v = take(mq); w.e = take(me); w.o = take(mq);
     w.p1 = take(mp); w.g = take(mg); w.c = take(mc);
     w.lens = take((e->blocks.size() + 1) * B);
+    w.qkv_stride = (w.k - w.q) / 4;                 // floats between the Q, K and V buffers (the stacked projection writes all three)
+    if (e->exact_split) {                           // split.hip: (B, H, Tg, Tg) attention scores of one block
+        size_t ms = 0;
+        for (size_t k = 0; k < e->blocks.size(); ++k) {
+            const EcBlock& b = e->blocks[k];
+            const int Tg = ec_round_up(s.Tin[k], b.group_size) / b.group_size;
+            ms = std::max(ms, sx_attention_scores_bytes(s.B, b.num_heads, Tg) / 4);
+        }
+        w.scores = take(ms);
+    }
     w.total = off;
     return w;
 }
@@ -892,14 +906,26 @@ const float* xget(EcEncoder* e, const std::string& k) {
 }
 
 int xgemm(EcEncoder* e, hipStream_t st, const float* A, int lda, int M, const std::string& prefix, int N, int K, float* C, int ldc, int epi = 0,
-          const float* R = nullptr, float alpha = 1.f, int a_rows = 0, int a_pitch = 0, int a_stride = 0, int c_rows = 0, int c_pitch = 0) {
+          const float* R = nullptr, float alpha = 1.f, int a_rows = 0, int a_pitch = 0, int a_stride = 0, int c_rows = 0, int c_pitch = 0,
+          int split_cols = 0, size_t split_stride = 0, int cls = PC_GEMM_OTHER) {
     ExGemmParams p{};
     p.A = A; p.lda = lda; p.a_rows = a_rows; p.a_pitch = a_pitch; p.a_stride = a_stride;
     p.W = xget(e, prefix + ".weight"); p.ldw = K; p.bias = xget(e, prefix + ".bias");
-    if (!p.W || !p.bias) return fail("exact mode: missing " + prefix);
+    if (!p.bias) return fail("exact mode: missing " + prefix);
     p.M = M; p.N = N; p.K = K; p.C = C; p.ldc = ldc; p.c_rows = c_rows; p.c_pitch = c_pitch;
+    p.split_cols = split_cols; p.split_stride = split_stride;
     p.R = R; p.ldr = ldc; p.alpha = alpha; p.epi = epi;
-    PROF(PC_GEMM_OTHER, 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
+    // flop: the algorithmic 2 M N K (the split kernels issue three MFMAs per product)
+    PROF(cls, 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
+    if (e->exact_split) {
+        auto it = e->xsplit.find(prefix);
+        if (it != e->xsplit.end()) {
+            SxGemmParams q{};
+            q.g = p; q.Whi = it->second.hi; q.Wlo = it->second.lo; q.ldh = it->second.ldh;
+            return launch_sx_gemm(q, st);
+        }
+    }
+    if (!p.W) return fail("exact mode: missing " + prefix);
     return launch_ex_gemm(p, st);
 }
 
@@ -951,8 +977,8 @@ int forward_core_exact(EcEncoder* e, const float* mel, const int64_t* in_len, in
         const std::string p = "blocks." + std::to_string(k);
         // ---- x += 1/2 FFN1(LN(x))   (blocks.py:122; modules.py:385-392)
         EC_TRY(launch_layernorm(x, M, D, W.ln_ffn1.g, W.ln_ffn1.b, a, nullptr, 0, nullptr, nullptr, st));
-        EC_TRY(xgemm(e, st, a, D, M, p + ".feed_forward_module1.layers.1", D * b.ff_ratio, D, hb, D * b.ff_ratio, 1));
-        EC_TRY(xgemm(e, st, hb, D * b.ff_ratio, M, p + ".feed_forward_module1.layers.4", D, D * b.ff_ratio, x, D, 2, x, 0.5f));
+        EC_TRY(xgemm(e, st, a, D, M, p + ".feed_forward_module1.layers.1", D * b.ff_ratio, D, hb, D * b.ff_ratio, 1, nullptr, 1.f, 0, 0, 0, 0, 0, 0, 0, PC_GEMM_FFN));
+        EC_TRY(xgemm(e, st, hb, D * b.ff_ratio, M, p + ".feed_forward_module1.layers.4", D, D * b.ff_ratio, x, D, 2, x, 0.5f, 0, 0, 0, 0, 0, 0, 0, PC_GEMM_FFN));
         snprintf(nm, sizeof(nm), "blocks.%d.x_ffn1", k); trace_add(e, st, nm, x, M, D, D, 0);
         // ---- x += MHSA(LN(x))   (blocks.py:125-126; attentions.py:549-718)
         const std::string m = p + ".multi_head_self_attention_module";
@@ -961,9 +987,13 @@ int forward_core_exact(EcEncoder* e, const float* mel, const int64_t* in_len, in
             if (hipMemsetAsync(q, 0, (size_t)B * Tp * D * 4, st) != hipSuccess || hipMemsetAsync(kk, 0, (size_t)B * Tp * D * 4, st) != hipSuccess ||
                 hipMemsetAsync(v, 0, (size_t)B * Tp * D * 4, st) != hipSuccess) return fail("memset failed");
         }
-        EC_TRY(xgemm(e, st, a, D, M, m + ".mhsa.query_layer", D, D, q, D, 0, nullptr, 1.f, 0, 0, 0, T, Tp));
-        EC_TRY(xgemm(e, st, a, D, M, m + ".mhsa.key_layer", D, D, kk, D, 0, nullptr, 1.f, 0, 0, 0, T, Tp));
-        EC_TRY(xgemm(e, st, a, D, M, m + ".mhsa.value_layer", D, D, v, D, 0, nullptr, 1.f, 0, 0, 0, T, Tp));
+        if (e->exact_split && e->xsplit.count(m + ".mhsa.qkv_layer")) {      // one stacked projection: column n -> buffer n / D (q | k | v), column n % D
+            EC_TRY(xgemm(e, st, a, D, M, m + ".mhsa.qkv_layer", 3 * D, D, q, D, 0, nullptr, 1.f, 0, 0, 0, T, Tp, D, w.qkv_stride));
+        } else {
+            EC_TRY(xgemm(e, st, a, D, M, m + ".mhsa.query_layer", D, D, q, D, 0, nullptr, 1.f, 0, 0, 0, T, Tp));
+            EC_TRY(xgemm(e, st, a, D, M, m + ".mhsa.key_layer", D, D, kk, D, 0, nullptr, 1.f, 0, 0, 0, T, Tp));
+            EC_TRY(xgemm(e, st, a, D, M, m + ".mhsa.value_layer", D, D, v, D, 0, nullptr, 1.f, 0, 0, 0, T, Tp));
+        }
         if (Tp > b.max_pos) return fail("sequence longer than max_pos_encoding");
         const float* tab = e->xtab[std::make_pair(b.max_pos, D)];
         EC_TRY(xgemm(e, st, tab + (size_t)(b.max_pos - Tp + G / 2) * D, D, 2 * Tp - G, m + ".mhsa.pos_layer", D, D, eb, D));
@@ -971,7 +1001,9 @@ int forward_core_exact(EcEncoder* e, const float* mel, const int64_t* in_len, in
         ap.q = q; ap.k = kk; ap.v = v; ap.e = eb; ap.u = W.u; ap.vb = W.v; ap.lens = lens + (size_t)k * B;
         ap.B = B; ap.H = H; ap.T = T; ap.Tp = Tp; ap.G = G; ap.D = D; ap.d = d; ap.Tg = Tg; ap.out = o; ap.variant = e->exact_attention;
         ap.att = (int)e->att_out.size() == nb ? e->att_out[k] : nullptr;
-        { PROF(PC_ATTENTION, 2.0 * B * H * (double)Tg * Tg * d * 3.0, (double)M * D * 4 * 5); EC_TRY(launch_ex_attention(ap, st)); }
+        { PROF(PC_ATTENTION, 2.0 * B * H * (double)Tg * Tg * d * 3.0, (double)M * D * 4 * 5);
+          if (e->exact_split && sx_attention_supported(d) && (long long)B * H <= 65535) EC_TRY(launch_sx_attention(ap, F32(w.scores), st));
+          else EC_TRY(launch_ex_attention(ap, st)); }
         EC_TRY(xgemm(e, st, o, D, M, m + ".mhsa.output_layer", D, D, x, D, 2, x, 1.0f, T, Tp, 1));
         snprintf(nm, sizeof(nm), "blocks.%d.x_mhsa", k); trace_add(e, st, nm, x, M, D, D, 0);
         // ---- x = conv_res(x) + ConvModule(x)   (blocks.py:129; modules.py:511-522)
@@ -990,8 +1022,8 @@ int forward_core_exact(EcEncoder* e, const float* mel, const int64_t* in_len, in
         snprintf(nm, sizeof(nm), "blocks.%d.x_conv", k); trace_add(e, st, nm, x, Mo, De, De, 0);
         // ---- x += 1/2 FFN2(LN(x)); x = LN(x)   (blocks.py:132-135)
         EC_TRY(launch_layernorm(x, Mo, De, W.ln_ffn2.g, W.ln_ffn2.b, a, nullptr, 0, nullptr, nullptr, st));
-        EC_TRY(xgemm(e, st, a, De, Mo, p + ".feed_forward_module2.layers.1", De * b.ff_ratio, De, hb, De * b.ff_ratio, 1));
-        EC_TRY(xgemm(e, st, hb, De * b.ff_ratio, Mo, p + ".feed_forward_module2.layers.4", De, De * b.ff_ratio, x, De, 2, x, 0.5f));
+        EC_TRY(xgemm(e, st, a, De, Mo, p + ".feed_forward_module2.layers.1", De * b.ff_ratio, De, hb, De * b.ff_ratio, 1, nullptr, 1.f, 0, 0, 0, 0, 0, 0, 0, PC_GEMM_FFN));
+        EC_TRY(xgemm(e, st, hb, De * b.ff_ratio, Mo, p + ".feed_forward_module2.layers.4", De, De * b.ff_ratio, x, De, 2, x, 0.5f, 0, 0, 0, 0, 0, 0, 0, PC_GEMM_FFN));
         float* xo = (k == nb - 1) ? out : xalt;
         EC_TRY(launch_layernorm(x, Mo, De, W.ln_out.g, W.ln_out.b, xo, nullptr, 0, nullptr, nullptr, st));
         if (k != nb - 1) std::swap(x, xalt);
@@ -1352,6 +1384,53 @@ int effconf_encoder_finalize(EcEncoder* e) {
             for (int ch = 0; ch < C; ++ch) sh[ch] += cbias->data[ch] * sc[ch];
             e->xsub_scale[l] = upload(e, sc); e->xsub_shift[l] = upload(e, sh);
         }
+        e->xsplit.clear();
+        if (e->exact_split) {
+            // every 2-D weight (nn.Linear [N][K], 1x1 Conv1d [N][K][1]) as two fp16 images h = fp16(w), l = fp16((w - h) * 2048), rows padded
+            // with zeros to whole 32-wide k-tiles; the three attention projections of a block additionally stacked (q | k | v)
+            auto half_bits = [](float f) { _Float16 h = (_Float16)f; uint16_t u; memcpy(&u, &h, 2); return u; };
+            auto clampf = [](float f) { return f > 65000.f ? 65000.f : (f < -65000.f ? -65000.f : f); };
+            auto add_split = [&](const std::string& prefix, const std::vector<const float*>& rows, int K) {
+                const int N = (int)rows.size(), ldh = ec_round_up(K, 32);
+                std::vector<uint16_t> hi((size_t)N * ldh, 0), lo(hi.size(), 0);
+                for (int n = 0; n < N; ++n)
+                    for (int k = 0; k < K; ++k) {
+                        const float wv = rows[n][k];
+                        const _Float16 h = (_Float16)clampf(wv);
+                        hi[(size_t)n * ldh + k] = half_bits((float)h);
+                        lo[(size_t)n * ldh + k] = half_bits(clampf((wv - (float)h) * 2048.0f));
+                    }
+                e->xsplit[prefix] = EcEncoder::SplitW{upload(e, hi), upload(e, lo), ldh};
+            };
+            for (auto& kv : e->host) {
+                const std::string& key = kv.first;
+                const HostTensor& t = kv.second;
+                if (key.size() < 8 || key.compare(key.size() - 7, 7, ".weight") != 0) continue;
+                const bool lin = t.shape.size() == 2, pw = t.shape.size() == 3 && t.shape[2] == 1 && key.find("subsampling") == std::string::npos;
+                if (!lin && !pw) continue;
+                const int N = (int)t.shape[0], K = (int)t.shape[1];
+                if (K % 4 || key == "fc.weight") continue;
+                std::vector<const float*> rows(N);
+                for (int n = 0; n < N; ++n) rows[n] = t.data.data() + (size_t)n * K;
+                add_split(key.substr(0, key.size() - 7), rows, K);
+            }
+            for (size_t k = 0; k < e->blocks.size(); ++k) {
+                const std::string m = "blocks." + std::to_string(k) + ".multi_head_self_attention_module.mhsa.";
+                const int D = e->blocks[k].dim_model;
+                std::vector<const float*> rows;
+                std::vector<float> bias;
+                bool ok = true;
+                for (const char* nm : {"query_layer", "key_layer", "value_layer"}) {
+                    const HostTensor *w = find(e, m + nm + ".weight"), *b = find(e, m + nm + ".bias");
+                    if (!w || !b || (int)w->data.size() != D * D || (int)b->data.size() != D) { ok = false; break; }
+                    for (int n = 0; n < D; ++n) rows.push_back(w->data.data() + (size_t)n * D);
+                    bias.insert(bias.end(), b->data.begin(), b->data.end());
+                }
+                if (!ok) continue;
+                add_split(m + "qkv_layer", rows, D);
+                e->xw[m + "qkv_layer.bias"] = upload(e, bias);
+            }
+        }
         for (const EcBlock& b : e->blocks) {
             auto key = std::make_pair(b.max_pos, b.dim_model);
             if (e->xtab.count(key)) continue;
@@ -1622,6 +1701,15 @@ int effconf_debug_gemm(const uint16_t* a, int32_t lda, const uint16_t* w, int32_
     return 0;
 }
 
+int effconf_debug_sx_gemm(const float* a, int32_t lda, const uint16_t* w_hi, const uint16_t* w_lo, int32_t ldh, const float* bias, int32_t m, int32_t n,
+                          int32_t k, int32_t epi, float* c, int32_t ldc, const float* r, int32_t ldr, float alpha, void* stream) {
+    SxGemmParams q{};
+    q.g.A = a; q.g.lda = lda; q.g.bias = bias; q.g.M = m; q.g.N = n; q.g.K = k; q.g.C = c; q.g.ldc = ldc; q.g.R = r; q.g.ldr = ldr; q.g.alpha = alpha; q.g.epi = epi;
+    q.Whi = w_hi; q.Wlo = w_lo; q.ldh = ldh;
+    const int rc = launch_sx_gemm(q, reinterpret_cast<hipStream_t>(stream));
+    return rc ? fail("sx_gemm launch failed rc=" + std::to_string(rc)) : 0;
+}
+
 int effconf_debug_spin(double microseconds, void* stream) {
     if (launch_debug_spin(microseconds, reinterpret_cast<hipStream_t>(stream)) != 0) return fail("spin launch failed");
     return 0;
@@ -1691,9 +1779,11 @@ int effconf_encoder_set_option(EcEncoder* e, const char* name, int32_t value) {
     if (!strcmp(name, "exact_attention")) { if (value < 0 || value > 2) return fail("exact_attention: 0 (tiled), 2 (tiled, 16-row workgroups) or 1 (one wave per query row)"); e->exact_attention = value; return 0; }
     if (!strcmp(name, "cache_pos_embeddings")) { e->e_cache_on = value != 0; e->e_cache.clear(); return 0; }
     if (!strcmp(name, "exact_fp32")) {
-        if (!e->finalized) { e->exact_pack = e->exact_on = value != 0; return 0; }
+        // 0 = bf16 path, 1 = fp32 operands on the fp32 matrix pipe (exact.hip), 2 = split fp16 operand pairs on the fp16 matrix pipe (split.hip)
+        if (!e->finalized) { e->exact_pack = e->exact_on = value != 0; e->exact_split = value == 2; return 0; }
         if (value && !e->exact_pack) return fail("exact_fp32 must be requested before effconf_encoder_finalize (the fp32 weights are uploaded there)");
-        e->exact_on = value != 0;
+        if (value == 2 && e->xsplit.empty()) return fail("exact_fp32 = 2 must be requested before effconf_encoder_finalize (the split weight images are built there)");
+        e->exact_on = value != 0; e->exact_split = value == 2;
         return 0;
     }
     return fail(std::string("unknown option ") + name);

@@ -215,6 +215,17 @@ struct ExAttnParams {              // natural-layout fp32 Q, K, V [B*Tp][D], E [
 };
 int launch_ex_attention(const ExAttnParams& p, hipStream_t s);
 
+// ---------------------------------------------------------------- split-precision mode  (split.hip): fp32 tensors, fp16 (h, l) operand pairs on the matrix pipe
+struct SxGemmParams {              // the ExGemmParams contract with W replaced by its two fp16 images [N][ldh] (ldh = round_up(K, 32), zero padded)
+    ExGemmParams g;
+    const uint16_t *Whi, *Wlo; int ldh;
+};
+int launch_sx_gemm(const SxGemmParams& p, hipStream_t s);
+struct SxAttnParams { ExAttnParams a; float* scores; int TgP; };
+bool sx_attention_supported(int d);
+size_t sx_attention_scores_bytes(int B, int H, int Tg);
+int launch_sx_attention(const ExAttnParams& p, float* scores, hipStream_t s);     // scores: sx_attention_scores_bytes(B, H, Tg) of scratch
+
 // ---------------------------------------------------------------- mel frontend  (mel.hip)
 struct MelTables {                 // device tables built once per encoder
     const float* window;           // [n_fft] Hann(win_length) centred in n_fft

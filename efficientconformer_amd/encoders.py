@@ -105,8 +105,8 @@ class ConformerEncoder(nn.Module):
         # (less padding with trim_sub_batches) at the same concurrency: range i runs on stream i % sub_batch_streams, in order.
         self.sub_batch_streams: Optional[int] = None
         self.sub_batch_min = 64
-        self._exact = False                # precision = "fp32": fp32-operand mode of the library (csrc/exact.hip)
-        self._exact_packed = False
+        self._exact = 0                    # precision: 0 "bf16", 1 "fp32" (csrc/exact.hip), 2 "split" (csrc/split.hip)
+        self._exact_packed = 0
         self.stagger_ranges = False        # True: range 0's stream gets the higher priority (set by dist.ShardedEncoder)
         # Trimmed row ranges (opt-in; bench.py's default): with `sub_batches` > 1 every row range runs as ITS OWN batch, padded to its
         # longest utterance instead of the whole batch's - length bucketing inside one forward.  A length-sorted LibriSpeech-shaped
@@ -144,23 +144,27 @@ class ConformerEncoder(nn.Module):
 
     @property
     def precision(self) -> str:
-        """"bf16" (default: bf16 MFMA operands, fp32 accumulation / residual stream) or "fp32": the library's exact mode - fp32
-        operands end to end, greedy label sequences identical to the reference's CPU fp32 path wherever its top-2 logit margins
-        exceed fp32 summation noise (reference model_ctc.py:99-133); about 10x slower."""
-        return "fp32" if self._exact else "bf16"
+        """"bf16" (default: bf16 MFMA operands, fp32 accumulation / residual stream), "fp32": the library's exact mode - fp32 operands on
+        the fp32 matrix pipe end to end, greedy label sequences identical to the reference's CPU fp32 path wherever its top-2 logit margins
+        exceed fp32 summation noise (reference model_ctc.py:99-133), about 10x slower - or "split": the same schedule with every GEMM and the
+        attention products on the fp16 matrix pipe with operands split into two fp16 numbers (csrc/split.hip: products accurate to ~2^-21,
+        three MFMAs per product): the fast label-exact mode."""
+        return ("bf16", "fp32", "split")[self._exact]
 
     @precision.setter
     def precision(self, value: str):
-        if value not in ("bf16", "fp32"):
-            raise ValueError("precision must be 'bf16' or 'fp32'")
-        want = value == "fp32"
+        if value not in ("bf16", "fp32", "split"):
+            raise ValueError("precision must be 'bf16', 'fp32' or 'split'")
+        want = ("bf16", "fp32", "split").index(value)
         if want == self._exact:
             return
         self._exact = want
-        if self._packed and (self._exact_packed or not want):
+        # the fp32 tensors (and, for "split", the fp16 weight images) are uploaded at finalize: a handle packed for "split" serves all
+        # three modes, one packed for "fp32" serves "fp32" and "bf16", one packed for "bf16" only itself
+        if self._packed and self._exact_packed >= want:
             _lib.check(_lib.load().effconf_encoder_set_option(self._handle, b"exact_fp32", int(want)), "set_option(exact_fp32)")
         else:
-            self._packed = False           # the fp32 tensors are uploaded at finalize: pack again
+            self._packed = False
 
     def _param_device(self):
         return self.linear.weight.device
@@ -225,7 +229,7 @@ class ConformerEncoder(nn.Module):
             raise _lib.EffconfError("effconf_encoder_create: %s" % lib.effconf_last_error().decode())
         self._handle = h
         if self._exact:
-            _lib.check(lib.effconf_encoder_set_option(h, b"exact_fp32", 1), "set_option(exact_fp32)")
+            _lib.check(lib.effconf_encoder_set_option(h, b"exact_fp32", int(self._exact)), "set_option(exact_fp32)")
         self._exact_packed = self._exact
         for oname, oval in self._options.items():
             _lib.check(lib.effconf_encoder_set_option(h, oname.encode(), oval), "set_option(%s)" % oname)
@@ -364,7 +368,7 @@ class ConformerEncoder(nn.Module):
         host_lens = None
         if self.ragged:
             if self._exact:
-                raise RuntimeError("ragged batches run on the bf16 path (precision = 'fp32' keeps rectangular batches)")
+                raise RuntimeError("ragged batches run on the bf16 path (precision = 'fp32' / 'split' keep rectangular batches)")
             hl = x_len_host if x_len_host is not None else lens.cpu()          # without host lengths: one device sync
             host_lens = np.ascontiguousarray(np.asarray(hl.cpu() if torch.is_tensor(hl) else hl, dtype=np.int64))
             if host_lens.shape != (batch,):

@@ -63,9 +63,10 @@ def _collapse(am, lens):
     return out
 
 
+@pytest.mark.parametrize("precision", ["fp32", "split"])      # split: fp16 operand pairs on the fp16 matrix pipe (csrc/split.hip), round 4
 @pytest.mark.parametrize("tm,lens", [(47, [47, 40, 23]), (100, [100, 77, 52])])
-def test_exact_mode_every_stage_vs_oracle(tm, lens):
-    m, sd = _model("Tiny", 7, "fp32")
+def test_exact_mode_every_stage_vs_oracle(tm, lens, precision):
+    m, sd = _model("Tiny", 7, precision)
     plan = m.encoder.plan
     mel, ln = synth.make_mel(3, 80, tm, lens, seed=4321 + tm)
     trace = {}
@@ -83,28 +84,33 @@ def test_exact_mode_every_stage_vs_oracle(tm, lens):
     for k in range(len(plan.blocks)):
         for tag in ("x_ffn1", "x_mhsa", "x_conv", "out"):
             rel("blocks.%d.%s" % (k, tag), got["blocks.%d.%s" % (k, tag)], trace["blocks.%d.%s" % (k, tag)])
-    print("exact mode worst relative stage error %.2e (%s)" % (max(worst.values()), max(worst, key=worst.get)))
+    print("%s mode worst relative stage error %.2e (%s)" % (precision, max(worst.values()), max(worst, key=worst.get)))
     assert max(worst.values()) < 2e-4, worst
     assert _err(out.cpu(), ref)[0] < 2e-4
     # the mode toggles per handle without re-packing, and the bf16 path is unchanged by it
     m.encoder.precision = "bf16"
     b16, _, _ = m.encoder.forward_mel(torch.from_numpy(mel).cuda(), torch.from_numpy(ln).cuda())
     assert 1e-4 < _err(b16.cpu(), ref)[0] < 0.08
-    m.encoder.precision = "fp32"
+    m.encoder.precision = precision
     again, _, _ = m.encoder.forward_mel(torch.from_numpy(mel).cuda(), torch.from_numpy(ln).cuda())
     assert torch.equal(again, out)
+    if precision == "split":      # a handle packed for "split" serves "fp32" too, and the two label-exact modes agree far below the bf16 path's error
+        m.encoder.precision = "fp32"
+        f32, _, _ = m.encoder.forward_mel(torch.from_numpy(mel).cuda(), torch.from_numpy(ln).cuda())
+        assert _err(f32.cpu(), out.cpu())[0] < 2e-4 and _err(f32.cpu(), ref)[0] < 2e-4
 
 
-def test_exact_mode_small_label_sequences_identical_to_the_reference(golden_dir):
+@pytest.mark.parametrize("precision", ["fp32", "split"])
+def test_exact_mode_small_label_sequences_identical_to_the_reference(golden_dir, precision):
     """north_star: "CTC greedy-decode label sequences bit-identical" - the reference's own greedy output (model_ctc.py:99-133) on
     the Small golden batch, every valid frame's argmax and the collapsed sequences."""
     g = np.load(os.path.join(golden_dir, "small_B4_T1001.npz"))
-    m, sd = _model("EfficientConformerCTCSmall", int(g["weight_seed"]), "fp32")
+    m, sd = _model("EfficientConformerCTCSmall", int(g["weight_seed"]), precision)
     mel, ln = synth.make_mel(4, 80, 1001, g["mel_len"].tolist(), seed=int(g["mel_seed"]))
     out, out_len, _ = m.encoder.forward_mel(torch.from_numpy(mel).cuda(), torch.from_numpy(ln).cuda())
     assert out_len.cpu().tolist() == g["out_len"].tolist()
     mx, mean = _err(out.cpu(), torch.from_numpy(g["out"]))
-    print("exact mode, Small: encoder out err max %.2e mean %.2e" % (mx, mean))
+    print("%s mode, Small: encoder out err max %.2e mean %.2e" % (precision, mx, mean))
     assert mx < 1e-3
     logits, labels, label_len = m._head(out, out_len, want_logits=True)
     am = logits.argmax(-1).cpu().numpy()
@@ -118,10 +124,11 @@ def test_exact_mode_small_label_sequences_identical_to_the_reference(golden_dir)
     assert m.greedy_labels(torch.from_numpy(mel).cuda(), torch.from_numpy(ln).cuda(), from_mel=True) == want
 
 
+@pytest.mark.parametrize("precision", ["fp32", "split"])
 @pytest.mark.parametrize("name,tm", [("EfficientConformerCTCMedium", 1001), ("EfficientConformerCTCLarge", 1001), ("ConformerCTCLarge", 501)])
-def test_exact_mode_other_configs_argmax_identical_outside_the_fp32_noise_band(golden_dir, name, tm):
+def test_exact_mode_other_configs_argmax_identical_outside_the_fp32_noise_band(golden_dir, name, tm, precision):
     g = np.load(os.path.join(golden_dir, name + "_B2.npz"))
-    m, sd = _model(name, int(g["weight_seed"]), "fp32")
+    m, sd = _model(name, int(g["weight_seed"]), precision)
     mel, ln = synth.make_mel(2, 80, tm, g["mel_len"].tolist(), seed=int(g["mel_seed"]))
     out, out_len, _ = m.encoder.forward_mel(torch.from_numpy(mel).cuda(), torch.from_numpy(ln).cuda())
     assert out_len.cpu().tolist() == g["out_len"].tolist()
@@ -132,8 +139,8 @@ def test_exact_mode_other_configs_argmax_identical_outside_the_fp32_noise_band(g
     valid = np.arange(t_out)[None, :] < g["out_len"][:, None]
     safe = valid & (g["margin"] > EXACT_MARGIN)
     flips = int(((am != g["argmax"]) & valid).sum())
-    print("exact mode, %s: err max %.2e mean %.2e; argmax flips %d of %d valid frames (%d inside the %.0e margin band)"
-          % (name, mx, mean, flips, int(valid.sum()), int((valid & ~safe).sum()), EXACT_MARGIN))
+    print("%s mode, %s: err max %.2e mean %.2e; argmax flips %d of %d valid frames (%d inside the %.0e margin band)"
+          % (precision, name, mx, mean, flips, int(valid.sum()), int((valid & ~safe).sum()), EXACT_MARGIN))
     assert mx < 2e-3
     assert np.array_equal(am[safe], g["argmax"][safe])
     if flips == 0:
@@ -219,7 +226,7 @@ def test_no_kernel_reads_past_a_parameter_buffer(name, precision, monkeypatch):
             assert torch.equal(o, outs["0", fs]), (name, precision, fs, float(d.max()), int((d.amax(-1) > 0).sum()), [torch.equal(outs["0", fs], outs["0", f2]) for f2 in (0, 1, 2) if ("0", f2) in outs], [torch.equal(outs["1", fs], outs["1", f2]) for f2 in (0, 1, 2) if ("1", f2) in outs])
 
 
-@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+@pytest.mark.parametrize("precision", ["bf16", "fp32", "split"])
 def test_empty_row_in_a_batch_follows_the_reference(precision):
     """x_len[b] = 0 (mel entry): every key of that row is masked; the reference's additive -1e9 makes its softmax uniform over ALL
     key groups (attentions.py:698-701) and its lengths stay 0 (floor division, modules.py:243).  The other rows are unaffected."""

