@@ -228,7 +228,18 @@ int effconf_rnnt_greedy(EcRnnt* r, const float* enc_out, const int64_t* out_len,
  * "exact_fp32" (default 0): fp32-operand precision mode (csrc/exact.hip): every GEMM on fp32 MFMA, fp32 attention / convolutions,
  *   so that greedy CTC label sequences equal the reference's CPU fp32 path (model_ctc.py:99-133) wherever its top-2 logit margins
  *   exceed fp32 summation-order noise; ~10x slower than the default bf16-operand path.  Set to 1 BEFORE effconf_encoder_finalize
- *   (the fp32 tensors are uploaded there; the workspace query then covers both modes); afterwards it toggles the mode per handle. */
+ *   (the fp32 tensors are uploaded there; the workspace query then covers both modes); afterwards it toggles the mode per handle.
+ *   2 (round 4, csrc/split.hip): the same schedule and fp32 tensors with every GEMM and the attention products on the fp16 matrix pipe, each
+ *   operand split into two fp16 numbers x = h + l / 2048 (three MFMAs per product, products accurate to ~2^-21): label sequences identical to
+ *   the reference's on every golden, 5.7x the bf16 step.  Set to 2 BEFORE finalize (the split weight images are built there; such a handle then
+ *   serves 2, 1 and 0); a handle finalized with 1 refuses 2.
+ * MODE MATRIX (what a forward accepts; everything else returns an error, never a silent fallback):
+ *   bf16 path (exact_fp32 = 0): rectangular batches (effconf_encoder_forward / _forward_mel), ragged batches (effconf_encoder_forward_ragged; head
+ *     widths <= 160 padded), streaming contexts / causal configurations (EcConfig; natural Q / K / V layout, head widths <= 160 padded), attention
+ *     maps (effconf_encoder_set_attention_outputs; rectangular batches only: a ragged batch has no (B, H, Tg, Tg) rectangle to write).
+ *   label-exact modes (exact_fp32 = 1 | 2): rectangular batches, attention maps; NOT ragged batches (effconf_encoder_forward_ragged fails), NOT
+ *     streaming contexts / causal configurations (the forward fails when a context is shorter than the sequence): their frame-mixing kernels
+ *     (attention, depthwise and subsampling convolutions) index (utterance, frame) rectangles and have no band mask / causal tables. */
 int effconf_encoder_set_option(EcEncoder* enc, const char* name, int32_t value);
 
 /* ---- per-launch event profiler (bench / tuning only) --------------------------------------- */
