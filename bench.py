@@ -43,13 +43,13 @@ from efficientconformer_amd import ModelCTC, Transducer, _lib, named_config, syn
 PEAK_BF16_TFLOPS = 2500.0     # dense MFMA bf16, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 # stated tolerance of the bf16 path on LayerNorm-ed O(1) encoder outputs: 1.5x the worst measured over all configs (0.039 max / 0.008 mean;
-# rounds 1 - 3 stated 0.10 / 0.012, three times the measurement: a regression could not fail it).  split = split-bf16 operands
-# (hi.hi + hi.lo + lo.hi, ~2^-16 relative per product), fp32 = fp32 operands.
+# rounds 1 - 3 stated 0.10 / 0.012, three times the measurement: a regression could not fail it).  split = fp16 operand pairs on the fp16
+# matrix pipe (csrc/split.hip: products accurate to ~2^-21), fp32 = fp32 operands on the fp32 matrix pipe: both label-exact modes share a bound.
 TOL_BF16 = (0.06, 0.010)
 
 
 def tolerance(precision):
-    return {"bf16": TOL_BF16, "split": (2e-3, 2e-4), "fp32": (2e-4, 2e-5)}[precision]
+    return {"bf16": TOL_BF16, "split": (2e-4, 2e-5), "fp32": (2e-4, 2e-5)}[precision]      # measured: split 5.3e-6 / 9.7e-7, fp32 4.8e-6 / 7.6e-7
 
 
 PROF_CLASSES = ["mel", "subsample_conv", "gemm_ffn", "gemm_other", "layernorm", "attention", "dwconv", "misc"]

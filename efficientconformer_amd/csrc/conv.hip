@@ -15,7 +15,8 @@ constexpr int SUB_TT = 8;     // output frames per workgroup
 
 __global__ __launch_bounds__(256) void subsample_conv_kernel(const float* __restrict__ mel, int F, int Tm, int T1,
                                                              const float* __restrict__ w9, const float* __restrict__ bias,
-                                                             int C, bf16_t* out, int ldo, const int* __restrict__ rag_tm) {
+                                                             int C, bf16_t* out, int ldo, const int* __restrict__ rag_tm,
+                                                             const int* __restrict__ rag_off, const int* __restrict__ rag_t1) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TW = 2 * SUB_TT + 1;                 // input frames needed: 2t-1 .. 2t+1
     float* sm = reinterpret_cast<float*>(smem);        // [F + 1][TW + 1]  row 0 = frequency -1 (zero pad)
@@ -25,6 +26,12 @@ __global__ __launch_bounds__(256) void subsample_conv_kernel(const float* __rest
     const int tid = threadIdx.x;
     const int F2 = F / 2;
     const int tmb = rag_tm ? rag_tm[b] : Tm;          // ragged batch: the conv's zero padding starts at the utterance's own last mel frame
+    // rag_off != null (round 4): the rows go straight into the RAGGED row space - utterance b owns rows [rag_off[b], rag_off[b + 1]) (its
+    // rag_t1[b] frames + the group-padding rows, written as zeros) - and the tiles behind an utterance's own end do nothing: no pad frames are
+    // computed or written, the Linear runs on the valid rows only and the gather pass is gone (Large: 31 % of the rectangle was padding).
+    int t1b = T1, tpb = T1;
+    size_t orow0 = (size_t)b * T1;
+    if (rag_off) { t1b = rag_t1[b]; tpb = rag_off[b + 1] - rag_off[b]; orow0 = (size_t)rag_off[b]; if (t0 >= tpb) return; }
     for (int i = tid; i < (F + 1) * TW; i += 256) {
         const int fr = i / TW, tc = i - fr * TW;
         const int f = fr - 1, t = 2 * t0 - 1 + tc;
@@ -42,7 +49,7 @@ __global__ __launch_bounds__(256) void subsample_conv_kernel(const float* __rest
     // looped frames outermost and fetched taps and window per output: 19 LDS reads per output, 70 % of the wave cycles in LDS waits
     // (profiles/r2_03_large_sq_counters.txt), 1.03 ms per launch on Large's C = 360 front end.
     const int pairs = C * F2 / 2;                      // F2 is even for F = 80
-    const int nt = (T1 - t0) < SUB_TT ? (T1 - t0) : SUB_TT;
+    const int nt = (tpb - t0) < SUB_TT ? (tpb - t0) : SUB_TT;
     for (int q = tid; q < pairs; q += 256) {
         const int c = q / (F2 / 2), f = 2 * (q - c * (F2 / 2));
         float w[10];
@@ -68,10 +75,10 @@ __global__ __launch_bounds__(256) void subsample_conv_kernel(const float* __rest
                     if (i >= 2) acc[1][tl] = fmaf(w[(i - 2) * 3 + j], row[2 * tl + j], acc[1][tl]);
                 }
         }
-        bf16_t* ocol = out + ((size_t)b * T1 + t0) * ldo + c * F2 + f;
+        bf16_t* ocol = out + (orow0 + t0) * ldo + c * F2 + f;
 #pragma unroll
         for (int tl = 0; tl < SUB_TT; ++tl)
-            if (tl < nt) *reinterpret_cast<uint32_t*>(ocol + (size_t)tl * ldo) = pack_bf2(swishf_(acc[0][tl]), swishf_(acc[1][tl]));
+            if (tl < nt) *reinterpret_cast<uint32_t*>(ocol + (size_t)tl * ldo) = t0 + tl < t1b ? pack_bf2(swishf_(acc[0][tl]), swishf_(acc[1][tl])) : 0u;
     }
 }
 
@@ -191,12 +198,14 @@ int launch_dw_t(const bf16_t* g, int B, int T, int To, int C, int ld, const floa
 }  // namespace
 
 int launch_subsample_conv(const float* mel, int B, int F, int Tm, int T1, const float* w9, const float* bias, int C,
-                          bf16_t* out, int ldo, hipStream_t s, const int* rag_tm) {
+                          bf16_t* out, int ldo, hipStream_t s, const int* rag_tm, const RaggedRows* rg) {
     if (B <= 0 || T1 <= 0) return 0;
     if (F % 4 || (C * (F / 2)) % 2) return -2;
-    const int tiles = (T1 + SUB_TT - 1) / SUB_TT;
+    if (rg && (!rag_tm || !rg->off || !rg->len)) return -2;
+    const int tiles = (T1 + SUB_TT - 1) / SUB_TT;      // ragged rows: T1 = an upper bound of every utterance's padded row count
     const size_t lds = ((size_t)(F + 1) * (2 * SUB_TT + 2) + (size_t)C * 10) * sizeof(float);
-    hipLaunchKernelGGL(subsample_conv_kernel, dim3(B * tiles), dim3(256), lds, s, mel, F, Tm, T1, w9, bias, C, out, ldo, rag_tm);
+    hipLaunchKernelGGL(subsample_conv_kernel, dim3(B * tiles), dim3(256), lds, s, mel, F, Tm, T1, w9, bias, C, out, ldo, rag_tm,
+                       rg ? rg->off : nullptr, rg ? rg->len : nullptr);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -93,6 +93,29 @@ __global__ __launch_bounds__(256) void neighbour_kernel(float* __restrict__ buf,
         }
         acc += c[0] + c[15];
     }
+    else if constexpr (KIND == 11 || KIND == 12 || KIND == 13 || KIND == 14) {
+        // matrix-pipe rate probes (tools/mfma_rate_probe.py): 11 / 12 = 32x32x16 bf16 / f16 on FOUR independent accumulators, 13 / 14 = the same on
+        // ONE accumulator (a dependent chain); iters * 16 MFMAs per wave
+        typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+        f32x16 c[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) c[j][r] = 0.f;
+        bf16x8 a, b;
+        f16x8_t ah, bh;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { a[r] = (__bf16)(0.001f * (tid + r)); b[r] = (__bf16)(0.002f * (tid - r)); ah[r] = (_Float16)(0.001f * (tid + r)); bh[r] = (_Float16)(0.002f * (tid - r)); }
+        for (int it = 0; it < iters * 4; ++it) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = (KIND >= 13) ? 0 : j;
+                if constexpr (KIND == 11 || KIND == 13) c[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c[k], 0, 0, 0);
+                else c[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c[k], 0, 0, 0);
+            }
+        }
+        acc += c[0][0] + c[1][15] + c[2][3] + c[3][7];
+    }
     if (acc == 123.456f) buf[0] = acc;    // keeps the work alive
 }
 
@@ -234,6 +257,10 @@ int launch_debug_neighbour(int kind, int blocks, int lds_bytes, int iters, float
         case 8: return launch_n<8>(blocks, lds_bytes, iters, buf, n, s);
         case 9: return launch_n<9>(blocks, lds_bytes, iters, buf, n, s);
         case 10: return launch_n<10>(blocks, lds_bytes, iters, buf, n, s);
+        case 11: return launch_n<11>(blocks, lds_bytes, iters, buf, n, s);
+        case 12: return launch_n<12>(blocks, lds_bytes, iters, buf, n, s);
+        case 13: return launch_n<13>(blocks, lds_bytes, iters, buf, n, s);
+        case 14: return launch_n<14>(blocks, lds_bytes, iters, buf, n, s);
     }
     return -2;
 }

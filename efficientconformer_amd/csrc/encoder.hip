@@ -404,7 +404,8 @@ Workspace make_workspace(const EcEncoder* e, const Shapes& s, bool from_audio) {
     const bool rag_unfused = s.ragged && !(e->fuse_subsample == 2 && e->lin_rs);        // (s.Tm = the input's row pitch in ragged batches)
     size_t T1r = (size_t)s.T1;
     if (s.ragged) { T1r = (size_t)s.Tm; for (int i = 0; i < e->cfg.sub_layers; ++i) T1r = (T1r - 1) / 2 + 1; }      // rows per utterance of the rectangular image
-    w.sub = take(s.ragged && !rag_unfused ? 0 : B * T1r * C * F * 2);      // scratch of the unfused front ends
+    // scratch of the unfused front ends; ragged rows: every utterance's frames rounded up to the first block's group size
+    w.sub = take(s.ragged && !rag_unfused ? 0 : B * (T1r + (s.ragged ? e->blocks[0].group_size - 1 : 0)) * C * F * 2);
     w.xrect = take(rag_unfused ? B * T1r * e->blocks[0].dim_model * 4 : 0);
     {   // two-layer subsampler: channel-last layer-1 activation [B][F/2][T after layer 1][Cp]
         const size_t tl1 = (s.Tm - 1) / 2 + 1;
@@ -622,13 +623,15 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
             // wide front ends (Large: 360 filters): conv (zero padding at every utterance's own last mel frame) + Linear on the RECTANGULAR
             // (B, T1 of the longest) rows, then the valid rows are gathered into the ragged row space (pad rows are computed and dropped:
             // the subsampler is a few percent of the step)
+            // Round 4: the conv writes the RAGGED rows itself (tiles behind an utterance's own end exit; group-padding rows = zeros) and the
+            // Linear runs on those rows only - until round 3 both ran on the (B, longest) rectangle (24 % padding on the bench batch) and a
+            // gather pass copied the valid rows.  Group-padding rows of x = the Linear's bias (finite; no kernel mixes them into valid rows).
             bf16_t* sub = reinterpret_cast<bf16_t*>(ws + w.sub);
-            float* xrect = reinterpret_cast<float*>(ws + w.xrect);
             const int T1r = (s.Tm - 1) / 2 + 1;            // rows per utterance of the rectangular image (pitch of the input)
-            { PROF(PC_SUBCONV, 2.0 * 9 * B * T1r * (double)Ksub, (double)B * c.n_mels * s.Tm * 4 + (double)B * T1r * Ksub * 2);
-              EC_TRY(launch_subsample_conv(mel, B, c.n_mels, s.Tm, T1r, e->sub_w9, e->sub_b, C0, sub, Ksub, st, mel_len)); }
-            EC_TRY(run_gemm(e, PC_GEMM_OTHER, st, sub, Ksub, B * T1r, e->lin, EPI_F32, xrect, e->lin.N));
-            { PROF(PC_MISC, 0, (double)s.Min[0] * e->lin.N * 8); EC_TRY(launch_gather_rows(xrect, e->lin.N, T1r, r0, x, st)); }
+            const int Tcover = T1r + e->blocks[0].group_size - 1;      // >= every utterance's frames rounded up to the group size
+            { PROF(PC_SUBCONV, 2.0 * 9 * (double)s.Min[0] * Ksub, (double)B * c.n_mels * s.Tm * 4 + (double)s.Min[0] * Ksub * 2);
+              EC_TRY(launch_subsample_conv(mel, B, c.n_mels, s.Tm, Tcover, e->sub_w9, e->sub_b, C0, sub, Ksub, st, mel_len, &r0)); }
+            EC_TRY(run_gemm(e, PC_GEMM_OTHER, st, sub, Ksub, (int)s.Min[0], e->lin, EPI_F32, x, e->lin.N));
         }
     } else {
         EC_TRY(run_subsample_linear(e, st, mel, B, s.Tm, s.T1, reinterpret_cast<bf16_t*>(ws + w.sub), reinterpret_cast<bf16_t*>(ws + w.sub1), x));
@@ -1386,8 +1389,8 @@ int effconf_encoder_finalize(EcEncoder* e) {
         }
         e->xsplit.clear();
         if (e->exact_split) {
-            // every 2-D weight (nn.Linear [N][K], 1x1 Conv1d [N][K][1]) as two fp16 images h = fp16(w), l = fp16((w - h) * 2048), rows padded
-            // with zeros to whole 32-wide k-tiles; the three attention projections of a block additionally stacked (q | k | v)
+            // every 2-D weight (nn.Linear [N][K], 1x1 Conv1d [N][K][1]) as two fp16 images h = fp16(w), l = fp16((w - h) * 2048), K padded
+            // with zeros to whole 32-wide k-tiles and stored k-tile major; the three attention projections of a block additionally stacked (q | k | v)
             auto half_bits = [](float f) { _Float16 h = (_Float16)f; uint16_t u; memcpy(&u, &h, 2); return u; };
             auto clampf = [](float f) { return f > 65000.f ? 65000.f : (f < -65000.f ? -65000.f : f); };
             auto add_split = [&](const std::string& prefix, const std::vector<const float*>& rows, int K) {
@@ -1397,8 +1400,9 @@ int effconf_encoder_finalize(EcEncoder* e) {
                     for (int k = 0; k < K; ++k) {
                         const float wv = rows[n][k];
                         const _Float16 h = (_Float16)clampf(wv);
-                        hi[(size_t)n * ldh + k] = half_bits((float)h);
-                        lo[(size_t)n * ldh + k] = half_bits(clampf((wv - (float)h) * 2048.0f));
+                        const size_t at = ((size_t)(k / 32) * N + n) * 32 + k % 32;       // k-tile major (kernels.h: SxGemmParams)
+                        hi[at] = half_bits((float)h);
+                        lo[at] = half_bits(clampf((wv - (float)h) * 2048.0f));
                     }
                 e->xsplit[prefix] = EcEncoder::SplitW{upload(e, hi), upload(e, lo), ldh};
             };

@@ -172,6 +172,44 @@ __global__ __launch_bounds__(256) void ex_dwconv_kernel(const float* __restrict_
     }
 }
 
+// The same depthwise convolution with the input window of TO consecutive output frames of one channel held in registers: S (TO - 1) + KS
+// loads for TO outputs instead of KS per output (2.9 ms -> per Small step of the label-exact modes for the kernel above: 15 dependent L2 round
+// trips per output).  Consecutive lanes <-> consecutive channels (coalesced); taps in registers; every output sums its taps in ascending order
+// with fmaf(w, 0, acc) = acc for the taps the kernel above skips: bit-identical to it.
+template <int KS, int S>
+__global__ __launch_bounds__(256) void ex_dwconv_tiled_kernel(const float* __restrict__ g, int B, int T, int To, int C, const float* __restrict__ w_kc,
+                                                              const float* __restrict__ bias, float* __restrict__ out) {
+    constexpr int TO = 8, W = S * (TO - 1) + KS, HALF = (KS - 1) / 2;
+    const int ntile = (To + TO - 1) / TO;
+    const long long total = (long long)B * ntile * C;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int c = (int)(idx % C);
+        const long long q = idx / C;
+        const int tile = (int)(q % ntile), b = (int)(q / ntile);
+        const int to0 = tile * TO, t0 = S * to0 - HALF;
+        const float* gp = g + (size_t)b * T * C + c;
+        float x[W], w[KS];
+#pragma unroll
+        for (int i = 0; i < W; ++i) {
+            const int t = t0 + i;
+            const bool ok = t >= 0 && t < T;
+            x[i] = ok ? gp[(size_t)(ok ? t : 0) * C] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < KS; ++j) w[j] = w_kc[(size_t)j * C + c];
+        const float bz = bias[c];
+#pragma unroll
+        for (int o = 0; o < TO; ++o) {
+            if (to0 + o >= To) break;
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < KS; ++j) acc = fmaf(w[j], x[S * o + j], acc);
+            const float y = acc + bz;
+            out[((size_t)b * To + to0 + o) * C + c] = y * ex_sigmoid(y);
+        }
+    }
+}
+
 // one wave per (utterance, head, grouped query row): S = ((Q+u) K^T + (Q+v) E[Tg-1+j-i]^T) / sqrt(d), additive -1e9 key mask,
 // softmax, P V  (attentions.py:549-718; closed form SURVEY.md 8a-6)
 __global__ __launch_bounds__(64) void ex_attention_kernel(ExAttnParams p) {
@@ -393,6 +431,13 @@ int launch_ex_glu(const float* in, long long M, int N, float* out, hipStream_t s
 }
 
 int launch_ex_dwconv(const float* g, int B, int T, int To, int C, const float* w_kc, const float* bias, int ks, int stride, float* out, hipStream_t s) {
+    {
+        const int grid = grid_for((long long)B * ((To + 7) / 8) * C);
+#define EX_DW_CASE(K, S) if (ks == K && stride == S) { hipLaunchKernelGGL((ex_dwconv_tiled_kernel<K, S>), dim3(grid), dim3(256), 0, s, g, B, T, To, C, w_kc, bias, out); \
+                                                       return hipGetLastError() == hipSuccess ? 0 : -1; }
+        EX_DW_CASE(15, 1) EX_DW_CASE(15, 2) EX_DW_CASE(31, 1) EX_DW_CASE(31, 2)
+#undef EX_DW_CASE
+    }
     hipLaunchKernelGGL(ex_dwconv_kernel, dim3(grid_for((long long)B * To * C)), dim3(256), 0, s, g, B, T, To, C, w_kc, bias, ks, stride, out);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

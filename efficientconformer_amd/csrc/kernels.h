@@ -165,8 +165,10 @@ int launch_attn_pad_rows_ragged(bf16_t* qu, bf16_t* kh, bf16_t* vt, const float*
 // ---------------------------------------------------------------- convolutions  (conv.hip)
 // mel (B, F, Tm) f32 -> (B*T1, C*F/2) bf16, feature index c*(F/2)+f; 3x3 s2 p1 conv (Cin=1) + folded BN + Swish
 // rag_tm != null (dev [B]): per-utterance mel frames (the zero padding starts there); rows stay rectangular (b, t < T1)
+// rg != null (with rag_tm): rows written straight into the ragged row space (utterance b: rows rg->off[b] .., rg->len[b] frames + zero
+// group-padding rows); T1 is then only an upper bound of an utterance's padded row count (tiles behind an utterance's end exit)
 int launch_subsample_conv(const float* mel, int B, int F, int Tm, int T1, const float* w9, const float* bias, int C,
-                          bf16_t* out, int ldo, hipStream_t s, const int* rag_tm = nullptr);
+                          bf16_t* out, int ldo, hipStream_t s, const int* rag_tm = nullptr, const RaggedRows* rg = nullptr);
 // rectangular fp32 rows (b, t) of B x t_pitch -> the ragged row space (row off[b] + t for t < len[b]; group-padding rows = zeros)
 int launch_gather_rows(const float* x, int D, int t_pitch, const RaggedRows& rg, float* out, hipStream_t s);
 // fused subsampling conv + Linear (sublinear.hip): mel (B, F, Tm) -> out fp32 (B*T1, N); W packed in (f-chunk, channel, f) K order
@@ -216,8 +218,8 @@ struct ExAttnParams {              // natural-layout fp32 Q, K, V [B*Tp][D], E [
 int launch_ex_attention(const ExAttnParams& p, hipStream_t s);
 
 // ---------------------------------------------------------------- split-precision mode  (split.hip): fp32 tensors, fp16 (h, l) operand pairs on the matrix pipe
-struct SxGemmParams {              // the ExGemmParams contract with W replaced by its two fp16 images [N][ldh] (ldh = round_up(K, 32), zero padded)
-    ExGemmParams g;
+struct SxGemmParams {              // the ExGemmParams contract with W replaced by its two fp16 images, k-tile major: [ldh / 32][N][32] (ldh = round_up(K, 32),
+    ExGemmParams g;                // zero padded): element (n, k) at ((k / 32) * N + n) * 32 + k % 32
     const uint16_t *Whi, *Wlo; int ldh;
 };
 int launch_sx_gemm(const SxGemmParams& p, hipStream_t s);

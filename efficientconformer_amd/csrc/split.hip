@@ -11,7 +11,8 @@
 // subsampling convolutions, residual stream) stays fp32 as in exact.hip; reference: models/encoders.py:97-142, blocks.py:119-137,
 // attentions.py:549-718, modules.py:385-395, 511-525.
 //
-//   sx_gemm_kernel    C = epi(A W^T + b): A fp32 (split while it is staged into LDS), W pre-split at finalize into two fp16 images;
+//   sx_gemm_kernel    C = epi(A W^T + b): A fp32 (split while it is staged into LDS), W pre-split at finalize into two fp16 images packed
+//                     k-tile major ([K / 32][N][32]: with row-major images a k-tile touched half a cache line per row);
 //                     128 x 128 x 32 tiles, 4 waves x (2 x 2) 32 x 32 MFMA tiles, register-staged prefetch of the next k-tile.
 //   sx_scores_kernel  one 64 x 64 (query, key) tile of S = ((Q + u) K^T + rel_to_abs((Q + v) E^T)) / sqrt(d) + mask: the positional product
 //                     on the 127-row band the tile touches, realigned through LDS (PE[i][j - i + 63]); scores go to a global fp32 buffer.
@@ -74,7 +75,11 @@ __device__ __forceinline__ float4 ld4u(const float* p) {          // 16-byte glo
 }
 
 // ------------------------------------------------------------------------------------------------ GEMM
-constexpr int SBM = 128, SBN = 128, SBK = 32, SROW = SBK * 2 + 16;     // 80-byte rows: the 16-byte fragment reads of 16 consecutive rows hit disjoint banks
+constexpr int SBM = 128, SBN = 128, SBK = 32, SROW = SBK * 2;          // 64-byte rows, the 16-byte chunk index XOR-ed with (row >> 2) & 3: rows r, r + 4, r + 8,
+// r + 12 start on the same banks and get four different chunk positions, so the fragment reads of a 16-lane group cover all 64 banks once.
+// (80-byte padded rows were conflict-free too, but two 80 KiB stage pairs are exactly the CU's 160 KiB: the second workgroup per CU did not
+// get in - 64 KiB leaves room for it.)
+__device__ __forceinline__ int sx_off(int row, int chunk) { return row * SROW + ((chunk ^ ((row >> 2) & 3)) << 4); }
 
 constexpr int SX_STAGE = 4 * SBM * SROW;                           // bytes of one LDS stage: A_hi | A_lo | W_hi | W_lo, [128][SROW] each
 constexpr int SX_CLD = 132;                                        // floats per row of the epilogue's staging tile
@@ -84,7 +89,9 @@ __global__ __launch_bounds__(256, 2) void sx_gemm_kernel(const SxGemmParams q) {
     extern __shared__ __attribute__((aligned(16))) char sm[];       // two stages (double buffer: one barrier per k-tile)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, kh = lane >> 5;
-    const int m0 = blockIdx.x * SBM, n0 = blockIdx.y * SBN;
+    // N tiles fastest: the workgroups that are resident together share their A rows (read once from HBM, then L2 hits) and walk the small W
+    // images; with M fastest every column of N tiles re-read the whole of A from HBM / MALL (2.3 GB per Large FFN GEMM at 3.3 TB/s: the bound)
+    const int m0 = blockIdx.y * SBM, n0 = blockIdx.x * SBN;
     // staging roles: A rows ar + 32 i (float4 at column akq of the k-tile), W rows wr + 64 i (8 halfs at wch) of both images
     const int ar = tid >> 3, akq = (tid & 7) * 4, wr = tid >> 2, wch = (tid & 3) * 8;
     // 32-bit element offsets from the (wave-uniform) base pointers instead of 64-bit pointers per row: 6 registers instead of 16 - the kernel
@@ -101,7 +108,7 @@ __global__ __launch_bounds__(256, 2) void sx_gemm_kernel(const SxGemmParams q) {
     for (int i = 0; i < 2; ++i) {
         int bn = n0 + wr + 64 * i;
         bn = bn < p.N ? bn : p.N - 1;
-        wo[i] = (uint32_t)((size_t)bn * q.ldh + wch);
+        wo[i] = (uint32_t)(bn * SBK + wch);              // images are packed k-tile major: [K / 32][N][32] - a k-tile's slice of 16 consecutive rows is 1 KiB contiguous
     }
     f32x16 acc[2][2], acx[2][2];
 #pragma unroll
@@ -116,18 +123,21 @@ __global__ __launch_bounds__(256, 2) void sx_gemm_kernel(const SxGemmParams q) {
     f4v ra[4];
     u4v rh[2], rl[2];
     float keep = 1.0f;
-    auto gload = [&](int k0) __attribute__((always_inline)) {
+    auto gload_a = [&](int k0) __attribute__((always_inline)) {
         const bool ok = k0 + akq < p.K;                          // K % 4 == 0: a float4 is inside or outside as a whole
         const int ko = ok ? k0 : 0;                              // always a valid address (the row's own first k-tile: finite data), scaled to zero
         keep = ok ? 1.0f : 0.0f;                                 // applied when the registers are published (a use here would wait for the loads inside the loop); branch-free: the loop body stays ONE basic block
 #pragma unroll
         for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const f4v*>(p.A + (ao[i] + (uint32_t)ko));
+    };
+    auto gload_w = [&](int k0) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            rh[i] = *reinterpret_cast<const u4v*>(q.Whi + (wo[i] + (uint32_t)k0));
-            rl[i] = *reinterpret_cast<const u4v*>(q.Wlo + (wo[i] + (uint32_t)k0));
+            rh[i] = *reinterpret_cast<const u4v*>(q.Whi + (wo[i] + (uint32_t)k0 * (uint32_t)p.N));       // k-tile k0 / 32 starts at (k0 / 32) * N * 32
+            rl[i] = *reinterpret_cast<const u4v*>(q.Wlo + (wo[i] + (uint32_t)k0 * (uint32_t)p.N));
         }
     };
+    auto gload = [&](int k0) __attribute__((always_inline)) { gload_a(k0); gload_w(k0); };
     typedef uint32_t u2v __attribute__((ext_vector_type(2)));
     u2v ph[4], pl[4];                                            // the A registers of the next k-tile, split
     auto split_regs = [&]() __attribute__((always_inline)) {
@@ -142,29 +152,29 @@ __global__ __launch_bounds__(256, 2) void sx_gemm_kernel(const SxGemmParams q) {
     auto write_regs = [&](char* st) __attribute__((always_inline)) {     // split A registers + W image registers -> LDS stage
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int o = (ar + 32 * i) * SROW + akq * 2;
+            const int o = sx_off(ar + 32 * i, akq >> 3) + (akq & 7) * 2;
             *reinterpret_cast<u2v*>(st + o) = ph[i];
             *reinterpret_cast<u2v*>(st + SBM * SROW + o) = pl[i];
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int o = (wr + 64 * i) * SROW + wch * 2;
+            const int o = sx_off(wr + 64 * i, wch >> 3);
             *reinterpret_cast<u4v*>(st + 2 * SBM * SROW + o) = rh[i];
             *reinterpret_cast<u4v*>(st + 3 * SBM * SROW + o) = rl[i];
         }
     };
     auto compute = [&](const char* st, int ks) __attribute__((always_inline)) {
-        const int ko = (ks * 16 + 8 * kh) * 2;
+        const int kc = ks * 2 + kh;                              // 16-byte chunk of the k-tile row
         f16x8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int o = (wm * 64 + 32 * i + lr) * SROW + ko;
+            const int o = sx_off(wm * 64 + 32 * i + lr, kc);
             ah[i] = *reinterpret_cast<const f16x8*>(st + o);
             al[i] = *reinterpret_cast<const f16x8*>(st + SBM * SROW + o);
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int o = (wn * 64 + 32 * j + lr) * SROW + ko;
+            const int o = sx_off(wn * 64 + 32 * j + lr, kc);
             bh[j] = *reinterpret_cast<const f16x8*>(st + 2 * SBM * SROW + o);
             bl[j] = *reinterpret_cast<const f16x8*>(st + 3 * SBM * SROW + o);
         }
@@ -189,12 +199,13 @@ __global__ __launch_bounds__(256, 2) void sx_gemm_kernel(const SxGemmParams q) {
     __syncthreads();
     for (int t = 0; t + 1 < nk; ++t) {                           // steady state: one basic block (no branch inside)
         const char* st = sm + (t & 1) * SX_STAGE;
+        const int t2 = t + 2 < nk ? t + 2 : nk - 1;              // past the end: the last k-tile again (never published)
         compute(st, 0);
         split_regs();
+        gload_a(t2 * SBK);                                       // the A registers are free as soon as they are split: a whole iteration for these loads to land
         compute(st, 1);
         write_regs(sm + ((t + 1) & 1) * SX_STAGE);
-        const int t2 = t + 2 < nk ? t + 2 : nk - 1;              // past the end: the last k-tile again (never published)
-        gload(t2 * SBK);
+        gload_w(t2 * SBK);
 #pragma unroll
         for (int g = 0; g < 12; ++g) {                           // one matrix instruction (32 cycles in the pipe), then a few of the split's VALU instructions
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -562,7 +573,8 @@ int launch_sx_gemm(const SxGemmParams& q, hipStream_t s) {
     if (p.N % 4 || p.ldc % 4 || (p.epi == 2 && p.ldr % 4) || (p.split_cols > 0 && p.split_cols % 4)) return -2;      // 16-byte row pieces in the epilogue
     static LdsAttr attr;
     ensure_dynamic_lds(reinterpret_cast<const void*>(&sx_gemm_kernel), 2 * SX_STAGE, attr);
-    hipLaunchKernelGGL(sx_gemm_kernel, dim3((p.M + SBM - 1) / SBM, (p.N + SBN - 1) / SBN), dim3(256), 2 * SX_STAGE, s, q);
+    if ((p.M + SBM - 1) / SBM > 65535) return -2;
+    hipLaunchKernelGGL(sx_gemm_kernel, dim3((p.N + SBN - 1) / SBN, (p.M + SBM - 1) / SBM), dim3(256), 2 * SX_STAGE, s, q);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

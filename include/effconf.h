@@ -278,8 +278,8 @@ int effconf_debug_gemm(const uint16_t* a, int32_t lda, const uint16_t* w, int32_
  * 3 v_log/v_exp_f32, 4 v_mul/v_add_f32, 5 integer, 6 wave-local LDS exchange); out dev f32 (blocks * 256 * 16). */
 int effconf_debug_victim(int32_t kind, int32_t blocks, int32_t iters, float* out, void* stream);
 /* One Linear layer on the split-precision GEMM kernel alone (csrc/split.hip; kernel-level tests and tools/sx_gemm_bench.py): c = epilogue(a w^T
- * + bias) with a fp32 [m][lda], w given as its two fp16 images h = fp16(w), l = fp16((w - h) * 2048), each [n][ldh] (ldh = round_up(k, 32), zero
- * padded), products accurate to ~2^-21.  epi: 0 plain, 1 Swish, 2 c = r + alpha * (...).  All pointers are device pointers. */
+ * + bias) with a fp32 [m][lda], w given as its two fp16 images h = fp16(w), l = fp16((w - h) * 2048), each packed k-tile major [ldh / 32][n][32]
+ * (ldh = round_up(k, 32), zero padded: element (row, col) at ((col / 32) * n + row) * 32 + col % 32), products accurate to ~2^-21.  epi: 0 plain, 1 Swish, 2 c = r + alpha * (...).  All pointers are device pointers. */
 int effconf_debug_sx_gemm(const float* a, int32_t lda, const uint16_t* w_hi, const uint16_t* w_lo, int32_t ldh, const float* bias, int32_t m, int32_t n,
                           int32_t k, int32_t epi, float* c, int32_t ldc, const float* r, int32_t ldr, float alpha, void* stream);
 /* One idle wave that occupies `stream` for `microseconds` (tools/overlap_probe.py: the duration of an xGMI transfer a single GPU cannot make). */

@@ -54,3 +54,40 @@ def test_split_bf16_head_reads_inside_its_weight_images_for_any_vocabulary(name,
         assert torch.equal(l2.argmax(-1)[safe], l1.argmax(-1)[safe])
         del m
     assert torch.equal(res["0"][0], res["1"][0]) and torch.equal(res["0"][1], res["1"][1]) and torch.equal(res["0"][2], res["1"][2])
+
+
+# ------------------------------------------------------------------ split-precision GEMM kernel alone (csrc/split.hip)
+@pytest.mark.parametrize("m,n,k,epi", [(333, 308, 52, 1), (1000, 100, 100, 0), (129, 4, 4, 2), (128, 128, 32, 0), (4097, 360, 120, 0), (2500, 120, 480, 2),
+                                       (777, 672, 168, 1), (64, 2880, 720, 1)])
+def test_split_gemm_kernel_alone_vs_float64(m, n, k, epi):
+    """sx_gemm_kernel through effconf_debug_sx_gemm: c = epilogue(a w^T + b) with the weight given as its two fp16 images (h = fp16(w),
+    l = fp16((w - h) * 2048)) against a float64 product - M / N / K tails (K % 32 != 0: zero-filled k-tile, N % 128, M % 128), one k-tile,
+    every epilogue (plain, Swish, residual).  Products are accurate to ~2^-21: relative error of the result below 2e-6 (measured 1 - 8e-7);
+    nothing outside the [m][n] block is written."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("sx_gemm_bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "sx_gemm_bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    lib = _lib.load()
+    g = np.random.default_rng(7 * m + n + k)
+    a = g.standard_normal((m, k), dtype=np.float32)
+    w = (g.standard_normal((n, k), dtype=np.float32) / np.sqrt(k)).astype(np.float32)
+    bias = (0.1 * g.standard_normal(n)).astype(np.float32)
+    r = g.standard_normal((m, n), dtype=np.float32)
+    hi, lo, ldh = mod.split_images(w)
+    ad, hd, ld, bd, rd = (torch.from_numpy(x).cuda() for x in (a, hi.view(np.int16), lo.view(np.int16), bias, r))
+    ldc = n + 8
+    c = torch.full((m + 3, ldc), 7.0, device="cuda")            # guard rows / columns: must stay untouched
+    _lib.check(lib.effconf_debug_sx_gemm(ad.data_ptr(), k, hd.data_ptr(), ld.data_ptr(), ldh, bd.data_ptr(), m, n, k, epi, c.data_ptr(), ldc,
+                                         rd.data_ptr(), n, C.c_float(0.5), torch.cuda.current_stream().cuda_stream), "sx_gemm")
+    torch.cuda.synchronize()
+    ref = a.astype(np.float64) @ w.astype(np.float64).T + bias
+    if epi == 1:
+        ref = ref / (1.0 + np.exp(-ref))
+    elif epi == 2:
+        ref = r + 0.5 * ref
+    got = c.cpu().numpy()
+    err = float(np.abs(got[:m, :n] - ref).max() / max(np.abs(ref).max(), 1.0))
+    print("sx_gemm %dx%dx%d epi %d: rel err %.2e" % (m, n, k, epi, err))
+    assert err < 2e-6
+    assert np.all(got[m:] == 7.0) and np.all(got[:, n:] == 7.0)

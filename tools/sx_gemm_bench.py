@@ -18,14 +18,16 @@ from efficientconformer_amd import _lib  # noqa: E402
 
 
 def split_images(w):
-    """h = fp16(w), l = fp16((w - h) * 2048), rows zero padded to a multiple of 32 columns (what effconf_encoder_finalize builds)."""
+    """h = fp16(w), l = fp16((w - h) * 2048), columns zero padded to a multiple of 32 and stored k-tile major (what effconf_encoder_finalize builds)."""
     n, k = w.shape
     ldh = (k + 31) // 32 * 32
     h = w.astype(np.float16)
     l = ((w - h.astype(np.float32)) * 2048.0).astype(np.float16)
     hi = np.zeros((n, ldh), np.float16); lo = np.zeros((n, ldh), np.float16)
     hi[:, :k] = h; lo[:, :k] = l
-    return hi, lo, ldh
+    # k-tile major: [ldh / 32][n][32]
+    tile = lambda a: np.ascontiguousarray(a.reshape(n, ldh // 32, 32).transpose(1, 0, 2))
+    return tile(hi), tile(lo), ldh
 
 
 def run(m, n, k, epi, reps=20, check=True):
