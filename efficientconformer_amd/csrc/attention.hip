@@ -576,7 +576,7 @@ int launch_attn_pad_rows(const GemmParams& p, int B, hipStream_t s) {
 // softmax of every block, (B, H, Tg, Tg)).  No caller of the hot path consumes them, so they are an opt-in side output
 // (effconf_encoder_set_attention_outputs): one wave per (query row, head, utterance) recomputes the scores in fp32 from the bf16 Q + u, K, E the
 // attention kernel reads, with the reference's additive -1e9 masks (a fully masked row is the uniform 1 / Tg, as there), and writes the
-// normalised row.  Rectangular batches; either Q / K / V layout (the strides of AttnParams).
+// normalised row.  Either Q / K / V layout (the strides of AttnParams); ragged batches (natural layout) since round 4.
 namespace {
 __global__ __launch_bounds__(64) void attention_probs_kernel(const AttnParams p, float* __restrict__ att) {
     extern __shared__ float pm[];
@@ -584,8 +584,25 @@ __global__ __launch_bounds__(64) void attention_probs_kernel(const AttnParams p,
     float* qv = pm + p.dpad;
     float* sc = pm + 2 * p.dpad;
     const int i = blockIdx.x, h = blockIdx.y, b = blockIdx.z, lane = threadIdx.x;
-    const int Tg = p.Tg, d = p.d;
-    const bf16_t* qrow = p.qu + (size_t)b * p.q_bstride + (size_t)h * p.q_hstride + (size_t)i * p.q_rowstride;
+    const int d = p.d;
+    // Ragged batch (round 4; natural layout): utterance b has its own grouped length, its rows start at rag_off[b], its positional rows are the
+    // last 2 Tg - 1 of the table built for the longest utterance (attention2.hip).  The maps keep the (B, H, Tgmax, Tgmax) rectangle of the
+    // reference's padded batch; an utterance's Tg x Tg block is the map of that utterance run alone, everything outside it is written as zero.
+    const int TgM = p.Tg;
+    int Tg = TgM;
+    size_t base = (size_t)b * p.q_bstride;
+    size_t eshift = 0;
+    if (p.rag_off) {
+        Tg = (p.lens[b] + p.G - 1) / p.G;
+        base = (size_t)p.rag_off[b] * p.D;
+        eshift = (size_t)(p.rag_tgmax - Tg) * p.e_rowstride;
+    }
+    float* row = att + (((size_t)b * p.H + h) * TgM + i) * TgM;
+    if (i >= Tg) {                                                  // rows behind this utterance's own grouped length (ragged only)
+        for (int j = lane; j < TgM; j += 64) row[j] = 0.f;
+        return;
+    }
+    const bf16_t* qrow = p.qu + base + (size_t)h * p.q_hstride + (size_t)i * p.q_rowstride;
     for (int x = lane; x < d; x += 64) {
         const float q = bf2f(qrow[x]);
         qu[x] = q;
@@ -596,10 +613,10 @@ __global__ __launch_bounds__(64) void attention_probs_kernel(const AttnParams p,
     const int erows = p.causal ? Tg : 2 * Tg - 1;
     float mx = -INFINITY;
     for (int j = lane; j < Tg; j += 64) {
-        const bf16_t* kr = p.kh + (size_t)b * p.q_bstride + (size_t)h * p.q_hstride + (size_t)j * p.q_rowstride;
+        const bf16_t* kr = p.kh + base + (size_t)h * p.q_hstride + (size_t)j * p.q_rowstride;
         int r = Tg - 1 + j - i;
         r = r < 0 ? 0 : (r >= erows ? erows - 1 : r);                 // causal, j > i: outside the table and masked below
-        const bf16_t* er = p.eh + (size_t)h * p.e_hstride + (size_t)r * p.e_rowstride;
+        const bf16_t* er = p.eh + eshift + (size_t)h * p.e_hstride + (size_t)r * p.e_rowstride;
         float s1 = 0.f, s2 = 0.f;
         for (int x = 0; x < d; ++x) { s1 = fmaf(qu[x], bf2f(kr[x]), s1); s2 = fmaf(qv[x], bf2f(er[x]), s2); }
         float s = (s1 + s2) * p.scale;
@@ -613,14 +630,13 @@ __global__ __launch_bounds__(64) void attention_probs_kernel(const AttnParams p,
     for (int j = lane; j < Tg; j += 64) { const float e = expf(sc[j] - mx); sc[j] = e; sum += e; }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-    float* row = att + (((size_t)b * p.H + h) * Tg + i) * Tg;
-    for (int j = lane; j < Tg; j += 64) row[j] = sc[j] / sum;
+    for (int j = lane; j < TgM; j += 64) row[j] = j < Tg ? sc[j] / sum : 0.f;
 }
 }  // namespace
 
 int launch_attention_probs(const AttnParams& p, float* att, hipStream_t s) {
     if (!att || p.B <= 0 || p.Tg <= 0) return 0;
-    if (p.rag_off) return -2;
+    if (p.rag_off && p.q_rowstride != p.G * p.D) return -2;          // ragged batches: natural layout
     const size_t lds = (size_t)(2 * p.dpad + p.Tg) * 4;
     if (lds > 64 * 1024) return -2;
     hipLaunchKernelGGL(attention_probs_kernel, dim3(p.Tg, p.H, p.B), dim3(64), lds, s, p, att);

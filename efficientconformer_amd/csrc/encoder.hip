@@ -759,7 +759,7 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
               if (e->attention_v2 && nat && relpos_attention2_supported(dpad)) EC_TRY(launch_relpos_attention2(ap, e->attention_v2, st));
               else EC_TRY(launch_relpos_attention(ap, st)); }
             if ((int)e->att_out.size() == nb && e->att_out[k]) {       // opt-in: the reference's att_w of this block (encoders.py:129)
-                if (rg) return fail("attention maps are written for rectangular batches only");
+                // ragged batches: (B, H, Tg of the LONGEST utterance, same) per block, an utterance's own Tg x Tg block = its map run alone, zeros elsewhere
                 EC_TRY(launch_attention_probs(ap, e->att_out[k], st));
             }
             snprintf(nm, sizeof(nm), "blocks.%d.att_o", k); trace_add(e, st, nm, o, M, D, ld8(D), 1);
@@ -936,10 +936,9 @@ int forward_core_exact(EcEncoder* e, const float* mel, const int64_t* in_len, in
                        char* ws, float* out, int64_t* out_len, hipStream_t st) {
     const EcConfig& c = e->cfg;
     const int B = s.B, nb = (int)e->blocks.size();
-    if (c.causal || c.left_context < (1 << 30) / 2 || c.right_context < (1 << 30) / 2) {
-        int tmax = 0; for (int t : s.Tin) tmax = std::max(tmax, t);
-        if (c.causal || c.left_context < tmax || c.right_context < tmax) return fail("the fp32-operand mode has no streaming contexts / causal kernels (bf16 path only)");
-    }
+    // finite left / right contexts: the band mask is part of the label-exact attention kernels since round 4; `causal` (causal relative tables,
+    // causal depthwise padding: attentions.py:506, 1243-1247; layers.py:97-101) stays on the bf16 path
+    if (c.causal) return fail("the label-exact modes have no causal kernels (causal relative tables / depthwise pre-padding): bf16 path only");
     e->trace.clear(); e->trace_used = 0;
     // this forward lays its own buffers over the caller's workspace: a positional-embedding cache the bf16 path left there is gone
     // (fp32 -> bf16 -> fp32 -> bf16 on one workspace otherwise ends with attention reading fp32 activations as E)
@@ -972,6 +971,7 @@ int forward_core_exact(EcEncoder* e, const float* mel, const int64_t* in_len, in
     float *a = F32(w.a), *hb = F32(w.h), *q = F32(w.q), *kk = F32(w.k), *v = F32(w.v), *eb = F32(w.e), *o = F32(w.o), *p1 = F32(w.p1), *g = F32(w.g),
           *cb = F32(w.c);
     char nm[64];
+    int xmask_stride = 1;                      // product of the strides of the blocks before block k
     for (int k = 0; k < nb; ++k) {
         const EcBlock& b = e->blocks[k];
         const BlockW& W = e->bw[k];
@@ -1004,6 +1004,11 @@ int forward_core_exact(EcEncoder* e, const float* mel, const int64_t* in_len, in
         ap.q = q; ap.k = kk; ap.v = v; ap.e = eb; ap.u = W.u; ap.vb = W.v; ap.lens = lens + (size_t)k * B;
         ap.B = B; ap.H = H; ap.T = T; ap.Tp = Tp; ap.G = G; ap.D = D; ap.d = d; ap.Tg = Tg; ap.out = o; ap.variant = e->exact_attention;
         ap.att = (int)e->att_out.size() == nb ? e->att_out[k] : nullptr;
+        {   // streaming mask of this block (encoders.py:132-136, attentions.py:698): contexts in frames after the subsampling, sliced ::stride after
+            // every strided block before this one and ::G in grouped attention
+            const long long unit = (long long)xmask_stride * G;
+            ap.band_l = (int)std::min<long long>(c.left_context / unit, 1 << 30); ap.band_r = (int)std::min<long long>(c.right_context / unit, 1 << 30);
+        }
         { PROF(PC_ATTENTION, 2.0 * B * H * (double)Tg * Tg * d * 3.0, (double)M * D * 4 * 5);
           if (e->exact_split && sx_attention_supported(d) && (long long)B * H <= 65535) EC_TRY(launch_sx_attention(ap, F32(w.scores), st));
           else EC_TRY(launch_ex_attention(ap, st)); }
@@ -1015,6 +1020,7 @@ int forward_core_exact(EcEncoder* e, const float* mel, const int64_t* in_len, in
         EC_TRY(xgemm(e, st, a, D, M, cm + ".2", 2 * De, D, p1, 2 * De));
         EC_TRY(launch_ex_glu(p1, M, De, g, st));
         EC_TRY(launch_ex_dwconv(g, B, T, To, De, W.dw_w, W.dw_b, b.kernel_size, b.conv_stride, cb, st));
+        xmask_stride *= b.conv_stride;
         if (D != De) {      // 1x1 strided conv on frames 0, s, 2s, ...  (blocks.py:106-110)
             EC_TRY(xgemm(e, st, x, D, Mo, p + ".conv_res.1", De, D, xalt, De, 0, nullptr, 1.f, To, T, b.conv_stride));
             std::swap(x, xalt);

@@ -235,7 +235,7 @@ __global__ __launch_bounds__(64) void ex_attention_kernel(ExAttnParams p) {
         float s1 = 0.f, s2 = 0.f;
         for (int x = 0; x < p.d; ++x) { s1 = fmaf(qu[x], kr[x], s1); s2 = fmaf(qv[x], er[x], s2); }
         float s = (s1 + s2) / rs;
-        if (p.G * j >= len) s += -1e9f;                             // attentions.py:698-701 (additive mask, as the reference)
+        if (p.G * j >= len || j - i > p.band_r || i - j > p.band_l) s += -1e9f;      // attentions.py:698-701, 1377-1403: ONE additive mask = max(padding, streaming)
         sc[j] = s;
         mx = fmaxf(mx, s);
     }
@@ -342,7 +342,8 @@ __global__ __launch_bounds__(XQT * 16) void ex_attention2_kernel(ExAttnParams p,
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 float s = (s1[rr] + s2[rr]) / rs;
-                if (p.G * j >= len) s += -1e9f;                             // attentions.py:698-701 (additive mask, as the reference)
+                const int qi = i0 + 4 * wave + rr;
+                if (p.G * j >= len || j - qi > p.band_r || qi - j > p.band_l) s += -1e9f;      // attentions.py:698-701, 1377-1403: ONE additive mask = max(padding, streaming)
                 sc[(4 * wave + rr) * TgP + j] = s;
             }
         }

@@ -214,6 +214,7 @@ struct ExAttnParams {              // natural-layout fp32 Q, K, V [B*Tp][D], E [
     float* out;
     float* att;                    // optional [B][H][Tg][Tg] softmax maps (null: not written)
     int variant;                   // 0: tiled kernel (default), 2: its 16-row shape, 1: one wave per query row (round 2's kernel); all agree bit for bit
+    int band_l, band_r;            // streaming contexts in grouped positions of the stage (key j of query i visible iff -band_l <= j - i <= band_r; >= Tg: unlimited)
 };
 int launch_ex_attention(const ExAttnParams& p, hipStream_t s);
 

@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256) void sx_scores_kernel(const SxAttnParams q) {
             const int m = 32 * wq + (r & 3) + 8 * (r >> 2) + 4 * kh, i = i0 + m;
             if (i >= Tg || j >= Tg) continue;
             float sv = (fmaf(s1x[r], LO_INV, s1h[r]) + sPE[m * PE_LD + jj - m + 63]) * irs;
-            if (p.G * j >= len) sv += -1e9f;
+            if (p.G * j >= len || j - i > p.band_r || i - j > p.band_l) sv += -1e9f;      // ONE additive mask = max(padding mask, streaming mask) (attentions.py:698-701, 1377-1403)
             srow[(size_t)i * q.TgP + j] = sv;
         }
         // the next iteration's staging overwrites sK and the (now free) lower half, not sPE: the skewed reads above are ordered against the

@@ -357,11 +357,15 @@ class ConformerEncoder(nn.Module):
         if return_attentions:
             # the reference's third return value (encoders.py:126-142): one (B, H, Tg, Tg) softmax map per block, written by the library
             # next to the forward (effconf_encoder_set_attention_outputs); the whole batch as ONE rectangular range
-            if self.ragged:
-                raise RuntimeError("return_attentions needs a rectangular batch (ConformerEncoder.ragged = False)")
+            # (ragged batches, round 4: the same rectangles sized for the LONGEST utterance of the batch; an utterance's own Tg x Tg block is
+            # its map when run alone, the rest is zero)
             nsub, nb = 1, len(self.plan.blocks)
             heads, tg = (C.c_int32 * nb)(), (C.c_int32 * nb)()
-            _lib.check(lib.effconf_encoder_attention_dims(self._handle, n, int(from_audio), heads, tg), "attention_dims")
+            n_att = n
+            if self.ragged:
+                hl_ = x_len_host if x_len_host is not None else lens.cpu()
+                n_att = int(max(int(v) for v in (hl_.tolist() if hasattr(hl_, "tolist") else hl_)))
+            _lib.check(lib.effconf_encoder_attention_dims(self._handle, n_att, int(from_audio), heads, tg), "attention_dims")
             attentions = [torch.empty(batch, heads[k], tg[k], tg[k], dtype=torch.float32, device=x.device) for k in range(nb)]
             _lib.check(lib.effconf_encoder_set_attention_outputs(self._handle, (C.c_void_p * nb)(*[a.data_ptr() for a in attentions]), nb),
                        "set_attention_outputs")

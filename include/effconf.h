@@ -236,10 +236,11 @@ int effconf_rnnt_greedy(EcRnnt* r, const float* enc_out, const int64_t* out_len,
  * MODE MATRIX (what a forward accepts; everything else returns an error, never a silent fallback):
  *   bf16 path (exact_fp32 = 0): rectangular batches (effconf_encoder_forward / _forward_mel), ragged batches (effconf_encoder_forward_ragged; head
  *     widths <= 160 padded), streaming contexts / causal configurations (EcConfig; natural Q / K / V layout, head widths <= 160 padded), attention
- *     maps (effconf_encoder_set_attention_outputs; rectangular batches only: a ragged batch has no (B, H, Tg, Tg) rectangle to write).
- *   label-exact modes (exact_fp32 = 1 | 2): rectangular batches, attention maps; NOT ragged batches (effconf_encoder_forward_ragged fails), NOT
- *     streaming contexts / causal configurations (the forward fails when a context is shorter than the sequence): their frame-mixing kernels
- *     (attention, depthwise and subsampling convolutions) index (utterance, frame) rectangles and have no band mask / causal tables. */
+ *     maps (effconf_encoder_set_attention_outputs; ragged batches since round 4: rectangles sized for the LONGEST utterance, utterance b's own
+ *     Tg(b) x Tg(b) block = its map run alone, zeros elsewhere).
+ *   label-exact modes (exact_fp32 = 1 | 2): rectangular batches, attention maps, finite left_context / right_context (round 4: the band mask is
+ *     part of their attention kernels); NOT ragged batches (effconf_encoder_forward_ragged fails: their frame-mixing kernels index (utterance,
+ *     frame) rectangles), NOT causal configurations (the forward fails: no causal relative tables / causal depthwise padding in these modes). */
 int effconf_encoder_set_option(EcEncoder* enc, const char* name, int32_t value);
 
 /* ---- per-launch event profiler (bench / tuning only) --------------------------------------- */
@@ -289,7 +290,7 @@ int effconf_debug_spin(double microseconds, void* stream);
  * (batch, heads, Tg, Tg) softmax rows; no caller on the hot path reads them, so they are opt-in).  effconf_encoder_attention_dims fills
  * heads[k] / tg[k] per block for inputs of n samples (from_audio) or mel frames; effconf_encoder_set_attention_outputs registers one device
  * buffer of batch * heads[k] * tg[k] * tg[k] floats per block (null entries skip a block; maps = null or n_blocks = 0 clears the
- * registration) - every following effconf_encoder_forward writes them (rectangular batches; bf16 path: recomputed in fp32 from the bf16
+ * registration) - every following effconf_encoder_forward / _forward_ragged writes them (ragged: dims for n = the longest utterance; bf16 path: recomputed in fp32 from the bf16
  * Q / K / E operands; fp32 path: the kernel's own probabilities). */
 int effconf_encoder_attention_dims(EcEncoder* enc, int32_t n, int32_t from_audio, int32_t* heads, int32_t* tg);
 int effconf_encoder_set_attention_outputs(EcEncoder* enc, float* const* maps, int32_t n_blocks);

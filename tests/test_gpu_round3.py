@@ -353,6 +353,32 @@ def test_streaming_ragged_batch_equals_utterances_alone_and_the_oracle(extra):
 
 
 @pytest.mark.parametrize("exact", ["fp32", "split"])
+@pytest.mark.parametrize("gname", [f for f in _STREAM if "_ctx_" in f])
+def test_label_exact_modes_with_finite_contexts_vs_reference_goldens(golden_dir, gname, exact):
+    """Round 4: finite left_context / right_context (reference attentions.py:1377-1403: ONE additive -1e9 on max(streaming mask, padding mask))
+    in the two label-exact modes, against the reference run with those settings: encoder output within 2e-4 (every frame, pad frames included),
+    per-frame argmax identical wherever the reference's top-2 margin exceeds 1e-3.  (`causal` stays on the bf16 path: next test.)"""
+    g = np.load(os.path.join(golden_dir, gname))
+    m, sd, small = _stream_model(gname, g)
+    m.encoder.precision = exact
+    lens = g["mel_len"].tolist()
+    mel, ln = synth.make_mel(len(lens), 80, max(lens), lens, seed=int(g["mel_seed"]))
+    out, out_len, _ = m.encoder.forward_mel(torch.from_numpy(mel).cuda(), torch.from_numpy(ln).cuda())
+    assert out_len.cpu().tolist() == g["out_len"].tolist()
+    ref = torch.from_numpy(g["out_rows"] if small else g["out"])
+    got = out.cpu()[:, ::4] if small else out.cpu()
+    d = (got - ref).abs()
+    print("%s %s: max %.2e mean %.2e" % (gname, exact, float(d.max()), float(d.mean())))
+    assert float(d.max()) < 2e-4
+    if small:
+        logits, _, _ = m._head(out, out_len, want_logits=True)
+        am = logits.argmax(-1).cpu().numpy()
+        valid = np.arange(am.shape[1])[None, :] < g["out_len"][:, None]
+        safe = (g["margin"] > 1e-3) & valid
+        assert safe.sum() > 20 and np.array_equal(am[safe], g["argmax"][safe])
+
+
+@pytest.mark.parametrize("exact", ["fp32", "split"])
 def test_exact_mode_rejects_streaming_contexts(exact):
     cfg = named_config("Tiny")
     cfg["encoder_params"] = dict(cfg["encoder_params"], causal=True)
@@ -362,7 +388,7 @@ def test_exact_mode_rejects_streaming_contexts(exact):
     m.encoder.precision = exact
     m = m.cuda()
     mel, ln = synth.make_mel(2, 80, 100, [100, 77], seed=1)
-    with pytest.raises(_lib.EffconfError, match="streaming|causal"):
+    with pytest.raises(_lib.EffconfError, match="causal"):
         m.encoder.forward_mel(torch.from_numpy(mel).cuda(), torch.from_numpy(ln).cuda())
 
 
@@ -484,7 +510,7 @@ def test_attention_maps_vs_the_reference(golden_dir, gname, precision):
 @pytest.mark.parametrize("extra", [dict(causal=True), dict(left_context=20, right_context=4), dict(causal=True, left_context=6)])
 def test_attention_maps_with_streaming_contexts_vs_oracle(extra):
     """The maps of a streaming / causal encoder carry the band mask (attentions.py:1377-1403: streaming_mask.maximum(padding_mask),
-    additive -1e9): masked entries are exactly zero, the rest matches the oracle; return_attentions is refused for ragged batches."""
+    additive -1e9): masked entries are exactly zero, the rest matches the oracle; ragged batches return the padded rectangles."""
     cfg = named_config("Tiny")
     cfg["encoder_params"] = dict(cfg["encoder_params"], **extra)
     m = ModelCTC.from_config(cfg)
@@ -501,9 +527,18 @@ def test_attention_maps_with_streaming_contexts_vs_oracle(extra):
         ref = trace["blocks.%d.att_w" % k]
         assert float((a.cpu() - ref).abs().max()) < 0.02, k
         assert bool((a.cpu()[ref == 0] == 0).all())
+    # ragged batch (round 4: no longer refused): every utterance's own Tg x Tg block of the padded rectangle is the map of that utterance
+    # run ALONE (rectangular path, B = 1) - bit for bit, band mask included - and everything outside the block is zero
     m.encoder.ragged = True
-    with pytest.raises(RuntimeError, match="rectangular"):
-        m.encoder.forward_mel(torch.from_numpy(mel).cuda(), torch.from_numpy(ln).cuda(), return_attentions=True)
+    rout, rlen, ratts = m.encoder.forward_mel(torch.from_numpy(mel).cuda(), torch.from_numpy(ln).cuda(), return_attentions=True, x_len_host=ln)
+    m.encoder.ragged = False
+    for b in range(3):
+        tb = int(ln[b])
+        _, _, alone = m.encoder.forward_mel(torch.from_numpy(mel[b:b + 1, :, :tb].copy()).cuda(), torch.from_numpy(ln[b:b + 1]).cuda(), return_attentions=True)
+        for k, (ra, al) in enumerate(zip(ratts, alone)):
+            tg = al.shape[-1]
+            assert torch.equal(ra[b, :, :tg, :tg], al[0]), (b, k, float((ra[b, :, :tg, :tg] - al[0]).abs().max()))
+            assert float(ra[b, :, tg:, :].abs().sum()) == 0.0 and float(ra[b, :, :, tg:].abs().sum()) == 0.0
 
 
 # ------------------------------------------------------------------ CTC head with split-bf16 operands (the bf16 path's default)
