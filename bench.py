@@ -97,6 +97,9 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1 (nccl = RCCL over xGMI; gloo + --one-device: N ranks on ONE GPU, a test of the multi-rank path)")
     ap.add_argument("--one-device", action="store_true", help="every rank uses cuda:0 (tests on a single-GPU box; never a benchmark)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="N = 1: run the multi-rank code path all the same - a one-rank process group (RCCL), per-range all-gather, head on the gathered "
+                         "chunk: what the protocol costs on the real backend when nothing has to cross xGMI (a diagnostic, not the N = 1 line)")
     ap.add_argument("--ragged", type=int, default=-1, choices=[-1, 0, 1],
                     help="1: ConformerEncoder.ragged - every utterance at its own length in one concatenated row space (no pad frames; an utterance's "
                          "output = the reference's for that utterance alone); 0: row ranges padded to their longest utterance (round 2's workload); "
@@ -566,28 +569,32 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    multi = world > 1 or args.force_dist          # the multi-rank code path (process group, ShardedEncoder)
+    if args.force_dist and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch N ranks with `python bench.py --gpus N` or with "
                          "torch.distributed.run --nproc-per-node N ... bench.py --gpus N" % (args.gpus, world))
     dist = None
-    if world > 1:
+    if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 
     if args.dry_run:           # CPU-only plumbing check (tests): same launcher, same batch plan, gloo instead of RCCL
-        if world > 1:
+        if multi:
             dist.init_process_group("gloo")
         audio_np, lens_np = make_batch(args, rank, world)
         t = torch.tensor([float(audio_np.shape[1]), float((lens_np // 160 + 1).sum())], dtype=torch.float64)
         lo = t.clone()
-        if world > 1:
+        if multi:
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         if rank == 0:
             r = result_skeleton(args, world, 0.0, 0.0, args.batch * world, {"parallelism": "dp%d" % world, "_padding": "dry run"})
             r.update({"dry_run": True, "padded_samples_equal_on_all_ranks": bool(t[0] == lo[0] * world), "valid_frames_per_step": float(t[1])})
             print(json.dumps(r))
-        if world > 1:
+        if multi:
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -595,7 +602,7 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (HIP path only)"
     dev = torch.device("cuda", 0 if args.one_device else local_rank)
     torch.cuda.set_device(dev)
-    if world > 1:
+    if multi:
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -648,7 +655,7 @@ def main():
     for opt in args.opt:                                      # tuning: any library option, e.g. --opt chain_max_dim=192
         k, v = opt.split("=")
         model.encoder.set_option(k, int(v))
-    if args.ragged and nsub > 1 and (world > 1 or args.range_frames):
+    if args.ragged and nsub > 1 and (multi or args.range_frames):
         # every rank must cut the SAME row ranges (the per-range collectives are fixed-size): frame-balanced (or --range-frames shares) cuts
         # computed from the MEAN cumulative valid frames over the ranks' batches - all known from the seeds, so no exchange is needed
         fr = np.mean([np.cumsum(synth.libri_lengths(args.batch, seed=1234 + r) // plan.hop_length + 1) for r in range(world)], axis=0) \
@@ -668,7 +675,7 @@ def main():
     if args.ragged:
         padded_frames = valid_frames                            # no pad frames exist (an utterance's rows are only rounded up to the group size)
     sharded = None
-    if world > 1:
+    if multi:
         from efficientconformer_amd.dist import ShardedEncoder
         if args.wire == "auto":
             args.wire = "bf16" if args.precision == "bf16" else "fp32"
@@ -679,7 +686,7 @@ def main():
     last = {}
 
     def full_step():
-        if world == 1:
+        if not multi:
             if isinstance(model, Transducer):
                 enc, enc_len, _ = model.encoder(audio, lens, range_pad=range_pad, **hkw)
                 last["labels"] = head(model, enc, enc_len)
@@ -711,7 +718,7 @@ def main():
     for _ in range(args.warmup):
         full_step()
     drain()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     # per-step distribution: one event per step on the caller's stream (every step joins its range streams there); no synchronisation
@@ -724,11 +731,11 @@ def main():
         marks[i + 1].record()
     drain()
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     tot = torch.tensor([elapsed, float(valid_frames), float(padded_frames)], dtype=torch.float64, device=dev)
-    if world > 1:
+    if multi:
         mx = tot.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
@@ -738,7 +745,7 @@ def main():
     result = None
     if rank == 0:
         par = "dp%d%s (utterance shards" % (world, ", ALL RANKS ON ONE GPU over gloo: a functional test, not a benchmark" if args.one_device else "")
-        if world > 1:
+        if multi:
             par += ", RCCL all-gather of %s per row range on a comm stream, wire %s%s" % ("encoder outputs" if args.gather == "outputs" else "label ids", args.wire,
                    ", pipelined: the head of a gathered chunk runs one step later" if (sharded is not None and sharded.pipelined) else "")
         step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
@@ -763,14 +770,14 @@ def main():
     #      (bit-identical) and (2) the oracle = the reference path on sampled utterances of each range, collated with the range's
     #      longest utterance (pad frames are live), within the bf16 tolerance of tests/test_gpu_encoder.py
     if rank == 0 and not args.no_check:
-        if world > 1 and args.gather == "outputs" and not isinstance(model, Transducer):
+        if multi and args.gather == "outputs" and not isinstance(model, Transducer):
             result["check"] = self_check_sharded(model, sd, plan, audio, lens, lens_np, cuts, range_pad, nsub, last, args, world)
         elif isinstance(model, Transducer):
-            if world == 1:
+            if not multi:
                 result["check"] = self_check_transducer(model, sd, plan, audio, lens, lens_np, last)
         else:
             result["check"] = self_check(model, sd, plan, audio, lens, lens_np, cuts, range_pad, nsub, last, args)
-            if world > 1:      # --gather labels: this rank's slice of the gathered label ids is its own head output
+            if multi:      # --gather labels: this rank's slice of the gathered label ids is its own head output
                 gl, gn = last["gathered_labels"]
                 same = bool(torch.equal(gl[rank], last["labels"][0]) and torch.equal(gn[rank], last["labels"][1]))
                 result["check"]["gathered_label_ids_of_this_rank_equal_its_head_output"] = same
@@ -917,7 +924,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0 and result.get("check") and not result["check"]["ok"]:

@@ -16,9 +16,13 @@ from efficientconformer_amd.dist import ShardedEncoder, shard_batch  # noqa: E40
 
 
 def main():
-    dist.init_process_group("gloo")
-    rank, world = dist.get_rank(), dist.get_world_size()
+    backend = os.environ.get("EFFCONF_TEST_BACKEND", "gloo")      # "nccl" = RCCL: one rank per device (a one-GPU box runs it with world size 1)
     torch.cuda.set_device(0)
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
     name = sys.argv[1] if len(sys.argv) > 1 else "Tiny"
     cfg = named_config(name)
     m = ModelCTC.from_config(cfg)
@@ -83,9 +87,37 @@ def main():
                     nl = int(seen[b][1])
                     ok = ok and torch.equal(o, want_out[b]) and int(l) == int(rag_len[b]) and nl == int(n_w[b]) and \
                         torch.equal(seen[b][0][:nl], lab_w[b, :nl])
+        # ---- pipelined protocol (ShardedEncoder(pipelined=True), bench.py's default at N > 1): a range's collective is issued asynchronously
+        #      (RCCL: async_op on the process group's stream) and its consumer runs one call later on that range's stream; flush() drains.
+        #      Two different batches in flight, consumers must see exactly their own call's gathered rows.
+        enc.sub_batches, enc.sub_batch_bounds = 2, [2]
+        lens2 = np.array([44000, 40000, 33000, 31000, 20000, 15000, 8000], dtype=np.int64)
+        audio2 = torch.from_numpy(synth.make_audio(lens2, seed=9)).cuda()
+        ln2 = torch.from_numpy(lens2).cuda()
+        if audio2.shape[1] < audio.shape[1]:
+            audio2 = torch.nn.functional.pad(audio2, (0, audio.shape[1] - audio2.shape[1]))
+        enc.sub_batches = 1
+        rag2, rag2_len, _ = enc(audio2, ln2, x_len_host=lens2)
+        enc.sub_batches = 2
+        shp = ShardedEncoder(enc, pipelined=True)
+        got = []
+        for tag, (au, l_d, l_h, ref, ref_len) in (("a", (audio, ln, lens, rag, rag_len)), ("b", (audio2, ln2, lens2, rag2, rag2_len)), ("a2", (audio, ln, lens, rag, rag_len))):
+            xs_, ls_ = shard_batch(au, l_d, rank, world, uniform=True)
+            idx_ = list(range(rank, au.shape[0], world))
+            hl_ = l_h[idx_ + [idx_[-1]] * (xs_.shape[0] - len(idx_))]
+            shp.encode_shard(xs_, ls_, au.shape[0], x_len_host=hl_,
+                             consumer=lambda ch, tag=tag, ref=ref, ref_len=ref_len: got.append((tag, ch.lo, ch.out.clone(), ch.out_len.clone(), ch.rows, ch.keep, ref, ref_len)))
+        n_before_flush = len(got)
+        shp.flush()
+        torch.cuda.synchronize()
+        ok = ok and n_before_flush == 4 and [g_[0] for g_ in got] == ["a", "a", "b", "b", "a2", "a2"]
+        for tag, lo, o, ol, rows, keep, ref, ref_len in got:
+            for r in torch.nonzero(keep).flatten().tolist():
+                b = int(rows[r])
+                ok = ok and torch.equal(o[r], ref[b]) and int(ol[r]) == int(ref_len[b])
         enc.ragged, enc.sub_batches, enc.sub_batch_bounds, enc.check_host_lengths = False, 1, None, False
     torch.cuda.synchronize()
-    flag = torch.tensor([1.0 if ok else 0.0])
+    flag = torch.tensor([1.0 if ok else 0.0], device="cuda" if backend == "nccl" else "cpu")
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if rank == 0:
         print("DIST_GPU_OK" if float(flag) == 1.0 else "DIST_GPU_FAILED")

@@ -30,6 +30,20 @@ def test_sharded_encoder_two_ranks_on_one_gpu_equals_unsharded(name):
     assert "DIST_GPU_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
 
 
+def test_sharded_encoder_one_rank_over_rccl():
+    """The same worker on the REAL backend: backend "nccl" = RCCL, one rank (a `gpurun` box has one GPU and RCCL takes one rank per device).
+    No xGMI transfer happens, but everything else of the N > 1 path runs on RCCL's own machinery: communicator creation on the MI355X, collectives
+    enqueued from the row ranges' streams onto the process group's stream, `async_op` Work objects and their stream-side wait() in the pipelined
+    protocol, allocator stream bookkeeping of the gathered chunks - with the bit-for-bit assertions of the two-rank gloo run."""
+    env = _env()
+    env["EFFCONF_TEST_BACKEND"] = "nccl"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_port()), os.path.join(ROOT, "tests", "dist_gpu_worker.py"), "Tiny"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert "DIST_GPU_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
 @pytest.mark.parametrize("gather", ["outputs", "labels"])
 def test_bench_two_ranks_on_one_gpu(gather):
     """`python bench.py --gpus 2` end to end (launcher, per-range all-gather on the comm stream, head on the gathered chunks on the head
