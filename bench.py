@@ -32,6 +32,27 @@ import subprocess
 import sys
 import time
 
+
+
+def _wants_ranks(argv):
+    """--gpus N > 1, a torchrun environment with WORLD_SIZE > 1, or --force-dist: the multi-rank code path (a process group exists)."""
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 or "--force-dist" in argv:
+        return True
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            return argv[i + 1].isdigit() and int(argv[i + 1]) > 1
+        if a.startswith("--gpus="):
+            return a[7:].isdigit() and int(a[7:]) > 1
+    return False
+
+
+# Multi-rank processes: eight hardware queues instead of the runtime's four, set BEFORE the HIP runtime initialises (it reads the variable
+# once).  HIP multiplexes streams onto GPU_MAX_HW_QUEUES queues; the forward uses three streams (caller's + two side streams) and an RCCL
+# process group brings its own - with four queues the step of a rank that merely HOLDS a process group is 7.2 ms instead of 5.5 (measured
+# on RCCL with one rank: `bench.py --force-dist`, profiles/r4_02_rccl_one_rank.txt), with eight it is 5.55.  N = 1 runs keep the default.
+if _wants_ranks(sys.argv):
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 import torch
 
@@ -121,6 +142,7 @@ def launch_ranks(args):
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this driver (RCCL needs it)
+    env.setdefault("GPU_MAX_HW_QUEUES", "8")               # see the top of this file: three forward streams + the process group's need more than four queues
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
     return subprocess.call(cmd, env=env)
 

@@ -23,7 +23,12 @@ output depends only on its own row and on the padded length (pad frames are live
     range's stream right after that call's encoder kernels - so collective k is on the wire under the WHOLE encoder of call k + 1 instead
     of the tail of call k (ranges cut for equal work finish together: one GPU measured 24 % of the collectives' time covered, tools/
     overlap_probe.py).  Results arrive one call late; `flush()` drains the last call;
-  * weights are replicated (<= 251 MB bf16), there is no other data-path collective.
+  * weights are replicated (<= 251 MB bf16), there is no other data-path collective;
+  * HARDWARE QUEUES: run multi-rank processes with `GPU_MAX_HW_QUEUES=8` in the environment BEFORE the HIP runtime initialises (the first
+    torch.cuda call).  HIP multiplexes streams onto that many hardware queues (default 4); the forward's three streams plus what an RCCL
+    process group brings exceed four, and streams that share a queue serialise: measured on RCCL with one rank (`bench.py --force-dist`), a rank
+    that merely holds a process group steps in 7.2 ms instead of 5.5 with four queues and in 5.55 ms with eight (profiles/r4_02_rccl_one_rank.txt).
+    `bench.py` sets it for its rank processes; `ShardedEncoder` warns when it is missing.
 """
 from __future__ import annotations
 
@@ -139,6 +144,15 @@ class ShardedEncoder:
         # unless the caller pins explicit `sub_batch_bounds` (bench.py: frame-balanced / staggered cuts computed from lengths all ranks know).
         if hasattr(encoder, "ragged_cut"):
             encoder.ragged_cut = "rows"
+        import os
+        import warnings
+        try:
+            nq = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
+        except ValueError:
+            nq = 4
+        if nq < 8 and torch.cuda.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl":
+            warnings.warn("efficientconformer_amd.dist: GPU_MAX_HW_QUEUES=%d - with an RCCL process group the forward's streams share hardware queues "
+                          "and serialise (+30 %% per step measured); export GPU_MAX_HW_QUEUES=8 before the HIP runtime initialises" % nq)
         fwd = getattr(encoder, "forward", encoder)
         try:
             self._hooked = "range_hook" in inspect.signature(fwd).parameters
