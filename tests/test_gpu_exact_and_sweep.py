@@ -199,7 +199,7 @@ def test_every_shipped_config_encoder_vs_oracle(name):
     assert mx < OUT_MAX and mean < OUT_MEAN, (name, mx, mean)
 
 
-@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+@pytest.mark.parametrize("precision", ["bf16", "fp32", "split"])
 @pytest.mark.parametrize("name", SHIPPED + ["SmallAligned", "Tiny"])
 def test_no_kernel_reads_past_a_parameter_buffer(name, precision, monkeypatch):
     """EFFCONF_POISON_GUARDS (read once at effconf_encoder_create) puts 16 KiB of 0xFF bytes - NaN as bf16 and as fp32 - on both
