@@ -721,7 +721,10 @@ def main():
             # encoder on this rank's utterances; per-row-range all-gather issued from each range's stream (dist.py); the head consumes
             # the gathered chunk on that same stream (no extra streams: see dist.py on the four-stream budget)
             def consume(ch):          # the CTC head on a gathered chunk, on its row range's stream (pipelined: one step after its collective was issued)
-                ch.labels = head(model, ch.out if ch.out.dtype == torch.float32 else ch.out.float(), ch.out_len)
+                # bf16 wire + CTC head: the gathered bf16 rows go to the head as they are (effconf_ctc_greedy_bf16: labels identical to the fp32-input
+                # head on the widened values, tests/test_gpu_round4.py); the transducer decode and the exact modes take fp32 rows
+                direct = ch.out.dtype == torch.float32 or (ch.out.dtype == torch.bfloat16 and not isinstance(model, Transducer))
+                ch.labels = head(model, ch.out if direct else ch.out.float(), ch.out_len)
             g = sharded.encode_shard(audio, lens, args.batch * world, range_pad=range_pad, consumer=consume, **hkw)
             last["chunks"] = g.chunks
         else:

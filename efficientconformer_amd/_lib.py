@@ -51,6 +51,7 @@ SIGNATURES = {
     "effconf_encoder_set_attention_outputs": (C.c_int, [_P, C.POINTER(C.c_void_p), _I32]),
     "effconf_host_pack_rows": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int64), _I32, C.c_void_p, C.c_int64, _I32, _I32]),
     "effconf_ctc_greedy": (C.c_int, [_P, _F32P, _I64P, _I32, _I32, _P, _P, _F32P, _P, _SZ, _P]),
+    "effconf_ctc_greedy_bf16": (C.c_int, [_P, _P, _I64P, _I32, _I32, _P, _P, _F32P, _P, _SZ, _P]),
     "effconf_rnnt_create": (_P, [C.POINTER(EcRnntConfig)]),
     "effconf_rnnt_destroy": (None, [_P]),
     "effconf_rnnt_load_tensor": (C.c_int, [_P, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), _I32]),

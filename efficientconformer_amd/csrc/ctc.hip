@@ -249,7 +249,10 @@ __global__ __launch_bounds__(256) void ctc_argmax_mfma_kernel(const float* __res
 // Same tiling as the fp32 kernel (ROWS frames x 256 columns per pass, wave = 64 columns); the frame tile is split once into two bf16 LDS
 // images (row pitch 2 Kp + 16 bytes: the 16-byte fragment reads of 16 consecutive rows fall on disjoint banks), the weight halves are
 // packed at finalize as MFMA B fragments ([k / 16][column][k-half][8] bf16: a wave's load is 1 KiB contiguous).
-template <int ROWS>
+// XBF = true (round 4): the frame rows arrive as bf16 (the gathered encoder outputs of the multi-rank path, bf16 wire): x_hi is the input itself,
+// x_lo = 0, so the x_lo W_hi term and the lo image of the frame tile vanish (2 MFMAs per 16 k, no conversion pass over the gathered chunk, half
+// the input bytes) - and the logits equal, bit for bit, those of the fp32-input kernel fed with the same values widened to fp32.
+template <int ROWS, bool XBF = false>
 __global__ __launch_bounds__(256) void ctc_argmax_bf16x3_kernel(const float* __restrict__ x, int M, int D, int Kp, const bf16_t* __restrict__ Whi,
                                                                 const bf16_t* __restrict__ Wlo, const float* __restrict__ bias, int V, int Vp,
                                                                 int* __restrict__ preds, float* __restrict__ logits) {
@@ -264,6 +267,12 @@ __global__ __launch_bounds__(256) void ctc_argmax_bf16x3_kernel(const float* __r
     for (int i = tid * 4; i < ROWS * Kp; i += 1024) {
         const int r = i / Kp, k = i - r * Kp;
         const int mr = m0 + r < M ? m0 + r : M - 1;
+        if constexpr (XBF) {
+            uint2 hv = make_uint2(0u, 0u);
+            if (k < D) hv = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(x) + (size_t)mr * D + k);
+            *reinterpret_cast<uint2*>(xh + r * pitch + k * 2) = hv;
+            continue;
+        }
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (k < D) v = *reinterpret_cast<const float4*>(x + (size_t)mr * D + k);        // D % 4 == 0: a quad is valid or pad as a whole
         const uint16_t h0 = f2bf(v.x), h1 = f2bf(v.y), h2 = f2bf(v.z), h3 = f2bf(v.w);
@@ -296,13 +305,16 @@ __global__ __launch_bounds__(256) void ctc_argmax_bf16x3_kernel(const float* __r
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
                 const int off = (rt * 32 + lc) * pitch + (16 * s + 8 * kh) * 2;
-                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(xh + off), al = *reinterpret_cast<const bf16x8*>(xl + off);
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(xh + off);
                 acc[rt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ch0, acc[rt][0], 0, 0, 0);
                 acc[rt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ch1, acc[rt][1], 0, 0, 0);
                 acc[rt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, cl0, acc[rt][0], 0, 0, 0);
                 acc[rt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, cl1, acc[rt][1], 0, 0, 0);
-                acc[rt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, ch0, acc[rt][0], 0, 0, 0);
-                acc[rt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, ch1, acc[rt][1], 0, 0, 0);
+                if constexpr (!XBF) {                      // bf16 rows: x_lo = 0, the term contributes exact zeros
+                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(xl + off);
+                    acc[rt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, ch0, acc[rt][0], 0, 0, 0);
+                    acc[rt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, ch1, acc[rt][1], 0, 0, 0);
+                }
             }
         }
         if (v0 > 0) __syncthreads();                                    // later passes: the previous logits tile was consumed
@@ -395,9 +407,24 @@ int launch_ctc_mfma(const float* x, int M, int D, const float* Wt, const float* 
 }
 
 int launch_ctc_split(const float* x, int M, int D, const bf16_t* Whi, const bf16_t* Wlo, const float* bias, int V, int* preds, float* logits,
-                     hipStream_t s) {
+                     hipStream_t s, int x_is_bf16) {
     if (M <= 0) return 0;
     if (D % 4 || !Whi || !Wlo) return -2;
+    if (x_is_bf16) {
+        const int Kp = (D + 15) / 16 * 16, Vp = (V + 255) / 256 * 256;
+        auto lds_b = [&](int rows) { return (size_t)2 * rows * (Kp * 2 + 16) + (size_t)rows * 257 * 4; };      // same layout (the lo image stays unused)
+        static LdsAttr b64, b32;
+        if (lds_b(64) <= 160 * 1024) {
+            ensure_dynamic_lds(reinterpret_cast<const void*>(&ctc_argmax_bf16x3_kernel<64, true>), (int)lds_b(64), b64);
+            hipLaunchKernelGGL((ctc_argmax_bf16x3_kernel<64, true>), dim3((M + 63) / 64), dim3(256), lds_b(64), s, x, M, D, Kp, Whi, Wlo, bias, V, Vp, preds, logits);
+        } else if (lds_b(32) <= 160 * 1024) {
+            ensure_dynamic_lds(reinterpret_cast<const void*>(&ctc_argmax_bf16x3_kernel<32, true>), (int)lds_b(32), b32);
+            hipLaunchKernelGGL((ctc_argmax_bf16x3_kernel<32, true>), dim3((M + 31) / 32), dim3(256), lds_b(32), s, x, M, D, Kp, Whi, Wlo, bias, V, Vp, preds, logits);
+        } else {
+            return -2;
+        }
+        return hipGetLastError() == hipSuccess ? 0 : -1;
+    }
     const int Kp = (D + 15) / 16 * 16, Vp = (V + 255) / 256 * 256;     // = finalize's packing (encoder.hip): a pass covers 256 columns
     auto lds_for = [&](int rows) { return (size_t)2 * rows * (Kp * 2 + 16) + (size_t)rows * 257 * 4; };
     static LdsAttr attr64, attr32;

@@ -1749,6 +1749,20 @@ int effconf_ctc_greedy(EcEncoder* e, const float* enc_out, const int64_t* out_le
     return 0;
 }
 
+int effconf_ctc_greedy_bf16(EcEncoder* e, const uint16_t* enc_out_bf16, const int64_t* out_len, int32_t batch, int32_t t_out,
+                            int32_t* labels, int32_t* label_len, float* logits, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!e || !e->finalized) return fail("encoder not finalized");
+    if (e->exact_on) return fail("effconf_ctc_greedy_bf16 belongs to the bf16 path (the label-exact modes keep fp32 rows and the fp32 head)");
+    if (!e->fc_hi || !e->fc_lo) return fail("no CTC head (fc.weight / fc.bias) loaded");
+    if (workspace_bytes < (size_t)batch * t_out * 4) return fail("workspace too small");
+    int* preds = reinterpret_cast<int*>(workspace);
+    hipStream_t st = (hipStream_t)stream;
+    EC_TRY(launch_ctc_split(reinterpret_cast<const float*>(enc_out_bf16), batch * t_out, e->blocks.back().dim_expand, e->fc_hi, e->fc_lo, e->fc_b,
+                            e->cfg.vocab_size, preds, logits, st, 1));
+    EC_TRY(launch_ctc_collapse(preds, out_len, batch, t_out, labels, label_len, st));
+    return 0;
+}
+
 /* Attention maps (reference encoders.py:126-142): maps[k] = device buffer of batch x heads[k] x tg[k] x tg[k] floats for block k, or null. */
 int effconf_encoder_attention_dims(EcEncoder* e, int32_t n, int32_t from_audio, int32_t* heads, int32_t* tg) {
     if (!e || !e->finalized || !heads || !tg) return fail("effconf_encoder_attention_dims: null argument / encoder not finalized");

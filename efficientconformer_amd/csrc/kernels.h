@@ -273,7 +273,9 @@ int launch_ctc_argmax(const float* x, int M, int D, const float* Wt, const float
                       int* preds, float* logits_or_null, hipStream_t s, int use_mfma = 1);   // use_mfma: fp32-MFMA kernel where the frame tile fits LDS
 // the same with split-bf16 operands on the bf16 matrix pipe (x_hi W_hi + x_hi W_lo + x_lo W_hi): Whi / Wlo [ceil(D / 16)][round_up(V, 64)][2][8]
 // bf16 (MFMA B fragments, packed at finalize); logits within ~2^-16 relative of the fp32 head
+// x_is_bf16: x points to bf16 rows [M][D] (gathered encoder outputs, bf16 wire): x_lo = 0, two MFMAs per 16 k, logits bit-identical to the fp32-input
+// kernel on the same values
 int launch_ctc_split(const float* x, int M, int D, const bf16_t* Whi, const bf16_t* Wlo, const float* bias, int V, int* preds, float* logits_or_null,
-                     hipStream_t s);
+                     hipStream_t s, int x_is_bf16 = 0);
 // drop blanks (0), collapse repeats, stop at len[b]  (model_ctc.py:99-133)
 int launch_ctc_collapse(const int* preds, const int64_t* lens, int B, int T, int* labels, int* label_len, hipStream_t s);

@@ -68,7 +68,10 @@ class ModelCTC(nn.Module):
         lib = _lib.load()
         if not enc.is_cuda:
             raise RuntimeError("efficientconformer_amd runs on a HIP device only (no CPU fallback)")
-        enc = enc.contiguous().float()
+        # bf16 rows (a gathered chunk of the multi-rank path on a bf16 wire) go to the head as they are: effconf_ctc_greedy_bf16 - no widening pass,
+        # two MFMAs per 16 k, labels identical to the fp32-input head on the same values
+        as_bf16 = enc.dtype == torch.bfloat16 and self.encoder.precision == "bf16"
+        enc = enc.contiguous() if as_bf16 else enc.contiguous().float()
         b, t, _ = enc.shape
         if enc_len is None:
             enc_len = torch.full((b,), t, dtype=torch.int64, device=enc.device)
@@ -79,9 +82,10 @@ class ModelCTC(nn.Module):
         ws = torch.empty(b * t * 4, dtype=torch.uint8, device=enc.device)
         with torch.cuda.device(enc.device):          # the C library launches on the current device
             self.encoder._ensure_packed()
-            _lib.check(lib.effconf_ctc_greedy(self.encoder._handle, enc.data_ptr(), enc_len.data_ptr(), b, t, labels.data_ptr(),
-                                              label_len.data_ptr(), logits.data_ptr() if want_logits else None, ws.data_ptr(),
-                                              ws.numel(), torch.cuda.current_stream(enc.device).cuda_stream), "ctc_greedy")
+            fn = lib.effconf_ctc_greedy_bf16 if as_bf16 else lib.effconf_ctc_greedy
+            _lib.check(fn(self.encoder._handle, enc.data_ptr(), enc_len.data_ptr(), b, t, labels.data_ptr(),
+                          label_len.data_ptr(), logits.data_ptr() if want_logits else None, ws.data_ptr(),
+                          ws.numel(), torch.cuda.current_stream(enc.device).cuda_stream), "ctc_greedy")
         return logits, labels, label_len
 
     def encode_greedy(self, x: torch.Tensor, x_len: Optional[torch.Tensor], from_mel: bool = False, **encoder_kwargs):

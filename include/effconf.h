@@ -125,6 +125,12 @@ int effconf_mel_frontend(EcEncoder* enc, const float* audio, int32_t batch, int3
  * logits (dev f32 (batch, T_out, vocab)) may be NULL.  Needs batch*T_out*4 bytes of workspace. */
 int effconf_ctc_greedy(EcEncoder* enc, const float* enc_out, const int64_t* out_len, int32_t batch, int32_t t_out,
                        int32_t* labels, int32_t* label_len, float* logits, void* workspace, size_t workspace_bytes, void* stream);
+/* The same head on bf16 rows (dev bf16 (batch, T_out, D_last)): what a rank holds after the all-gather of encoder outputs on a bf16 wire
+ * (reference sharding: main.py:33-35, 217-220; the head itself: model_ctc.py:49, 90-133).  bf16 path only.  x = x_hi exactly, so the split head issues
+ * two MFMAs per 16 k instead of three and skips the conversion pass; logits and labels are bit-identical to effconf_ctc_greedy on the same values
+ * widened to fp32. */
+int effconf_ctc_greedy_bf16(EcEncoder* enc, const uint16_t* enc_out_bf16, const int64_t* out_len, int32_t batch, int32_t t_out,
+                            int32_t* labels, int32_t* label_len, float* logits, void* workspace, size_t workspace_bytes, void* stream);
 
 /* (Grouped)RelPosMultiHeadSelfAttention core alone (reference attentions.py:549-718 between the input projections and the output
  * projection): natural-layout bf16 device buffers qu = Q + u, k, v of (batch * Tp, dim) rows (Tp = frames rounded up to the group

@@ -91,3 +91,30 @@ def test_split_gemm_kernel_alone_vs_float64(m, n, k, epi):
     print("sx_gemm %dx%dx%d epi %d: rel err %.2e" % (m, n, k, epi, err))
     assert err < 2e-6
     assert np.all(got[m:] == 7.0) and np.all(got[:, n:] == 7.0)
+
+
+# ------------------------------------------------------------------ CTC head on bf16 rows (gathered chunks of the multi-rank path, bf16 wire)
+@pytest.mark.parametrize("name,vocab", [("EfficientConformerCTCSmall", 256), ("EfficientConformerCTCSmall", 300), ("EfficientConformerCTCLarge", 1000), ("Tiny", 65)])
+def test_ctc_head_on_bf16_rows_is_bit_identical_to_the_fp32_input_head_on_the_widened_rows(name, vocab):
+    """effconf_ctc_greedy_bf16 (include/effconf.h): bf16 rows are their own hi half, the lo half is zero - the kernel drops the x_lo W_hi MFMAs and
+    the widening pass; logits, label ids and label counts equal those of effconf_ctc_greedy on the same rows widened to fp32, bit for bit
+    (reference: the head after the all-gather, main.py:217-220 + model_ctc.py:90-133).  Exact modes refuse bf16 rows by widening them in
+    ModelCTC._head (they keep the fp32 head)."""
+    m, _ = _model(name, 9, vocab=vocab)
+    m.encoder._ensure_packed()
+    enc = torch.randn(5, 83, m.encoder.plan.dim_out, generator=torch.Generator().manual_seed(4)).cuda().to(torch.bfloat16)
+    ln = torch.tensor([83, 60, 33, 1, 0]).cuda()
+    l_b, lab_b, n_b = m._head(enc, ln, want_logits=True)
+    l_f, lab_f, n_f = m._head(enc.float(), ln, want_logits=True)
+    assert torch.equal(l_b, l_f) and torch.equal(n_b, n_f)
+    for b in range(5):
+        assert torch.equal(lab_b[b, :int(n_b[b])], lab_f[b, :int(n_f[b])])
+    _, lab_b2, n_b2 = m._head(enc, ln)                              # the label-only launch (no logits buffer)
+    assert torch.equal(n_b2, n_b) and all(torch.equal(lab_b2[b, :int(n_b[b])], lab_b[b, :int(n_b[b])]) for b in range(5))
+    lib = _lib.load()
+    m.encoder.precision = "fp32"
+    m.encoder._ensure_packed()
+    ws = torch.empty(5 * 83 * 4, dtype=torch.uint8, device="cuda")
+    rc = lib.effconf_ctc_greedy_bf16(m.encoder._handle, enc.data_ptr(), ln.data_ptr(), 5, 83, lab_b.data_ptr(), n_b.data_ptr(), None, ws.data_ptr(), ws.numel(),
+                                     torch.cuda.current_stream().cuda_stream)
+    assert rc != 0 and b"bf16 path" in lib.effconf_last_error()
