@@ -683,14 +683,26 @@ int launch_chain_t(const ChainParams& p, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+// Workgroup shape.  A chain workgroup streams ALL weights of its chain through its LDS ring, one 32-unit chunk per barrier interval - a fixed
+// sequence of ~40 (D = 120) to ~70 dependent chunk steps however few rows the launch has: at B = 4 x 10 s the chain launches took 52 - 90 us each,
+// the same as with 100 x the rows, and were 1.7 of the forward's 2.2 ms (profiles/r4_03_small_batch_routes.txt).  The default shapes (8 waves = 256
+// rows at D <= 192: two waves per SIMD alternating between the matrix pipe and the VALU, one barrier for eight waves) are the throughput shapes.
+// Launches of at most `small_m` rows (option chain_small_m, default 4096: B <= 8 utterances of 10 s at the first stage) run as 2-WAVE workgroups
+// (64 rows): four times the workgroups, one wave per SIMD (a chunk step is the wave's own dependency chain, not two waves' issue slots), a
+// two-wave barrier.  Every wave computes its 32 rows exactly as in the wide shapes (same instruction sequence per wave, weights in the same
+// order): the rows are bit-identical whichever shape ran them (tests/test_gpu_round4.py).  Measured: 90 -> 77 us (D = 168), 55 -> 48 us (D = 120)
+// per chain-A launch, forward at B = 4: 2.18 -> 2.08 ms.  The rest IS the dependency chain of one wave (12 accumulating MFMAs, Swish on 16
+// values, 12 MFMAs, per chunk, 42 FFN chunks + 8 Q/K/V chunks): going below needs the hidden units of a chunk split across waves, i.e. a
+// different summation order than the throughput shapes (not bit-identical) - not built.
 template <int KIND>
 int launch_chain_kind(const ChainParams& p, hipStream_t s) {
     const int ks = 2 * ((p.D + 31) / 32);
+    const bool small = p.small_m > 0 && p.M <= p.small_m;
     if (ks <= 2) return launch_chain_t<2, 4, 4, KIND>(p, s);
-    if (ks <= 4) return launch_chain_t<4, 8, 4, KIND>(p, s);
-    if (ks <= 8) return p.variant == 1 ? launch_chain_t<8, 4, 2, KIND>(p, s) : launch_chain_t<8, 8, 4, KIND>(p, s);
-    if (ks <= 12) return launch_chain_t<12, 8, 3, KIND>(p, s);
-    return launch_chain_t<16, 4, 3, KIND>(p, s);
+    if (ks <= 4) return small ? launch_chain_t<4, 2, 4, KIND>(p, s) : launch_chain_t<4, 8, 4, KIND>(p, s);
+    if (ks <= 8) return small ? launch_chain_t<8, 2, 4, KIND>(p, s) : (p.variant == 1 ? launch_chain_t<8, 4, 2, KIND>(p, s) : launch_chain_t<8, 8, 4, KIND>(p, s));
+    if (ks <= 12) return small ? launch_chain_t<12, 2, 3, KIND>(p, s) : launch_chain_t<12, 8, 3, KIND>(p, s);
+    return launch_chain_t<16, 4, 3, KIND>(p, s);          // D = 240 / 256 already runs one wave per SIMD (4 waves); its 2-wave shape measured slower (84 against 79 us)
 }
 
 }  // namespace

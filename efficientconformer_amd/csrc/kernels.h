@@ -103,6 +103,7 @@ struct ChainParams {
     bf16_t* glu; int ldg, Ng;           // GLU output [M][ldg], Ng channels
     const float* consts;                // biases / block-norm gamma, beta / u, v as ONE zero padded block laid out by chain_const_layout
     int variant;                        // option "chain_variant": 1 = 4-wave workgroups (two per CU) at KS = 8
+    int small_m;                        // option "chain_small_m": launches of at most this many rows use 2-wave workgroups (64 rows): see launch_chain_kind
 };
 enum { CHAIN_B = 0, CHAIN_A_FULL = 1, CHAIN_A_HEAD = 2, CHAIN_A_TAIL = 3 };   // HEAD: first block (no previous tail); TAIL: last block (no next head)
 bool chain_supported(int D);

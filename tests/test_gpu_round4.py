@@ -118,3 +118,34 @@ def test_ctc_head_on_bf16_rows_is_bit_identical_to_the_fp32_input_head_on_the_wi
     rc = lib.effconf_ctc_greedy_bf16(m.encoder._handle, enc.data_ptr(), ln.data_ptr(), 5, 83, lab_b.data_ptr(), n_b.data_ptr(), None, ws.data_ptr(), ws.numel(),
                                      torch.cuda.current_stream().cuda_stream)
     assert rc != 0 and b"bf16 path" in lib.effconf_last_error()
+
+
+# ------------------------------------------------------------------ small launches: 2-wave chain workgroups (option chain_small_m)
+@pytest.mark.parametrize("name,batch,seconds", [("EfficientConformerCTCSmall", 4, 10.0), ("EfficientConformerCTCSmall", 1, 3.3), ("EfficientConformerCTCMedium", 3, 6.0),
+                                                 ("EfficientConformerTransducerSmall", 2, 5.0)])
+def test_small_launches_on_two_wave_chain_workgroups_are_bit_identical(name, batch, seconds):
+    """Chain launches of at most chain_small_m rows (default 4096) run as 2-wave workgroups, 64 rows each, instead of 8-wave ones (csrc/chain.hip,
+    launch_chain_kind: small-batch latency).  A wave computes its 32 rows with the same instruction sequence in both shapes, so the encoder output
+    is bit-identical with the option off (chain_small_m = 0: the wide shapes for every launch) - rectangular and ragged batches."""
+    cfg = named_config(name)
+    from efficientconformer_amd import Transducer
+    m = (Transducer if cfg["model_type"] == "Transducer" else ModelCTC).from_config(cfg)
+    sd = synth.make_state_dict(m.encoder.plan, 3, None, prefix="encoder.")
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    m = m.cuda()
+    lens = np.array([int(16000 * seconds * (1.0 - 0.13 * i)) for i in range(batch)], dtype=np.int64)
+    audio = torch.from_numpy(synth.make_audio(lens, seed=5)).cuda()
+    ln = torch.from_numpy(lens).cuda()
+    outs = {}
+    for small in (4096, 0):
+        m.encoder.set_option("chain_small_m", small)
+        for ragged in (False, True):
+            m.encoder.ragged = ragged
+            kw = {"x_len_host": lens} if ragged else {}
+            enc, el, _ = m.encoder(audio, ln, **kw)
+            outs[(small, ragged)] = (enc.clone(), el.clone())
+    for ragged in (False, True):
+        a, b = outs[(4096, ragged)], outs[(0, ragged)]
+        assert torch.equal(a[1], b[1])
+        assert torch.isfinite(a[0].float()).all()
+        assert torch.equal(a[0], b[0]), (name, ragged, float((a[0].float() - b[0].float()).abs().max()))

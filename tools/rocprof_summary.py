@@ -32,6 +32,11 @@ def main():
         for name, calls, tot, avg, pct in rows:
             f.write("%-110s %8d %14.1f %12.3f %8.2f %12.1f %10.1f\n" % (name[:110], calls, tot, avg, pct, tot / n, calls / n))
         f.write("# sum of kernel time: %.1f us = %.1f us per step\n" % (sum(r[2] for r in rows), sum(r[2] for r in rows) / n))
+        setup = [r for r in rows if r[0].startswith("__amd_rocclr_") or "at::native" in r[0]]
+        if setup:
+            t = sum(r[2] for r in setup)
+            f.write("# of which runtime / torch kernels outside the forward step (parameter upload at pack time, input synthesis, output checks - no hipMemcpy "
+                    "or torch op runs inside effconf_encoder_forward): %.1f us; library kernels only: %.1f us per step\n" % (t, (sum(r[2] for r in rows) - t) / n))
     print(open(out).read())
 
 
