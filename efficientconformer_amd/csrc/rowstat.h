@@ -25,6 +25,13 @@ __device__ __forceinline__ void glds16(const char* base, uint32_t off, char* lds
     const uint32_t l = (uint32_t)(uintptr_t)(lds_void_t*)lds_wave_base;
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(l), "v"(off), "s"(base) : "memory", "m0");
 }
+// The same instruction WITHOUT the "memory" clobber: for refills placed between the MFMAs of an iteration (chain.hip).  The ring protocol orders
+// the DMA against the accesses that matter - it follows the barrier that released its buffer and precedes the next one (volatile asm statements
+// keep their order among themselves) - and the LDS reads of the iteration touch other buffers, so the compiler may schedule them across it.
+__device__ __forceinline__ void glds16_nc(const char* base, uint32_t off, char* lds_wave_base) {
+    const uint32_t l = (uint32_t)(uintptr_t)(lds_void_t*)lds_wave_base;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(l), "v"(off), "s"(base) : "m0");
+}
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
     static_assert(N >= 0 && N < 64, "vmcnt immediate is 6 bits");
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
