@@ -227,6 +227,8 @@ int effconf_rnnt_greedy(EcRnnt* r, const float* enc_out, const int64_t* out_len,
  * "ctc_mfma" (default 2): the CTC head (fc + argmax).  2: split-bf16 operands on the bf16 MFMA (x_hi W_hi + x_hi W_lo + x_lo W_hi, fp32
  *   accumulation: logits within ~2^-16 relative of the fp32 head) - bf16 path only, the fp32-operand mode runs 1; 1: the fp32 MFMA; 0: the VALU
  *   kernel.  1 and 0 are k-ordered fp32 fma chains: bit-identical logits and labels.
+ * "chain_small_m" (default 4096): chain launches (csrc/chain.hip) of at most this many rows run 2-wave workgroups (64 rows) instead of 8-wave ones:
+ *   small-batch latency (B <= 8 utterances of 10 s); a wave computes its 32 rows identically in both shapes, so outputs do not depend on it.  0 = off.
  * "chain_variant" (0 / 1), "chain_full_max" (widest stage that runs chain A as one kernel; set before finalize to widen), "attn_waves"
  *   (4 / 8, attention.hip), "rs_variant" (0 / 1), "ffn_variant" (0 .. 2), "head_major_odd" (0 / 1), "exact_attention" (0 tiled / 2 tiled with 16-row workgroups / 1 one wave per query row; fp32 mode, bit-identical): tuning / test switches of the kernel launchers that were
  *   process-global EFFCONF_* environment variables until round 2; per handle now.  (Still read from the environment, once, as
