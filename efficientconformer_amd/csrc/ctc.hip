@@ -30,8 +30,9 @@ __global__ void lengths_kernel(const int64_t* __restrict__ x_len, int B, int fro
 }
 
 
-// Ragged batches (see kernels.h): lengths of every stage, then the prefix sums the ragged kernels index with.  One workgroup of four
-// waves: thread b computes utterance b's lengths; then every (position, array) pair is one wave-parallel exclusive scan (64 utterances per
+// Ragged batches (see kernels.h): lengths of every stage, then the prefix sums the ragged kernels index with.  One workgroup of sixteen
+// waves (four until round 4: the 48 scans of a 15-block encoder ran twelve deep per wave, 20 us at the head of every range's stream; three
+// deep now): thread b computes utterance b's lengths; then every (position, array) pair is one wave-parallel exclusive scan (64 utterances per
 // step, __shfl_up ladder) - a serial scan per thread cost ~0.1 ms of dependent global accesses at the head of every forward.
 __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
 #pragma unroll
@@ -39,7 +40,7 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
     return v;
 }
 
-__global__ __launch_bounds__(256) void lengths_ragged_kernel(const int64_t* __restrict__ x_len, int B, int from_audio, int hop, int sub_layers,
+__global__ __launch_bounds__(1024) void lengths_ragged_kernel(const int64_t* __restrict__ x_len, int B, int from_audio, int hop, int sub_layers,
                                                              const int* __restrict__ block_stride, const int* __restrict__ group,
                                                              const int* __restrict__ heads, int n_blocks, int* stage_lens, int* mel_len,
                                                              int* row_off, int* wg_off, int* tile_off, int64_t* out_len) {
@@ -380,7 +381,7 @@ int launch_lengths_ragged(const int64_t* x_len, int B, int from_audio, int hop, 
                           int64_t* out_len, hipStream_t s) {
     if (B <= 0) return 0;
     if (B > 4096) return -2;
-    hipLaunchKernelGGL(lengths_ragged_kernel, dim3(1), dim3(256), 0, s, x_len, B, from_audio, hop, sub_layers, block_stride, group, heads,
+    hipLaunchKernelGGL(lengths_ragged_kernel, dim3(1), dim3(1024), 0, s, x_len, B, from_audio, hop, sub_layers, block_stride, group, heads,
                        n_blocks, stage_lens, mel_len, row_off, wg_off, tile_off, out_len);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
