@@ -291,3 +291,59 @@ int launch_debug_spin(double microseconds, hipStream_t s) {
     hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, s, (long long)(microseconds * 100.0));
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
+
+// How fast does a CU fill its LDS from L2?  (round 4: the D = 240 chains stream a 32 KiB weight chunk per barrier interval through every workgroup; their
+// phase profiles put the cost of a refill at ~30 bytes per cycle and CU - tools/lds_fill_rate_probe.py measures the path alone.)  Every workgroup walks the same
+// `window` bytes of `src` (L2 resident after the first pass) in 1 KiB wave-instructions, `kib_per_wave` of them per wave and pass:
+//   mode 0: global_load_lds_dwordx4 straight into a 4 x 32 KiB LDS ring (the chains' refill);
+//   mode 1: global_load_dwordx4 into registers, 8 in flight per wave, then ds_write_b128.
+// out[2 * workgroup] = cycles (s_memtime) of the whole walk as wave 0 saw it, out[2 * workgroup + 1] = bytes the workgroup moved.
+namespace {
+template <int MODE>
+__global__ __launch_bounds__(512) void lds_fill_kernel(const char* __restrict__ src, size_t window, int kib_per_wave, int passes, unsigned long long* out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    size_t pos = 0;
+    for (int p = 0; p < passes; ++p) {
+        for (int i0 = 0; i0 < kib_per_wave; i0 += 8) {
+            typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+            u4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const size_t o = (pos + ((size_t)(i0 + j) * nw + wave) * 1024) % window;
+                char* dst = smem + ((((i0 + j) * nw + wave) * 1024) & (128 * 1024 - 1));
+                if constexpr (MODE == 0) {
+                    const uint32_t l = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)dst;
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(l), "v"((uint32_t)(lane * 16)), "s"(src + o) : "memory", "m0");
+                } else {
+                    v[j] = *reinterpret_cast<const u4*>(src + o + lane * 16);
+                }
+            }
+            if constexpr (MODE == 1) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) *reinterpret_cast<u4*>(smem + ((((i0 + j) * nw + wave) * 1024) & (128 * 1024 - 1)) + lane * 16) = v[j];
+            }
+        }
+        pos += (size_t)kib_per_wave * nw * 1024;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) { out[2 * blockIdx.x] = t1 - t0; out[2 * blockIdx.x + 1] = (unsigned long long)passes * kib_per_wave * nw * 1024ull; }
+}
+}  // namespace
+
+int launch_debug_lds_fill(int mode, int blocks, int waves, const char* src, size_t window, int kib_per_wave, int passes, unsigned long long* out, hipStream_t s) {
+    if (waves < 1 || waves > 8 || kib_per_wave % 8 || window % 1024 || window < (size_t)kib_per_wave * waves * 1024) return -2;
+    static LdsAttr a0, a1;
+    if (mode == 0) {
+        ensure_dynamic_lds(reinterpret_cast<const void*>(&lds_fill_kernel<0>), 128 * 1024, a0);
+        hipLaunchKernelGGL((lds_fill_kernel<0>), dim3(blocks), dim3(waves * 64), 128 * 1024, s, src, window, kib_per_wave, passes, out);
+    } else {
+        ensure_dynamic_lds(reinterpret_cast<const void*>(&lds_fill_kernel<1>), 128 * 1024, a1);
+        hipLaunchKernelGGL((lds_fill_kernel<1>), dim3(blocks), dim3(waves * 64), 128 * 1024, s, src, window, kib_per_wave, passes, out);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}

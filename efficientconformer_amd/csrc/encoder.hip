@@ -1726,6 +1726,11 @@ int effconf_debug_spin(double microseconds, void* stream) {
     return 0;
 }
 
+int effconf_debug_lds_fill(int32_t mode, int32_t blocks, int32_t waves, const void* src, size_t window, int32_t kib_per_wave, int32_t passes, uint64_t* out, void* stream) {
+    EC_TRY(launch_debug_lds_fill(mode, blocks, waves, reinterpret_cast<const char*>(src), window, kib_per_wave, passes, reinterpret_cast<unsigned long long*>(out), (hipStream_t)stream));
+    return 0;
+}
+
 int effconf_debug_victim(int32_t kind, int32_t blocks, int32_t iters, float* out, void* stream) {
     EC_TRY(launch_debug_victim(kind, blocks, iters, out, (hipStream_t)stream));
     return 0;

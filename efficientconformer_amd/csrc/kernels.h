@@ -250,6 +250,8 @@ int launch_mel_debug(int variant, int extra_lds, const float* audio, int B, int 
 // synthetic single-resource neighbour kernels (debug.hip)
 int launch_debug_neighbour(int kind, int blocks, int lds_bytes, int iters, float* buf, size_t n, hipStream_t s);
 int launch_debug_spin(double microseconds, hipStream_t s);
+// tools/lds_fill_rate_probe.py: L2 -> LDS fill rate of a CU (mode 0 LDS-DMA, 1 loads + ds_write); out[2 * blocks] = {cycles, bytes} per workgroup
+int launch_debug_lds_fill(int mode, int blocks, int waves, const char* src, size_t window, int kib_per_wave, int passes, unsigned long long* out, hipStream_t s);
 int launch_debug_victim(int kind, int blocks, int iters, float* out, hipStream_t s);
 // mel.hip compiled a second time WITH packed-fp32 VALU instructions (diagnostics: variant bit 8 = the hazardous round-1 kernel)
 int launch_mel_debug_pk(int variant, int extra_lds, const float* audio, int B, int L, const MelTables& t, int n_fft, int hop, int n_mels,

@@ -293,6 +293,10 @@ int effconf_debug_sx_gemm(const float* a, int32_t lda, const uint16_t* w_hi, con
                           int32_t k, int32_t epi, float* c, int32_t ldc, const float* r, int32_t ldr, float alpha, void* stream);
 /* One idle wave that occupies `stream` for `microseconds` (tools/overlap_probe.py: the duration of an xGMI transfer a single GPU cannot make). */
 int effconf_debug_spin(double microseconds, void* stream);
+/* diagnostics (tools/lds_fill_rate_probe.py): `blocks` workgroups of `waves` waves each walk the same `window` bytes of `src` (dev) into LDS, `kib_per_wave`
+ * (multiple of 8) 1-KiB wave-instructions per wave and pass; mode 0 = LDS-DMA (global_load_lds_dwordx4), 1 = loads + ds_write_b128.
+ * out (dev, 2 * blocks uint64): {cycles, bytes} per workgroup. */
+int effconf_debug_lds_fill(int32_t mode, int32_t blocks, int32_t waves, const void* src, size_t window, int32_t kib_per_wave, int32_t passes, uint64_t* out, void* stream);
 
 /* ---- attention maps: the third return value of the reference's ConformerEncoder.forward (encoders.py:126-142: att_w of every block,
  * (batch, heads, Tg, Tg) softmax rows; no caller on the hot path reads them, so they are opt-in).  effconf_encoder_attention_dims fills
