@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4, call 35: A / B on ONE box - attention2.hip of this round (lookup in one round trip, prologue loads together, branch-free block loads) against
-# round 3's file (tools/experiments/ab/attention2_round3.hip), rebuilt in place on the box between the runs
+# round 3's file (kept for the run as tools/experiments/ab/attention2_round3.hip = git show f15a03e:efficientconformer_amd/csrc/attention2.hip; removed afterwards), rebuilt in place on the box between the runs
 set -u
 repo=$(pwd); out=$repo/gpurun_out/r4_35; mkdir -p $out
 run() {

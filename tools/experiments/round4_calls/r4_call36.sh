@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4, call 36: software-pipelined FFN stage in the D <= 128 chains (chain.hip, PIPE) - tests, then A / B on ONE box against the unpipelined file
-# (tools/experiments/ab/chain_round3.hip.txt, rebuilt in place on the box between the runs)
+# (kept for the run as tools/experiments/ab/chain_round3.hip.txt = git show f15a03e:efficientconformer_amd/csrc/chain.hip + the chain_small_m plumbing; removed afterwards), rebuilt in place on the box between the runs
 set -u
 repo=$(pwd); out=$repo/gpurun_out/r4_36; mkdir -p $out
 timeout 900 python -m pytest tests/test_gpu_round4.py tests/test_gpu_encoder.py tests/test_gpu_round3.py -q -m gpu -x 2>&1 | tail -4 | tee $out/pytest.txt
