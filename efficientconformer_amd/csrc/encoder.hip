@@ -77,6 +77,7 @@ struct EcEncoder {
     int attention_v2 = 1;                    // 0: attention.hip; 1 (default) / 2: attention2.hip variants where they support the head width (padded <= 160)
     // tuning / test options that used to be process-global environment switches (effconf_encoder_set_option)
     int chain_variant = 0, chain_full_max = 192, attn_waves = 4, rs_variant = 0, ffn_variant = 0;
+    int chain_pair = 0, chain_pair_min_m = 0;   // chain2.hip (column-pair chains at padded width 192 / 256): 0 off, 1 burst refills, 2 hooked; launches below chain_pair_min_m rows stay on chain.hip
     int chain_small_m = 4096;                // chain launches of at most this many rows run as 2-wave workgroups (small-batch latency; bit-identical rows)
     int chain_max_dim = 256;                 // fused chains only for stage widths <= this (tuning: wider stages on the per-GEMM / tiled kernels)
     int tiled_min_k = 256;                   // with wide_gemm >= 2: layers with K > this leave the row-stationary kernels for LayerNorm + tiled GEMMs
@@ -689,7 +690,7 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
             // FFN1 and the Q/K/V projection of this block already ran inside the previous block's tail chain
         } else if (chain_head) {
             ChainParams cp{};
-            cp.variant = e->chain_variant; cp.small_m = e->chain_small_m;
+            cp.variant = e->chain_variant; cp.small_m = e->chain_small_m; cp.pair = e->chain_pair; cp.pair_small_max = e->chain_pair_min_m - 1;
             fill_chain_head(cp, W, D, F1c(b), qT, qTp, p);
             cp.M = M; cp.X = x; cp.ldx = D; cp.Y = x; cp.ldy = D; cp.consts = W.cc_head;
             PROF(PC_GEMM_FFN, 2.0 * M * (double)D * (2.0 * D * b.ff_ratio + 3.0 * D), (double)M * D * 16 + 22.0 * D * D);
@@ -766,7 +767,7 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
             snprintf(nm, sizeof(nm), "blocks.%d.att_o", k); trace_add(e, st, nm, o, M, D, ld8(D), 1);
             if (chain_b) {
                 ChainParams cp{};
-                cp.variant = e->chain_variant; cp.small_m = e->chain_small_m;
+                cp.variant = e->chain_variant; cp.small_m = e->chain_small_m; cp.pair = e->chain_pair; cp.pair_small_max = e->chain_pair_min_m - 1;
                 cp.M = M; cp.D = D; cp.X = x; cp.ldx = D; cp.Y = x; cp.ldy = D; cp.A = o; cp.lda = ld8(D);
                 cp.g0 = ChainGemm{W.c_outp.w, W.c_outp.ldw, W.c_outp.bias, 0};
                 cp.ln[0] = ChainLn{W.ln_conv.g, W.ln_conv.b};
@@ -810,7 +811,7 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
                 next_head = W.cc_full && nbk.dim_model <= e->chain_max_dim && e->bw[k + 1].chain_in && chain_full_supported(De, e->chain_full_max) && (((nbk.group_size * nbk.dim_model / nbk.num_heads) % 2) == 0 || !head_major_odd) && nbk.dim_model == De;
             }
             ChainParams cp{};
-            cp.variant = e->chain_variant; cp.small_m = e->chain_small_m;
+            cp.variant = e->chain_variant; cp.small_m = e->chain_small_m; cp.pair = e->chain_pair; cp.pair_small_max = e->chain_pair_min_m - 1;
             cp.M = Mo; cp.D = De; cp.X = x; cp.ldx = De; cp.Y = xo; cp.ldy = De; cp.A = cbuf; cp.lda = ld8(De);
             cp.g0 = ChainGemm{W.c_pw2.w, W.c_pw2.ldw, W.c_pw2.bias, 0};
             cp.ln[0] = ChainLn{W.ln_ffn2.g, W.ln_ffn2.b};
@@ -1804,6 +1805,8 @@ int effconf_encoder_set_option(EcEncoder* e, const char* name, int32_t value) {
     if (!strcmp(name, "rs_variant")) { if (value != 0 && value != 1) return fail("rs_variant: 0 or 1 (8-wave row-stationary GEMM workgroups)"); e->rs_variant = value; return 0; }
     if (!strcmp(name, "chain_max_dim")) { e->chain_max_dim = value; return 0; }
     if (!strcmp(name, "chain_small_m")) { e->chain_small_m = value; return 0; }
+    if (!strcmp(name, "chain_pair")) { if (value < 0 || value > 2) return fail("chain_pair: 0 (chain.hip everywhere), 1 / 2 (chain2.hip's column-pair kernels at padded width 192 / 256; 2 = refills hooked behind the MFMA groups)"); e->chain_pair = value; return 0; }
+    if (!strcmp(name, "chain_pair_min_m")) { e->chain_pair_min_m = value; return 0; }
     if (!strcmp(name, "tiled_min_k")) { e->tiled_min_k = value; return 0; }
     if (!strcmp(name, "ffn_variant")) { if (value < 0 || value > 2) return fail("ffn_variant: 0, 1 or 2 (fused-FFN workgroup shapes)"); e->ffn_variant = value; return 0; }
     if (!strcmp(name, "head_major_odd")) { e->head_major_odd = value != 0; return 0; }

@@ -104,6 +104,8 @@ struct ChainParams {
     const float* consts;                // biases / block-norm gamma, beta / u, v as ONE zero padded block laid out by chain_const_layout
     int variant;                        // option "chain_variant": 1 = 4-wave workgroups (two per CU) at KS = 8
     int small_m;                        // option "chain_small_m": launches of at most this many rows use 2-wave workgroups (64 rows): see launch_chain_kind
+    int pair_small_max;                 // option "chain_pair_min_m" - 1: launches of at most this many rows stay on chain.hip's shapes (-1: none)
+    int pair;                           // option "chain_pair": != 0 = the column-pair kernels of chain2.hip where they exist (padded width 192 / 256); 1 = burst refills, 2 = hooked
 };
 enum { CHAIN_B = 0, CHAIN_A_FULL = 1, CHAIN_A_HEAD = 2, CHAIN_A_TAIL = 3 };   // HEAD: first block (no previous tail); TAIL: last block (no next head)
 bool chain_supported(int D);
@@ -113,6 +115,9 @@ bool chain_head_supported(int D);   // FFN1 + Q/K/V half (chain A head / full)
 bool chain_tail_supported(int D);   // pointwise-2 + FFN2 + block norm half
 bool chain_full_supported(int D, int dmax = 192);   // tail + next block's head in one kernel (dmax: option "chain_full_max")
 int launch_chain(const ChainParams& p, int kind, hipStream_t s);
+// chain2.hip: the same chains with a PAIR of waves per 32 rows (column halves), 8-wave 128-row workgroups at two waves per SIMD; rows bit-identical to chain.hip's
+bool chain2_supported(int D);
+int launch_chain2(const ChainParams& p, int kind, hipStream_t s);
 
 // ---------------------------------------------------------------- normalisation / casts  (norm.hip)
 // y = LayerNorm(x) over the last dim (eps 1e-6), two-pass fp32 statistics, one wave per row.
