@@ -853,7 +853,7 @@ bool chain_full_supported(int D, int dmax) { return chain_head_supported(D) && D
 int launch_chain(const ChainParams& p, int kind, hipStream_t s) {
     if (p.M <= 0) return 0;
     if (!chain_supported(p.D)) return -2;
-    if (p.pair && chain2_supported(p.D) && !(p.pair_small_max >= 0 && p.M <= p.pair_small_max)) return launch_chain2(p, kind, s);
+    if (p.pair && chain2_supported(p.D) && p.D >= p.pair_min_d && !(p.pair_small_max >= 0 && p.M <= p.pair_small_max)) return launch_chain2(p, kind, s);
     switch (kind) {
         case CHAIN_B: return launch_chain_kind<CHAIN_B>(p, s);
         case CHAIN_A_FULL: return launch_chain_kind<CHAIN_A_FULL>(p, s);

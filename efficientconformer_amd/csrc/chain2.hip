@@ -27,6 +27,8 @@
 #include "kernels.h"
 #include "rowstat.h"
 
+#include <cstdio>
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -62,13 +64,21 @@ template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& 
 
 // ---- 128-byte-window staging (private to a wave): lane = (row 8i + lane / 8, piece lane % 8)
 template <int OFF, int N>
-__device__ __forceinline__ void s2_load(const char* base, size_t pitch, int row_bytes, int m_base, int M, int wbyte, int lane, u32x4 (&v)[N]) {
+__device__ __forceinline__ void s2_load(const char* base, size_t pitch, int row_bytes, int m_base, int M, int wbyte, int lane, u32x4 (&v)[N], bool nt = false) {
     int cb = wbyte + 16 * (lane & 7);
     cb = cb < row_bytes - 16 ? cb : row_bytes - 16;
+    if (nt) {               // streamed once: keep the rows from displacing the weights in L2 (wave-uniform branch)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m_base + 8 * i + (lane >> 3);
-        v[OFF + i] = *reinterpret_cast<const u32x4*>(base + (size_t)(m < M ? m : M - 1) * pitch + cb);
+        for (int i = 0; i < 4; ++i) {
+            const int m = m_base + 8 * i + (lane >> 3);
+            v[OFF + i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(base + (size_t)(m < M ? m : M - 1) * pitch + cb));
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m_base + 8 * i + (lane >> 3);
+            v[OFF + i] = *reinterpret_cast<const u32x4*>(base + (size_t)(m < M ? m : M - 1) * pitch + cb);
+        }
     }
 }
 template <int OFF, int N>
@@ -76,20 +86,27 @@ __device__ __forceinline__ void s2_put(char* stg, int lane, const u32x4 (&v)[N])
 #pragma unroll
     for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(stg + (8 * i + (lane >> 3)) * S2_ROW + 16 * (lane & 7)) = v[OFF + i];
 }
-__device__ __forceinline__ void s2_store(const char* stg, char* base, size_t pitch, int row_bytes, int m_base, int M, int wbyte, int lane) {
+__device__ __forceinline__ void s2_store(const char* stg, char* base, size_t pitch, int row_bytes, int m_base, int M, int wbyte, int lane, bool nt = false) {
     const int cb = wbyte + 16 * (lane & 7);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = m_base + 8 * i + (lane >> 3);
         const u32x4 v = *reinterpret_cast<const u32x4*>(stg + (8 * i + (lane >> 3)) * S2_ROW + 16 * (lane & 7));
-        if (m < M && cb < row_bytes) *reinterpret_cast<u32x4*>(base + (size_t)m * pitch + cb) = v;
+        if (m < M && cb < row_bytes) {
+            if (nt) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(base + (size_t)m * pitch + cb));
+            else *reinterpret_cast<u32x4*>(base + (size_t)m * pitch + cb) = v;
+        }
     }
 }
 
 // DMA: 0 = every wave issues its refill in one burst right behind the chunk barrier; 1 = the owner of an FFN chunk hangs its wave-DMAs behind the MFMA groups
 // of its first GEMM (its partner, which has the slack, still bursts)
-template <int KS, int KIND, int DMA>
-__global__ __launch_bounds__(NW2 * 64, 1) void chain2_kernel(const ChainDev2 cd) {
+// PROF (tuning only, EFFCONF_CHAIN2_PHASES=<10 KS + kind>): s_memtime per phase, wave A and wave B of every 8th workgroup's first pair
+template <int KS, int KIND, int DMA, bool PROF = false>
+__global__ __launch_bounds__(NW2 * 64, 1) void chain2_kernel(const ChainDev2 cd, unsigned long long* prof = nullptr) {
+    unsigned long long ph[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0;
+    if constexpr (PROF) t0 = __builtin_readcyclecounter();
+#define C2_TICK(i) do { if constexpr (PROF) { asm volatile("" ::: "memory"); const unsigned long long t1_ = __builtin_readcyclecounter(); ph[i] += t1_ - t0; t0 = t1_; } } while (0)
     using G = Geo2<KS>;
     constexpr int NT = G::NT, NTH = G::NTH, KSH = G::KSH, P1 = G::P1, HALF = G::HALF, BUF = G::BUF, PER = G::PER, DP = G::DP;
     constexpr bool ISB = KIND == CHAIN_B;
@@ -116,12 +133,19 @@ __global__ __launch_bounds__(NW2 * 64, 1) void chain2_kernel(const ChainDev2 cd)
     const int r_f0 = n_f0 + (n_f0 ? 1 : 0), r_f1 = n_f1 + (n_f1 ? 1 : 0);
     const int e0 = n_g0, e1 = e0 + r_f0, e2 = e1 + r_f1, total = e2 + n_g1;
 
-    uint32_t off_r[PER], off_f[PER];
+    // DUTY (DMA >= 2): the two waves of a pair take the refills in turns - ring chunk k is issued (2 PER wave-DMAs, wave-instructions pr + 4 k') by the
+    // waves with cw == (k & 1), in iteration k - 2; the FFN stages make the OTHER wave of that iteration the owner of the hidden chunk (first GEMM +
+    // Swish: the long half), the Q/K/V / GLU stages the same wave (its partner writes the previous chunk out)
+    constexpr bool DUTY = DMA >= 2;
+    constexpr int NOFF = DUTY ? 2 * PER : PER, ISTR = DUTY ? 4 : NW2;
+    const int i0 = DUTY ? pr : wave;
+    const bool cm = p.w2cm && (!PRE || p.f[0].w2cm) && (!POST || p.f[1].w2cm);      // second FFN weights from their chunk-major images
+    uint32_t off_r[NOFF], off_f[NOFF];
 #pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        const int i = wave + NW2 * k;
+    for (int k = 0; k < NOFF; ++k) {
+        const int i = i0 + ISTR * k;
         off_r[k] = i < KS ? dma_rows32_off<P1>(cd.ldr, i, lane) : dma_rows32_off<P1>(cd.ldr, i - KS, lane) + (uint32_t)(32 * cd.ldr) * 2u;
-        off_f[k] = i < KS ? off_r[k] : dma_w2_off(cd.ld2, i - KS, lane);
+        off_f[k] = i < KS ? off_r[k] : (cm ? (uint32_t)((i - KS) * 1024 + lane * 16) : dma_w2_off(cd.ld2, i - KS, lane));
     }
     struct Refill { const char* b_lo; const char* b_hi; char* buf; bool ffn; };
     auto issue_prep = [&](int c) __attribute__((always_inline)) -> Refill {
@@ -132,44 +156,54 @@ __global__ __launch_bounds__(NW2 * 64, 1) void chain2_kernel(const ChainDev2 cd)
         int c1 = cf < nh ? cf : nh - 1, c2 = cf - 1;
         c1 = c1 > 0 ? c1 : 0; c2 = c2 > 0 ? c2 : 0;
         const bf16_t* fw1 = second ? p.f[1].w1 : p.f[0].w1;
-        const bf16_t* fw2 = second ? p.f[1].w2 : p.f[0].w2;
+        const bf16_t* fw2 = cm ? (second ? p.f[1].w2cm : p.f[0].w2cm) : (second ? p.f[1].w2 : p.f[0].w2);
         const bool first_g = c < e0;
         const bf16_t* gw = first_g ? p.g0.w : p.g1.w;
         const int cg = first_g ? c : c - e2;
         const char* w1 = reinterpret_cast<const char*>(fw1 + (size_t)c1 * CH * cd.ldr);
-        const char* w2 = reinterpret_cast<const char*>(fw2 + c2 * CH);
+        const char* w2 = reinterpret_cast<const char*>(fw2 + (cm ? (size_t)c2 * (DP * 32) : (size_t)c2 * CH));
         const char* w = reinterpret_cast<const char*>(gw + (size_t)(cg > 0 ? cg : 0) * 64 * cd.ldr);
         return Refill{ffn ? w1 : w, ffn ? w2 : w, smem + (c % NBUF2) * BUF, ffn};
     };
     static_assert(HALF == 64 * KS * 16, "second half of a buffer = wave-instruction KS");
     auto issue_one = [&](const Refill& r, int k, auto nc) __attribute__((always_inline)) {
-        const int i = wave + NW2 * k;
+        const int i = i0 + ISTR * k;
         if constexpr (decltype(nc)::value) glds16_nc(i < KS ? r.b_lo : r.b_hi, r.ffn ? off_f[k] : off_r[k], r.buf + 1024 * i);
         else glds16(i < KS ? r.b_lo : r.b_hi, r.ffn ? off_f[k] : off_r[k], r.buf + 1024 * i);
     };
     auto issue = [&](int c) __attribute__((always_inline)) {
         const Refill r = issue_prep(c);
 #pragma unroll
-        for (int k = 0; k < PER; ++k) issue_one(r, k, std::false_type{});
+        for (int k = 0; k < NOFF; ++k) issue_one(r, k, std::false_type{});
     };
     // Ring protocol of chain.hip (plain rule): barrier k = chunk k has landed for everybody and everybody is done with chunk k - 1, whose
     // buffer takes chunk k + 2 - issued anywhere in iteration k, but BEFORE the iteration's global stores (counted waits: [refill, stores])
     int gc = 0, st1 = 0, st2 = 0;
     auto advance = [&]() __attribute__((always_inline)) -> const char* {
-        constexpr int MAXC = NBUF2 - 2;
-        int ahead = total - 1 - gc;
-        const int rem = ahead;
-        ahead = ahead < 0 ? 0 : (ahead > MAXC ? MAXC : ahead);
-        if (st1 + st2 == 0) wait_chunks<PER, MAXC>(rem);
-        else wait_vmcnt_dyn(PER * ahead + st1 + st2);
+        if constexpr (DUTY) {
+            // the issuer of chunk gc has nothing younger in its queue than the stores it issued since (chunk gc + 2 comes in iteration gc)
+            if (cw == (gc & 1)) wait_vmcnt_dyn(st1 + st2);
+        } else {
+            constexpr int MAXC = NBUF2 - 2;
+            int ahead = total - 1 - gc;
+            const int rem = ahead;
+            ahead = ahead < 0 ? 0 : (ahead > MAXC ? MAXC : ahead);
+            if (st1 + st2 == 0) wait_chunks<PER, MAXC>(rem);
+            else wait_vmcnt_dyn(PER * ahead + st1 + st2);
+        }
+        C2_TICK(1);
         st2 = st1; st1 = 0;
         wg_barrier();
+        C2_TICK(0);
         const char* buf = smem + (gc % NBUF2) * BUF;
         ++gc;
         return buf;
     };
+    // the refill of iteration gc - 1 (chunk gc + 1); DUTY: only the waves whose turn it is (cw == parity of the iteration = of the chunk)
     auto refill = [&]() __attribute__((always_inline)) {
+        if (DUTY && cw != ((gc - 1) & 1)) return;
         if (gc + NBUF2 - 2 < total) issue(gc + NBUF2 - 2);
+        C2_TICK(11);
     };
 
     float* s_b0 = sf + cd.nf[0];
@@ -183,7 +217,7 @@ __global__ __launch_bounds__(NW2 * 64, 1) void chain2_kernel(const ChainDev2 cd)
     for (int i = wave; i < cd.nfl_kb; i += NW2) glds16(reinterpret_cast<const char*>(p.consts) + (size_t)i * 1024 + lane * 16, reinterpret_cast<char*>(sf) + i * 1024);
 #pragma unroll
     for (int c = 0; c < NBUF2 - 1; ++c)
-        if (c < total) issue(c);
+        if (c < total && (!DUTY || cw == (c & 1))) issue(c);
 
     // ---- this wave's state: NTH residual tiles (its column half), the whole normalised row as B fragments
     f32x16 xc[NTH];
@@ -217,12 +251,12 @@ __global__ __launch_bounds__(NW2 * 64, 1) void chain2_kernel(const ChainDev2 cd)
     {
         const char* xb = reinterpret_cast<const char*>(p.X);
         u32x4 vx[4 * NTH] = {};
-        static_for<0, NTH>([&](auto I) { constexpr int tt = decltype(I)::value; s2_load<4 * tt>(xb, (size_t)p.ldx * 4, D * 4, m_base, p.M, 128 * (ct0 + tt), lane, vx); });
+        static_for<0, NTH>([&](auto I) { constexpr int tt = decltype(I)::value; s2_load<4 * tt>(xb, (size_t)p.ldx * 4, D * 4, m_base, p.M, 128 * (ct0 + tt), lane, vx, (p.nt & 1) != 0); });
         constexpr int NWA = (KSH + 3) / 4;                   // 128-byte windows (4 k-steps) of the wave's half of the operand row
         u32x4 va[4 * NWA] = {};
         if constexpr (ISB || PRE) {
             const char* ab = reinterpret_cast<const char*>(p.A);
-            static_for<0, NWA>([&](auto I) { constexpr int w = decltype(I)::value; s2_load<4 * w>(ab, (size_t)p.lda * 2, p.lda * 2, m_base, p.M, cw * KSH * 32 + 128 * w, lane, va); });
+            static_for<0, NWA>([&](auto I) { constexpr int w = decltype(I)::value; s2_load<4 * w>(ab, (size_t)p.lda * 2, p.lda * 2, m_base, p.M, cw * KSH * 32 + 128 * w, lane, va, (p.nt & 1) != 0); });
         }
         static_for<0, NTH>([&](auto I) {
             constexpr int tt = decltype(I)::value;
@@ -262,8 +296,9 @@ __global__ __launch_bounds__(NW2 * 64, 1) void chain2_kernel(const ChainDev2 cd)
         }
     }
     // constants and the first chunk visible to everybody
-    if (total >= NBUF2) wait_vmcnt<PER * (NBUF2 - 2)>(); else wait_vmcnt<0>();
+    if (!DUTY && total >= NBUF2) wait_vmcnt<PER * (NBUF2 - 2)>(); else wait_vmcnt<0>();
     wg_barrier();
+    C2_TICK(6);
 
     const int q0 = (half + lr) % P1;
     const int w1row = lr * (P1 * 16);
@@ -323,6 +358,7 @@ __global__ __launch_bounds__(NW2 * 64, 1) void chain2_kernel(const ChainDev2 cd)
         wg_barrier();
         if (cw == 0) rstd = *pa;
         asm volatile("" : "+v"(mean));
+        C2_TICK(5);
     };
     // bf16((x - mean) * rstd) of the wave's columns as K-permuted B fragments, then both halves to both waves
     auto norm_xf = [&](float mean, float rstd) __attribute__((always_inline)) {
@@ -337,6 +373,7 @@ __global__ __launch_bounds__(NW2 * 64, 1) void chain2_kernel(const ChainDev2 cd)
                                           pack_bf2(fmaf(xc[s >> 1][r + 6], rstd, nm), fmaf(xc[s >> 1][r + 7], rstd, nm))));
         }
         publish_xf(own);
+        C2_TICK(5);
     };
     auto store_x2 = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -346,9 +383,10 @@ __global__ __launch_bounds__(NW2 * 64, 1) void chain2_kernel(const ChainDev2 cd)
             for (int q = 0; q < 4; ++q)
                 *reinterpret_cast<float4*>(stg + lr * S2_ROW + (q * 8 + half * 4) * 4) = make_float4(xc[tt][4 * q + 0], xc[tt][4 * q + 1], xc[tt][4 * q + 2], xc[tt][4 * q + 3]);
             wave_sync();
-            s2_store(stg, reinterpret_cast<char*>(p.Y), (size_t)p.ldy * 4, D * 4, m_base, p.M, 128 * (ct0 + tt), lane);
+            s2_store(stg, reinterpret_cast<char*>(p.Y), (size_t)p.ldy * 4, D * 4, m_base, p.M, 128 * (ct0 + tt), lane, (p.nt & 2) != 0);
         }
         st1 += 4 * NTH;
+        C2_TICK(10);
     };
 
     // ---- stage: x += g0(A).  Ring chunk c carries the weight rows of tiles 2c and 2c + 1: wave A's tiles come first, then wave B's
@@ -374,6 +412,8 @@ __global__ __launch_bounds__(NW2 * 64, 1) void chain2_kernel(const ChainDev2 cd)
                     }
                 }
             }
+            if constexpr (PROF) asm volatile("s_nop 0" :: "v"(xc[0][0]), "v"(xc[NTH - 1][15]));
+            C2_TICK(7);
         }
     }
 
@@ -423,35 +463,55 @@ __global__ __launch_bounds__(NW2 * 64, 1) void chain2_kernel(const ChainDev2 cd)
             bf16x8 u0 = {}, u1 = {};
             if constexpr (!FIRST) { u0 = *reinterpret_cast<const bf16x8*>(stgp + lane * 16); u1 = *reinterpret_cast<const bf16x8*>(stgp + 1024 + lane * 16); }
             f32x16 h;
-            if (DMA == 1 && gc + NBUF2 - 2 < total) {
+            if constexpr (DMA == 3 && !FIRST) {
+                // the second GEMM of chunk j - 1 (independent accumulators) between the MFMAs of the first GEMM's dependent chain: one column tile
+                // (two MFMAs) behind every group of FB1
+                static_assert(NTH <= G1, "a column tile per MFMA group");
+                h = gemm1(buf, sb1 + j * CH + 4 * half, [&](int g) __attribute__((always_inline)) {
+                    if (g < NTH) {
+                        const bf16x8 wb0 = *reinterpret_cast<const bf16x8*>(buf + HALF + g * 2048 + w2off0);
+                        const bf16x8 wb1 = *reinterpret_cast<const bf16x8*>(buf + HALF + g * 2048 + w2off1);
+                        xc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb0, u0, xc[g], 0, 0, 0);
+                        xc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb1, u1, xc[g], 0, 0, 0);
+                    }
+                });
+            } else if (DMA == 1 && gc + NBUF2 - 2 < total) {
                 const Refill rf = issue_prep(gc + NBUF2 - 2);
                 h = gemm1(buf, sb1 + j * CH + 4 * half, [&](int g) __attribute__((always_inline)) { issue_one(rf, g, std::true_type{}); });
             } else {
                 refill();
                 h = gemm1(buf, sb1 + j * CH + 4 * half, no_hook);
             }
+            if constexpr (PROF) asm volatile("s_nop 0" :: "v"(h[0]), "v"(h[15]));
+            C2_TICK(2);
             uint32_t w[8];
 #pragma unroll
             for (int r = 0; r < 16; r += 2) w[r >> 1] = pack_bf2(swishf_(h[r]), swishf_(h[r + 1]));
             ho0 = as_bf16x8(make_uint4(w[0], w[1], w[2], w[3])); ho1 = as_bf16x8(make_uint4(w[4], w[5], w[6], w[7]));
-            if constexpr (!FIRST) gemm2(buf + HALF, u0, u1);
+            if constexpr (!FIRST && DMA != 3) gemm2(buf + HALF, u0, u1);
             *reinterpret_cast<bf16x8*>(stg + lane * 16) = ho0;
             *reinterpret_cast<bf16x8*>(stg + 1024 + lane * 16) = ho1;
+            if constexpr (PROF) asm volatile("s_nop 0" :: "v"(xc[0][0]), "v"(xc[NTH - 1][15]));
+            C2_TICK(3);
         };
+        // owner of hidden chunk j: cw == (j & 1) - DUTY: the wave whose turn it is NOT to refill in iteration j (global ring index gc + j)
+        const int op = DUTY ? ((gc + 1) & 1) : 0;            // owner(j) = the waves with cw == ((j + op) & 1)
         {   // j = 0
             const char* buf = advance();
-            if (cw == 0) own_iter(buf, 0, std::true_type{}); else refill();
+            if (cw == op) own_iter(buf, 0, std::true_type{}); else refill();
         }
         for (int j = 1; j < n; ++j) {
             const char* buf = advance();
-            if ((j & 1) == cw) own_iter(buf, j, std::false_type{});
-            else { refill(); gemm2(buf + HALF, ho0, ho1); }
+            if (((j + op) & 1) == cw) own_iter(buf, j, std::false_type{});
+            else { refill(); gemm2(buf + HALF, ho0, ho1); if constexpr (PROF) asm volatile("s_nop 0" :: "v"(xc[0][0]), "v"(xc[NTH - 1][15])); C2_TICK(4); }
         }
         {   // j = n: the second GEMM of the last hidden chunk
             const char* buf = advance();
             refill();
-            if (((n - 1) & 1) == cw) gemm2(buf + HALF, ho0, ho1);
+            if (((n - 1 + op) & 1) == cw) gemm2(buf + HALF, ho0, ho1);
             else gemm2(buf + HALF, *reinterpret_cast<const bf16x8*>(stgp + lane * 16), *reinterpret_cast<const bf16x8*>(stgp + 1024 + lane * 16));
+            if constexpr (PROF) asm volatile("s_nop 0" :: "v"(xc[0][0]), "v"(xc[NTH - 1][15]));
+            C2_TICK(4);
         }
     };
 
@@ -510,13 +570,14 @@ __global__ __launch_bounds__(NW2 * 64, 1) void chain2_kernel(const ChainDev2 cd)
             }
             st1 += 2;
         };
+        const int op = DUTY ? (gc & 1) : 0;                  // owner(c) = the waves with cw == ((c + op) & 1): DUTY - the wave that refills in that iteration
         for (int c = 0; c < n_g1; ++c) {
             const char* buf = advance();
             refill();
-            if ((c & 1) == cw) { acc_bias(acc, c); g1_mfma(acc, buf); }
-            else if (c >= 1) glu_out(c - 1);
+            if (((c + op) & 1) == cw) { acc_bias(acc, c); g1_mfma(acc, buf); if constexpr (PROF) asm volatile("s_nop 0" :: "v"(acc[0][0]), "v"(acc[1][15])); C2_TICK(8); }
+            else if (c >= 1) { glu_out(c - 1); C2_TICK(9); }
         }
-        if (n_g1 >= 1 && ((n_g1 - 1) & 1) == cw) glu_out(n_g1 - 1);
+        if (n_g1 >= 1 && ((n_g1 - 1 + op) & 1) == cw) glu_out(n_g1 - 1);
     } else {
         if constexpr (PRE) {
             ffn_stage(s_f0b1, s_f0b2, n_f0);                                        // FFN2 of the previous block
@@ -586,7 +647,7 @@ __global__ __launch_bounds__(NW2 * 64, 1) void chain2_kernel(const ChainDev2 cd)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const u32x4 v = *reinterpret_cast<const u32x4*>(stg + (8 * i + (lane >> 3)) * S2_ROW + 16 * (lane & 7));
-                        if (colok && qok[i]) *reinterpret_cast<u32x4*>(dst + qoff[i] + nn0) = v;
+                        if (colok && qok[i]) { if (p.nt & 2) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dst + qoff[i] + nn0)); else *reinterpret_cast<u32x4*>(dst + qoff[i] + nn0) = v; }
                     }
                     st1 += 4;
                 } else {                               // D % 8 == 4 (Medium's D = 180): two 8-byte halves, each inside one tensor
@@ -605,17 +666,40 @@ __global__ __launch_bounds__(NW2 * 64, 1) void chain2_kernel(const ChainDev2 cd)
                     st1 += 8;
                 }
             };
+            const int op = DUTY ? (gc & 1) : 0;              // owner(c) = the waves with cw == ((c + op) & 1): DUTY - the wave that refills in that iteration
             for (int c = 0; c < n_g1; ++c) {
                 const char* buf = advance();
                 refill();
-                if ((c & 1) == cw) { acc_bias(acc, c); g1_mfma(acc, buf); }
-                else if (c >= 1) qkv_out(c - 1);
+                if (((c + op) & 1) == cw) { acc_bias(acc, c); g1_mfma(acc, buf); if constexpr (PROF) asm volatile("s_nop 0" :: "v"(acc[0][0]), "v"(acc[1][15])); C2_TICK(8); }
+                else if (c >= 1) { qkv_out(c - 1); C2_TICK(9); }
             }
-            if (n_g1 >= 1 && ((n_g1 - 1) & 1) == cw) qkv_out(n_g1 - 1);
+            if (n_g1 >= 1 && ((n_g1 - 1 + op) & 1) == cw) qkv_out(n_g1 - 1);
         }
     }
     // ---- residual rows out
     if constexpr (!POST) store_x2();
+    if constexpr (PROF) {
+        C2_TICK(12);
+        if (lane == 0 && pr == 0 && (blockIdx.x & 7) == 0) {
+            for (int i = 0; i < 13; ++i) atomicAdd(prof + 16 * cw + i, ph[i]);
+            atomicAdd(prof + 16 * cw + 15, 1ull);
+        }
+    }
+#undef C2_TICK
+}
+
+unsigned long long* g_chain2_prof = nullptr;
+void chain2_prof_dump() {
+    unsigned long long h[32];
+    if (!g_chain2_prof || hipMemcpy(h, g_chain2_prof, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess || !h[15]) return;
+    static const char* names[13] = {"barrier", "vmcnt wait", "ffn gemm1", "ffn swish+gemm2", "ffn gemm2 only", "LN + exchange", "prologue", "g0 mfma", "g1 mfma", "g1 write-out", "store_x", "refill issue", "tail"};
+    for (int w = 0; w < 2; ++w) {
+        const unsigned long long* q = h + 16 * w;
+        unsigned long long tot = 0;
+        for (int i = 0; i < 13; ++i) tot += q[i];
+        fprintf(stderr, "[chain2 phases] %s wave %c: waves %llu, cycles/wave %.0f\n", getenv("EFFCONF_CHAIN2_PHASES"), w ? 'B' : 'A', q[15], (double)tot / q[15]);
+        for (int i = 0; i < 13; ++i) fprintf(stderr, "[chain2 phases]   %-16s %10.0f cyc/wave  %5.1f%%\n", names[i], (double)q[i] / q[15], 100.0 * q[i] / tot);
+    }
 }
 
 template <int KS, int KIND, int DMA>
@@ -644,17 +728,33 @@ int launch_chain2_t(const ChainParams& p, hipStream_t s) {
     const int lds = NBUF2 * G::BUF + NW2 * S2_BYTES + nfl * 4;
     if (lds > 160 * 1024) return -4;
     static LdsAttr attr;
-    ensure_dynamic_lds(reinterpret_cast<const void*>(&chain2_kernel<KS, KIND, DMA>), lds, attr);
-    hipLaunchKernelGGL((chain2_kernel<KS, KIND, DMA>), dim3((p.M + 127) / 128), dim3(NW2 * 64), lds, s, cd);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(&chain2_kernel<KS, KIND, DMA, false>), lds, attr);
+    if constexpr (DMA >= 1) {
+        static const bool prof = getenv("EFFCONF_CHAIN2_PHASES") != nullptr && atoi(getenv("EFFCONF_CHAIN2_PHASES")) == DMA * 1000 + KS * 10 + KIND;
+        if (prof) {
+            if (!g_chain2_prof) {
+                if (hipMalloc(&g_chain2_prof, 256) != hipSuccess || hipMemset(g_chain2_prof, 0, 256) != hipSuccess) return -1;
+                atexit(chain2_prof_dump);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chain2_kernel<KS, KIND, DMA, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            }
+            hipLaunchKernelGGL((chain2_kernel<KS, KIND, DMA, true>), dim3((p.M + 127) / 128), dim3(NW2 * 64), lds, s, cd, g_chain2_prof);
+            return hipGetLastError() == hipSuccess ? 0 : -1;
+        }
+    }
+    hipLaunchKernelGGL((chain2_kernel<KS, KIND, DMA, false>), dim3((p.M + 127) / 128), dim3(NW2 * 64), lds, s, cd, nullptr);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 template <int KIND>
 int launch_chain2_kind(const ChainParams& p, hipStream_t s) {
     const int ks = chain_padded_width(p.D) / 16;
-    const bool hook = p.pair != 1;                 // option chain_pair: 1 = burst refills, 2 = the FFN owner's refill behind its MFMA groups
-    if (ks == 12) return hook ? launch_chain2_t<12, KIND, 1>(p, s) : launch_chain2_t<12, KIND, 0>(p, s);
-    if (ks == 16) return hook ? launch_chain2_t<16, KIND, 1>(p, s) : launch_chain2_t<16, KIND, 0>(p, s);
+    // option chain_pair: 1 = burst refills by every wave, 2 = the FFN owner's refill behind its MFMA groups, 3 = refills in turns (the wave with the
+    // short half of the iteration), 4 = 3 + the second GEMM between the MFMAs of the first
+#define C2_MODES(KSV) switch (p.pair) { case 1: return launch_chain2_t<KSV, KIND, 0>(p, s); case 2: return launch_chain2_t<KSV, KIND, 1>(p, s); \
+                                        case 3: return launch_chain2_t<KSV, KIND, 2>(p, s); default: return launch_chain2_t<KSV, KIND, 3>(p, s); }
+    if (ks == 12) C2_MODES(12)
+    if (ks == 16) C2_MODES(16)
+#undef C2_MODES
     return -2;
 }
 

@@ -23,6 +23,16 @@ int fail(const std::string& m) { g_err = m; return -1; }
 
 inline int ld8(int d) { return ec_round_up(d, 8); }
 
+// Timing-only ablation build (tools/build_ablate.py: -DEFFCONF_ABLATE into a SEPARATE library, never the product): EFFCONF_SKIP = bit mask of kernel
+// families whose launches are dropped (1 attention, 2 chain A, 4 chain B, 8 depthwise conv, 16 mel, 32 subsampling, 64 glue) - what a family costs the
+// STEP when three row ranges overlap on three streams (results are wrong by construction)
+#ifdef EFFCONF_ABLATE
+static int ablate_mask() { static const int m = getenv("EFFCONF_SKIP") ? atoi(getenv("EFFCONF_SKIP")) : 0; return m; }
+#define EC_ABL(bit, stmt) do { if (!(ablate_mask() & (bit))) { stmt; } } while (0)
+#else
+#define EC_ABL(bit, stmt) do { stmt; } while (0)
+#endif
+
 uint16_t h_f2bf(float f) {
     uint32_t u; memcpy(&u, &f, 4);
     u += 0x7FFFu + ((u >> 16) & 1u);
@@ -44,6 +54,7 @@ struct BlockW {
     // fused row-local chains (chain.hip): every weight with its K index permuted per 16; FFN second weight / bias pre-scaled by 1/2
     bool chain_in = false, chain_out = false;          // chain-packed weights exist for the D-wide / De-wide parts of the block
     PackedLinear c_outp, c_pw1, c_pw2, c_qkv, c_f1a, c_f2a;
+    const bf16_t *c_f1b_cm = nullptr, *c_f2b_cm = nullptr;      // the same second weights chunk-major (chain2.hip): every 32-hidden-unit slab contiguous, in LDS slot order
     const bf16_t *c_f1b = nullptr, *c_f2b = nullptr; const float *c_f1b2 = nullptr, *c_f2b2 = nullptr;
     int c_qkv_chunks = 0, c_pw1_chunks = 0;
     std::vector<float> h_ln_out_g, h_ln_out_b, h_u, h_v, h_f1b2, h_f2b2;     // host copies for the chains' constant blocks
@@ -76,8 +87,9 @@ struct EcEncoder {
     int ctc_mfma = 2;                        // CTC head: 2 split-bf16 operands on the bf16 MFMA (bf16 path; fp32 mode falls back to 1), 1 fp32 MFMA (bit-identical to 0), 0 the VALU kernel
     int attention_v2 = 1;                    // 0: attention.hip; 1 (default) / 2: attention2.hip variants where they support the head width (padded <= 160)
     // tuning / test options that used to be process-global environment switches (effconf_encoder_set_option)
-    int chain_variant = 0, chain_full_max = 192, attn_waves = 4, rs_variant = 0, ffn_variant = 0;
-    int chain_pair = 0, chain_pair_min_m = 0;   // chain2.hip (column-pair chains at padded width 192 / 256): 0 off, 1 burst refills, 2 hooked; launches below chain_pair_min_m rows stay on chain.hip
+    int chain_variant = 1, chain_full_max = 192, attn_waves = 4, rs_variant = 0, ffn_variant = 0;
+    int chain_pair_min_d = 193, chain_nt = 0, chain_w2cm = 1;   // round 5 defaults: the column-pair kernels at padded width 256 (D = 240: 147 -> 119 us per tail + head; at 192 they cost more per row than chain.hip's 256-row workgroups)
+    int chain_pair = 4, chain_pair_min_m = 0;   // chain2.hip (column-pair chains at padded width 192 / 256): 0 off, 1 burst refills, 2 hooked; launches below chain_pair_min_m rows stay on chain.hip
     int chain_small_m = 4096;                // chain launches of at most this many rows run as 2-wave workgroups (small-batch latency; bit-identical rows)
     int chain_max_dim = 256;                 // fused chains only for stage widths <= this (tuning: wider stages on the per-GEMM / tiled kernels)
     int tiled_min_k = 256;                   // with wide_gemm >= 2: layers with K > this leave the row-stationary kernels for LayerNorm + tiled GEMMs
@@ -214,6 +226,28 @@ const bf16_t* pack_ffn2_permuted(EcEncoder* e, const std::string& prefix, int D,
             const int src = g * 16 + 4 * hh + 8 * (ee >> 2) + (ee & 3);
             if (src < F) out[(size_t)n * Kp + k] = h_f2bf(scale * w->data[(size_t)n * F + src]);
         }
+    return upload(e, out);
+}
+
+// The same weight chunk-major for chain2.hip: slab c (hidden units 32c .. 32c + 31 of all DP output rows, 64 B per row) is contiguous and already in
+// the LDS image's slot order (piece pc of row n at slot 4n + ((pc + (n >> 2)) & 3), rowstat.h dma_w2_off), so a wave-DMA reads 1 KiB of consecutive
+// bytes (row-major: sixteen 64-byte half lines per wave-DMA, the other half of every line belonging to the next slab)
+const bf16_t* pack_ffn2_chunkmajor(EcEncoder* e, const std::string& prefix, int D, int F, float scale, int DP) {
+    const HostTensor* w = find(e, prefix + ".weight");
+    if (!w || (int64_t)w->data.size() != (int64_t)D * F) return nullptr;
+    const int nch = ec_round_up(F, 32) / 32;
+    std::vector<uint16_t> out((size_t)nch * DP * 32, 0);
+    for (int c = 0; c < nch; ++c)
+        for (int n = 0; n < DP; ++n)
+            for (int pc = 0; pc < 4; ++pc) {
+                const int slot = 4 * n + ((pc + (n >> 2)) & 3);
+                for (int i = 0; i < 8; ++i) {
+                    const int k = 32 * c + 8 * pc + i;
+                    const int g = k / 16, pp = k % 16, hh = pp >> 3, ee = pp & 7;
+                    const int src = g * 16 + 4 * hh + 8 * (ee >> 2) + (ee & 3);
+                    if (n < D && src < F) out[((size_t)c * DP * 4 + slot) * 8 + i] = h_f2bf(scale * w->data[(size_t)n * F + src]);
+                }
+            }
     return upload(e, out);
 }
 
@@ -488,7 +522,7 @@ void fill_chain_head(ChainParams& cp, const BlockW& W, int D, int Fp, int T, int
     cp.D = D;
     cp.ln[2] = ChainLn{W.ln_ffn1.g, W.ln_ffn1.b};
     cp.ln[3] = ChainLn{W.ln_att.g, W.ln_att.b};
-    cp.f[1] = ChainFfn{W.c_f1a.w, W.c_f1a.ldw, W.c_f1a.bias, W.c_f1b, W.ffn1_b.ldw, W.c_f1b2, Fp};
+    cp.f[1] = ChainFfn{W.c_f1a.w, W.c_f1a.ldw, W.c_f1a.bias, W.c_f1b, W.ffn1_b.ldw, W.c_f1b2, Fp, W.c_f1b_cm};
     cp.g1 = ChainGemm{W.c_qkv.w, W.c_qkv.ldw, W.c_qkv.bias, W.c_qkv_chunks};
     cp.qu = q.qu; cp.kh = q.kh; cp.vt = q.vt; cp.u = W.u; cp.v = W.v; cp.T = T; cp.Tp = Tp;
 }
@@ -572,6 +606,9 @@ int run_subsample_linear(EcEncoder* e, hipStream_t st, const float* mel, int B, 
     return 0;
 }
 
+// chain launches of width D and M rows that go to chain2.hip (launch_chain's rule): there the tail and the next head of chain A are one kernel up to D = 256
+static bool pair_on(const EcEncoder* e, int D, int M) { return e->chain_pair && chain2_supported(D) && D >= e->chain_pair_min_d && M >= e->chain_pair_min_m; }
+
 // Ragged batches (s.ragged): every utterance runs at its own length in one concatenated row space (kernels.h: RaggedRows) - the row-local
 // kernels (chains, GEMMs, LayerNorms) just see M rows; the frame-mixing ones (subsampling, attention, depthwise conv, conv_res decimation)
 // index utterances through the descriptor arrays lengths_ragged_kernel leaves in the workspace.  out: (B, out_frames, D_last), zero filled
@@ -620,7 +657,7 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
             { PROF(PC_MISC, 0, (double)s.Min[0] * e->lin.N * 8); EC_TRY(launch_gather_rows(xrect, e->lin.N, T1r, r0, x, st)); }
         } else if (e->fuse_subsample == 2 && e->lin_rs) {        // sublinear2.hip indexes the ragged rows itself
             PROF(PC_SUBCONV, 2.0 * 9 * (double)s.Min[0] * Ksub + 2.0 * (double)s.Min[0] * Ksub * e->lin.N, (double)B * c.n_mels * s.Tm * 4 + (double)s.Min[0] * e->lin.N * 4);
-            EC_TRY(launch_sublinear2(mel, B, c.n_mels, s.Tm, s.T1, e->conv_tab, e->lin_rs, e->lin.bias, C0, e->lin.N, x, e->lin.N, st, &r0, mel_len));
+            EC_ABL(32, EC_TRY(launch_sublinear2(mel, B, c.n_mels, s.Tm, s.T1, e->conv_tab, e->lin_rs, e->lin.bias, C0, e->lin.N, x, e->lin.N, st, &r0, mel_len)));
         } else {
             // wide front ends (Large: 360 filters): conv (zero padding at every utterance's own last mel frame) + Linear on the RECTANGULAR
             // (B, T1 of the longest) rows, then the valid rows are gathered into the ragged row space (pad rows are computed and dropped:
@@ -690,11 +727,11 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
             // FFN1 and the Q/K/V projection of this block already ran inside the previous block's tail chain
         } else if (chain_head) {
             ChainParams cp{};
-            cp.variant = e->chain_variant; cp.small_m = e->chain_small_m; cp.pair = e->chain_pair; cp.pair_small_max = e->chain_pair_min_m - 1;
+            cp.variant = e->chain_variant; cp.small_m = e->chain_small_m; cp.pair = e->chain_pair; cp.pair_small_max = e->chain_pair_min_m - 1; cp.pair_min_d = e->chain_pair_min_d; cp.nt = e->chain_nt; cp.w2cm = e->chain_w2cm;
             fill_chain_head(cp, W, D, F1c(b), qT, qTp, p);
             cp.M = M; cp.X = x; cp.ldx = D; cp.Y = x; cp.ldy = D; cp.consts = W.cc_head;
             PROF(PC_GEMM_FFN, 2.0 * M * (double)D * (2.0 * D * b.ff_ratio + 3.0 * D), (double)M * D * 16 + 22.0 * D * D);
-            EC_TRY(launch_chain(cp, CHAIN_A_HEAD, st));
+            EC_ABL(2, EC_TRY(launch_chain(cp, CHAIN_A_HEAD, st)));
         } else {
             // ---- x += 1/2 FFN1(x)   (blocks.py:122; modules.py:385-392)
             { PROF(PC_LAYERNORM, 0, (double)M * D * 6); if (!have_a) EC_TRY(launch_layernorm(x, M, D, W.ln_ffn1.g, W.ln_ffn1.b, nullptr, a, ld8(D), nullptr, nullptr, st)); }
@@ -718,7 +755,7 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
         // ---- x += MHSA(LN(x))   (blocks.py:125-126; attentions.py:549-718)
         {
             { PROF(PC_MISC, 0, 0);
-              if (rg) EC_TRY(launch_attn_pad_rows_ragged(p.qu, p.kh, p.vt, W.u, D, G, rows_at(k), st));
+              if (rg) EC_ABL(64, EC_TRY(launch_attn_pad_rows_ragged(p.qu, p.kh, p.vt, W.u, D, G, rows_at(k), st)));
               else EC_TRY(nat ? launch_attn_pad_rows_nat(p, B, st) : launch_attn_pad_rows(p, B, st)); }
             // positional embeddings E = pos_layer(R) (attentions.py:588 / 678): input independent, tiny (2Tp-G rows)
             GemmParams pe{};
@@ -755,7 +792,7 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
                 ap.rag_off = row_off + (size_t)k * (B + 1); ap.rag_wg = wg_off + (size_t)k * (B + 1); ap.rag_nwg = s.wgs[k]; ap.rag_tgmax = Tg;
             }
             { PROF(PC_ATTENTION, 2.0 * H * (rg ? s.tg2[k] : (double)B * Tg * Tg) * d * 3.0, (double)M * D * 2 * 5);
-              if (rg || streaming) EC_TRY(launch_relpos_attention2(ap, 1, st)); else
+              if (rg || streaming) EC_ABL(1, EC_TRY(launch_relpos_attention2(ap, 1, st))); else
               // attention2.hip reads the natural layout only (its column masks assume the next head's finite data behind a head span); the
               // head-major test layout of odd head widths (EFFCONF_HEAD_MAJOR_ODD) stays on attention.hip
               if (e->attention_v2 && nat && relpos_attention2_supported(dpad)) EC_TRY(launch_relpos_attention2(ap, e->attention_v2, st));
@@ -767,14 +804,14 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
             snprintf(nm, sizeof(nm), "blocks.%d.att_o", k); trace_add(e, st, nm, o, M, D, ld8(D), 1);
             if (chain_b) {
                 ChainParams cp{};
-                cp.variant = e->chain_variant; cp.small_m = e->chain_small_m; cp.pair = e->chain_pair; cp.pair_small_max = e->chain_pair_min_m - 1;
+                cp.variant = e->chain_variant; cp.small_m = e->chain_small_m; cp.pair = e->chain_pair; cp.pair_small_max = e->chain_pair_min_m - 1; cp.pair_min_d = e->chain_pair_min_d; cp.nt = e->chain_nt; cp.w2cm = e->chain_w2cm;
                 cp.M = M; cp.D = D; cp.X = x; cp.ldx = D; cp.Y = x; cp.ldy = D; cp.A = o; cp.lda = ld8(D);
                 cp.g0 = ChainGemm{W.c_outp.w, W.c_outp.ldw, W.c_outp.bias, 0};
                 cp.ln[0] = ChainLn{W.ln_conv.g, W.ln_conv.b};
                 cp.g1 = ChainGemm{W.c_pw1.w, W.c_pw1.ldw, W.c_pw1.bias, W.c_pw1_chunks};
                 cp.glu = gbuf; cp.ldg = ld8(De); cp.Ng = De; cp.T = qT; cp.Tp = qTp; cp.consts = W.cc_b;
                 PROF(PC_GEMM_OTHER, 2.0 * M * (double)D * (D + 2.0 * De), (double)M * D * 10 + (double)M * De * 2 + 2.0 * D * (D + 2.0 * De));
-                EC_TRY(launch_chain(cp, CHAIN_B, st));
+                EC_ABL(4, EC_TRY(launch_chain(cp, CHAIN_B, st)));
             } else {
                 EC_TRY(run_rs_or_tiled(e, PC_GEMM_OTHER, st, o, ld8(D), M, W.outp, 0, EPI_RESID_F32, x, D, x, D, 1.0f));
             }
@@ -792,11 +829,11 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
         RaggedConv rc{};
         if (rg) { rc.in_off = row_off + (size_t)k * (B + 1); rc.in_len = lens + (size_t)k * B; rc.out_off = row_off + (size_t)(k + 1) * (B + 1);
                   rc.out_len = lens + (size_t)(k + 1) * B; rc.tile_off = tile_off + (size_t)k * (B + 1); rc.tiles = s.tiles[k]; rc.n = B; rc.out_rows = Mo; }
-        { PROF(PC_DWCONV, 2.0 * Mo * (double)De * b.kernel_size, (double)M * De * 2 + (double)Mo * De * 2); EC_TRY(launch_dwconv(gbuf, B, T, To, De, ld8(De), W.dw_w, W.dw_b, b.kernel_size, b.conv_stride, cbuf, st, rg ? &rc : nullptr, c.causal)); }
+        { PROF(PC_DWCONV, 2.0 * Mo * (double)De * b.kernel_size, (double)M * De * 2 + (double)Mo * De * 2); EC_ABL(8, EC_TRY(launch_dwconv(gbuf, B, T, To, De, ld8(De), W.dw_w, W.dw_b, b.kernel_size, b.conv_stride, cbuf, st, rg ? &rc : nullptr, c.causal))); }
         mask_stride *= b.conv_stride;
         snprintf(nm, sizeof(nm), "blocks.%d.dw", k); trace_add(e, st, nm, cbuf, Mo, De, ld8(De), 1);
         if (D != De) {   // 1x1 strided conv on frames 0, s, 2s, ...  (blocks.py:106-110)
-            { PROF(PC_MISC, 0, (double)Mo * D * 6); EC_TRY(launch_cast_rows(x, D, T, b.conv_stride, To, B, xs, ld8(D), st, rg ? &rc : nullptr)); }
+            { PROF(PC_MISC, 0, (double)Mo * D * 6); EC_ABL(64, EC_TRY(launch_cast_rows(x, D, T, b.conv_stride, To, B, xs, ld8(D), st, rg ? &rc : nullptr))); }
             EC_TRY(run_rs_or_tiled(e, PC_GEMM_OTHER, st, xs, ld8(D), Mo, W.res, 1, EPI_F32, xalt, De));
             std::swap(x, xalt);
         } else if (b.conv_stride > 1) {
@@ -808,15 +845,15 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
             bool next_head = false;
             if (!last) {
                 const EcBlock& nbk = e->blocks[k + 1];
-                next_head = W.cc_full && nbk.dim_model <= e->chain_max_dim && e->bw[k + 1].chain_in && chain_full_supported(De, e->chain_full_max) && (((nbk.group_size * nbk.dim_model / nbk.num_heads) % 2) == 0 || !head_major_odd) && nbk.dim_model == De;
+                next_head = W.cc_full && nbk.dim_model <= e->chain_max_dim && e->bw[k + 1].chain_in && chain_full_supported(De, pair_on(e, De, Mo) ? 256 : e->chain_full_max) && (((nbk.group_size * nbk.dim_model / nbk.num_heads) % 2) == 0 || !head_major_odd) && nbk.dim_model == De;
             }
             ChainParams cp{};
-            cp.variant = e->chain_variant; cp.small_m = e->chain_small_m; cp.pair = e->chain_pair; cp.pair_small_max = e->chain_pair_min_m - 1;
+            cp.variant = e->chain_variant; cp.small_m = e->chain_small_m; cp.pair = e->chain_pair; cp.pair_small_max = e->chain_pair_min_m - 1; cp.pair_min_d = e->chain_pair_min_d; cp.nt = e->chain_nt; cp.w2cm = e->chain_w2cm;
             cp.M = Mo; cp.D = De; cp.X = x; cp.ldx = De; cp.Y = xo; cp.ldy = De; cp.A = cbuf; cp.lda = ld8(De);
             cp.g0 = ChainGemm{W.c_pw2.w, W.c_pw2.ldw, W.c_pw2.bias, 0};
             cp.ln[0] = ChainLn{W.ln_ffn2.g, W.ln_ffn2.b};
             cp.ln[1] = ChainLn{W.ln_out.g, W.ln_out.b};
-            cp.f[0] = ChainFfn{W.c_f2a.w, W.c_f2a.ldw, W.c_f2a.bias, W.c_f2b, W.ffn2_b.ldw, W.c_f2b2, ec_round_up(De * b.ff_ratio, 32)};
+            cp.f[0] = ChainFfn{W.c_f2a.w, W.c_f2a.ldw, W.c_f2a.bias, W.c_f2b, W.ffn2_b.ldw, W.c_f2b2, ec_round_up(De * b.ff_ratio, 32), W.c_f2b_cm};
             double fl = 2.0 * Mo * (double)De * (De + 2.0 * De * b.ff_ratio), by = (double)Mo * De * 10 + 2.0 * De * De * (1 + 2.0 * b.ff_ratio);
             if (next_head) {
                 const EcBlock& nbk = e->blocks[k + 1];
@@ -829,7 +866,7 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
                 fl += 2.0 * Mo * (double)De * (2.0 * De * nbk.ff_ratio + 3.0 * De); by += (double)Mo * De * 8 + 2.0 * De * De * (3 + 2.0 * nbk.ff_ratio);
             }
             cp.consts = next_head ? W.cc_full : W.cc_tail;
-            { PROF(PC_GEMM_FFN, fl, by); EC_TRY(launch_chain(cp, next_head ? CHAIN_A_FULL : CHAIN_A_TAIL, st)); }
+            { PROF(PC_GEMM_FFN, fl, by); EC_ABL(2, EC_TRY(launch_chain(cp, next_head ? CHAIN_A_FULL : CHAIN_A_TAIL, st))); }
             head_done = next_head;
             have_a = false;
             if (last) { snprintf(nm, sizeof(nm), "blocks.%d.out", k); trace_add(e, st, nm, xo, Mo, De, De, 0); }
@@ -1237,6 +1274,7 @@ int effconf_encoder_finalize(EcEncoder* e) {
             if (!b2 || !pack_named_linear(e, p + ".feed_forward_module1.layers.1", F1, D, &W.c_f1a, &err, true, p + ".feed_forward_module1.layers.0") ||
                 !pack_named_linear(e, m + ".mhsa.output_layer", D, D, &W.c_outp, &err, true)) return fail("chain packing failed: " + err);
             W.c_f1b = pack_ffn2_permuted(e, p + ".feed_forward_module1.layers.4", D, F1, 0.5f);
+            if (chain2_supported(D)) W.c_f1b_cm = pack_ffn2_chunkmajor(e, p + ".feed_forward_module1.layers.4", D, F1, 0.5f, chain_padded_width(D));
             std::vector<float> hb(b2->data); for (float& x : hb) x *= 0.5f;
             W.c_f1b2 = upload(e, hb); W.h_f1b2 = hb;
             if (!W.c_f1b || !W.c_f1b2) return fail("upload failed");
@@ -1247,6 +1285,7 @@ int effconf_encoder_finalize(EcEncoder* e) {
             if (!b2 || !pack_named_linear(e, p + ".feed_forward_module2.layers.1", F2, De, &W.c_f2a, &err, true, p + ".feed_forward_module2.layers.0") ||
                 !pack_named_linear(e, p + ".convolution_module.layers.7", De, De, &W.c_pw2, &err, true)) return fail("chain packing failed: " + err);
             W.c_f2b = pack_ffn2_permuted(e, p + ".feed_forward_module2.layers.4", De, F2, 0.5f);
+            if (chain2_supported(De)) W.c_f2b_cm = pack_ffn2_chunkmajor(e, p + ".feed_forward_module2.layers.4", De, F2, 0.5f, chain_padded_width(De));
             std::vector<float> hb(b2->data); for (float& x : hb) x *= 0.5f;
             W.c_f2b2 = upload(e, hb); W.h_f2b2 = hb;
             const HostTensor *og = find(e, p + ".norm.weight"), *ob = find(e, p + ".norm.bias");
@@ -1350,7 +1389,7 @@ int effconf_encoder_finalize(EcEncoder* e) {
         }
         if (W.chain_out && chain_tail_supported(De)) {
             W.cc_tail = build(CHAIN_A_TAIL, De, &W, nullptr, &b, nullptr);
-            if (chain_full_supported(De, e->chain_full_max) && k + 1 < e->blocks.size() && e->bw[k + 1].chain_in && e->blocks[k + 1].dim_model == De)
+            if (chain_full_supported(De, std::max(e->chain_full_max, chain2_supported(De) ? 256 : 0)) && k + 1 < e->blocks.size() && e->bw[k + 1].chain_in && e->blocks[k + 1].dim_model == De)
                 W.cc_full = build(CHAIN_A_FULL, De, &W, &e->bw[k + 1], &b, &e->blocks[k + 1]);
         }
     }
@@ -1558,7 +1597,7 @@ int effconf_encoder_forward_ragged(EcEncoder* e, const float* x, const int64_t* 
     if (from_audio) {
         float* m = reinterpret_cast<float*>(ws + w.mel);
         PROF(PC_MEL, 0, (double)batch * n * 4 + (double)batch * e->cfg.n_mels * s.Tm * 4);
-        EC_TRY(launch_mel(x, batch, n, e->mel, e->cfg.n_fft, e->cfg.hop_length, e->cfg.n_mels, s.Tm, e->cfg.normalize, e->cfg.mean, e->cfg.std, m, st, x_len));
+        EC_ABL(16, EC_TRY(launch_mel(x, batch, n, e->mel, e->cfg.n_fft, e->cfg.hop_length, e->cfg.n_mels, s.Tm, e->cfg.normalize, e->cfg.mean, e->cfg.std, m, st, x_len)));
         mel = m;
     }
     return forward_core(e, mel, x_len, from_audio, s, w, ws, out, out_len, st, out_frames);
@@ -1805,8 +1844,11 @@ int effconf_encoder_set_option(EcEncoder* e, const char* name, int32_t value) {
     if (!strcmp(name, "rs_variant")) { if (value != 0 && value != 1) return fail("rs_variant: 0 or 1 (8-wave row-stationary GEMM workgroups)"); e->rs_variant = value; return 0; }
     if (!strcmp(name, "chain_max_dim")) { e->chain_max_dim = value; return 0; }
     if (!strcmp(name, "chain_small_m")) { e->chain_small_m = value; return 0; }
-    if (!strcmp(name, "chain_pair")) { if (value < 0 || value > 2) return fail("chain_pair: 0 (chain.hip everywhere), 1 / 2 (chain2.hip's column-pair kernels at padded width 192 / 256; 2 = refills hooked behind the MFMA groups)"); e->chain_pair = value; return 0; }
+    if (!strcmp(name, "chain_pair")) { if (value < 0 || value > 4) return fail("chain_pair: 0 (chain.hip everywhere), 1 .. 4 (chain2.hip's column-pair kernels at padded width 192 / 256; refill modes, see launch_chain2_kind)"); e->chain_pair = value; return 0; }
     if (!strcmp(name, "chain_pair_min_m")) { e->chain_pair_min_m = value; return 0; }
+    if (!strcmp(name, "chain_pair_min_d")) { e->chain_pair_min_d = value; return 0; }
+    if (!strcmp(name, "chain_nt")) { e->chain_nt = value; return 0; }
+    if (!strcmp(name, "chain_w2cm")) { e->chain_w2cm = value; return 0; }
     if (!strcmp(name, "tiled_min_k")) { e->tiled_min_k = value; return 0; }
     if (!strcmp(name, "ffn_variant")) { if (value < 0 || value > 2) return fail("ffn_variant: 0, 1 or 2 (fused-FFN workgroup shapes)"); e->ffn_variant = value; return 0; }
     if (!strcmp(name, "head_major_odd")) { e->head_major_odd = value != 0; return 0; }

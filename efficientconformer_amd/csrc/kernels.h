@@ -88,7 +88,7 @@ int launch_ffn_fused(const FfnParams& p, hipStream_t s);
 // One kernel runs a whole row-local stretch of the Conformer block on a 32-row tile per wave, the fp32 residual row staying in
 // registers between GEMMs (see chain.hip).  All weights are K-permuted per 16 (pack_linear_kperm), rows padded to 64.
 struct ChainGemm { const bf16_t* w; int ldw; const float* bias; int nchunks; };        // nchunks = 64-row chunks
-struct ChainFfn { const bf16_t* w1; int ldw1; const float* b1; const bf16_t* w2; int ldw2; const float* b2; int Fp; };   // w2, b2 pre-scaled by 1/2
+struct ChainFfn { const bf16_t* w1; int ldw1; const float* b1; const bf16_t* w2; int ldw2; const float* b2; int Fp; const bf16_t* w2cm; };   // w2cm: w2 chunk-major (chain2.hip; may be null)   // w2, b2 pre-scaled by 1/2
 struct ChainLn { const float* g; const float* b; };
 struct ChainParams {
     int M, D;
@@ -104,6 +104,9 @@ struct ChainParams {
     const float* consts;                // biases / block-norm gamma, beta / u, v as ONE zero padded block laid out by chain_const_layout
     int variant;                        // option "chain_variant": 1 = 4-wave workgroups (two per CU) at KS = 8
     int small_m;                        // option "chain_small_m": launches of at most this many rows use 2-wave workgroups (64 rows): see launch_chain_kind
+    int pair_min_d;                     // option "chain_pair_min_d": narrower stages stay on chain.hip
+    int w2cm;                           // option "chain_w2cm": chain2.hip streams the FFN second weights from their chunk-major images
+    int nt;                             // option "chain_nt": non-temporal hints on the activation loads (1) / stores (2) of chain2.hip (3 = both)
     int pair_small_max;                 // option "chain_pair_min_m" - 1: launches of at most this many rows stay on chain.hip's shapes (-1: none)
     int pair;                           // option "chain_pair": != 0 = the column-pair kernels of chain2.hip where they exist (padded width 192 / 256); 1 = burst refills, 2 = hooked
 };

@@ -31,9 +31,11 @@ def test_column_pair_chains_are_bit_identical_to_the_single_wave_chains(name, ba
     audio = torch.from_numpy(synth.make_audio(lens, seed=5)).cuda()
     ln = torch.from_numpy(lens).cuda()
     m.encoder.set_option("chain_small_m", 0)           # chain.hip's wide shapes as the reference for every launch
+    m.encoder.set_option("chain_pair_min_d", 0)        # the pair kernels wherever they exist (default: padded width 256 only)
     outs = {}
-    for pair, full in ((0, 192), (1, 192), (2, 192), (2, 256), (1, 256)):
-        m.encoder.set_option("chain_full_max", full)
+    variants = ((1, 192), (2, 192), (3, 256), (4, 192), (4, 256))      # (refill mode, second FFN weights row-major (192) / chunk-major (256))
+    for pair, full in ((0, 192),) + variants:
+        m.encoder.set_option("chain_w2cm", 1 if full == 256 else 0)
         m.encoder.set_option("chain_pair", pair)
         for ragged in (False, True):
             m.encoder.ragged = ragged
@@ -43,7 +45,7 @@ def test_column_pair_chains_are_bit_identical_to_the_single_wave_chains(name, ba
     for ragged in (False, True):
         a = outs[(0, 192, ragged)]
         assert torch.isfinite(a[0].float()).all()
-        for key in ((1, 192), (2, 192), (2, 256), (1, 256)):
+        for key in variants:
             b = outs[key + (ragged,)]
             assert torch.equal(a[1], b[1])
             assert torch.equal(a[0], b[0]), (name, key, ragged, float((a[0].float() - b[0].float()).abs().max()))

@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+"""Timing-only library for tools/ablate_bench.py: the product objects with encoder.hip recompiled under -DEFFCONF_ABLATE (EFFCONF_SKIP = bit mask of
+kernel families whose launches are dropped).  Written to efficientconformer_amd/build/libeffconf_ablate.so; never loaded by the package."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from efficientconformer_amd import _build as B  # noqa: E402
+
+B.build()
+objdir = os.path.join(B.HERE, "build")
+obj = os.path.join(objdir, "encoder_ablate.o")
+subprocess.check_call([B._hipcc()] + B.FLAGS + B.NO_PACKED_FP32 + ["-DEFFCONF_ABLATE", "-c", os.path.join(B.CSRC, "encoder.hip"), "-o", obj])
+objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in B.SOURCES if s != "encoder.hip"] + [os.path.join(objdir, v[1]) for v in B.VARIANT_OBJECTS] + [obj]
+out = os.path.join(objdir, "libeffconf_ablate.so")
+subprocess.check_call([B._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+print("built", out)

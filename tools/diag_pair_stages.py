@@ -16,6 +16,7 @@ def main():
     tm = int(sys.argv[2]) if len(sys.argv) > 2 else 700
     pair = int(sys.argv[3]) if len(sys.argv) > 3 else 1
     full = int(sys.argv[4]) if len(sys.argv) > 4 else 192
+    extra = [a.split("=") for a in sys.argv[5:]]
     cfg = named_config(name)
     m = ModelCTC.from_config(cfg)
     sd = synth.make_state_dict(m.encoder.plan, 7, cfg["tokenizer_params"]["vocab_size"], prefix="encoder.")
@@ -29,6 +30,8 @@ def main():
     m.encoder.set_option("chain_pair", 0)
     out0, _, t0 = m.encoder.trace_forward_mel(mel, ln)
     m.encoder.set_option("chain_pair", pair)
+    for k, v in extra:
+        m.encoder.set_option(k, int(v))
     out1, _, t1 = m.encoder.trace_forward_mel(mel, ln)
     bad = 0
     for k, v in t0.items():
