@@ -853,6 +853,8 @@ bool chain_full_supported(int D, int dmax) { return chain_head_supported(D) && D
 int launch_chain(const ChainParams& p, int kind, hipStream_t s) {
     if (p.M <= 0) return 0;
     if (!chain_supported(p.D)) return -2;
+    if (p.pair >= 5 && kind != CHAIN_B && chain3_supported(p.D) && p.D >= p.pair_min_d && !(p.pair_small_max >= 0 && p.M <= p.pair_small_max) &&
+        (kind == CHAIN_A_HEAD || p.f[0].w2cm) && (kind == CHAIN_A_TAIL || p.f[1].w2cm)) return launch_chain3(p, kind, s);
     if (p.pair && chain2_supported(p.D) && p.D >= p.pair_min_d && !(p.pair_small_max >= 0 && p.M <= p.pair_small_max)) return launch_chain2(p, kind, s);
     switch (kind) {
         case CHAIN_B: return launch_chain_kind<CHAIN_B>(p, s);

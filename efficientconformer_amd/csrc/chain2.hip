@@ -751,7 +751,7 @@ int launch_chain2_kind(const ChainParams& p, hipStream_t s) {
     // option chain_pair: 1 = burst refills by every wave, 2 = the FFN owner's refill behind its MFMA groups, 3 = refills in turns (the wave with the
     // short half of the iteration), 4 = 3 + the second GEMM between the MFMAs of the first
 #define C2_MODES(KSV) switch (p.pair) { case 1: return launch_chain2_t<KSV, KIND, 0>(p, s); case 2: return launch_chain2_t<KSV, KIND, 1>(p, s); \
-                                        case 3: return launch_chain2_t<KSV, KIND, 2>(p, s); default: return launch_chain2_t<KSV, KIND, 3>(p, s); }
+                                        case 3: return launch_chain2_t<KSV, KIND, 2>(p, s); default: return launch_chain2_t<KSV, KIND, 3>(p, s); }   /* 5: chain3.hip where it exists, mode 4 here */
     if (ks == 12) C2_MODES(12)
     if (ks == 16) C2_MODES(16)
 #undef C2_MODES

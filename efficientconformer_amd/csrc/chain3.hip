@@ -32,7 +32,7 @@ namespace {
 constexpr int NW3 = 12, NBUF3 = 3, NB3 = 8;                  // waves; ring buffers; waves that issue the ring (the B waves)
 constexpr int S3_ROW = 144;                                  // staging window: 32 rows x (128 + 16) bytes
 constexpr int S3_WIN = 32 * S3_ROW;                          // 4608: one window per B wave; [0, 4096) also carries hf slots / fragment exchanges
-constexpr int S3_TILE = 2 * S3_WIN + 512;                    // per row tile: window 0, window 1, LayerNorm hand-off slots
+constexpr int S3_TILE = 2 * S3_WIN + 512 + 256;              // per row tile: window 0, window 1, LayerNorm hand-off slots, the sink of wave A's L2 prefetches
 
 template <int KS>
 struct Geo3 {
@@ -51,6 +51,14 @@ struct ChainDev3 {
     int nfl_kb;
     int ldr;
 };
+
+// `ofs` (feeding the next addresses) made to depend on a whole accumulator tile.  Device pass only: on the host side of the compilation a 64-byte "v" operand is
+// not a valid x86 constraint, and the failed instantiation silently leaves the kernel's host stub undefined
+#if defined(__HIP_DEVICE_COMPILE__)
+#define C3_PIN_TILE(ofs, tile) asm volatile("" : "+v"(ofs) : "v"(tile))
+#else
+#define C3_PIN_TILE(ofs, tile) ((void)0)
+#endif
 
 template <int V> using ic3 = std::integral_constant<int, V>;
 template <int I, int N, class F> __device__ __forceinline__ void static_for3(F&& f) {
@@ -88,8 +96,18 @@ __device__ __forceinline__ void s3_store(const char* stg, char* base, size_t pit
 //   FFN stage: 4 (statistics)  XB  n + 2 advances                  (PRE: ffn0, POST: ffn1)
 //   block norm: 4                                                  (PRE)
 //   Q/K/V:     4  XB  n_g1 advances  2 (drain)                     (POST)
-template <int KS, int KIND>
-__global__ __launch_bounds__(NW3 * 64, 1) void chain3_kernel(const ChainDev3 cd) {
+// PROF (tuning only, EFFCONF_CHAIN3_PHASES=<kind>): s_memtime per phase, the three waves of every 8th workgroup's first row tile
+template <int KS, int KIND, bool PROF = false>
+__global__ __launch_bounds__(NW3 * 64, 1) void chain3_kernel(const ChainDev3 cd, unsigned long long* prof = nullptr) {
+    unsigned long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0;
+    if constexpr (PROF) t0 = __builtin_readcyclecounter();
+#define C3_TICK(i) do { if constexpr (PROF) { asm volatile("" ::: "memory"); const unsigned long long t1_ = __builtin_readcyclecounter(); ph[i] += t1_ - t0; t0 = t1_; } } while (0)
+#define C3_DUMP() do { if constexpr (PROF) { C3_TICK(9); if (lane == 0 && pr == 0 && (blockIdx.x & 7) == 0) { for (int i = 0; i < 10; ++i) atomicAdd(prof + 16 * role + i, ph[i]); atomicAdd(prof + 16 * role + 15, 1ull); } } } while (0)
+    if constexpr (PROF) {          // which SIMD does wave w of a 12-wave workgroup run on?  (HW_REG_HW_ID bits 5:4; workgroup 0 reports)
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) prof[48 + (threadIdx.x >> 6)] = ((hwid >> 4) & 3) | (((hwid >> 8) & 15) << 4) | (1u << 16);
+    }
     using G = Geo3<KS>;
     constexpr int NT = G::NT, NTH = G::NTH, KSH = G::KSH, P1 = G::P1, HALF = G::HALF, BUF = G::BUF, PER = G::PER, DP = G::DP, XR = G::XR;
     constexpr bool PRE = KIND == CHAIN_A_FULL || KIND == CHAIN_A_TAIL;
@@ -219,6 +237,7 @@ __global__ __launch_bounds__(NW3 * 64, 1) void chain3_kernel(const ChainDev3 cd)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
         int mine = (role + 3 - op) % 3;                      // first chunk of this wave
+#pragma unroll 1
         for (int c = 0; c < n_g1 + 2; ++c) {
             const char* buf = nullptr;
             if (c < n_g1) buf = adv(); else wg_barrier();
@@ -226,8 +245,8 @@ __global__ __launch_bounds__(NW3 * 64, 1) void chain3_kernel(const ChainDev3 cd)
             if (ph == 0 && c < n_g1) { acc_bias(acc, c); g1_mfma(acc, xf, buf); rf(); }
             else {
                 rf();
-                if (ph == 1) st += qkv_out_tile(acc[0], mine, 0, win0);
-                else if (ph == 2) { st += qkv_out_tile(acc[1], mine, 1, win1); mine += 3; }
+                if (ph == 1 && mine < n_g1) st += qkv_out_tile(acc[0], mine, 0, win0);
+                else if (ph == 2 && mine < n_g1) { st += qkv_out_tile(acc[1], mine, 1, win1); mine += 3; }
             }
         }
     };
@@ -235,13 +254,46 @@ __global__ __launch_bounds__(NW3 * 64, 1) void chain3_kernel(const ChainDev3 cd)
     if (role == 0) {
         // =================================================================== role A: first GEMM + Swish of every hidden chunk
         int gc = 0;
+        // L2 prefetch.  Every weight chunk is a FIRST touch for the XCD's L2 (the workgroups of a launch walk the weight stream in step, nothing is reused
+        // later, and the activation traffic of the launch evicts it before the next one): with two chunks of LDS prefetch the ring fill waited for memory-side
+        // latency in every iteration (vmcnt wait = 1/3 of a B wave's life, profiles/r5_10_*).  Wave A, which idles at the barriers more than half of its
+        // life, touches every 128-byte line of chunk gc + PFD once per iteration: one 4-byte LDS-DMA per lane (4 A waves x 64 lanes = the chunk's 256 lines)
+        // into a sink nobody reads - no destination register, nothing to wait for until the kernel ends
+        const int PFD = (p.nt >> 4) & 15;                    // tuning (option chain_nt, bits 4..7): prefetch distance in chunks, 0 = off
+        char* sink = win0 + 2 * S3_WIN + 512;
+        const uint32_t pf_off = (uint32_t)(((pr * 64 + lane) & 127) * 128);
+        auto prefetch = [&](int c) __attribute__((always_inline)) {
+            if (!(PFD > 0 && c < total)) return;
+            const bool ffn = c >= e0 && c < e2;
+            const bool second = c >= e1;
+            const int cf = c - (second ? e1 : e0);
+            const int nh = second ? n_f1 : n_f0;
+            int c1 = cf < nh ? cf : nh - 1, c2 = cf - 2;
+            c1 = c1 > 0 ? c1 : 0; c2 = c2 > 0 ? c2 : 0;
+            const bf16_t* fw1 = second ? p.f[1].w1 : p.f[0].w1;
+            const bf16_t* fw2 = second ? p.f[1].w2cm : p.f[0].w2cm;
+            const bool first_g = c < e0;
+            const bf16_t* gw = first_g ? p.g0.w : p.g1.w;
+            const int cg = first_g ? c : c - e2;
+            const char* w1 = reinterpret_cast<const char*>(fw1 + (size_t)c1 * CH * cd.ldr);
+            const char* w2 = reinterpret_cast<const char*>(fw2 + (size_t)c2 * (DP * 32));
+            const char* w = reinterpret_cast<const char*>(gw + (size_t)(cg > 0 ? cg : 0) * 64 * cd.ldr);
+            const char* lo = ffn ? w1 : w;
+            const char* hi = ffn ? w2 : w + (size_t)32 * cd.ldr * 2;
+            const char* base = (pr & 2) ? hi : lo;            // A waves 0, 1: the chunk's first 16 KiB (128 lines), 2, 3: its second
+            const uint32_t l = (uint32_t)(uintptr_t)(lds_void_t*)sink;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(l), "v"(pf_off), "s"(base) : "memory", "m0");
+        };
         auto advanceA = [&]() __attribute__((always_inline)) -> const char* {
             wg_barrier();
+            C3_TICK(0);
             const char* buf = smem + (gc % NBUF3) * BUF;
             ++gc;
+            prefetch(gc + NBUF3 - 2 + PFD);
             return buf;
         };
         auto no_rf = []() {};
+        for (int c = NBUF3 - 1; c < NBUF3 - 1 + PFD; ++c) prefetch(c);
         bf16x8 xf[KS];
         if constexpr (PRE) {
 #pragma unroll
@@ -249,6 +301,7 @@ __global__ __launch_bounds__(NW3 * 64, 1) void chain3_kernel(const ChainDev3 cd)
         }
         wg_barrier();
         if constexpr (PRE)
+#pragma unroll 1
             for (int c = 0; c < n_g0; ++c) (void)advanceA();
         auto gemm1 = [&](const char* buf, const float* b1, auto between) __attribute__((always_inline)) -> f32x16 {
             f32x16 h;
@@ -292,11 +345,15 @@ __global__ __launch_bounds__(NW3 * 64, 1) void chain3_kernel(const ChainDev3 cd)
                 const char* buf = advanceA();
                 hp = gemm1(buf, sb1 + 4 * half, [](int) {});
             }
+#pragma unroll 1
             for (int i = 1; i < n; ++i) {
                 const char* buf = advanceA();
+                if (p.nt & 256) continue;                    // timing-only ablation (option chain_nt bit 8): no first GEMM / Swish
                 const f32x16 hn = gemm1(buf, sb1 + i * CH + 4 * half, [](int) {});
                 swish_out(hp, ((i - 1) & 1) ? win1 : win0);
                 hp = hn;
+                if constexpr (PROF) asm volatile("s_nop 0" :: "v"(hp[0]), "v"(hp[15]));
+                C3_TICK(2);
             }
             {   // i = n
                 (void)advanceA();
@@ -321,8 +378,12 @@ __global__ __launch_bounds__(NW3 * 64, 1) void chain3_kernel(const ChainDev3 cd)
             });
             wg_barrier();
             int st = 0;
+            C3_TICK(5);
             qkv_stage(xf, advanceA, no_rf, st, gc % 3);
+            C3_TICK(8);
         }
+        wait_vmcnt<0>();                                      // the prefetches write LDS: nothing may be in flight when the workgroup's LDS is handed on
+        C3_DUMP();
         return;
     }
 
@@ -371,14 +432,17 @@ __global__ __launch_bounds__(NW3 * 64, 1) void chain3_kernel(const ChainDev3 cd)
         ahead = ahead < 0 ? 0 : (ahead > MAXC ? MAXC : ahead);
         if (st1 + st2 == 0) wait_chunks<PER, MAXC>(rem);
         else wait_vmcnt_dyn(PER * ahead + st1 + st2);
+        C3_TICK(1);
         st2 = st1; st1 = 0;
         wg_barrier();
+        C3_TICK(0);
         const char* buf = smem + (gc % NBUF3) * BUF;
         ++gc;
         return buf;
     };
     auto refill = [&]() __attribute__((always_inline)) {
         if (gc + NBUF3 - 2 < total) issue(gc + NBUF3 - 2);
+        C3_TICK(3);
     };
     for (int i = bidx; i < cd.nfl_kb; i += NB3) glds16(reinterpret_cast<const char*>(p.consts) + (size_t)i * 1024 + lane * 16, reinterpret_cast<char*>(sf) + i * 1024);
 #pragma unroll
@@ -447,13 +511,18 @@ __global__ __launch_bounds__(NW3 * 64, 1) void chain3_kernel(const ChainDev3 cd)
         }
     };
     auto add_cvec = [&](const float* sv) __attribute__((always_inline)) {
+        int ofs = 32 * ct0 + 4 * half;
 #pragma unroll
-        for (int tt = 0; tt < NTH; ++tt)
+        for (int tt = 0; tt < NTH; ++tt) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float4 v = *reinterpret_cast<const float4*>(sv + 32 * (ct0 + tt) + 8 * q + 4 * half);
+                const float4 v = *reinterpret_cast<const float4*>(sv + ofs + 32 * tt + 8 * q);
                 xc[tt][4 * q + 0] += v.x; xc[tt][4 * q + 1] += v.y; xc[tt][4 * q + 2] += v.z; xc[tt][4 * q + 3] += v.w;
             }
+            // the next tile's addresses depend on this tile's result: keeps the compiler from reading the whole vector first (64 registers on top of
+            // the rows and the operand fragments)
+            C3_PIN_TILE(ofs, xc[tt]);
+        }
     };
     auto store_x = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -491,31 +560,37 @@ __global__ __launch_bounds__(NW3 * 64, 1) void chain3_kernel(const ChainDev3 cd)
         // ---- x += g0(A): the bf16 operand rows (each B wave loads half of the k-steps, both end up with all of them), then the wave's own column tiles
         bf16x8 xa[KS];
         {
-            constexpr int NWA = (KSH + 3) / 4;
+            // one exchange round per 128-byte window (4 k-steps) of the wave's half of the operand row: load, fragments, window, barrier, both halves back.
+            // Window by window (not all loads first): with xc and the growing xa live, a second set of staging registers does not fit 168
+            static_assert(XR == (KSH + 3) / 4, "one round per window");
             const char* ab = reinterpret_cast<const char*>(p.A);
-            u32x4 va[4 * NWA] = {};
-            static_for3<0, NWA>([&](auto I) { constexpr int w = decltype(I)::value; s3_load<4 * w>(ab, (size_t)p.lda * 2, p.lda * 2, m_base, p.M, cw * KSH * 32 + 128 * w, lane, va); });
-            bf16x8 own[KSH];
-            static_for3<0, NWA>([&](auto I) {
+            static_for3<0, XR>([&](auto I) {
                 constexpr int w = decltype(I)::value;
+                u32x4 va[4] = {};
+                s3_load<0>(ab, (size_t)p.lda * 2, p.lda * 2, m_base, p.M, cw * KSH * 32 + 128 * w, lane, va);
+                if (w > 0) wg_barrier();                     // the previous round has been read
                 wave_sync();
-                s3_put<4 * w>(stg, lane, va);
+                s3_put<0>(stg, lane, va);
                 wave_sync();
+                bf16x8 own4[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    if (4 * w + j < KSH) {
-                        const int s = cw * KSH + 4 * w + j;
-                        const char* src = stg + lr * S3_ROW + (16 * j + 4 * half) * 2;
-                        uint2 lo = *reinterpret_cast<const uint2*>(src), hi = *reinterpret_cast<const uint2*>(src + 16);
-                        const int c0 = 16 * s + 4 * half;
-                        if (c0 >= D || m_base + lr >= p.M) lo = make_uint2(0u, 0u);
-                        if (c0 + 8 >= D || m_base + lr >= p.M) hi = make_uint2(0u, 0u);
-                        own[4 * w + j] = as_bf16x8(make_uint4(lo.x, lo.y, hi.x, hi.y));
-                    }
+                    const int s = cw * KSH + 4 * w + j;
+                    const char* src = stg + lr * S3_ROW + (16 * j + 4 * half) * 2;
+                    uint2 lo = *reinterpret_cast<const uint2*>(src), hi = *reinterpret_cast<const uint2*>(src + 16);
+                    const int c0 = 16 * s + 4 * half;
+                    if (c0 >= D || m_base + lr >= p.M) lo = make_uint2(0u, 0u);
+                    if (c0 + 8 >= D || m_base + lr >= p.M) hi = make_uint2(0u, 0u);
+                    own4[j] = as_bf16x8(make_uint4(lo.x, lo.y, hi.x, hi.y));
                 }
+                wave_sync();
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (4 * w + j < KSH) *reinterpret_cast<bf16x8*>(stg + j * 1024 + lane * 16) = own4[j];
+                wg_barrier();
+                read_round(xa, ic3<4 * w>{});
             });
-            wave_sync();
-            publish(own, xa, true);
+            wg_barrier();
         }
         if (total >= NBUF3) wait_vmcnt<PER * (NBUF3 - 2)>(); else wait_vmcnt<0>();
         wg_barrier();
@@ -526,7 +601,7 @@ __global__ __launch_bounds__(NW3 * 64, 1) void chain3_kernel(const ChainDev3 cd)
             refill();
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                constexpr int FB = 4;
+                constexpr int FB = 2;                        // xc + the operand fragments are 128 registers here: small batches keep the stage inside 168
                 const int t = 2 * c + j;
                 if (t < NT && cw == t / NTH) {
                     const int tt = t % NTH;
@@ -568,14 +643,19 @@ __global__ __launch_bounds__(NW3 * 64, 1) void chain3_kernel(const ChainDev3 cd)
         }
         add_cvec(sb2);
         // iteration i: second GEMM of hidden chunk i - 2 (hf from window (i - 2) & 1, published by A in iteration i - 1), and the refill
+        const bool rf_first = (p.nt & 4) == 0;               // tuning (option chain_nt, bit 4): the refill behind the second GEMM instead of in front of it
+#pragma unroll 1
         for (int i = 0; i < n + 2; ++i) {
             const char* buf = advance();
-            if (i >= 2) {
+            if (rf_first && !(p.nt & 1024)) refill();          // bit 10 (timing-only ablation): no weight stream
+            if (i >= 2 && !(p.nt & 512)) {                   // bit 9 (timing-only ablation): no second GEMM
                 const char* slot = ((i - 2) & 1) ? win1 : win0;
                 const bf16x8 h0 = *reinterpret_cast<const bf16x8*>(slot + lane * 16), h1 = *reinterpret_cast<const bf16x8*>(slot + 1024 + lane * 16);
                 gemm2(buf + HALF, h0, h1);
+                if constexpr (PROF) asm volatile("s_nop 0" :: "v"(xc[0][0]), "v"(xc[NTH - 1][15]));
             }
-            refill();
+            C3_TICK(2);
+            if (!rf_first) refill();
         }
     };
     if constexpr (PRE) {
@@ -595,7 +675,7 @@ __global__ __launch_bounds__(NW3 * 64, 1) void chain3_kernel(const ChainDev3 cd)
                 xc[t][4 * q + 2] = (xc[t][4 * q + 2] - mean) * rstd * g.z + b.z;
                 xc[t][4 * q + 3] = (xc[t][4 * q + 3] - mean) * rstd * g.w + b.w;
             }
-            asm volatile("" : "+v"(ofs) : "v"(xc[t][15]));
+            C3_PIN_TILE(ofs, xc[t]);
         }
     }
     if constexpr (POST) {
@@ -606,12 +686,35 @@ __global__ __launch_bounds__(NW3 * 64, 1) void chain3_kernel(const ChainDev3 cd)
         {
             bf16x8 own[KSH];
             norm_own(mean, rstd, own);
+            store_x();                                       // x is final: its registers are free before the full fragment set arrives
             publish(own, xf, true);
         }
-        store_x();
+        C3_TICK(5);
         qkv_stage(xf, advance, refill, st1, gc % 3);
+        C3_TICK(8);
     } else {
         store_x();
+    }
+    C3_DUMP();
+#undef C3_TICK
+#undef C3_DUMP
+}
+
+unsigned long long* g_chain3_prof = nullptr;
+void chain3_prof_dump() {
+    unsigned long long h[64];
+    if (!g_chain3_prof || hipMemcpy(h, g_chain3_prof, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess || !h[15]) return;
+    fprintf(stderr, "[chain3 phases] wave -> SIMD (CU) of workgroup 0:");
+    for (int w = 0; w < 12; ++w) fprintf(stderr, " %d:%llu(%llu)", w, h[48 + w] & 3, (h[48 + w] >> 4) & 15);
+    fprintf(stderr, "\n");
+    static const char* names[10] = {"barrier", "vmcnt wait (B)", "ffn compute", "refill issue (B)", "-", "LN / exchange / g0 / rows", "-", "-", "qkv stage", "rest"};
+    for (int w = 0; w < 3; ++w) {
+        const unsigned long long* q = h + 16 * w;
+        if (!q[15]) continue;
+        unsigned long long tot = 0;
+        for (int i = 0; i < 10; ++i) tot += q[i];
+        fprintf(stderr, "[chain3 phases] kind %s role %d: waves %llu, cycles/wave %.0f\n", getenv("EFFCONF_CHAIN3_PHASES"), w, q[15], (double)tot / q[15]);
+        for (int i = 0; i < 10; ++i) if (q[i]) fprintf(stderr, "[chain3 phases]   %-26s %10.0f cyc/wave  %5.1f%%\n", names[i], (double)q[i] / q[15], 100.0 * q[i] / tot);
     }
 }
 
@@ -637,9 +740,20 @@ int launch_chain3_t(const ChainParams& p, hipStream_t s) {
     if (!p.consts) return -5;
     const int lds = NBUF3 * G::BUF + 4 * S3_TILE + nfl * 4;
     if (lds > 160 * 1024) return -4;
+    if (getenv("EFFCONF_CHAIN3_DEBUG")) fprintf(stderr, "[chain3] kind %d M %d D %d nt %d pair %d w2cm %d\n", KIND, p.M, p.D, p.nt, p.pair, p.w2cm);
     static LdsAttr attr;
-    ensure_dynamic_lds(reinterpret_cast<const void*>(&chain3_kernel<KS, KIND>), lds, attr);
-    hipLaunchKernelGGL((chain3_kernel<KS, KIND>), dim3((p.M + 127) / 128), dim3(NW3 * 64), lds, s, cd);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(&chain3_kernel<KS, KIND, false>), lds, attr);
+    static const bool prof = getenv("EFFCONF_CHAIN3_PHASES") != nullptr && atoi(getenv("EFFCONF_CHAIN3_PHASES")) == KIND;
+    if (prof) {
+        if (!g_chain3_prof) {
+            if (hipMalloc(&g_chain3_prof, 512) != hipSuccess || hipMemset(g_chain3_prof, 0, 512) != hipSuccess) return -1;
+            atexit(chain3_prof_dump);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chain3_kernel<KS, KIND, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        }
+        hipLaunchKernelGGL((chain3_kernel<KS, KIND, true>), dim3((p.M + 127) / 128), dim3(NW3 * 64), lds, s, cd, g_chain3_prof);
+        return hipGetLastError() == hipSuccess ? 0 : -1;
+    }
+    hipLaunchKernelGGL((chain3_kernel<KS, KIND, false>), dim3((p.M + 127) / 128), dim3(NW3 * 64), lds, s, cd, nullptr);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -1844,7 +1844,7 @@ int effconf_encoder_set_option(EcEncoder* e, const char* name, int32_t value) {
     if (!strcmp(name, "rs_variant")) { if (value != 0 && value != 1) return fail("rs_variant: 0 or 1 (8-wave row-stationary GEMM workgroups)"); e->rs_variant = value; return 0; }
     if (!strcmp(name, "chain_max_dim")) { e->chain_max_dim = value; return 0; }
     if (!strcmp(name, "chain_small_m")) { e->chain_small_m = value; return 0; }
-    if (!strcmp(name, "chain_pair")) { if (value < 0 || value > 4) return fail("chain_pair: 0 (chain.hip everywhere), 1 .. 4 (chain2.hip's column-pair kernels at padded width 192 / 256; refill modes, see launch_chain2_kind)"); e->chain_pair = value; return 0; }
+    if (!strcmp(name, "chain_pair")) { if (value < 0 || value > 5) return fail("chain_pair: 0 (chain.hip everywhere), 5 (chain3.hip for chain A at padded width 256, chain2.hip mode 4 elsewhere), 1 .. 4 (chain2.hip's column-pair kernels at padded width 192 / 256; refill modes, see launch_chain2_kind)"); e->chain_pair = value; return 0; }
     if (!strcmp(name, "chain_pair_min_m")) { e->chain_pair_min_m = value; return 0; }
     if (!strcmp(name, "chain_pair_min_d")) { e->chain_pair_min_d = value; return 0; }
     if (!strcmp(name, "chain_nt")) { e->chain_nt = value; return 0; }

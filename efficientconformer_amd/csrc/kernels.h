@@ -121,6 +121,10 @@ int launch_chain(const ChainParams& p, int kind, hipStream_t s);
 // chain2.hip: the same chains with a PAIR of waves per 32 rows (column halves), 8-wave 128-row workgroups at two waves per SIMD; rows bit-identical to chain.hip's
 bool chain2_supported(int D);
 int launch_chain2(const ChainParams& p, int kind, hipStream_t s);
+// chain3.hip: chain A at padded width 256 with the row tile spread over THREE waves (first GEMM + Swish | second GEMM on a column half + the weight stream,
+// twice): 12-wave 128-row workgroups, three waves per SIMD; needs the chunk-major second FFN weights (ChainFfn::w2cm); rows bit-identical to chain.hip's
+bool chain3_supported(int D);
+int launch_chain3(const ChainParams& p, int kind, hipStream_t s);
 
 // ---------------------------------------------------------------- normalisation / casts  (norm.hip)
 // y = LayerNorm(x) over the last dim (eps 1e-6), two-pass fp32 statistics, one wave per row.

@@ -33,7 +33,7 @@ def test_column_pair_chains_are_bit_identical_to_the_single_wave_chains(name, ba
     m.encoder.set_option("chain_small_m", 0)           # chain.hip's wide shapes as the reference for every launch
     m.encoder.set_option("chain_pair_min_d", 0)        # the pair kernels wherever they exist (default: padded width 256 only)
     outs = {}
-    variants = ((1, 192), (2, 192), (3, 256), (4, 192), (4, 256))      # (refill mode, second FFN weights row-major (192) / chunk-major (256))
+    variants = ((1, 192), (2, 192), (3, 256), (4, 192), (4, 256), (5, 256))      # (refill mode, second FFN weights row-major (192) / chunk-major (256))
     for pair, full in ((0, 192),) + variants:
         m.encoder.set_option("chain_w2cm", 1 if full == 256 else 0)
         m.encoder.set_option("chain_pair", pair)
