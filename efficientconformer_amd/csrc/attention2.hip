@@ -17,6 +17,9 @@
 // softmax are those of attention.hip, so the two kernels are interchangeable (option "attention_v2", tests compare both).
 #include "kernels.h"
 
+#include <cstdlib>
+#include <type_traits>
+
 namespace {
 
 constexpr int BJ = 64;          // keys per block
@@ -86,15 +89,16 @@ __global__ __launch_bounds__(NWV * 64, (QT == 1 && NWV == 4 && DP <= 96) ? 2 : 1
     int Tg = p.Tg, T = p.T, qt_wg, h, b;
     {
         const int per_b = p.H * qtiles, q8 = p.B >> 3, r8 = p.B & 7;
-        const int u = p.rag_off ? ragged_find(p.rag_wg, p.B, id) : id / per_b;
+        const int u = p.rag_off ? ((p.ablate & 8) ? (id * p.B) / (int)gridDim.x : ragged_find(p.rag_wg, p.B, id)) : id / per_b;
         int x, j;
         if (u < r8 * (q8 + 1)) { x = u / (q8 + 1); j = u - x * (q8 + 1); }
         else { const int u2 = u - r8 * (q8 + 1); x = u2 / q8; j = u2 - x * q8; x += r8; }
         b = x + 8 * j;
-        int local = id - (p.rag_off ? p.rag_wg[u] : u * per_b);
+        int local = id - (p.rag_off ? ((p.ablate & 8) ? id : p.rag_wg[u]) : u * per_b);
         if (p.rag_off) { T = p.lens[b]; Tg = (T + p.G - 1) / p.G; qtiles = (Tg + BI - 1) / BI; }
         qt_wg = local % qtiles; h = local / qtiles;
     }
+    if (p.ablate & 128) return;                                  // timing-only: dispatch + utterance lookup alone
     const int i0 = qt_wg * BI, iw0 = i0 + wave * 16 * QT;
     const size_t orow0 = p.rag_off ? (size_t)p.rag_off[b] : (size_t)b * p.T;          // first row of the utterance in the un-grouped output
     const size_t qoff = (p.rag_off ? orow0 * p.D : (size_t)b * p.q_bstride) + (size_t)h * p.q_hstride;
@@ -136,7 +140,7 @@ __global__ __launch_bounds__(NWV * 64, (QT == 1 && NWV == 4 && DP <= 96) ? 2 : 1
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const int x = ks * 32 + g * 8;
-                ra[ks] = ld16(Qu + (size_t)ic * RS + (x < dceil ? x : 0));
+                ra[ks] = (p.ablate & 32) ? make_uint4(0, 0, 0, 0) : ld16(Qu + (size_t)ic * RS + (x < dceil ? x : 0));
             }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
@@ -164,7 +168,7 @@ __global__ __launch_bounds__(NWV * 64, (QT == 1 && NWV == 4 && DP <= 96) ? 2 : 1
             const int rr = q / CPR, x = (q - rr * CPR) * 8;
             const int r = R0 + (rr < BI + 63 ? rr : BI + 62);
             const int rc = r < 0 ? 0 : (r >= erows ? erows - 1 : r);
-            fb[n] = ld16(Eh + (size_t)rc * ERS + (x < dceil ? x : 0));
+            fb[n] = (p.ablate & 16) ? make_uint4(0, 0, 0, 0) : ld16(Eh + (size_t)rc * ERS + (x < dceil ? x : 0));
         }
 #pragma unroll
         for (int n = 0; n < NB; ++n) {
@@ -215,6 +219,7 @@ __global__ __launch_bounds__(NWV * 64, (QT == 1 && NWV == 4 && DP <= 96) ? 2 : 1
         koffs[n] = (uint32_t)(r * RS + xc) * 2u;                // BYTE offsets: wave-uniform base + 32-bit lane offset
     }
     auto issue_loads = [&](Stage& st_, int jn) __attribute__((always_inline)) {
+        if (((p.ablate & 2) && jn > kbeg) || (p.ablate & 64)) return;
         // unmasked fast path: every 16-byte chunk of the block stays inside the library's own (finite) data.  With a head width that
         // is not a multiple of 8 (d = 90 / 135 / 42) the chunk that closes a head span reads dceil - d elements of the NEXT span; behind
         // the last key row of the last head of the last utterance that is the never-written slack of the buffer (NaN patterns times the
@@ -277,11 +282,15 @@ __global__ __launch_bounds__(NWV * 64, (QT == 1 && NWV == 4 && DP <= 96) ? 2 : 1
         __syncthreads();
     };
 
-    auto compute_block = [&](int j0, int par) __attribute__((always_inline)) {
+    // JTV = 16-key tiles of the block that are computed: 4, or 2 for an utterance's LAST block when at most 32 of its keys exist (the other tiles' scores
+    // are masked, their probabilities exactly zero: S, positional band, softmax and P V of 32 keys instead of 64 - an utterance of 142 frames has 14
+    // keys in its third block).  Same operations on the computed tiles, in the same order: bit-identical to the full block
+    auto compute_block = [&](int j0, int par, auto jtv) __attribute__((always_inline)) {
+        constexpr int JTV = decltype(jtv)::value;
         // ---- S^T tiles of both query tiles: every K fragment feeds two MFMAs
-        f32x4 st[QT][4];
+        f32x4 st[QT][JTV];
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt) {
+        for (int jt = 0; jt < JTV; ++jt) {
 #pragma unroll
             for (int t = 0; t < QT; ++t) st[t][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -293,13 +302,14 @@ __global__ __launch_bounds__(NWV * 64, (QT == 1 && NWV == 4 && DP <= 96) ? 2 : 1
         }
         // ---- positional band of the pair: 96 rows = 6 fragment rows; tile 1 uses rows 0 .. 79, tile 0 rows 16 .. 95
         const int rw1 = woff1 + 64 * par;                       // ring row of the wave's band row 0 (ring row = band row + key offset mod 128)
-        f32x4 pe[QT][5];
+        constexpr int PU = JTV + 1;                             // band tiles per query tile: 16 queries + 16 JTV keys - 1 rows
+        f32x4 pe[QT][PU];
 #pragma unroll
         for (int t = 0; t < QT; ++t)
 #pragma unroll
-            for (int u = 0; u < 5; ++u) pe[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int u = 0; u < PU; ++u) pe[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int u = 0; u < 4 + QT; ++u) {
+        for (int u = 0; u < JTV + QT; ++u) {
             const int er = ((rw1 + u * 16) & (ERING - 1)) + c;      // (multiples of 16) + c: no carry into the wrap
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
@@ -307,14 +317,14 @@ __global__ __launch_bounds__(NWV * 64, (QT == 1 && NWV == 4 && DP <= 96) ? 2 : 1
 #pragma unroll
                 for (int t = 0; t < QT; ++t) {                 // tile t covers fragment rows QT - 1 - t .. QT + 3 - t
                     const int ut = u - (QT - 1 - t);
-                    if (ut >= 0 && ut < 5) pe[t][ut] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qv[t][ks], pe[t][ut], 0, 0, 0);
+                    if (ut >= 0 && ut < PU) pe[t][ut] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qv[t][ks], pe[t][ut], 0, 0, 0);
                 }
             }
         }
 #pragma unroll
         for (int t = 0; t < QT; ++t)
 #pragma unroll
-            for (int u = 0; u < 5; ++u) *reinterpret_cast<f32x4*>(skew0 + t * 16 * SKEW_LD + u * 16 + g * 4) = pe[t][u];
+            for (int u = 0; u < PU; ++u) *reinterpret_cast<f32x4*>(skew0 + t * 16 * SKEW_LD + u * 16 + g * 4) = pe[t][u];
         wave_sync();
 
         // ---- realign, mask, online softmax, per tile.  Raw scores s = S + PE; the running maximum is tracked in raw units and
@@ -326,7 +336,7 @@ __global__ __launch_bounds__(NWV * 64, (QT == 1 && NWV == 4 && DP <= 96) ? 2 : 1
             const float* skew = skew0 + t * 16 * SKEW_LD;
             float mloc = -INFINITY;
 #pragma unroll
-            for (int jt = 0; jt < 4; ++jt)
+            for (int jt = 0; jt < JTV; ++jt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int jl = jt * 16 + g * 4 + r;
@@ -337,7 +347,7 @@ __global__ __launch_bounds__(NWV * 64, (QT == 1 && NWV == 4 && DP <= 96) ? 2 : 1
             if (j0 + BJ > nkv || (banded && (j0 - (iq0 + 15) < -band_l || j0 + BJ - 1 - iq0 > band_r))) {
                 const int iq = iq0 + c;
 #pragma unroll
-                for (int jt = 0; jt < 4; ++jt)
+                for (int jt = 0; jt < JTV; ++jt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int j = j0 + jt * 16 + g * 4 + r, dj = j - iq;
@@ -347,12 +357,12 @@ __global__ __launch_bounds__(NWV * 64, (QT == 1 && NWV == 4 && DP <= 96) ? 2 : 1
             if (tile_dead) {                                   // rows that see no key at all: every score equal -> uniform softmax over all key groups
                 const bool dead = nkv < 1 || iq0 + c - band_l >= nkv;
 #pragma unroll
-                for (int jt = 0; jt < 4; ++jt)
+                for (int jt = 0; jt < JTV; ++jt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) st[t][jt][r] = dead ? (j0 + jt * 16 + g * 4 + r < Tg ? 0.f : NEG_BIG) : st[t][jt][r];
             }
 #pragma unroll
-            for (int jt = 0; jt < 4; ++jt)
+            for (int jt = 0; jt < JTV; ++jt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) mloc = fmaxf(mloc, st[t][jt][r]);
             mloc = fmaxf(mloc, __shfl_xor(mloc, 16));
@@ -368,7 +378,7 @@ __global__ __launch_bounds__(NWV * 64, (QT == 1 && NWV == 4 && DP <= 96) ? 2 : 1
             const float nm = -m_run[t] * scale2;
             float lsum = 0.f;
 #pragma unroll
-            for (int jt = 0; jt < 4; ++jt)
+            for (int jt = 0; jt < JTV; ++jt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float e = __builtin_amdgcn_exp2f(fmaf(st[t][jt][r], scale2, nm));
@@ -380,7 +390,7 @@ __global__ __launch_bounds__(NWV * 64, (QT == 1 && NWV == 4 && DP <= 96) ? 2 : 1
         // ---- O^T += V^T P^T for both tiles; contraction slot (g, e) <-> key (2*c2 + (e>>2))*16 + g*4 + (e&3) on both operands;
         //      the V^T fragment is two transposing reads of the key-major V tile
 #pragma unroll
-        for (int c2 = 0; c2 < 2; ++c2) {
+        for (int c2 = 0; c2 < JTV / 2; ++c2) {
             bf16x8 pf[QT];
 #pragma unroll
             for (int t = 0; t < QT; ++t) {
@@ -402,6 +412,15 @@ __global__ __launch_bounds__(NWV * 64, (QT == 1 && NWV == 4 && DP <= 96) ? 2 : 1
         }
     };
 
+    // waves whose 16 queries all lie behind the utterance's last grouped row (the last query tile of an utterance of 142 rows: three of its four waves)
+    // stage and publish with the workgroup but compute nothing: their SIMD's issue slots go to the other workgroup of the CU
+    const bool wave_idle = iw0 >= Tg;
+    const bool short_ok = !tile_dead;                           // dead rows spread a uniform softmax over ALL key groups: full blocks
+    auto run_block = [&](int j0, int par) __attribute__((always_inline)) {
+        if (wave_idle || (p.ablate & 1)) return;
+        if (short_ok && nkeys - j0 <= 32) compute_block(j0, par, std::integral_constant<int, 2>{});
+        else compute_block(j0, par, std::integral_constant<int, 4>{});
+    };
     // two staging sets (loads two key blocks ahead) while they fit the register file; one set (one block ahead) for the widest heads
     // of the 2-wave workgroup, whose threads stage twice as many chunks
     constexpr bool TWO_SETS = SETS == 2 || (SETS == 0 && !(NWV == 2 && DP >= 96));
@@ -415,7 +434,7 @@ __global__ __launch_bounds__(NWV * 64, (QT == 1 && NWV == 4 && DP <= 96) ? 2 : 1
             if (j0 >= nkeys) break;
             if (half2 == 0) publish(sa, j0, 0); else publish(sb, j0, 1);
             if (j0 + 2 * BJ < nkeys) { if (half2 == 0) issue_loads(sa, j0 + 2 * BJ); else issue_loads(sb, j0 + 2 * BJ); }
-            compute_block(j0, half2);
+            run_block(j0, half2);
         }
     } else {
         for (int jb = kbeg; jb < nkeys; jb += 2 * BJ)
@@ -425,7 +444,7 @@ __global__ __launch_bounds__(NWV * 64, (QT == 1 && NWV == 4 && DP <= 96) ? 2 : 1
             if (j0 >= nkeys) break;
             publish(sa, j0, half2);
             if (j0 + BJ < nkeys) issue_loads(sa, j0 + BJ);
-            compute_block(j0, half2);
+            run_block(j0, half2);
         }
     }
 
@@ -436,7 +455,7 @@ __global__ __launch_bounds__(NWV * 64, (QT == 1 && NWV == 4 && DP <= 96) ? 2 : 1
         l_tot += __shfl_xor(l_tot, 32);
         const float inv = 1.0f / l_tot;
         const int i = iw0 + 16 * t + c;
-        if (i >= Tg) continue;
+        if (i >= Tg || (p.ablate & 4)) continue;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             const int x0 = dt * 16 + g * 4;
@@ -486,8 +505,11 @@ bool relpos_attention2_supported(int dpad) { return dpad == 32 || dpad == 64 || 
 
 // variant: 1 = 16 queries per wave, 4-wave 64-query workgroups, two per CU (attention.hip's shape: the default);
 //          2 = 32 queries per wave, 2-wave 64-query workgroups (one wave per SIMD: measured slower, kept for experiments)
-int launch_relpos_attention2(const AttnParams& p, int waves, hipStream_t s) {
-    if (p.B <= 0 || p.Tg <= 0) return 0;
+int launch_relpos_attention2(const AttnParams& p0, int waves, hipStream_t s) {
+    if (p0.B <= 0 || p0.Tg <= 0) return 0;
+    static const int abl = getenv("EFFCONF_ATTN_ABLATE") ? atoi(getenv("EFFCONF_ATTN_ABLATE")) : 0;
+    AttnParams p = p0;
+    p.ablate = abl;
     if (p.dpad < p.d || p.q_rowstride != p.e_rowstride) return -2;
     if (p.rag_off && (waves != 1 || !p.rag_wg || p.q_rowstride != p.G * p.D)) return -2;      // ragged: natural layout, 64-query workgroups
 #define ATT2_CASE(DPV) case DPV: return waves == 1 ? launch2<DPV, 4, 1>(p, s) : launch2<DPV, 2, 2>(p, s);

@@ -740,7 +740,6 @@ int launch_chain3_t(const ChainParams& p, hipStream_t s) {
     if (!p.consts) return -5;
     const int lds = NBUF3 * G::BUF + 4 * S3_TILE + nfl * 4;
     if (lds > 160 * 1024) return -4;
-    if (getenv("EFFCONF_CHAIN3_DEBUG")) fprintf(stderr, "[chain3] kind %d M %d D %d nt %d pair %d w2cm %d\n", KIND, p.M, p.D, p.nt, p.pair, p.w2cm);
     static LdsAttr attr;
     ensure_dynamic_lds(reinterpret_cast<const void*>(&chain3_kernel<KS, KIND, false>), lds, attr);
     static const bool prof = getenv("EFFCONF_CHAIN3_PHASES") != nullptr && atoi(getenv("EFFCONF_CHAIN3_PHASES")) == KIND;

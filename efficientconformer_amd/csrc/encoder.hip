@@ -89,7 +89,7 @@ struct EcEncoder {
     // tuning / test options that used to be process-global environment switches (effconf_encoder_set_option)
     int chain_variant = 1, chain_full_max = 192, attn_waves = 4, rs_variant = 0, ffn_variant = 0;
     int chain_pair_min_d = 193, chain_nt = 0, chain_w2cm = 1;   // round 5 defaults: the column-pair kernels at padded width 256 (D = 240: 147 -> 119 us per tail + head; at 192 they cost more per row than chain.hip's 256-row workgroups)
-    int chain_pair = 4, chain_pair_min_m = 0;   // chain2.hip (column-pair chains at padded width 192 / 256): 0 off, 1 burst refills, 2 hooked; launches below chain_pair_min_m rows stay on chain.hip
+    int chain_pair = 5, chain_pair_min_m = 0;   // chain2.hip (column-pair chains at padded width 192 / 256): 0 off, 1 burst refills, 2 hooked; launches below chain_pair_min_m rows stay on chain.hip
     int chain_small_m = 4096;                // chain launches of at most this many rows run as 2-wave workgroups (small-batch latency; bit-identical rows)
     int chain_max_dim = 256;                 // fused chains only for stage widths <= this (tuning: wider stages on the per-GEMM / tiled kernels)
     int tiled_min_k = 256;                   // with wide_gemm >= 2: layers with K > this leave the row-stationary kernels for LayerNorm + tiled GEMMs
@@ -964,7 +964,10 @@ int xgemm(EcEncoder* e, hipStream_t st, const float* A, int lda, int M, const st
         if (it != e->xsplit.end()) {
             SxGemmParams q{};
             q.g = p; q.Whi = it->second.hi; q.Wlo = it->second.lo; q.ldh = it->second.ldh;
-            return launch_sx_gemm(q, st);
+            const int rc = launch_sx_gemm(q, st);
+            // -2 = a shape the split kernel does not take (N, lda or ldc not a multiple of 4, rows * lda >= 2^32 elements, more than 65535 column tiles):
+            // the fp32-MFMA kernel handles those, and its weights are uploaded in split mode too (advisor, round 4)
+            if (rc != -2 || !p.W) return rc;
         }
     }
     if (!p.W) return fail("exact mode: missing " + prefix);

@@ -163,6 +163,7 @@ struct AttnParams {
     // streaming contexts / causal (attention2.hip): key j of query i (grouped positions) is visible iff -band_l <= j - i <= band_r
     // (>= Tg: unlimited); causal: `eh` holds the Tg rows of the non-negative distances only (index Tg - 1 + j - i, j <= i)
     int band_l, band_r, causal;
+    int ablate;                             // timing-only ablations of attention2.hip (EFFCONF_ATTN_ABLATE, tools only): 1 no compute, 2 no K / V / E loads after the first block, 4 no epilogue stores, 8 no utterance search
 };
 int launch_relpos_attention(const AttnParams& p, hipStream_t s);
 // opt-in side output: att [B][H][Tg][Tg] fp32 softmax maps (the reference's att_w), recomputed from the same bf16 operands; rectangular batches

@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void sx_gemm_kernel(const SxGemmParams q) {
                 float v[4] = {a.x + bz.x, a.y + bz.y, a.z + bz.z, a.w + bz.w};
                 if (p.epi == 1) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = v[e] * sx_rcp(1.0f + sx_expf(-v[e]));          // Swish (modules.py:389)
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] * sx_rcp(1.0f + sx_expf(fminf(-v[e], 87.0f)));   // Swish (modules.py:389); the clamp: exp2 overflows beyond ~88.7, inf then turns sx_rcp's Newton step into NaN - x sigmoid(x) is -x e^x -> 0 there (the reference's value to fp32)
                 } else if (p.epi == 2) {
                     const float4 rr = *reinterpret_cast<const float4*>(p.R + (size_t)m * p.ldr + n);
                     v[0] = fmaf(p.alpha, v[0], rr.x); v[1] = fmaf(p.alpha, v[1], rr.y); v[2] = fmaf(p.alpha, v[2], rr.z); v[3] = fmaf(p.alpha, v[3], rr.w);

@@ -132,6 +132,25 @@ class ShardedEncoder:
     what a consumer computes from a gathered chunk is bit-identical to what the producing rank would compute locally;
     `torch.bfloat16` halves the xGMI bytes."""
 
+    def close(self):
+        """Hand the wrapped encoder back as it was found (its ragged cut policy); pipelined: run the consumers of the last call first."""
+        if self._pending:
+            self.flush()
+        if self._saved_cut is not None and hasattr(self.encoder, "ragged_cut"):
+            self.encoder.ragged_cut = self._saved_cut
+        self._saved_cut = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_pending", None):
+                import warnings
+                warnings.warn("efficientconformer_amd.dist.ShardedEncoder dropped with %d gathered chunk(s) whose consumer never ran: call flush() "
+                              "(or close()) after the last pipelined forward" % len(self._pending))
+            if getattr(self, "_saved_cut", None) is not None and hasattr(self.encoder, "ragged_cut"):
+                self.encoder.ragged_cut = self._saved_cut
+        except Exception:
+            pass
+
     def __init__(self, encoder: Callable, group=None, wire_dtype: Optional[torch.dtype] = None, pipelined: bool = False):
         self.encoder, self.group, self.wire_dtype = encoder, group, wire_dtype
         self.pipelined = bool(pipelined)
@@ -142,6 +161,7 @@ class ShardedEncoder:
         # ranges for equal valid frames of the lengths it is handed - different on every rank (mismatched collectives: a hang or a
         # corrupted gather).  Under this class it cuts by row count instead (rank-independent: every shard has the same number of rows),
         # unless the caller pins explicit `sub_batch_bounds` (bench.py: frame-balanced / staggered cuts computed from lengths all ranks know).
+        self._saved_cut = getattr(encoder, "ragged_cut", None)     # restored by close(): the encoder cuts for equal frames again when used on its own
         if hasattr(encoder, "ragged_cut"):
             encoder.ragged_cut = "rows"
         import os

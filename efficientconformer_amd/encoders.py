@@ -125,13 +125,23 @@ class ConformerEncoder(nn.Module):
         # THIS call's lengths; "rows" = the rank-independent equal-count cut of the rectangular path.  Under `dist.ShardedEncoder` every
         # range ends in a fixed-size collective, so all ranks must cut identical ranges: it sets "rows" (or pass explicit bounds).
         self.ragged_cut = "frames"
-        # True: a caller-supplied `x_len_host` is compared with the device lengths (one synchronisation per forward; tests / debugging).
-        # Contract otherwise: `x_len_host[b] == x_len[b]` - grids and the workspace are sized from the host copy, the kernels index with
-        # the device copy (include/effconf.h: effconf_encoder_forward_ragged).
-        self.check_host_lengths = False
+        # True (default since round 5): a caller-supplied `x_len_host` is compared with the device lengths - grids and the workspace are sized from
+        # the host copy, the kernels index with the device copy (include/effconf.h: effconf_encoder_forward_ragged), so a mismatch is an out-of-bounds
+        # access, not a wrong answer.  The comparison costs one synchronisation; it is made once per (device tensor, its version, host values) and
+        # remembered, so a serving loop that re-submits the same length tensors (bench.py) pays it on the first call only, and never while a stream
+        # is being captured into a graph.  False: the caller vouches for `x_len_host[b] == x_len[b]`.
+        self.check_host_lengths = True
+        self._len_verified = None
         self._sub_streams: Dict[tuple, torch.cuda.Stream] = {}
         self.caller_stream_slot = True     # stream slot 0 of the row ranges = the caller's stream (False: every range on a side stream, as round 2)
         self.eval()
+
+    @staticmethod
+    def _capturing(device) -> bool:
+        try:
+            return device.type == "cuda" and torch.cuda.is_current_stream_capturing()
+        except Exception:
+            return False
 
     # ------------------------------------------------------------------ weights
     def attach_head(self, fc: Optional[nn.Linear]):
@@ -354,6 +364,21 @@ class ConformerEncoder(nn.Module):
         nsub = self.sub_batches if self.sub_batches is not None else (2 if batch >= self.sub_batch_min else 1)
         nsub = max(1, min(int(nsub), batch))
         attentions = [None] * len(self.plan.blocks)
+        host_lens = None
+        if self.ragged:            # the host copy of the lengths ONCE, validated before anything is sized from it (without x_len_host: one device sync)
+            if self._exact:
+                raise RuntimeError("ragged batches run on the bf16 path (precision = 'fp32' / 'split' keep rectangular batches)")
+            hl = x_len_host if x_len_host is not None else lens.cpu()
+            host_lens = np.ascontiguousarray(np.asarray(hl.cpu() if torch.is_tensor(hl) else hl, dtype=np.int64))
+            if host_lens.shape != (batch,):
+                raise ValueError("x_len_host needs one length per utterance")
+            if x_len_host is not None and self.check_host_lengths and not self._capturing(x.device):
+                key = (lens.data_ptr(), lens._version, host_lens.tobytes())
+                if key != self._len_verified:
+                    if not np.array_equal(host_lens, lens.cpu().numpy()):
+                        raise ValueError("x_len_host differs from x_len: the ragged forward sizes its grids and workspace from the host lengths "
+                                         "and indexes with the device lengths - they must be the same numbers")
+                    self._len_verified = key
         if return_attentions:
             # the reference's third return value (encoders.py:126-142): one (B, H, Tg, Tg) softmax map per block, written by the library
             # next to the forward (effconf_encoder_set_attention_outputs); the whole batch as ONE rectangular range
@@ -361,25 +386,12 @@ class ConformerEncoder(nn.Module):
             # its map when run alone, the rest is zero)
             nsub, nb = 1, len(self.plan.blocks)
             heads, tg = (C.c_int32 * nb)(), (C.c_int32 * nb)()
-            n_att = n
-            if self.ragged:
-                hl_ = x_len_host if x_len_host is not None else lens.cpu()
-                n_att = int(max(int(v) for v in (hl_.tolist() if hasattr(hl_, "tolist") else hl_)))
+            n_att = int(host_lens.max()) if self.ragged else n
             _lib.check(lib.effconf_encoder_attention_dims(self._handle, n_att, int(from_audio), heads, tg), "attention_dims")
-            attentions = [torch.empty(batch, heads[k], tg[k], tg[k], dtype=torch.float32, device=x.device) for k in range(nb)]
+            # zeros: "an utterance's own block = its map, the rest zero" does not depend on the kernel writing every element (opt-in path, cheap)
+            attentions = [torch.zeros(batch, heads[k], tg[k], tg[k], dtype=torch.float32, device=x.device) for k in range(nb)]
             _lib.check(lib.effconf_encoder_set_attention_outputs(self._handle, (C.c_void_p * nb)(*[a.data_ptr() for a in attentions]), nb),
                        "set_attention_outputs")
-        host_lens = None
-        if self.ragged:
-            if self._exact:
-                raise RuntimeError("ragged batches run on the bf16 path (precision = 'fp32' / 'split' keep rectangular batches)")
-            hl = x_len_host if x_len_host is not None else lens.cpu()          # without host lengths: one device sync
-            host_lens = np.ascontiguousarray(np.asarray(hl.cpu() if torch.is_tensor(hl) else hl, dtype=np.int64))
-            if host_lens.shape != (batch,):
-                raise ValueError("x_len_host needs one length per utterance")
-            if x_len_host is not None and self.check_host_lengths and not np.array_equal(host_lens, lens.cpu().numpy()):
-                raise ValueError("x_len_host differs from x_len: the ragged forward sizes its grids and workspace from the host lengths "
-                                 "and indexes with the device lengths - they must be the same numbers")
         ranges = self.row_ranges(batch, nsub, host_lens)
         pads = None if self.ragged else self._range_pads(ranges, n, from_audio, lens, lens_given, x_len_host, range_pad)
         fn_ragged = lib.effconf_encoder_forward_ragged

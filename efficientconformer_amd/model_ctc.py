@@ -70,7 +70,9 @@ class ModelCTC(nn.Module):
             raise RuntimeError("efficientconformer_amd runs on a HIP device only (no CPU fallback)")
         # bf16 rows (a gathered chunk of the multi-rank path on a bf16 wire) go to the head as they are: effconf_ctc_greedy_bf16 - no widening pass,
         # two MFMAs per 16 k, labels identical to the fp32-input head on the same values
-        as_bf16 = enc.dtype == torch.bfloat16 and self.encoder.precision == "bf16"
+        # (only while the handle's head IS the split-bf16 kernel, option ctc_mfma = 2, the default: with 0 / 1 the fp32 head is a k-ordered fp32 chain and the
+        # bf16 rows are widened to it, so gathered and local chunks keep producing the same labels)
+        as_bf16 = enc.dtype == torch.bfloat16 and self.encoder.precision == "bf16" and self.encoder._options.get("ctc_mfma", 2) == 2
         enc = enc.contiguous() if as_bf16 else enc.contiguous().float()
         b, t, _ = enc.shape
         if enc_len is None:

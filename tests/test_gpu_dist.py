@@ -30,7 +30,8 @@ def test_sharded_encoder_two_ranks_on_one_gpu_equals_unsharded(name):
     assert "DIST_GPU_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
 
 
-def test_sharded_encoder_one_rank_over_rccl():
+@pytest.mark.parametrize("name", ["Tiny", "EfficientConformerCTCLarge"])      # Large = BASELINE.json configs[2] (the driver-run test was Tiny only)
+def test_sharded_encoder_one_rank_over_rccl(name):
     """The same worker on the REAL backend: backend "nccl" = RCCL, one rank (a `gpurun` box has one GPU and RCCL takes one rank per device).
     No xGMI transfer happens, but everything else of the N > 1 path runs on RCCL's own machinery: communicator creation on the MI355X, collectives
     enqueued from the row ranges' streams onto the process group's stream, `async_op` Work objects and their stream-side wait() in the pipelined
@@ -39,7 +40,7 @@ def test_sharded_encoder_one_rank_over_rccl():
     env["EFFCONF_TEST_BACKEND"] = "nccl"
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
-                        "--master-port", str(_port()), os.path.join(ROOT, "tests", "dist_gpu_worker.py"), "Tiny"],
+                        "--master-port", str(_port()), os.path.join(ROOT, "tests", "dist_gpu_worker.py"), name],
                        capture_output=True, text=True, timeout=600, env=env)
     assert "DIST_GPU_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
 

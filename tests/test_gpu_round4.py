@@ -73,6 +73,8 @@ def test_split_gemm_kernel_alone_vs_float64(m, n, k, epi):
     a = g.standard_normal((m, k), dtype=np.float32)
     w = (g.standard_normal((n, k), dtype=np.float32) / np.sqrt(k)).astype(np.float32)
     bias = (0.1 * g.standard_normal(n)).astype(np.float32)
+    if epi == 1:                 # outlier pre-activations (advisor, round 4): Swish(-100) .. Swish(-2000) must be 0 (-x e^x underflows), not NaN from exp2 overflow
+        bias[: min(n, 6)] = np.array([-100.0, -89.0, -88.0, -2000.0, 95.0, -1e4], dtype=np.float32)[: min(n, 6)]
     r = g.standard_normal((m, n), dtype=np.float32)
     hi, lo, ldh = mod.split_images(w)
     ad, hd, ld, bd, rd = (torch.from_numpy(x).cuda() for x in (a, hi.view(np.int16), lo.view(np.int16), bias, r))
@@ -83,12 +85,14 @@ def test_split_gemm_kernel_alone_vs_float64(m, n, k, epi):
     torch.cuda.synchronize()
     ref = a.astype(np.float64) @ w.astype(np.float64).T + bias
     if epi == 1:
-        ref = ref / (1.0 + np.exp(-ref))
+        with np.errstate(over="ignore"):
+            ref = ref / (1.0 + np.exp(-ref))
     elif epi == 2:
         ref = r + 0.5 * ref
     got = c.cpu().numpy()
     err = float(np.abs(got[:m, :n] - ref).max() / max(np.abs(ref).max(), 1.0))
     print("sx_gemm %dx%dx%d epi %d: rel err %.2e" % (m, n, k, epi, err))
+    assert np.isfinite(got[:m, :n]).all()
     assert err < 2e-6
     assert np.all(got[m:] == 7.0) and np.all(got[:, n:] == 7.0)
 

@@ -49,3 +49,54 @@ def test_column_pair_chains_are_bit_identical_to_the_single_wave_chains(name, ba
             b = outs[key + (ragged,)]
             assert torch.equal(a[1], b[1])
             assert torch.equal(a[0], b[0]), (name, key, ragged, float((a[0].float() - b[0].float()).abs().max()))
+
+
+# ------------------------------------------------------------------ the rectangular path as alternating range shapes on one stream
+def test_alternating_rectangular_range_shapes_on_one_stream_cost_what_each_shape_costs_alone():
+    """Two kept profiles of round 4 (profiles/r4_03_bench_ragged0.json, r4_04_bench_ragged0.json) show the roofline leg of `bench.py --ragged 0` - the step's
+    three trimmed row ranges as three forwards of different shapes, one after the other on one stream - with the class gemm_other (chain B + projections) at
+    14.6 / 17.1 ms per step in a 5.9 ms step; r4_02, three commits earlier, at 1.8 ms.  It does not reproduce (round 5: 1.79 - 1.83 ms on this tree AND on round
+    4's kernel selection, profiles/r5_20_*; the records came from tools/gpu_evidence.sh sessions) - this test is the guard the verdict asked for: per class, the
+    library's own launch brackets (effconf_profile_*) of shapes A, B, C alternating cost at most 1.5 x what the same forwards cost with every shape repeated
+    back to back (positional-embedding cache misses of the alternation included: its projections are part of gemm_other)."""
+    import ctypes as C
+    from efficientconformer_amd import _lib
+    m = _any_model("EfficientConformerCTCSmall", 3)
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    shapes = [(24, 15.2), (40, 11.0), (56, 7.4)]                      # rows x seconds: the bench's three trimmed ranges in miniature
+    batches = []
+    for b, sec in shapes:
+        lens = np.sort((16000 * sec * (1.0 - 0.25 * rng.random(b))).astype(np.int64))[::-1].copy()
+        lens[0] = int(16000 * sec)
+        batches.append((torch.from_numpy(synth.make_audio(lens, seed=b)).cuda(), torch.from_numpy(lens).cuda()))
+    enc = m.encoder
+    enc.ragged, enc.sub_batches = False, 1
+    enc._ensure_packed()
+    h = enc._handle
+    names = ["mel", "subsample_conv", "gemm_ffn", "gemm_other", "layernorm", "attention", "dwconv", "misc"]
+
+    def run(order, reps):
+        for a, l in batches:                                          # un-profiled pass: workspaces, caches
+            enc(a, l)
+        torch.cuda.synchronize()
+        _lib.check(lib.effconf_profile_enable(h, 1), "profile_enable")
+        for _ in range(reps):
+            for i in order:
+                enc(*batches[i])
+        torch.cuda.synchronize()
+        out = {}
+        for ci, cname in enumerate(names):
+            ms, n, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+            _lib.check(lib.effconf_profile_read(h, ci, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)), "profile_read")
+            out[cname] = (ms.value, n.value)
+        _lib.check(lib.effconf_profile_enable(h, 0), "profile_enable")
+        return out
+    alone = {k: 0.0 for k in names}
+    for i in range(3):
+        r = run([i], 4)
+        for k in names:
+            alone[k] += r[k][0]
+    mixed = run([0, 1, 2], 4)
+    for k in names:
+        assert mixed[k][0] <= 1.5 * alone[k] + 0.2, (k, mixed[k], alone[k])          # ms over 12 forwards each way; + 0.2 ms of slack for the small classes
