@@ -15,14 +15,18 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libeffconf.so")
-SOURCES = ["gemm.hip", "gemm256.hip", "rsgemm.hip", "chain.hip", "chain2.hip", "chain3.hip", "norm.hip", "conv.hip", "sublinear.hip", "sublinear2.hip", "conv2.hip", "mel.hip", "ctc.hip", "rnnt.hip", "attention.hip", "attention2.hip", "exact.hip", "split.hip", "debug.hip", "hostpack.hip", "encoder.hip"]
+LIB_DEBUG = os.path.join(HERE, "libeffconf_debug.so")
+SOURCES = ["gemm.hip", "gemm256.hip", "rsgemm.hip", "chain.hip", "chain2.hip", "chain3.hip", "norm.hip", "conv.hip", "sublinear.hip", "sublinear2.hip", "conv2.hip", "mel.hip", "ctc.hip", "rnnt.hip", "attention.hip", "attention2.hip", "exact.hip", "split.hip", "hostpack.hip", "encoder.hip"]
 # (source, object, extra flags): further compilations of a source under other flags
 # No packed-fp32 VALU instructions in product kernels: v_pk_{add,mul,fma}_f32 with an op_sel low-lane swizzle return wrong values
 # next to another wave's bf16 MFMA on gfx950 (measured: profiles/r2_mel_packed_fp32_hazard.txt; guard: _isa_guard.py).
 # Cost of the flag for the whole library: 7.56 -> 7.60 ms per bench step.
 NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
-DIAGNOSTIC_SOURCES = {"debug.hip"}        # the hazard reproducer needs the instructions it demonstrates
-VARIANT_OBJECTS = [("mel.hip", "mel_pk.o", ["-DMEL_PK_BUILD"])]
+# libeffconf_debug.so (tests / tools only, include/effconf_debug.h) = the product objects with encoder.hip and mel.hip recompiled under -DEFFCONF_DEBUG_ABI
+# (the effconf_debug_* entry points, the diagnostic mel_kernel variants) + debug.hip and the packed-fp32 build of mel.hip - the hazard reproducers need the
+# instructions they demonstrate, so those two are compiled WITHOUT the flag below.  Nothing of this is linked into libeffconf.so.
+DEBUG_REPLACES = {"encoder.hip": "encoder_dbg.o", "mel.hip": "mel_dbg.o"}
+DEBUG_OBJECTS = [("debug.hip", "debug.o", []), ("mel.hip", "mel_pk.o", ["-DMEL_PK_BUILD"])]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result",
          "-Wno-inline-asm"]   # rowstat.h clobbers m0 on purpose (LDS-DMA destination register)
 
@@ -35,7 +39,7 @@ def _hipcc() -> str:
 
 
 def _stale() -> bool:
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(LIB_DEBUG):
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "effconf.h")]
@@ -64,9 +68,13 @@ def build(force: bool = False, verbose: bool = True) -> str:
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-4000:]))
         return obj
-    jobs = [(s, s.replace(".hip", ".o"), [] if s in DIAGNOSTIC_SOURCES else NO_PACKED_FP32) for s in SOURCES] + VARIANT_OBJECTS
-    with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
-        objs = list(ex.map(compile_one, jobs))
+    jobs = [(s, s.replace(".hip", ".o"), NO_PACKED_FP32) for s in SOURCES]
+    djobs = [(s, o, NO_PACKED_FP32 + ["-DEFFCONF_DEBUG_ABI"]) for s, o in DEBUG_REPLACES.items()] + DEBUG_OBJECTS
+    with ThreadPoolExecutor(max_workers=min(8, len(jobs) + len(djobs))) as ex:
+        allobjs = list(ex.map(compile_one, jobs + djobs))
+    objs, dobjs = allobjs[:len(jobs)], allobjs[len(jobs):]
+    replaced = {os.path.join(objdir, s.replace(".hip", ".o")) for s in DEBUG_REPLACES}
+    debug_link = [o for o in objs if o not in replaced] + dobjs
     # link to a temporary name, run the ISA guard on it, and only then move it into place: a library that fails the guard never
     # becomes importable (before: the first build raised AFTER writing libeffconf.so and the next import passed silently)
     tmp = LIB + ".tmp"
@@ -80,8 +88,11 @@ def build(force: bool = False, verbose: bool = True) -> str:
         os.remove(tmp)
         raise
     os.replace(tmp, LIB)
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_DEBUG] + debug_link, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link of the diagnostic library failed:\n%s" % r.stderr[-4000:])
     if verbose:
-        print("built %s (%d KB)" % (LIB, os.path.getsize(LIB) // 1024))
+        print("built %s (%d KB) and %s (%d KB)" % (LIB, os.path.getsize(LIB) // 1024, os.path.basename(LIB_DEBUG), os.path.getsize(LIB_DEBUG) // 1024))
     return LIB
 
 

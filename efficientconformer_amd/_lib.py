@@ -70,6 +70,14 @@ SIGNATURES = {
     "effconf_conv_module": (C.c_int, [_P, _I32, _F32P, _I32, _I32, _F32P, _P, _SZ, _P]),
     "effconf_subsample": (C.c_int, [_P, _F32P, _I32, _I32, _F32P, _P, _SZ, _P]),
     "effconf_layernorm_residual": (C.c_int, [_P, _I32, _I32, _F32P, _F32P, C.c_float, _I32, _F32P, _P]),
+    "effconf_encoder_set_trace": (C.c_int, [_P, _P, _SZ]),
+    "effconf_encoder_trace_count": (_I32, [_P]),
+    "effconf_encoder_trace_entry": (C.c_int, [_P, _I32, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                               C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+}
+
+# include/effconf_debug.h: exported by libeffconf_debug.so only (tests / tools; load_debug())
+DEBUG_SIGNATURES = {
     "effconf_debug_mel": (C.c_int, [_P, _I32, _I32, _F32P, _I32, _I32, _F32P, _P, _P]),
     "effconf_debug_neighbour": (C.c_int, [_I32, _I32, _I32, _I32, _F32P, _SZ, _P]),
     "effconf_debug_victim": (C.c_int, [_I32, _I32, _I32, _F32P, _P]),
@@ -77,13 +85,10 @@ SIGNATURES = {
     "effconf_debug_lds_fill": (C.c_int, [_I32, _I32, _I32, _P, _SZ, _I32, _I32, _P, _P]),
     "effconf_debug_sx_gemm": (C.c_int, [_F32P, _I32, _P, _P, _I32, _F32P, _I32, _I32, _I32, _I32, _F32P, _I32, _F32P, _I32, C.c_float, _P]),
     "effconf_debug_gemm": (C.c_int, [_P, _I32, _P, _I32, _P, _I32, _I32, _I32, _I32, _I32, _P, _I32, _P, _I32, C.c_float, _P]),
-    "effconf_encoder_set_trace": (C.c_int, [_P, _P, _SZ]),
-    "effconf_encoder_trace_count": (_I32, [_P]),
-    "effconf_encoder_trace_entry": (C.c_int, [_P, _I32, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
-                                               C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
 }
 
 _lib = None
+_lib_debug = None
 
 
 class EffconfError(RuntimeError):
@@ -109,7 +114,27 @@ def load():
     return lib
 
 
-def check(rc: int, what: str):
+def load_debug():
+    """dlopen libeffconf_debug.so (the product objects + the diagnostics of include/effconf_debug.h) and bind the product AND the diagnostic symbols.
+    Tests and tools only: nothing of the package calls this."""
+    global _lib_debug
+    if _lib_debug is not None:
+        return _lib_debug
+    path = os.path.join(HERE, "libeffconf_debug.so")
+    if not os.path.exists(path):
+        raise EffconfError("libeffconf_debug.so not built: run `python -m efficientconformer_amd._build`")
+    lib = C.CDLL(path)
+    for name, (res, args) in list(SIGNATURES.items()) + list(DEBUG_SIGNATURES.items()):
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib_debug = lib
+    return lib
+
+
+def check(rc: int, what: str, lib=None):
     if rc != 0:
-        msg = load().effconf_last_error()
+        msg = (lib or load()).effconf_last_error()
+        if not msg and _lib_debug is not None:
+            msg = _lib_debug.effconf_last_error()
         raise EffconfError("%s failed (rc=%d): %s" % (what, rc, msg.decode() if msg else "?"))

@@ -6,6 +6,12 @@
 // ConformerBlock.forward (models/blocks.py:119-137); see DESIGN.md for the kernel map.
 #include "kernels.h"
 #include "../../include/effconf.h"
+#ifdef EFFCONF_DEBUG_ABI
+#include "../../include/effconf_debug.h"
+#endif
+#ifdef EFFCONF_DEBUG_ABI
+#include "../../include/effconf_debug.h"
+#endif
 
 #include <cmath>
 #include <cstdio>
@@ -1614,6 +1620,7 @@ int effconf_mel_frontend(EcEncoder* e, const float* audio, int32_t batch, int32_
     return 0;
 }
 
+#ifdef EFFCONF_DEBUG_ABI        // libeffconf_debug.so only (include/effconf_debug.h)
 int effconf_debug_mel(EcEncoder* e, int32_t variant, int32_t extra_lds, const float* audio, int32_t batch, int32_t n_samples, float* mel,
                       uint32_t* counters, void* stream) {
     if (!e || !e->finalized) return fail("encoder not finalized");
@@ -1627,6 +1634,8 @@ int effconf_debug_neighbour(int32_t kind, int32_t blocks, int32_t lds_bytes, int
     EC_TRY(launch_debug_neighbour(kind, blocks, lds_bytes, iters, buf, n_floats, (hipStream_t)stream));
     return 0;
 }
+
+#endif
 
 int effconf_relpos_attention(const uint16_t* qu, const uint16_t* k, const uint16_t* v, const uint16_t* e, const float* dvu, int32_t dvu_ld,
                              const int32_t* lens, int32_t batch, int32_t heads, int32_t frames, int32_t group, int32_t dim, uint16_t* out,
@@ -1742,6 +1751,7 @@ int effconf_layernorm_residual(EcEncoder* e, int32_t block, int32_t which, const
     return 0;
 }
 
+#ifdef EFFCONF_DEBUG_ABI        // libeffconf_debug.so only (include/effconf_debug.h)
 int effconf_debug_gemm(const uint16_t* a, int32_t lda, const uint16_t* w, int32_t ldw, const float* bias, int32_t m, int32_t n, int32_t k,
                        int32_t epi, int32_t wide, void* c, int32_t ldc, const float* r, int32_t ldr, float alpha, void* stream) {
     if (!a || !w || !bias || !c) return fail("null argument");
@@ -1778,6 +1788,8 @@ int effconf_debug_victim(int32_t kind, int32_t blocks, int32_t iters, float* out
     EC_TRY(launch_debug_victim(kind, blocks, iters, out, (hipStream_t)stream));
     return 0;
 }
+
+#endif
 
 int effconf_ctc_greedy(EcEncoder* e, const float* enc_out, const int64_t* out_len, int32_t batch, int32_t t_out,
                        int32_t* labels, int32_t* label_len, float* logits, void* workspace, size_t workspace_bytes, void* stream) {

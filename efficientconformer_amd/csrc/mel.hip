@@ -292,6 +292,7 @@ int launch_mel(const float* audio, int B, int L, const MelTables& t, int n_fft, 
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+#if defined(EFFCONF_DEBUG_ABI) || defined(MEL_PK_BUILD)        // libeffconf_debug.so only: the product library instantiates mel_kernel<0> alone
 // diagnostics only (tools/mel_repro.py): kernel variant V, `extra_lds` bytes of unused dynamic LDS per workgroup, counters dbg[8]
 int launch_mel_debug(int variant, int extra_lds, const float* audio, int B, int L, const MelTables& t, int n_fft, int hop, int n_mels,
                      int Tm, int normalize, float mean, float std, float* mel, unsigned int* dbg, hipStream_t s) {
@@ -310,3 +311,4 @@ int launch_mel_debug(int variant, int extra_lds, const float* audio, int B, int 
 #undef MEL_DBG_CASE
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
+#endif

@@ -267,36 +267,7 @@ int32_t effconf_encoder_trace_count(const EcEncoder* enc);
 int effconf_encoder_trace_entry(const EcEncoder* enc, int32_t i, char* name64, int64_t* offset, int64_t* rows, int64_t* cols,
                                 int64_t* ld, int32_t* dtype);
 
-/* ---- diagnostics (tools/mel_repro.py; not on the product path) ------------------------------ */
-/* effconf_mel_frontend with a diagnostic variant of mel_kernel (csrc/mel.hip: 1 canaries, 2 self-verifying hand-offs,
- * 4 workgroup barriers, 8 the build WITH packed-fp32 VALU instructions = round 1's hazardous kernel; bits combine), `extra_lds` bytes of unused dynamic LDS per workgroup, and 8 u32 counters (dev). */
-int effconf_debug_mel(EcEncoder* enc, int32_t variant, int32_t extra_lds, const float* audio, int32_t batch, int32_t n_samples,
-                      float* mel, uint32_t* counters, void* stream);
-/* One synthetic kernel that loads a single compute-unit resource (csrc/debug.hip): kind 0 LDS 16-byte hammer, 1 VALU +
- * transcendental, 2 global loads, 3 global stores, 4 MFMA, 5 LDS publish + barrier loop, 6 LDS 4-byte hammer. */
-int effconf_debug_neighbour(int32_t kind, int32_t blocks, int32_t lds_bytes, int32_t iters, float* buf, size_t n_floats, void* stream);
-/* One Linear layer on the tiled bf16 GEMM kernels alone (kernel-level tests and tuning of csrc/gemm.hip and csrc/gemm256.hip; reference
- * models/layers.py:57-67): c = epilogue(a w^T + bias).  a: bf16 [m][lda]; w: bf16 [>= round_up(n, 128)][ldw = round_up(k, 64)], zero
- * padded (for GLU: rows interleaved per 32 channels, a | b); bias: [>= round_up(n, 128)].  epi: 0 fp32 [m][ldc], 1 bf16, 2 Swish
- * bf16, 3 fp32 r + alpha * (...), 4 GLU bf16 [m][n / 2].  wide: 0 tile picked by shape, 1 the 128 x 128 kernel, 2 / 3 the LDS-DMA
- * kernel with 256 x 256 / 256 x 128 tiles.  All pointers are device pointers. */
-int effconf_debug_gemm(const uint16_t* a, int32_t lda, const uint16_t* w, int32_t ldw, const float* bias, int32_t m, int32_t n, int32_t k,
-                       int32_t epi, int32_t wide, void* c, int32_t ldc, const float* r, int32_t ldr, float alpha, void* stream);
-
-/* One self-contained victim: 16 chains per lane of a single instruction class (0 v_fma_f32, 1 v_pk_fma_f32, 2 v_pk_mul/add_f32,
- * 3 v_log/v_exp_f32, 4 v_mul/v_add_f32, 5 integer, 6 wave-local LDS exchange); out dev f32 (blocks * 256 * 16). */
-int effconf_debug_victim(int32_t kind, int32_t blocks, int32_t iters, float* out, void* stream);
-/* One Linear layer on the split-precision GEMM kernel alone (csrc/split.hip; kernel-level tests and tools/sx_gemm_bench.py): c = epilogue(a w^T
- * + bias) with a fp32 [m][lda], w given as its two fp16 images h = fp16(w), l = fp16((w - h) * 2048), each packed k-tile major [ldh / 32][n][32]
- * (ldh = round_up(k, 32), zero padded: element (row, col) at ((col / 32) * n + row) * 32 + col % 32), products accurate to ~2^-21.  epi: 0 plain, 1 Swish, 2 c = r + alpha * (...).  All pointers are device pointers. */
-int effconf_debug_sx_gemm(const float* a, int32_t lda, const uint16_t* w_hi, const uint16_t* w_lo, int32_t ldh, const float* bias, int32_t m, int32_t n,
-                          int32_t k, int32_t epi, float* c, int32_t ldc, const float* r, int32_t ldr, float alpha, void* stream);
-/* One idle wave that occupies `stream` for `microseconds` (tools/overlap_probe.py: the duration of an xGMI transfer a single GPU cannot make). */
-int effconf_debug_spin(double microseconds, void* stream);
-/* diagnostics (tools/lds_fill_rate_probe.py): `blocks` workgroups of `waves` waves each walk the same `window` bytes of `src` (dev) into LDS, `kib_per_wave`
- * (multiple of 8) 1-KiB wave-instructions per wave and pass; mode 0 = LDS-DMA (global_load_lds_dwordx4), 1 = loads + ds_write_b128.
- * out (dev, 2 * blocks uint64): {cycles, bytes} per workgroup. */
-int effconf_debug_lds_fill(int32_t mode, int32_t blocks, int32_t waves, const void* src, size_t window, int32_t kib_per_wave, int32_t passes, uint64_t* out, void* stream);
+/* ---- diagnostics: include/effconf_debug.h, exported by the SEPARATE library libeffconf_debug.so (tests and tools only); libeffconf.so has none of them */
 
 /* ---- attention maps: the third return value of the reference's ConformerEncoder.forward (encoders.py:126-142: att_w of every block,
  * (batch, heads, Tg, Tg) softmax rows; no caller on the hot path reads them, so they are opt-in).  effconf_encoder_attention_dims fills

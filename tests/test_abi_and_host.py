@@ -4,6 +4,7 @@ to run without a GPU tensor (no silent fallback)."""
 import ctypes
 import os
 import re
+import subprocess
 
 import numpy as np
 import pytest
@@ -26,6 +27,17 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), "libeffconf.so does not export %s" % name
     assert sorted(_lib.SIGNATURES) == declared, "ctypes binding out of sync with include/effconf.h"
     assert _lib.load().effconf_abi_version() == _lib.ABI_VERSION == 2
+    # the diagnostics live in a SEPARATE library (include/effconf_debug.h, libeffconf_debug.so = the product objects + csrc/debug.hip + the packed-fp32 mel
+    # build): the product library exports none of them, the diagnostic one exports them and the whole product ABI
+    dhdr = open(os.path.join(ROOT, "include", "effconf_debug.h")).read()
+    ddecl = sorted(set(re.findall(r"\b(effconf_debug_[a-z_0-9]+)\s*\(", dhdr)))
+    assert len(ddecl) == 7 and sorted(_lib.DEBUG_SIGNATURES) == ddecl
+    assert not [n for n in declared if n.startswith("effconf_debug")]
+    exported = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "effconf_debug" not in exported and "debug_neighbour" not in exported
+    dlib = ctypes.CDLL(os.path.join(os.path.dirname(_lib.LIB_PATH), "libeffconf_debug.so"))
+    for name in declared + ddecl:
+        assert hasattr(dlib, name), "libeffconf_debug.so does not export %s" % name
 
 
 def test_create_rejects_bad_config_and_reports_error():

@@ -168,7 +168,7 @@ def test_mel_frontend_vs_float64_dft():
 
 def _dbg(lib_h):
     from efficientconformer_amd import _lib
-    return _lib.load(), _lib
+    return _lib.load_debug(), _lib
 
 
 def test_mel_kernel_is_bit_identical_next_to_mfma_kernels_of_another_stream():

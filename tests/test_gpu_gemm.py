@@ -75,7 +75,7 @@ def _case(M, N, K, epi, wide, seed=0, lda_pad=0):
         ldc = _ru(ch, 8)
         c = torch.full((M, ldc), float("nan"), dtype=torch.bfloat16, device="cuda")
         want = ref[:, :ch] * torch.sigmoid(ref[:, ch:])
-    lib = _lib.load()
+    lib = _lib.load_debug()
     rc = lib.effconf_debug_gemm(_ptr(a_dev), lda, _ptr(w_dev), Kp, _ptr(b_dev), M, N, K, epi, wide, _ptr(c), ldc,
                                 _ptr(r_dev) if r_dev is not None else None, N, C.c_float(alpha), None)
     _lib.check(rc, "effconf_debug_gemm")

@@ -68,7 +68,7 @@ def test_split_gemm_kernel_alone_vs_float64(m, n, k, epi):
     spec = importlib.util.spec_from_file_location("sx_gemm_bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "sx_gemm_bench.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    lib = _lib.load()
+    lib = _lib.load_debug()
     g = np.random.default_rng(7 * m + n + k)
     a = g.standard_normal((m, k), dtype=np.float32)
     w = (g.standard_normal((n, k), dtype=np.float32) / np.sqrt(k)).astype(np.float32)

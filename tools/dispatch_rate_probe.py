@@ -18,7 +18,7 @@ from efficientconformer_amd import _lib       # noqa: E402
 
 
 def main():
-    lib = _lib.load()
+    lib = _lib.load_debug()
     dev = torch.device("cuda", 0)
     buf = torch.zeros(8192 * 256 * 16, device=dev)
     st = torch.cuda.current_stream(dev)

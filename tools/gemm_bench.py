@@ -24,7 +24,7 @@ def ru(x, m):
 
 
 def run(M, N, K, epi, wide, reps=20):
-    lib = _lib.load()
+    lib = _lib.load_debug()
     a = torch.randn(M, ru(K, 8), device="cuda").to(torch.bfloat16)
     w = (torch.randn(ru(N, 128), ru(K, 64), device="cuda") / K ** 0.5).to(torch.bfloat16)
     b = torch.zeros(ru(N, 128), device="cuda")

@@ -20,7 +20,7 @@ from efficientconformer_amd import _lib       # noqa: E402
 
 
 def main():
-    lib = _lib.load()
+    lib = _lib.load_debug()
     dev = torch.device("cuda", 0)
     window = 1 << 20
     src = torch.randint(0, 255, (window + 4096,), dtype=torch.uint8, device=dev)

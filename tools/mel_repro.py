@@ -17,7 +17,7 @@ import bench
 from efficientconformer_amd import synth, _lib
 
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 4
-lib = _lib.load()
+lib = _lib.load_debug()
 cfg, model, sd = bench.build_model("EfficientConformerCTCSmall")
 enc = model.cuda().encoder
 enc.sub_batches = 1

@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from efficientconformer_amd import _lib  # noqa: E402
 
-lib = _lib.load()
+lib = _lib.load_debug()
 buf = torch.zeros(1 << 16, device="cuda")
 st = torch.cuda.current_stream().cuda_stream
 for kind, name in ((11, "32x32x16 bf16, 4 accumulators"), (12, "32x32x16 f16,  4 accumulators"), (13, "32x32x16 bf16, 1 accumulator (dependent chain)"),

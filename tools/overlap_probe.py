@@ -43,7 +43,7 @@ def main():
     import ctypes as C
     import numpy as np
     from efficientconformer_amd import _lib
-    lib = _lib.load()
+    lib = _lib.load_debug()
     dev = torch.device("cuda", 0)
     cfg = named_config(args.model)
     model = ModelCTC.from_config(cfg)

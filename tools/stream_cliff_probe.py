@@ -19,7 +19,7 @@ def child(prio):
     import torch
     sys.path.insert(0, ROOT)
     from efficientconformer_amd import _lib
-    lib = _lib.load()
+    lib = _lib.load_debug()
     dev = torch.device("cuda", 0)
     buf = torch.zeros(1 << 20, device=dev)
     K, blocks, iters = 40, 32, 40           # ~30 us per kernel (a dependent exp / rcp / fma chain), 32 workgroups = 1 / 8 of the CUs

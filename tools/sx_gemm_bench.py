@@ -31,7 +31,7 @@ def split_images(w):
 
 
 def run(m, n, k, epi, reps=20, check=True):
-    lib = _lib.load()
+    lib = _lib.load_debug()
     g = np.random.default_rng(m + n + k)
     a = g.standard_normal((m, k), dtype=np.float32)
     w = (g.standard_normal((n, k), dtype=np.float32) / np.sqrt(k)).astype(np.float32)
