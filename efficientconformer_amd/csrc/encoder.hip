@@ -559,7 +559,7 @@ int run_ffn(EcEncoder* e, hipStream_t st, const bf16_t* a, int M, int D, const P
 // (the two paths round differently; tools/robustness_sweep.py) - the gemm.hip / gemm256.hip choice does not (bit-identical kernels).
 bool prefer_tiled(const EcEncoder* e, int M, int N, int K) {
     (void)M; (void)N;
-    return e->wide_gemm >= 2 && K > e->tiled_min_k && K % 8 == 0;
+    return (e->wide_gemm == 2 || e->wide_gemm == 3) && K > e->tiled_min_k && K % 8 == 0;
 }
 
 // row-stationary single GEMM when K <= 384, else the tiled kernel
@@ -1850,7 +1850,7 @@ int effconf_encoder_set_option(EcEncoder* e, const char* name, int32_t value) {
     if (!strcmp(name, "fuse_subsample")) { if (value < 0 || value > 2) return fail("fuse_subsample: 0, 1 or 2"); e->fuse_subsample = value; return 0; }
     if (!strcmp(name, "fuse_chain")) { e->fuse_chain = value != 0; return 0; }
     if (!strcmp(name, "ctc_mfma")) { if (value < 0 || value > 2) return fail("ctc_mfma: 0 (VALU), 1 (fp32 MFMA) or 2 (split-bf16 MFMA)"); e->ctc_mfma = value; return 0; }
-    if (!strcmp(name, "wide_gemm")) { if (value < 0 || value > 3) return fail("wide_gemm: 0 (by shape), 1 (never), 2 (256-column tile), 3 (128-column tile)"); e->wide_gemm = value; return 0; }
+    if (!strcmp(name, "wide_gemm")) { if (value < 0 || (value > 3 && value < 16)) return fail("wide_gemm: 0 (by shape), 1 (never), 2 (256-column tile), 3 (128-column tile), >= 16 (by shape with this many 256 x 256 tiles as the threshold)"); e->wide_gemm = value; return 0; }
     if (!strcmp(name, "attention_v2")) { if (value != 0 && value != 1 && value != 2) return fail("attention_v2: 0, 1 or 2"); e->attention_v2 = value; return 0; }
     // former EFFCONF_* environment switches (process-global statics): per-handle options now
     if (!strcmp(name, "chain_variant")) { if (value != 0 && value != 1) return fail("chain_variant: 0 (8-wave chain workgroups) or 1 (4-wave, two per CU, at 65..128-wide stages)"); e->chain_variant = value; return 0; }

@@ -414,6 +414,8 @@ int launch_bn(const GemmDev& gd, hipStream_t s) {
 
 }  // namespace
 
+constexpr long GEMM256_MIN_TILES = 100;     // Large 35.4 -> 34.3 ms per step, ConformerCTC-Large 48.9 -> 47.1, Medium unchanged (profiles/r5_22_gemm256_tile_threshold.txt); 200 until round 4
+
 int launch_gemm(const GemmParams& p, int epi, hipStream_t s) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return 0;
     if (p.lda % 8 || p.ldw % 64) return -2;
@@ -421,8 +423,13 @@ int launch_gemm(const GemmParams& p, int epi, hipStream_t s) {
         // gemm256.hip when its 256 x 256 tiles fill the chip (256 CUs, one 8-wave workgroup each).  Measured on the Large layer shapes
         // (tools/gemm_bench.py, in situ with bench.py --wide-gemm): >= 200 tiles: up to 1.4x over the 128 x 128 kernel (FFN, D = 720),
         // never behind; fewer tiles, or its 256 x 128 tile at any size: behind.  `wide` 2 / 3 force a tile (kernel-level tests).
+        // Round 5: the threshold was tuned on kernels running ALONE (a launch of 141 tiles leaves 45 % of the CUs idle and loses to the 128 x 128 kernel's
+        // 564 workgroups); in the forward three row ranges run on three streams and the chip is saturated (throughput flat from B = 256 to 1024,
+        // profiles/r5_03_*), so what a launch costs is its CU time, not its latency - and per CU the 256 x 256 LDS-DMA kernel is the efficient one.
+        // `wide` >= 16 = the tile threshold itself (option wide_gemm; default GEMM256_MIN_TILES)
         const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
-        if (p.wide == 2 || (p.wide == 0 && p.N >= 192 && t256 >= 200)) return launch_gemm256(p, epi, 256, s);
+        const long min_tiles = p.wide >= 16 ? p.wide : GEMM256_MIN_TILES;
+        if (p.wide == 2 || ((p.wide == 0 || p.wide >= 16) && p.N >= 192 && t256 >= min_tiles)) return launch_gemm256(p, epi, 256, s);
         if (p.wide == 3) return launch_gemm256(p, epi, 128, s);
     }
     GemmDev gd;
