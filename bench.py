@@ -10,7 +10,7 @@ Conformer blocks, then fc + argmax + CTC collapse) over one synthetic LibriSpeec
 already resident in HBM (default: 256 utterances per GPU, `--streams 3`).  `--streams S` runs the batch as S contiguous row
 ranges on S HIP streams inside ConformerEncoder.forward (`sub_batches`, efficientconformer_amd/encoders.py): every kernel of the
 path is a one-round launch that alternates HBM-bound load/store bursts with compute, and a second stream fills one's bursts with the
-other's compute (+10-13 %, bit-identical to `--streams 1`; the mel frontend stays one launch: DESIGN.md section 5).
+other's compute (+10-13 %, bit-identical to `--streams 1`; the mel frontend stays one launch: HISTORY.md section 5).
 
 Multi-GPU: one process per GPU.  `--gpus N` without a torchrun environment re-executes this script under
 `python -m torch.distributed.run --nproc-per-node N` (the reference spawns one process per GPU the same way: main.py:217-220);

@@ -1,6 +1,6 @@
 // Diagnostics (not on the product path): synthetic "neighbour" kernels that load ONE hardware resource of a compute unit each.
 // tools/mel_repro.py runs them on one HIP stream next to mel_kernel variants on another to name what mel_kernel is sensitive to
-// (profiles/r2_mel_repro.txt).
+// (HISTORY.md section 5; profiles/r2_mel_repro.txt).
 #include "kernels.h"
 
 namespace {

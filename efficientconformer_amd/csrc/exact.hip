@@ -1,6 +1,6 @@
 // fp32-operand ("exact") kernels: the opt-in precision mode of libeffconf (effconf_encoder_set_option "exact_fp32").
 //
-// The product path rounds MFMA operands to bf16 (DESIGN.md numerics policy); on random-weight models a few per-frame top-2 logit
+// The product path rounds MFMA operands to bf16 (HISTORY.md numerics policy); on random-weight models a few per-frame top-2 logit
 // margins are smaller than that rounding, so greedy labels can flip.  This mode runs the same forward (reference
 // models/encoders.py:97-142, blocks.py:119-137, attentions.py:549-718, modules.py:232-249, 385-395, 511-525) with fp32 operands
 // end to end - fp32 MFMA (v_mfma_f32_32x32x2_f32: exact products, fp32 accumulation) for every GEMM, fp32 attention, fp32

@@ -7,7 +7,7 @@ libeffconf.so through the C ABI of include/effconf.h.  The ``nn.Module`` tree be
 parameters under the reference's names; none of those sub-modules is ever called, and there is no
 PyTorch/CPU fallback: without the HIP library or without a GPU tensor, ``forward`` raises.
 
-Differences from the reference, by design:
+Differences from the reference, by design (HISTORY.md):
   * eval-mode only (SpecAugment, dropout, variational noise and BatchNorm statistics updates are
     training-time features, reference encoders.py:103-104, layers.py:63);
   * the third return value is a list of ``None`` (the reference returns per-block attention maps that no
@@ -99,7 +99,7 @@ class ConformerEncoder(nn.Module):
         # Un-trimmed ranges share ONE mel launch for the whole batch on the caller's stream (fewer, fuller launches); trimmed ranges
         # run their own mel frontend.  (Round 1 forked at the mel boundary for correctness: its mel kernel returned perturbed spectra
         # next to another stream's MFMA kernels - a packed-fp32 `op_sel` hazard, fixed by building the library without packed-fp32
-        # VALU instructions; any number of independent forwards may overlap now.)
+        # VALU instructions, HISTORY.md section 5a; any number of independent forwards may overlap now.)
         self.sub_batches: Optional[int] = 1
         # at most this many HIP streams for the row ranges (None: one per range).  More ranges than streams = finer length buckets
         # (less padding with trim_sub_batches) at the same concurrency: range i runs on stream i % sub_batch_streams, in order.

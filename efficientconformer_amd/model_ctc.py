@@ -4,7 +4,7 @@
 (``encoder.*``, ``fc.*``) and method names (including the reference's spelling
 ``gready_search_decoding``), but the head and the greedy collapse run as HIP kernels
 (effconf_ctc_greedy) instead of ``nn.Linear`` + a Python loop with ``.item()`` per token.
-Training (losses, optimizer, schedules), beam search and WER scoring are out of scope.
+Training (losses, optimizer, schedules), beam search and WER scoring are out of scope (HISTORY.md).
 """
 from __future__ import annotations
 

@@ -5,7 +5,7 @@ Keeps the reference's attribute names (``encoder``, ``decoder.embedding``, ``dec
 state-dict keys and method names (``gready_search_decoding``, the reference's spelling).  The per-utterance Python loop
 of the reference — one decoder call, one joint call and one ``.argmax()`` host sync per decision — runs as one
 persistent HIP kernel per batch (effconf_rnnt_greedy).  Training (``forward`` over the full (T, U) lattice, RNN-T loss),
-beam search and the LM fusion are out of scope.
+beam search and the LM fusion are out of scope (HISTORY.md).
 """
 from __future__ import annotations
 

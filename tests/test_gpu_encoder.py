@@ -281,7 +281,7 @@ def test_other_configs_vs_reference_golden(golden_dir, name, tm):
     assert out_len.cpu().tolist() == g["out_len"].tolist()
     mx, mean = _err(out[:, ::8].cpu(), torch.from_numpy(g["out_rows"]))
     print("%s err max %.4f mean %.5f" % (name, mx, mean))
-    assert mx < OUT_MAX and mean < OUT_MEAN          # the stated tolerance of the bf16 path
+    assert mx < OUT_MAX and mean < OUT_MEAN          # the stated tolerance of the bf16 path (HISTORY.md section 2)
 
 
 def test_batch_rows_are_independent_given_the_padded_length():
@@ -524,7 +524,7 @@ def test_sub_batch_streams_are_bit_identical_to_one_stream():
 def test_sub_batch_streams_are_bit_identical_at_librispeech_batch_sizes():
     """The case the robustness sweep (tools/robustness_sweep.py) used to fail: EfficientConformerCTCSmall, an odd LibriSpeech-sized
     batch with one very short utterance, 2 and 3 row ranges in flight.  The mel frontend runs once for the whole batch and the
-    streams fork at the mel boundary (encoders.py; DESIGN.md section 5: mel_kernel workgroups next to another stream's subsampling
+    streams fork at the mel boundary (encoders.py; HISTORY.md section 5: mel_kernel workgroups next to another stream's subsampling
     workgroups were the one sensitivity), so every split is bit-identical to one stream - outputs, lengths and labels."""
     m, _ = _model("EfficientConformerCTCSmall", 3)
     B = 65

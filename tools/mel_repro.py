@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""What is mel_kernel sensitive to?  (GPU box; DESIGN.md section 5, profiles/r2_mel_repro.txt)
+"""What is mel_kernel sensitive to?  (GPU box; HISTORY.md section 5, profiles/r2_mel_repro.txt)
 
     python tools/mel_repro.py [trials]
 

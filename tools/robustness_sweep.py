@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Odd batch sizes / one very short utterance / sub-batch splits: every split must reproduce the one-stream result bit for bit.
-This failed for the larger batches while the mel frontend was split across the streams (DESIGN.md section 5,
+This failed for the larger batches while the mel frontend was split across the streams (HISTORY.md section 5,
 profiles/r1_16_stream_sensitivity.txt) and passes since ConformerEncoder forks its streams at the mel boundary."""
 import sys, torch, numpy as np
 sys.path.insert(0, ".")

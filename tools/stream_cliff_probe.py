@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""What is the "more than four active HIP streams stop overlapping" cliff?
+"""What is the "more than four active HIP streams stop overlapping" cliff (HISTORY.md section 6)?
 
 N streams each run a chain of K small kernels that fill 1 / 8 of the chip (32 workgroups of a VALU loop): if the streams overlap, the wall
 time stays flat up to N = 8; where they serialise it grows by one chain per extra stream.  Run for N = 1 .. 8, in child processes with

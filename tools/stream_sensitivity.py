@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Which kernels of ANOTHER stream disturb the mel frontend?  (GPU box; DESIGN.md section 5, profiles/r1_16_stream_sensitivity.txt)
+"""Which kernels of ANOTHER stream disturb the mel frontend?  (GPU box; HISTORY.md section 5, profiles/r1_16_stream_sensitivity.txt)
 
     python tools/stream_sensitivity.py [default|nochain|nofusesub|frommel|melmel] [victim: mel|blocks]
 
