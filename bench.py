@@ -538,6 +538,15 @@ def cpu_baseline(sd, plan, budget_s=24.0):
             "runs": runs}
 
 
+def _nccl_version():
+    """RCCL's version as torch reports it (None if this build does not expose it: never a reason to fail a multi-rank run)."""
+    try:
+        v = torch.cuda.nccl.version()
+        return ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+    except Exception:
+        return None
+
+
 def pmc_traffic(args, kernel_prefix):
     """HBM bytes per launch of the dominant kernel class from the committed PMC passes (profiles/pmc_traffic.json, written
     by tools/pmc_summary.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command).  Counters
@@ -789,7 +798,7 @@ def main():
         info = {"rank": rank, "backend": dist.get_backend(), "comm_nranks": dist.get_world_size(), "device": str(dev),
                 "device_name": torch.cuda.get_device_name(dev), "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
                 "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
-                "nccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if dist.get_backend() == "nccl" else None,
+                "nccl_version": _nccl_version() if dist.get_backend() == "nccl" else None,
                 "wire_bytes_sent_per_step": mine, "wire_bytes_received_per_step": mine * (world - 1)}
         gathered = [None] * world
         dist.all_gather_object(gathered, info)
