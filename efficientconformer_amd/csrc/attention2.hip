@@ -23,7 +23,9 @@
 namespace {
 
 constexpr int BJ = 64;          // keys per block
-constexpr int SKEW_LD = 84;     // floats per query row of a skew buffer
+constexpr int SKEW_LD = 68;     // floats per query row of a skew buffer: the 64 key columns of a block + 4 (16-byte rows on rotating banks).  Round 5: the skew is
+                                // applied by the WRITER (band position -> key column), rows are 64 instead of 80 + 4 floats: 52 KB of LDS at head width 64 - three
+                                // workgroups per CU fit (56 KB: two)
 constexpr float RESCALE_T = 4.0f;   // deferred accumulator rescale: threshold on the growth of a row maximum, log2 units
 constexpr float NEG_BIG = -1.0e30f;  // masked score / initial row maximum: finite, so that (max - max) never becomes inf - inf; whatever a row
                                      // accumulates while its maximum still is NEG_BIG is wiped by the first real score (alpha = exp2(-huge) = 0)
@@ -64,7 +66,7 @@ struct Attn2Smem {
 };
 
 template <int DP, int NWV, int QT, int SETS = 0>      // SETS: staging register sets (0 = by shape, 1 = loads one key block ahead, 2 = two ahead)
-__global__ __launch_bounds__(NWV * 64, (QT == 1 && NWV == 4 && DP <= 96) ? 2 : 1) void relpos_attention2_kernel(const AttnParams p) {
+__global__ __launch_bounds__(NWV * 64, (QT == 1 && NWV == 4 && DP <= 96) ? ((DP <= 64 && SETS == 1) ? 3 : 2) : 1) void relpos_attention2_kernel(const AttnParams p) {
     using SM = Attn2Smem<DP, NWV, QT>;
     constexpr int KS = DP / 32, DT = DP / 16, BI = SM::BI, NTHR = NWV * 64, CPR = DP / 8, ERING = SM::ERING;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(NWV * 64, (QT == 1 && NWV == 4 && DP <= 96) ? 2 : 1
     int Tg = p.Tg, T = p.T, qt_wg, h, b;
     {
         const int per_b = p.H * qtiles, q8 = p.B >> 3, r8 = p.B & 7;
-        const int u = p.rag_off ? ((p.ablate & 8) ? (id * p.B) / (int)gridDim.x : ragged_find(p.rag_wg, p.B, id)) : id / per_b;
+        const int u = p.rag_off ? ((p.ablate & 8) ? (id * p.B) / (int)gridDim.x : ragged_find_wave(p.rag_wg, p.B, id)) : id / per_b;
         int x, j;
         if (u < r8 * (q8 + 1)) { x = u / (q8 + 1); j = u - x * (q8 + 1); }
         else { const int u2 = u - r8 * (q8 + 1); x = u2 / q8; j = u2 - x * q8; x += r8; }
@@ -189,6 +191,7 @@ __global__ __launch_bounds__(NWV * 64, (QT == 1 && NWV == 4 && DP <= 96) ? 2 : 1
     }
     const float scale2 = p.scale * 1.44269504088896340736f;
     float* skew0 = sS + (wave * QT) * 16 * SKEW_LD + c * SKEW_LD;          // tile t: skew0 + t * 16 * SKEW_LD
+    const int wcol = c - 15 + 4 * g;                             // key column of the lane's band element r = 0 of band tile 0
     const int woff1 = BI - 16 * QT - 16 * QT * wave;             // first band row (workgroup band) of the wave's (64 + 16 QT)-row band: the LAST tile starts here, tile t 16 (QT - 1 - t) rows later
     const char* vbase = sV + (4 * g + (c >> 2)) * SM::VP + (c & 3) * 8;
 
@@ -321,10 +324,21 @@ __global__ __launch_bounds__(NWV * 64, (QT == 1 && NWV == 4 && DP <= 96) ? 2 : 1
                 }
             }
         }
+        // realignment on the way INTO the buffer: band position q of query c is key column q - 15 + c.  The first and the last band tile hold the columns
+        // outside [0, 16 JTV) in complementary elements (q - 15 + c < 0 in tile 0 exactly where it is >= 16 JTV in tile JTV): ONE store serves both
 #pragma unroll
-        for (int t = 0; t < QT; ++t)
+        for (int t = 0; t < QT; ++t) {
+            float* row = skew0 + t * 16 * SKEW_LD + wcol;
 #pragma unroll
-            for (int u = 0; u < PU; ++u) *reinterpret_cast<f32x4*>(skew0 + t * 16 * SKEW_LD + u * 16 + g * 4) = pe[t][u];
+            for (int r = 0; r < 4; ++r) {
+                const bool lo = wcol + r >= 0;
+                row[r + (lo ? 0 : 16 * JTV)] = lo ? pe[t][0][r] : pe[t][JTV][r];
+            }
+#pragma unroll
+            for (int u = 1; u < JTV; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) row[u * 16 + r] = pe[t][u][r];
+        }
         wave_sync();
 
         // ---- realign, mask, online softmax, per tile.  Raw scores s = S + PE; the running maximum is tracked in raw units and
@@ -336,12 +350,11 @@ __global__ __launch_bounds__(NWV * 64, (QT == 1 && NWV == 4 && DP <= 96) ? 2 : 1
             const float* skew = skew0 + t * 16 * SKEW_LD;
             float mloc = -INFINITY;
 #pragma unroll
-            for (int jt = 0; jt < JTV; ++jt)
+            for (int jt = 0; jt < JTV; ++jt) {
+                const f32x4 s4 = *reinterpret_cast<const f32x4*>(skew + jt * 16 + g * 4);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int jl = jt * 16 + g * 4 + r;
-                    st[t][jt][r] += skew[jl + 15 - c];
-                }
+                for (int r = 0; r < 4; ++r) st[t][jt][r] += s4[r];
+            }
             // masks only where the (query tile, key block) pair is not fully visible (wave-uniform test): padding tail or band edge
             const int iq0 = iw0 + 16 * t;
             if (j0 + BJ > nkv || (banded && (j0 - (iq0 + 15) < -band_l || j0 + BJ - 1 - iq0 > band_r))) {
@@ -517,6 +530,9 @@ int launch_relpos_attention2(const AttnParams& p0, int waves, hipStream_t s) {
     // and reloads loop-invariant addresses from scratch inside the key loop; ONE set (loads one key block ahead) fits: attention class
     // 1.625 -> 1.555 ms per step (option attn_waves = 2 restores the two sets for comparison)
     if (waves == 1 && p.dpad == 96 && p.force_waves != 2) return launch2<96, 4, 1, 1>(p, s);
+    // head width 64 (stages 2 / 3 of EfficientConformer Small): since the skew rows hold 64 floats the workgroup needs 52 KB of LDS, and with ONE staging set
+    // 168 registers - THREE workgroups per CU instead of two (the kernel is bound by per-workgroup latency): step 5.235 -> 5.14 ms (profiles/r5_27_*)
+    if (waves == 1 && p.dpad == 64 && p.force_waves != 2) return launch2<64, 4, 1, 1>(p, s);
     switch (p.dpad) {
         ATT2_CASE(32) ATT2_CASE(64) ATT2_CASE(96) ATT2_CASE(128)
         case 160: return launch2<160, 4, 1>(p, s);       // d = 135 (Medium / Large stage 1): one wave per SIMD either way; the 32-query variant spills

@@ -75,5 +75,21 @@ __device__ __forceinline__ int ragged_find(const int* __restrict__ off, int n, i
     return lo;
 }
 
+// The same search by a whole wave (all 64 lanes active, m wave-uniform): every lane loads 4 entries per 256 (coalesced dwords) and the count of entries
+// <= m comes from ballots - ONE memory round trip for n <= 256 instead of log2(n) dependent ones at the head of every workgroup of the ragged attention and
+// depthwise-convolution launches (round 5; the search was 4 % of the attention kernel, profiles/r5_17_attention_ablations.txt).
+__device__ __forceinline__ int ragged_find_wave(const int* __restrict__ off, int n, int m) {
+    const int lane = threadIdx.x & 63;
+    int cnt = 0;
+    for (int base = 0; base < n; base += 256) {
+        int e[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int i = base + 64 * k + lane; e[k] = i < n ? off[i] : 0x7fffffff; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cnt += __popcll(__ballot(e[k] <= m));
+    }
+    return __builtin_amdgcn_readfirstlane(cnt) - 1;
+}
+
 static inline int ec_round_up(int x, int m) { return (x + m - 1) / m * m; }
 static inline int ec_cdiv(int a, int b) { return (a + b - 1) / b; }

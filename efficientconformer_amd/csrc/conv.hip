@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const bf16_t* __restrict__ 
         // ragged batch: utterance b has its own T / To ("same" zero padding at ITS ends), its rows start at in_off[b] / out_off[b] of the
         // concatenated row spaces; rc.tile_off = prefix sums of the utterances' time tiles.  Output rows To .. Top - 1 pad the utterance
         // to a multiple of the NEXT stage's attention group size and are written as zeros.
-        b = ragged_find(rc.tile_off, rc.n, id); tt = id - rc.tile_off[b];
+        b = ragged_find_wave(rc.tile_off, rc.n, id); tt = id - rc.tile_off[b];
         T = rc.in_len[b]; To = rc.out_len[b];
         grow0 = (size_t)rc.in_off[b]; orow0 = (size_t)rc.out_off[b]; Top = rc.out_off[b + 1] - rc.out_off[b];
     } else { tt = id % ttiles; b = id / ttiles; grow0 = (size_t)b * T; orow0 = (size_t)b * To; }

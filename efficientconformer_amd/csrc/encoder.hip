@@ -1855,7 +1855,7 @@ int effconf_encoder_set_option(EcEncoder* e, const char* name, int32_t value) {
     // former EFFCONF_* environment switches (process-global statics): per-handle options now
     if (!strcmp(name, "chain_variant")) { if (value != 0 && value != 1) return fail("chain_variant: 0 (8-wave chain workgroups) or 1 (4-wave, two per CU, at 65..128-wide stages)"); e->chain_variant = value; return 0; }
     if (!strcmp(name, "chain_full_max")) { if (value < 0 || value > 256) return fail("chain_full_max: widest stage (0..256) that runs chain A as ONE kernel"); e->chain_full_max = value; return 0; }   // widening takes effect at the next finalize (the combined constant blocks are built there)
-    if (!strcmp(name, "attn_waves")) { if (value != 4 && value != 8 && value != 2) return fail("attn_waves: 4 or 8 (attention.hip workgroup size); 2: attention2.hip with two staging sets at head width 96 (tuning)"); e->attn_waves = value; return 0; }
+    if (!strcmp(name, "attn_waves")) { if (value != 4 && value != 8 && value != 2) return fail("attn_waves: 4 or 8 (attention.hip workgroup size); 2: attention2.hip with two staging sets at head widths 64 / 96 (two workgroups per CU at 64: tuning)"); e->attn_waves = value; return 0; }
     if (!strcmp(name, "rs_variant")) { if (value != 0 && value != 1) return fail("rs_variant: 0 or 1 (8-wave row-stationary GEMM workgroups)"); e->rs_variant = value; return 0; }
     if (!strcmp(name, "chain_max_dim")) { e->chain_max_dim = value; return 0; }
     if (!strcmp(name, "chain_small_m")) { e->chain_small_m = value; return 0; }
