@@ -22,6 +22,13 @@
 
 namespace {
 
+// Timing-only builds (tools/build_ablate.py, -DEFFCONF_ABLATE, a separate library): parts of the kernel switched off by a run-time mask.  The product kernel
+// compiles the mask as the constant 0 - no branch around any load (they kept the prologue's loads in separate basic blocks)
+#ifdef EFFCONF_ABLATE
+#define ABLATE(p) ((p).ablate)
+#else
+#define ABLATE(p) 0
+#endif
 constexpr int BJ = 64;          // keys per block
 constexpr int SKEW_LD = 68;     // floats per query row of a skew buffer: the 64 key columns of a block + 4 (16-byte rows on rotating banks).  Round 5: the skew is
                                 // applied by the WRITER (band position -> key column), rows are 64 instead of 80 + 4 floats: 52 KB of LDS at head width 64 - three
@@ -91,16 +98,16 @@ __global__ __launch_bounds__(NWV * 64, (QT == 1 && NWV == 4 && DP <= 96) ? ((DP 
     int Tg = p.Tg, T = p.T, qt_wg, h, b;
     {
         const int per_b = p.H * qtiles, q8 = p.B >> 3, r8 = p.B & 7;
-        const int u = p.rag_off ? ((p.ablate & 8) ? (id * p.B) / (int)gridDim.x : ragged_find_wave(p.rag_wg, p.B, id)) : id / per_b;
+        const int u = p.rag_off ? ((ABLATE(p) & 8) ? (id * p.B) / (int)gridDim.x : ragged_find_wave(p.rag_wg, p.B, id)) : id / per_b;
         int x, j;
         if (u < r8 * (q8 + 1)) { x = u / (q8 + 1); j = u - x * (q8 + 1); }
         else { const int u2 = u - r8 * (q8 + 1); x = u2 / q8; j = u2 - x * q8; x += r8; }
         b = x + 8 * j;
-        int local = id - (p.rag_off ? ((p.ablate & 8) ? id : p.rag_wg[u]) : u * per_b);
+        int local = id - (p.rag_off ? ((ABLATE(p) & 8) ? id : p.rag_wg[u]) : u * per_b);
         if (p.rag_off) { T = p.lens[b]; Tg = (T + p.G - 1) / p.G; qtiles = (Tg + BI - 1) / BI; }
         qt_wg = local % qtiles; h = local / qtiles;
     }
-    if (p.ablate & 128) return;                                  // timing-only: dispatch + utterance lookup alone
+    if (ABLATE(p) & 128) return;                                  // timing-only: dispatch + utterance lookup alone
     const int i0 = qt_wg * BI, iw0 = i0 + wave * 16 * QT;
     const size_t orow0 = p.rag_off ? (size_t)p.rag_off[b] : (size_t)b * p.T;          // first row of the utterance in the un-grouped output
     const size_t qoff = (p.rag_off ? orow0 * p.D : (size_t)b * p.q_bstride) + (size_t)h * p.q_hstride;
@@ -131,70 +138,11 @@ __global__ __launch_bounds__(NWV * 64, (QT == 1 && NWV == 4 && DP <= 96) ? ((DP 
         nkeys = ke < nkv ? ke : nkv;
     }
 
-    // ---- the wave's two query tiles: B operands of S^T = K Q^T (Q + u) and of the positional product (Q + v = (Q + u) + (v - u))
-    bf16x8 qu[QT][KS], qv[QT][KS];
-    {
-        const float* dv = p.dvu + (size_t)h * p.dvu_ld;
-#pragma unroll
-        for (int t = 0; t < QT; ++t) {
-            const int i = iw0 + 16 * t + c, ic = i < Tg ? i : Tg - 1;
-            uint4 ra[KS];
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const int x = ks * 32 + g * 8;
-                ra[ks] = (p.ablate & 32) ? make_uint4(0, 0, 0, 0) : ld16(Qu + (size_t)ic * RS + (x < dceil ? x : 0));
-            }
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const int x = ks * 32 + g * 8;
-                const float4 da = *reinterpret_cast<const float4*>(dv + x), db = *reinterpret_cast<const float4*>(dv + x + 4);
-                const int valid = i < Tg ? p.d - x : 0;
-                const uint4 m = mask_chunk(ra[ks], valid);
-                qu[t][ks] = as_bf16x8(m);
-                const uint4 w = make_uint4(pack_bf2(__uint_as_float(m.x << 16) + da.x, __uint_as_float(m.x & 0xFFFF0000u) + da.y),
-                                           pack_bf2(__uint_as_float(m.y << 16) + da.z, __uint_as_float(m.y & 0xFFFF0000u) + da.w),
-                                           pack_bf2(__uint_as_float(m.z << 16) + db.x, __uint_as_float(m.z & 0xFFFF0000u) + db.y),
-                                           pack_bf2(__uint_as_float(m.w << 16) + db.z, __uint_as_float(m.w & 0xFFFF0000u) + db.w));
-                qv[t][ks] = as_bf16x8(mask_chunk(w, valid));
-            }
-        }
-    }
-    // ---- first positional band of the workgroup: absolute E rows R0 .. R0 + BI + 62
+    // ---- first positional band of the workgroup: absolute E rows R0 .. R0 + BI + 62.  Round 5: the first key block's K / V loads and the band's loads are
+    //      ISSUED before the query rows are waited for and converted (one memory round trip at the head of the workgroup instead of three)
     const int R0 = Tg - 1 - i0 - (BI - 1) + kbeg;                 // absolute E row of band row 0 of the FIRST visited key block
-    {
-        constexpr int NB = ((BI + 63) * CPR + NTHR - 1) / NTHR;
-        uint4 fb[NB];
-#pragma unroll
-        for (int n = 0; n < NB; ++n) {
-            const int q = tid + NTHR * n;
-            const int rr = q / CPR, x = (q - rr * CPR) * 8;
-            const int r = R0 + (rr < BI + 63 ? rr : BI + 62);
-            const int rc = r < 0 ? 0 : (r >= erows ? erows - 1 : r);
-            fb[n] = (p.ablate & 16) ? make_uint4(0, 0, 0, 0) : ld16(Eh + (size_t)rc * ERS + (x < dceil ? x : 0));
-        }
-#pragma unroll
-        for (int n = 0; n < NB; ++n) {
-            const int q = tid + NTHR * n;
-            const int rr = q / CPR, x = (q - rr * CPR) * 8;
-            if (q < (BI + 63) * CPR)      // ring row = band row + key offset (mod 2 BI): block 0's band sits at rows 0 .. BI + 62
-                *reinterpret_cast<uint4*>(sE + SM::koff(rr, x >> 3)) = mask_chunk(fb[n], p.d - x);
-        }
-    }
-
-    f32x4 acc[QT][DT];
-    float m_run[QT], l_run[QT];
-#pragma unroll
-    for (int t = 0; t < QT; ++t) {
-        m_run[t] = NEG_BIG; l_run[t] = 0.f;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) acc[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    const float scale2 = p.scale * 1.44269504088896340736f;
-    float* skew0 = sS + (wave * QT) * 16 * SKEW_LD + c * SKEW_LD;          // tile t: skew0 + t * 16 * SKEW_LD
-    const int wcol = c - 15 + 4 * g;                             // key column of the lane's band element r = 0 of band tile 0
-    const int woff1 = BI - 16 * QT - 16 * QT * wave;             // first band row (workgroup band) of the wave's (64 + 16 QT)-row band: the LAST tile starts here, tile t 16 (QT - 1 - t) rows later
-    const char* vbase = sV + (4 * g + (c >> 2)) * SM::VP + (c & 3) * 8;
-
+    constexpr int NB = ((BI + 63) * CPR + NTHR - 1) / NTHR;
+    uint4 fb[NB];
     // ---- K / V / new-E staging registers, two sets (loads run two key blocks ahead)
     constexpr int NK = (BJ * CPR + NTHR - 1) / NTHR;
     struct Stage { uint4 lk[NK], lv[NK], le[NK]; };
@@ -222,7 +170,7 @@ __global__ __launch_bounds__(NWV * 64, (QT == 1 && NWV == 4 && DP <= 96) ? ((DP 
         koffs[n] = (uint32_t)(r * RS + xc) * 2u;                // BYTE offsets: wave-uniform base + 32-bit lane offset
     }
     auto issue_loads = [&](Stage& st_, int jn) __attribute__((always_inline)) {
-        if (((p.ablate & 2) && jn > kbeg) || (p.ablate & 64)) return;
+        if (((ABLATE(p) & 2) && jn > kbeg) || (ABLATE(p) & 64)) return;
         // unmasked fast path: every 16-byte chunk of the block stays inside the library's own (finite) data.  With a head width that
         // is not a multiple of 8 (d = 90 / 135 / 42) the chunk that closes a head span reads dceil - d elements of the NEXT span; behind
         // the last key row of the last head of the last utterance that is the never-written slack of the buffer (NaN patterns times the
@@ -257,6 +205,65 @@ __global__ __launch_bounds__(NWV * 64, (QT == 1 && NWV == 4 && DP <= 96) ? ((DP 
             }
         }
     };
+    issue_loads(sa, kbeg);
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+        const int q = tid + NTHR * n;
+        const int rr = q / CPR, x = (q - rr * CPR) * 8;
+        const int r = R0 + (rr < BI + 63 ? rr : BI + 62);
+        const int rc = r < 0 ? 0 : (r >= erows ? erows - 1 : r);
+        fb[n] = (ABLATE(p) & 16) ? make_uint4(0, 0, 0, 0) : ld16(Eh + (size_t)rc * ERS + (x < dceil ? x : 0));
+    }
+    // ---- the wave's two query tiles: B operands of S^T = K Q^T (Q + u) and of the positional product (Q + v = (Q + u) + (v - u))
+    bf16x8 qu[QT][KS], qv[QT][KS];
+    {
+        const float* dv = p.dvu + (size_t)h * p.dvu_ld;
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            const int i = iw0 + 16 * t + c, ic = i < Tg ? i : Tg - 1;
+            uint4 ra[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int x = ks * 32 + g * 8;
+                ra[ks] = (ABLATE(p) & 32) ? make_uint4(0, 0, 0, 0) : ld16(Qu + (size_t)ic * RS + (x < dceil ? x : 0));
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int x = ks * 32 + g * 8;
+                const float4 da = *reinterpret_cast<const float4*>(dv + x), db = *reinterpret_cast<const float4*>(dv + x + 4);
+                const int valid = i < Tg ? p.d - x : 0;
+                const uint4 m = mask_chunk(ra[ks], valid);
+                qu[t][ks] = as_bf16x8(m);
+                const uint4 w = make_uint4(pack_bf2(__uint_as_float(m.x << 16) + da.x, __uint_as_float(m.x & 0xFFFF0000u) + da.y),
+                                           pack_bf2(__uint_as_float(m.y << 16) + da.z, __uint_as_float(m.y & 0xFFFF0000u) + da.w),
+                                           pack_bf2(__uint_as_float(m.z << 16) + db.x, __uint_as_float(m.z & 0xFFFF0000u) + db.y),
+                                           pack_bf2(__uint_as_float(m.w << 16) + db.z, __uint_as_float(m.w & 0xFFFF0000u) + db.w));
+                qv[t][ks] = as_bf16x8(mask_chunk(w, valid));
+            }
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+        const int q = tid + NTHR * n;
+        const int rr = q / CPR, x = (q - rr * CPR) * 8;
+        if (q < (BI + 63) * CPR)      // ring row = band row + key offset (mod 2 BI): block 0's band sits at rows 0 .. BI + 62
+            *reinterpret_cast<uint4*>(sE + SM::koff(rr, x >> 3)) = mask_chunk(fb[n], p.d - x);
+    }
+
+    f32x4 acc[QT][DT];
+    float m_run[QT], l_run[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        m_run[t] = NEG_BIG; l_run[t] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) acc[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const float scale2 = p.scale * 1.44269504088896340736f;
+    float* skew0 = sS + (wave * QT) * 16 * SKEW_LD + c * SKEW_LD;          // tile t: skew0 + t * 16 * SKEW_LD
+    const int wcol = c - 15 + 4 * g;                             // key column of the lane's band element r = 0 of band tile 0
+    const int woff1 = BI - 16 * QT - 16 * QT * wave;             // first band row (workgroup band) of the wave's (64 + 16 QT)-row band: the LAST tile starts here, tile t 16 (QT - 1 - t) rows later
+    const char* vbase = sV + (4 * g + (c >> 2)) * SM::VP + (c & 3) * 8;
+
     // LDS byte offsets of the thread's chunks: K / V tile rows, and the ring rows of a new-row batch for even / odd key blocks
     // (ring row = band row + key offset mod 2 BI = 128: the batch starts at row BI - 1 + 64 * parity)
     static_assert(BI == 64, "ring phases: two (BI == BJ)");
@@ -430,14 +437,13 @@ __global__ __launch_bounds__(NWV * 64, (QT == 1 && NWV == 4 && DP <= 96) ? ((DP 
     const bool wave_idle = iw0 >= Tg;
     const bool short_ok = !tile_dead;                           // dead rows spread a uniform softmax over ALL key groups: full blocks
     auto run_block = [&](int j0, int par) __attribute__((always_inline)) {
-        if (wave_idle || (p.ablate & 1)) return;
+        if (wave_idle || (ABLATE(p) & 1)) return;
         if (short_ok && nkeys - j0 <= 32) compute_block(j0, par, std::integral_constant<int, 2>{});
         else compute_block(j0, par, std::integral_constant<int, 4>{});
     };
     // two staging sets (loads two key blocks ahead) while they fit the register file; one set (one block ahead) for the widest heads
     // of the 2-wave workgroup, whose threads stage twice as many chunks
     constexpr bool TWO_SETS = SETS == 2 || (SETS == 0 && !(NWV == 2 && DP >= 96));
-    issue_loads(sa, kbeg);
     if constexpr (TWO_SETS) {
         if (kbeg + BJ < nkeys) issue_loads(sb, kbeg + BJ);
         for (int jb = kbeg; jb < nkeys; jb += 2 * BJ)
@@ -468,7 +474,7 @@ __global__ __launch_bounds__(NWV * 64, (QT == 1 && NWV == 4 && DP <= 96) ? ((DP 
         l_tot += __shfl_xor(l_tot, 32);
         const float inv = 1.0f / l_tot;
         const int i = iw0 + 16 * t + c;
-        if (i >= Tg || (p.ablate & 4)) continue;
+        if (i >= Tg || (ABLATE(p) & 4)) continue;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             const int x0 = dt * 16 + g * 4;
