@@ -100,3 +100,27 @@ def test_alternating_rectangular_range_shapes_on_one_stream_cost_what_each_shape
     mixed = run([0, 1, 2], 4)
     for k in names:
         assert mixed[k][0] <= 1.5 * alone[k] + 0.2, (k, mixed[k], alone[k])          # ms over 12 forwards each way; + 0.2 ms of slack for the small classes
+
+
+# ------------------------------------------------------------------ the wave-parallel utterance search beyond one 256-entry chunk
+@pytest.mark.parametrize("name,batch", [("Tiny", 300), ("Tiny", 700), ("EfficientConformerCTCSmall", 520)])
+def test_ragged_launches_of_more_than_256_utterances(name, batch):
+    """`ragged_find_wave` (common.h; the head of every attention and depthwise-convolution workgroup of a ragged launch) counts the prefix sums <= the
+    workgroup id with ballots, 256 entries per pass: batches of more than 256 (two passes) and 512 (three) utterances in ONE row range, some of them one
+    workgroup long, against sampled utterances run alone - bit-identical."""
+    m = _any_model(name, 11)
+    rng = np.random.default_rng(batch)
+    lens = np.sort((16000 * (0.05 + 2.4 * rng.random(batch))).astype(np.int64))[::-1].copy()
+    lens[-3:] = (400, 320, 260)                                       # down to the shortest legal utterance (n_fft / 2 < samples)
+    audio = torch.from_numpy(synth.make_audio(lens, seed=9)).cuda()
+    ln = torch.from_numpy(lens).cuda()
+    enc = m.encoder
+    enc.ragged, enc.sub_batches = True, 1
+    out, out_len, _ = enc(audio, ln, x_len_host=lens)
+    assert torch.isfinite(out.float()).all()
+    enc.ragged = False
+    for b in (0, 1, 255, 256, 257, batch // 2, batch - 2, batch - 1):
+        li = int(lens[b])
+        alone, alone_len, _ = enc(audio[b:b + 1, :li].contiguous(), ln[b:b + 1].contiguous())
+        tb = int(alone_len[0])
+        assert int(out_len[b]) == tb and torch.equal(out[b, :tb], alone[0]) and float(out[b, tb:].float().abs().sum()) == 0.0, b
