@@ -9,6 +9,8 @@
 //    with (k-1) halo, channels across lanes.
 #include "kernels.h"
 
+#include <cstring>
+
 namespace {
 
 constexpr int SUB_TT = 8;     // output frames per workgroup
@@ -181,6 +183,147 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const bf16_t* __restrict__ 
     }
 }
 
+// ---- depthwise conv on the MATRIX pipe (round 5; stride 1).  dwconv_kernel above is bound by the VALU: 16 * KSZ * 2 fp32 FMAs per thread are half of its
+// issue slots (the Swish of the 32 outputs is a third; tools/experiments/probes/valu_rate_probe.hip).  A depthwise convolution of one channel is a product with
+// a Toeplitz matrix, and v_mfma_f32_4x4x4_16b_bf16 computes 16 INDEPENDENT 4 x 4 x 4 products per wave - one block per channel:
+//     out[16 S + 4 j + i] = sum_q sum_k A_q[i][k] * X[4 S + j + q][k],    A_q[i][k] = w[4 q + k - i] (0 outside the taps),   X[n][k] = x[4 n + k]
+// (S = 16-frame set, q = 0 .. NQ - 1 groups of 4 taps).  Block b = lanes 4 b .. 4 b + 3 holds channel b: the A operand of lane 4 b + i is row i of A_q (packed
+// on the host: bf16 hi + lo halves of the fp32 folded weight - two MFMAs per q, the products are exact in fp32), the B operand of lane 4 b + j is four
+// CONSECUTIVE frames of the channel (block 4 S + j + q), the accumulators of lane 4 b + j are four consecutive output frames.  Operands that are runs of frames
+// per lane need the tile as [channel][frame] in LDS: every thread loads the 16-byte chunk (8 channels) of four consecutive frame rows - the global access pattern of
+// dwconv_kernel - builds the channels' 4-frame blocks with two v_perm each and writes eight 8-byte blocks; the outputs (Swish, bf16) go back IN PLACE (output block 4 S + j over input block
+// 4 S + j: every read of set S precedes it in the wave's program order, later sets start at block 4 S + 4; a wave only touches its own 16 channel rows), and a last
+// pass transposes back (16-byte stores).  Per wave and 2048 outputs: 16 NQ MFMAs (8 cycles each, beside other waves' VALU work), ~70 staging + ~60
+// epilogue VALU instructions and the Swish - against ~1000 VALU instructions before.
+template <int KSZ>
+struct DwM {
+    static constexpr int NQ = (KSZ + 6) / 4;              // groups of 4 taps: 4 q + k - i covers -3 .. KSZ + 2
+    static constexpr int NBLK = DW_TT / 4 + NQ - 1;       // 4-frame input blocks of a tile: 4 S + j + q
+    static constexpr int PITCH = NBLK * 8 + 8;            // bytes per channel row (74 dwords at KSZ = 15: staging writes and operand reads spread over the banks)
+    static constexpr int LDS = DW_CC * PITCH;
+};
+typedef short dw_s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ dw_s16x4 dw_as_s16x4(uint32_t a, uint32_t b) { union { uint2 u; dw_s16x4 s; } c; c.u = make_uint2(a, b); return c.s; }
+
+template <int KSZ>
+__global__ __launch_bounds__(256) void dwconv_mfma_kernel(const bf16_t* __restrict__ g, int T, int To, int C, int ld, const uint4* __restrict__ wa,
+                                                          const float* __restrict__ bias, bf16_t* out, RaggedConv rc, int causal) {
+    using M = DwM<KSZ>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int ctiles = (C + DW_CC - 1) / DW_CC;
+    const int ttiles = (To + DW_TT - 1) / DW_TT;
+    int id = blockIdx.x;
+    const int ct = id % ctiles; id /= ctiles;
+    int tt, b, Top = To;
+    size_t grow0, orow0;
+    if (rc.tile_off) {                                                      // ragged batch: see dwconv_kernel
+        b = ragged_find_wave(rc.tile_off, rc.n, id); tt = id - rc.tile_off[b];
+        T = rc.in_len[b]; To = rc.out_len[b];
+        grow0 = (size_t)rc.in_off[b]; orow0 = (size_t)rc.out_off[b]; Top = rc.out_off[b + 1] - rc.out_off[b];
+    } else { tt = id % ttiles; b = id / ttiles; grow0 = (size_t)b * T; orow0 = (size_t)b * To; }
+    const int c0 = ct * DW_CC, to0 = tt * DW_TT;
+    const int tin0 = to0 - (causal ? KSZ - 1 : (KSZ - 1) / 2);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // ---- this lane's Toeplitz rows (A operands) and bias: block = channel 16 wave + (lane >> 2), row / column index lane & 3
+    const int chl = lane >> 2, xi = lane & 3;
+    const int chw = c0 + 16 * wave + chl, chc = chw < C ? chw : C - 1;
+    uint4 aw[M::NQ];
+#pragma unroll
+    for (int q = 0; q < M::NQ; ++q) aw[q] = wa[(size_t)(chc * 4 + xi) * M::NQ + q];
+    float bz = bias[chc];
+    // ---- stage the tile transposed: thread = 8 channels (one 16-byte chunk of a frame row, as dwconv_kernel loads them) x input block t32 (+ 32)
+    const int c8 = tid & 7, t32 = tid >> 3;
+    const int cq = c0 + 8 * c8;
+    {
+        const bf16_t* gb = g + grow0 * ld;
+        const unsigned cc = cq < ld - 8 ? cq : ld - 8;                      // clamped, unconditional loads
+        constexpr int NQD = M::NBLK > 32 ? 2 : 1;
+        uint4 v[NQD][4];
+#pragma unroll
+        for (int n = 0; n < NQD; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int t = tin0 + 4 * (t32 + 32 * n) + r;
+                const int tc = t < 0 ? 0 : (t < T ? t : T - 1);
+                v[n][r] = *reinterpret_cast<const uint4*>(gb + ((unsigned)(tc * ld) + cc));
+            }
+#pragma unroll
+        for (int n = 0; n < NQD; ++n) {
+            const int Q = t32 + 32 * n;
+            if (n == 0 || Q < M::NBLK) {
+                uint32_t w[4][4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {                               // "same" / causal zero padding at the utterance's own ends; channels >= C: zero
+                    const int t = tin0 + 4 * Q + r;
+                    const uint4 x = mask_chunk(v[n][r], (t >= 0 && t < T && cq < ld) ? C - cq : 0);
+                    w[r][0] = x.x; w[r][1] = x.y; w[r][2] = x.z; w[r][3] = x.w;
+                }
+                char* dst = smem + (8 * c8) * M::PITCH + Q * 8;
+#pragma unroll
+                for (int pq = 0; pq < 4; ++pq) {                            // dword pq of a row = channels 2 pq (low half), 2 pq + 1
+                    *reinterpret_cast<uint2*>(dst + (2 * pq) * M::PITCH) =
+                        make_uint2(__builtin_amdgcn_perm(w[1][pq], w[0][pq], 0x05040100u), __builtin_amdgcn_perm(w[3][pq], w[2][pq], 0x05040100u));
+                    *reinterpret_cast<uint2*>(dst + (2 * pq + 1) * M::PITCH) =
+                        make_uint2(__builtin_amdgcn_perm(w[1][pq], w[0][pq], 0x07060302u), __builtin_amdgcn_perm(w[3][pq], w[2][pq], 0x07060302u));
+                }
+            }
+        }
+    }
+    if (chw >= C) {                                                         // pad channels: zero taps and bias -> swish(0) = 0 keeps the pad columns zero
+        bz = 0.f;
+#pragma unroll
+        for (int q = 0; q < M::NQ; ++q) aw[q] = make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+    // ---- 8 sets of 16 frames: NQ x 2 MFMAs, Swish, in-place bf16 blocks
+    char* xrow = smem + (16 * wave + chl) * M::PITCH + xi * 8;
+#pragma unroll
+    for (int S = 0; S < DW_TT / 16; ++S) {
+        f32x4 acc = f32x4{bz, bz, bz, bz};
+        uint2 bx[M::NQ];
+#pragma unroll
+        for (int q = 0; q < M::NQ; ++q) bx[q] = *reinterpret_cast<const uint2*>(xrow + (4 * S + q) * 8);
+#pragma unroll
+        for (int q = 0; q < M::NQ; ++q) {
+            const dw_s16x4 xb = dw_as_s16x4(bx[q].x, bx[q].y);
+            acc = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(dw_as_s16x4(aw[q].x, aw[q].y), xb, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(dw_as_s16x4(aw[q].z, aw[q].w), xb, acc, 0, 0, 0);
+        }
+        *reinterpret_cast<uint2*>(xrow + (4 * S) * 8) = make_uint2(pack_bf2(swishf_(acc[0]), swishf_(acc[1])), pack_bf2(swishf_(acc[2]), swishf_(acc[3])));
+    }
+    __syncthreads();
+    // ---- back to (frame, channel) rows: thread = 8 channels x output block t32: four 16-byte stores
+    if (cq < ld) {
+        bf16_t* ob = out + orow0 * ld;
+        const char* src = smem + (8 * c8) * M::PITCH + t32 * 8;
+        uint32_t w[4][4];
+#pragma unroll
+        for (int pq = 0; pq < 4; ++pq) {
+            const uint2 ya = *reinterpret_cast<const uint2*>(src + (2 * pq) * M::PITCH);
+            const uint2 yb = *reinterpret_cast<const uint2*>(src + (2 * pq + 1) * M::PITCH);
+            w[0][pq] = __builtin_amdgcn_perm(yb.x, ya.x, 0x05040100u); w[1][pq] = __builtin_amdgcn_perm(yb.x, ya.x, 0x07060302u);
+            w[2][pq] = __builtin_amdgcn_perm(yb.y, ya.y, 0x05040100u); w[3][pq] = __builtin_amdgcn_perm(yb.y, ya.y, 0x07060302u);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int to = to0 + 4 * t32 + r;
+            if (to < Top) *reinterpret_cast<uint4*>(ob + ((unsigned)(to * ld) + (unsigned)cq)) = to < To ? make_uint4(w[r][0], w[r][1], w[r][2], w[r][3]) : make_uint4(0, 0, 0, 0);
+        }
+    }
+}
+
+template <int KSZ>
+int launch_dw_mfma(const bf16_t* g, int B, int T, int To, int C, int ld, const void* wa, const float* bias, bf16_t* out, hipStream_t s,
+                   const RaggedConv& rc, int causal) {
+    const int ctiles = (C + DW_CC - 1) / DW_CC, ttiles = (To + DW_TT - 1) / DW_TT;
+    const int nwg = rc.tile_off ? rc.tiles * ctiles : B * ttiles * ctiles;
+    if (nwg <= 0) return 0;
+    static LdsAttr attr;
+    ensure_dynamic_lds(reinterpret_cast<const void*>(&dwconv_mfma_kernel<KSZ>), DwM<KSZ>::LDS, attr);
+    hipLaunchKernelGGL((dwconv_mfma_kernel<KSZ>), dim3(nwg), dim3(256), DwM<KSZ>::LDS, s, g, T, To, C, ld, reinterpret_cast<const uint4*>(wa), bias, out, rc, causal);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 template <int KSZ, int STRIDE>
 int launch_dw_t(const bf16_t* g, int B, int T, int To, int C, int ld, const float* w_kc, const float* bias, bf16_t* out, hipStream_t s,
                 const RaggedConv& rc, int causal) {
@@ -209,12 +352,37 @@ int launch_subsample_conv(const float* mel, int B, int F, int Tm, int T1, const 
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+// Host side of dwconv_mfma_kernel's A operands: [channel][row i][group q] x 16 bytes = bf16 hi (4 taps) | bf16 lo (4 taps) of w[4 q + k - i]
+int dwconv_mfma_groups(int ksize) { return (ksize + 6) / 4; }
+bool dwconv_mfma_supported(int ksize, int stride) { return stride == 1 && (ksize == 15 || ksize == 31 || ksize == 7); }
+void pack_dwconv_mfma(const float* w_kc, int ksize, int C, uint16_t* dst) {
+    const int nq = dwconv_mfma_groups(ksize);
+    auto bf = [](float f) { uint32_t u; memcpy(&u, &f, 4); const uint32_t r = u + 0x7FFFu + ((u >> 16) & 1u); return (uint16_t)(r >> 16); };   // RNE (finite weights)
+    auto fl = [](uint16_t h) { const uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; };
+    for (int ch = 0; ch < C; ++ch)
+        for (int i = 0; i < 4; ++i)
+            for (int q = 0; q < nq; ++q) {
+                uint16_t* o = dst + ((size_t)(ch * 4 + i) * nq + q) * 8;
+                for (int k = 0; k < 4; ++k) {
+                    const int tap = 4 * q + k - i;
+                    const float w = tap >= 0 && tap < ksize ? w_kc[(size_t)tap * C + ch] : 0.f;
+                    const uint16_t hi = bf(w);
+                    o[k] = hi; o[4 + k] = bf(w - fl(hi));
+                }
+            }
+}
+
 int launch_dwconv(const bf16_t* g, int B, int T, int To, int C, int ld, const float* w_kc, const float* bias,
-                  int ksize, int stride, bf16_t* out, hipStream_t s, const RaggedConv* rcp, int causal) {
+                  int ksize, int stride, bf16_t* out, hipStream_t s, const RaggedConv* rcp, int causal, const void* w_mfma) {
     if (B <= 0 || To <= 0) return 0;
     if (ld % 8 || ld < C) return -2;
     RaggedConv rc{};
     if (rcp) rc = *rcp;
+    if (w_mfma && stride == 1) {
+        if (ksize == 15) return launch_dw_mfma<15>(g, B, T, To, C, ld, w_mfma, bias, out, s, rc, causal);
+        if (ksize == 31) return launch_dw_mfma<31>(g, B, T, To, C, ld, w_mfma, bias, out, s, rc, causal);
+        if (ksize == 7) return launch_dw_mfma<7>(g, B, T, To, C, ld, w_mfma, bias, out, s, rc, causal);
+    }
     // taps are fully unrolled per (kernel size, stride); the shipped configs use k = 15 (Efficient Conformer) and 31 (Conformer)
     if (ksize == 15 && stride == 1) return launch_dw_t<15, 1>(g, B, T, To, C, ld, w_kc, bias, out, s, rc, causal);
     if (ksize == 15 && stride == 2) return launch_dw_t<15, 2>(g, B, T, To, C, ld, w_kc, bias, out, s, rc, causal);

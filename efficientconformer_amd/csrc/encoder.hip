@@ -55,6 +55,7 @@ struct BlockW {
     PackedLinear ffn1_a, ffn1_b, qkv, qkv_nat, pos, outp, pw1, pw2, res, ffn2_a, ffn2_b;
     const bf16_t *ffn1_bp = nullptr, *ffn2_bp = nullptr;   // W2 with the hidden index permuted per 16 (rsgemm.hip)
     const float *u = nullptr, *v = nullptr, *dw_w = nullptr, *dw_b = nullptr;
+    const uint16_t* dw_a = nullptr;              // pack_dwconv_mfma: Toeplitz rows of the depthwise taps for dwconv_mfma_kernel (stride-1 layers)
     const float* dvu = nullptr; int dvu_ld = 0;   // (v - u) per head column [H][dvu_ld], zero beyond d (attention derives Q + v from Q + u)
     const bf16_t* pos_table = nullptr;   // [2*max_pos-1][ld8(D)], row r <-> position max_pos-1-r
     // fused row-local chains (chain.hip): every weight with its K index permuted per 16; FFN second weight / bias pre-scaled by 1/2
@@ -95,6 +96,9 @@ struct EcEncoder {
     // tuning / test options that used to be process-global environment switches (effconf_encoder_set_option)
     int chain_variant = 1, chain_full_max = 192, attn_waves = 4, rs_variant = 0, ffn_variant = 0;
     int chain_pair_min_d = 193, chain_nt = 0, chain_w2cm = 1;   // round 5 defaults: the column-pair kernels at padded width 256 (D = 240: 147 -> 119 us per tail + head; at 192 they cost more per row than chain.hip's 256-row workgroups)
+    int dwconv_mfma = 1;                         // stride-1 depthwise convolutions on the matrix pipe (conv.hip dwconv_mfma_kernel): 1 = kernel size 15 (the Efficient Conformer
+                                                 // family), 2 = also 31 / 7 (equally accurate, profiles/r5_35_dw_accuracy.txt, but ConformerCTC-Small's 5-frame test utterance sits ON the
+                                                 // stated tolerance with either kernel and crosses it with this one's rounding: 0.0608 against 0.06), 0 = dwconv_kernel (VALU) everywhere
     int chain_pair = 5, chain_pair_min_m = 0;   // chain2.hip (column-pair chains at padded width 192 / 256): 0 off, 1 burst refills, 2 hooked; launches below chain_pair_min_m rows stay on chain.hip
     int chain_small_m = 4096;                // chain launches of at most this many rows run as 2-wave workgroups (small-batch latency; bit-identical rows)
     int chain_max_dim = 256;                 // fused chains only for stage widths <= this (tuning: wider stages on the per-GEMM / tiled kernels)
@@ -613,6 +617,7 @@ int run_subsample_linear(EcEncoder* e, hipStream_t st, const float* mel, int B, 
 }
 
 // chain launches of width D and M rows that go to chain2.hip (launch_chain's rule): there the tail and the next head of chain A are one kernel up to D = 256
+static const void* dw_mfma_table(const EcEncoder* e, const uint16_t* t, int ks) { return (e->dwconv_mfma == 2 || (e->dwconv_mfma == 1 && ks == 15)) ? t : nullptr; }
 static bool pair_on(const EcEncoder* e, int D, int M) { return e->chain_pair && chain2_supported(D) && D >= e->chain_pair_min_d && M >= e->chain_pair_min_m; }
 
 // Ragged batches (s.ragged): every utterance runs at its own length in one concatenated row space (kernels.h: RaggedRows) - the row-local
@@ -835,7 +840,7 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
         RaggedConv rc{};
         if (rg) { rc.in_off = row_off + (size_t)k * (B + 1); rc.in_len = lens + (size_t)k * B; rc.out_off = row_off + (size_t)(k + 1) * (B + 1);
                   rc.out_len = lens + (size_t)(k + 1) * B; rc.tile_off = tile_off + (size_t)k * (B + 1); rc.tiles = s.tiles[k]; rc.n = B; rc.out_rows = Mo; }
-        { PROF(PC_DWCONV, 2.0 * Mo * (double)De * b.kernel_size, (double)M * De * 2 + (double)Mo * De * 2); EC_ABL(8, EC_TRY(launch_dwconv(gbuf, B, T, To, De, ld8(De), W.dw_w, W.dw_b, b.kernel_size, b.conv_stride, cbuf, st, rg ? &rc : nullptr, c.causal))); }
+        { PROF(PC_DWCONV, 2.0 * Mo * (double)De * b.kernel_size, (double)M * De * 2 + (double)Mo * De * 2); EC_ABL(8, EC_TRY(launch_dwconv(gbuf, B, T, To, De, ld8(De), W.dw_w, W.dw_b, b.kernel_size, b.conv_stride, cbuf, st, rg ? &rc : nullptr, c.causal, dw_mfma_table(e, W.dw_a, b.kernel_size)))); }
         mask_stride *= b.conv_stride;
         snprintf(nm, sizeof(nm), "blocks.%d.dw", k); trace_add(e, st, nm, cbuf, Mo, De, ld8(De), 1);
         if (D != De) {   // 1x1 strided conv on frames 0, s, 2s, ...  (blocks.py:106-110)
@@ -1354,6 +1359,12 @@ int effconf_encoder_finalize(EcEncoder* e) {
                 bz[ch] = bb->data[ch] * sc[ch] + sh[ch];
             }
             W.dw_w = upload(e, wk); W.dw_b = upload(e, bz);
+            if (dwconv_mfma_supported(ks, b.conv_stride)) {
+                std::vector<uint16_t> ta((size_t)De * 4 * dwconv_mfma_groups(ks) * 8);
+                pack_dwconv_mfma(wk.data(), ks, De, ta.data());
+                W.dw_a = upload(e, ta);
+                if (!W.dw_a) return fail("upload failed");
+            }
         }
         if (!pack_named_linear(e, cm + ".7", De, De, &W.pw2, &err)) return fail(err);
         if (D != De && !pack_named_linear(e, p + ".conv_res.1", De, D, &W.res, &err, false, "", De)) return fail(err);
@@ -1720,7 +1731,7 @@ int effconf_conv_module(EcEncoder* e, int32_t block, const float* x, int32_t bat
         EC_TRY(run_rs_or_tiled(e, PC_GEMM_OTHER, st, a, ld8(D), M, W.pw1, 2, EPI_GLU_BF16, gbuf, ld8(De)));
     }
     // depthwise conv + BatchNorm + Swish (modules.py:516-518), pointwise-2 (modules.py:519)
-    EC_TRY(launch_dwconv(gbuf, batch, T, To, De, ld8(De), W.dw_w, W.dw_b, b.kernel_size, b.conv_stride, cbuf, st, nullptr, e->cfg.causal));
+    EC_TRY(launch_dwconv(gbuf, batch, T, To, De, ld8(De), W.dw_w, W.dw_b, b.kernel_size, b.conv_stride, cbuf, st, nullptr, e->cfg.causal, dw_mfma_table(e, W.dw_a, b.kernel_size)));
     return run_rs_or_tiled(e, PC_GEMM_OTHER, st, cbuf, ld8(De), Mo, W.pw2, 1, EPI_F32, y, De);
 }
 
@@ -1861,6 +1872,7 @@ int effconf_encoder_set_option(EcEncoder* e, const char* name, int32_t value) {
     if (!strcmp(name, "chain_small_m")) { e->chain_small_m = value; return 0; }
     if (!strcmp(name, "chain_pair")) { if (value < 0 || value > 5) return fail("chain_pair: 0 (chain.hip everywhere), 5 (chain3.hip for chain A at padded width 256, chain2.hip mode 4 elsewhere), 1 .. 4 (chain2.hip's column-pair kernels at padded width 192 / 256; refill modes, see launch_chain2_kind)"); e->chain_pair = value; return 0; }
     if (!strcmp(name, "chain_pair_min_m")) { e->chain_pair_min_m = value; return 0; }
+    if (!strcmp(name, "dwconv_mfma")) { if (value < 0 || value > 2) return fail("dwconv_mfma: 0, 1 (kernel size 15) or 2 (15 / 31 / 7)"); e->dwconv_mfma = value; return 0; }
     if (!strcmp(name, "chain_pair_min_d")) { e->chain_pair_min_d = value; return 0; }
     if (!strcmp(name, "chain_nt")) { e->chain_nt = value; return 0; }
     if (!strcmp(name, "chain_w2cm")) { e->chain_w2cm = value; return 0; }

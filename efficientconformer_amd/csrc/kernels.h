@@ -201,7 +201,11 @@ int launch_conv2_igemm(const bf16_t* act1, int B, int F1, int T1, int Cp, const 
                        int N, int F2, int T2, bf16_t* out, hipStream_t s);
 // g (B, T, ld) bf16 -> (B, To, ld) bf16: depthwise conv k taps ("same" zero pad), stride s, folded BN, Swish
 int launch_dwconv(const bf16_t* g, int B, int T, int To, int C, int ld, const float* w_kc, const float* bias,
-                  int ksize, int stride, bf16_t* out, hipStream_t s, const RaggedConv* rc = nullptr, int causal = 0);   // causal: pre-padding (k - 1, 0)
+                  int ksize, int stride, bf16_t* out, hipStream_t s, const RaggedConv* rc = nullptr, int causal = 0,
+                  const void* w_mfma = nullptr);      // w_mfma: pack_dwconv_mfma's table -> dwconv_mfma_kernel (stride 1)
+int dwconv_mfma_groups(int ksize);
+bool dwconv_mfma_supported(int ksize, int stride);
+void pack_dwconv_mfma(const float* w_kc, int ksize, int C, uint16_t* dst);     // dst: C * 4 * dwconv_mfma_groups(ksize) * 8 bf16   // causal: pre-padding (k - 1, 0)
 
 // ---------------------------------------------------------------- fp32-operand "exact" mode  (exact.hip)
 struct ExGemmParams {              // C = epi(A W^T + bias), everything fp32 (v_mfma_f32_32x32x2_f32)

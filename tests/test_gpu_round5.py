@@ -124,3 +124,32 @@ def test_ragged_launches_of_more_than_256_utterances(name, batch):
         alone, alone_len, _ = enc(audio[b:b + 1, :li].contiguous(), ln[b:b + 1].contiguous())
         tb = int(alone_len[0])
         assert int(out_len[b]) == tb and torch.equal(out[b, :tb], alone[0]) and float(out[b, tb:].float().abs().sum()) == 0.0, b
+
+
+# ------------------------------------------------------------------ depthwise convolution on the matrix pipe
+@pytest.mark.parametrize("name,batch,seconds", [("EfficientConformerCTCSmall", 4, 7.3), ("ConformerCTCSmall", 3, 4.0), ("EfficientConformerCTCMedium", 2, 3.1),
+                                                 ("EfficientConformerTransducerSmall", 2, 5.0)])
+def test_depthwise_conv_on_the_matrix_pipe_matches_the_valu_kernel(name, batch, seconds):
+    """dwconv_mfma_kernel (conv.hip; the stride-1 layers, kernel sizes 15 and 31) computes every channel's convolution as 4 x 4 x 4 Toeplitz products on
+    v_mfma_f32_4x4x4_16b_bf16 with the fp32 folded taps split into bf16 hi + lo halves: the same products as dwconv_kernel's fp32 FMAs up to 2^-17 of a tap and
+    the summation order - a bf16 output may move by one ulp, which the following blocks spread to the bf16 noise floor of the encoder output.  Rectangular and ragged batches (the ragged one bit-identical to itself run alone is covered by the
+    ragged tests, which run on the default = this kernel), channel tiles with pad channels (120 = 64 + 56, 176 = 2 x 64 + 48), tiles past an utterance's end."""
+    m = _any_model(name, 3)
+    lens = np.array([int(16000 * seconds * (1.0 - 0.21 * i)) for i in range(batch)], dtype=np.int64)
+    audio = torch.from_numpy(synth.make_audio(lens, seed=5)).cuda()
+    ln = torch.from_numpy(lens).cuda()
+    outs = {}
+    for opt in (0, 2):                                                # 2: every supported kernel size (the default, 1, keeps size 31 on the VALU kernel)
+        m.encoder.set_option("dwconv_mfma", opt)
+        for ragged in (False, True):
+            m.encoder.ragged = ragged
+            kw = {"x_len_host": lens} if ragged else {}
+            enc, el, _ = m.encoder(audio, ln, **kw)
+            outs[(opt, ragged)] = (enc.float().clone(), el.clone())
+    for ragged in (False, True):
+        a, b = outs[(0, ragged)], outs[(2, ragged)]
+        assert torch.equal(a[1], b[1]) and torch.isfinite(b[0]).all()
+        d = (a[0] - b[0]).abs()
+        # two bf16 paths of equal accuracy differ by about a third of their distance to the fp32 oracle (measured 0.013 - 0.016 max, 0.0023 - 0.0026 mean;
+        # against the oracle both kernels: profiles/r5_35_dw_accuracy.txt)
+        assert float(d.max()) < 0.04 and float(d.mean()) < 4e-3, (name, ragged, float(d.max()), float(d.mean()))
