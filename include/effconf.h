@@ -229,6 +229,11 @@ int effconf_rnnt_greedy(EcRnnt* r, const float* enc_out, const int64_t* out_len,
  *   kernel.  1 and 0 are k-ordered fp32 fma chains: bit-identical logits and labels.
  * "chain_small_m" (default 4096): chain launches (csrc/chain.hip) of at most this many rows run 2-wave workgroups (64 rows) instead of 8-wave ones:
  *   small-batch latency (B <= 8 utterances of 10 s); a wave computes its 32 rows identically in both shapes, so outputs do not depend on it.  0 = off.
+ * "dwconv_mfma" (default 1; round 5): stride-1 depthwise convolutions on the matrix pipe (csrc/conv.hip dwconv_mfma_kernel: 4 x 4 x 4 Toeplitz blocks, one per
+ *   channel, fp32 taps as bf16 hi + lo halves): 1 = kernel size 15, 2 = also 31 / 7, 0 = the VALU kernel everywhere.  Outputs agree with the VALU kernel's
+ *   up to the summation order (a bf16 output may move by one ulp).
+ * "attn_waves" = 2 (round 5): attention2.hip with two staging sets (two workgroups per CU at head width 64; the default is one set, three workgroups).
+ * "chain_pair" (default 5), "chain_pair_min_d", "chain_w2cm", "chain_nt": kernel selection of the chains at padded width 256 (csrc/chain2.hip, chain3.hip; bit-identical).
  * "chain_variant" (0 / 1), "chain_full_max" (widest stage that runs chain A as one kernel; set before finalize to widen), "attn_waves"
  *   (4 / 8, attention.hip), "rs_variant" (0 / 1), "ffn_variant" (0 .. 2), "head_major_odd" (0 / 1), "exact_attention" (0 tiled / 2 tiled with 16-row workgroups / 1 one wave per query row; fp32 mode, bit-identical): tuning / test switches of the kernel launchers that were
  *   process-global EFFCONF_* environment variables until round 2; per handle now.  (Still read from the environment, once, as
