@@ -15,7 +15,7 @@ def is_copy(n):
 
 
 def is_encoder(n):
-    return any(k in n for k in ("chain_kernel", "relpos_attention", "dwconv_kernel", "sublinear", "mel_kernel", "rs_gemm", "gemm_kernel", "ffn_fused"))
+    return any(k in n for k in ("chain_kernel", "chain2_kernel", "chain3_kernel", "relpos_attention", "dwconv_kernel", "dwconv_mfma_kernel", "sublinear", "mel_kernel", "rs_gemm", "gemm_kernel", "ffn_fused"))
 
 
 def main():
