@@ -153,3 +153,28 @@ def test_depthwise_conv_on_the_matrix_pipe_matches_the_valu_kernel(name, batch, 
         # two bf16 paths of equal accuracy differ by about a third of their distance to the fp32 oracle (measured 0.013 - 0.016 max, 0.0023 - 0.0026 mean;
         # against the oracle both kernels: profiles/r5_35_dw_accuracy.txt)
         assert float(d.max()) < 0.04 and float(d.mean()) < 4e-3, (name, ragged, float(d.max()), float(d.mean()))
+
+
+# ------------------------------------------------------------------ host lengths that disagree with the device lengths
+def test_ragged_forward_refuses_host_lengths_that_differ_from_the_device_lengths():
+    """`check_host_lengths` is True by default since round 5: grids and the workspace of a ragged forward are sized from `x_len_host`, the kernels index with the
+    device `x_len` - a caller whose copies disagree gets a ValueError instead of an out-of-bounds access.  The comparison is remembered per (device tensor,
+    version, host values): an in-place change of the device lengths is seen, and opting out (False) restores round 4's behaviour for callers that vouch for them."""
+    m = _any_model("Tiny", 2)
+    enc = m.encoder
+    lens = np.array([30000, 24000, 17000, 9000], dtype=np.int64)
+    audio = torch.from_numpy(synth.make_audio(lens, seed=3)).cuda()
+    ln = torch.from_numpy(lens).cuda()
+    enc.ragged, enc.sub_batches = True, 1
+    assert enc.check_host_lengths is True
+    out, out_len, _ = enc(audio, ln, x_len_host=lens)
+    wrong = lens.copy(); wrong[2] -= 160
+    with pytest.raises(ValueError):
+        enc(audio, ln, x_len_host=wrong)
+    out2, _, _ = enc(audio, ln, x_len_host=lens)                      # the memo holds the verified pair, a wrong one in between did not replace it
+    assert torch.equal(out, out2)
+    ln[2] -= 160                                                      # in-place change of the device tensor: its version moves, the pair is compared again
+    with pytest.raises(ValueError):
+        enc(audio, ln, x_len_host=lens)
+    out3, out_len3, _ = enc(audio, ln, x_len_host=wrong)              # now `wrong` is right
+    assert int(out_len3[2]) <= int(out_len[2]) and torch.isfinite(out3.float()).all()
