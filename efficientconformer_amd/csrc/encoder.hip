@@ -1785,6 +1785,14 @@ int effconf_debug_sx_gemm(const float* a, int32_t lda, const uint16_t* w_hi, con
     return rc ? fail("sx_gemm launch failed rc=" + std::to_string(rc)) : 0;
 }
 
+int effconf_debug_pack_dwconv_mfma(const float* w_kc, int32_t ksize, int32_t channels, uint16_t* dst, size_t dst_elems) {
+    if (!w_kc || !dst || channels <= 0) return fail("null argument");
+    if (!dwconv_mfma_supported(ksize, 1)) return fail("kernel size: 15, 31 or 7");
+    if (dst_elems != (size_t)channels * 4 * dwconv_mfma_groups(ksize) * 8) return fail("dst: channels * 4 * groups * 8 bf16");
+    pack_dwconv_mfma(w_kc, ksize, channels, dst);          // host memory in, host memory out
+    return 0;
+}
+
 int effconf_debug_spin(double microseconds, void* stream) {
     if (launch_debug_spin(microseconds, reinterpret_cast<hipStream_t>(stream)) != 0) return fail("spin launch failed");
     return 0;

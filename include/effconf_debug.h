@@ -34,6 +34,9 @@ int effconf_debug_victim(int32_t kind, int32_t blocks, int32_t iters, float* out
  * (ldh = round_up(k, 32), zero padded: element (row, col) at ((col / 32) * n + row) * 32 + col % 32), products accurate to ~2^-21.  epi: 0 plain, 1 Swish, 2 c = r + alpha * (...).  All pointers are device pointers. */
 int effconf_debug_sx_gemm(const float* a, int32_t lda, const uint16_t* w_hi, const uint16_t* w_lo, int32_t ldh, const float* bias, int32_t m, int32_t n,
                           int32_t k, int32_t epi, float* c, int32_t ldc, const float* r, int32_t ldr, float alpha, void* stream);
+/* HOST function (no GPU): the A-operand table of dwconv_mfma_kernel (csrc/conv.hip) for folded depthwise taps w_kc [ksize][channels] (fp32):
+ * dst [channels][4 rows i][groups q = (ksize + 6) / 4][bf16 hi (4 taps) | bf16 lo (4 taps)] of w[4 q + k - i] (zero outside the taps); tests/test_abi_and_host.py. */
+int effconf_debug_pack_dwconv_mfma(const float* w_kc, int32_t ksize, int32_t channels, uint16_t* dst, size_t dst_elems);
 /* One idle wave that occupies `stream` for `microseconds` (tools/overlap_probe.py: the duration of an xGMI transfer a single GPU cannot make). */
 int effconf_debug_spin(double microseconds, void* stream);
 /* diagnostics (tools/lds_fill_rate_probe.py): `blocks` workgroups of `waves` waves each walk the same `window` bytes of `src` (dev) into LDS, `kib_per_wave`

@@ -31,13 +31,46 @@ def test_library_exports_every_declared_symbol():
     # build): the product library exports none of them, the diagnostic one exports them and the whole product ABI
     dhdr = open(os.path.join(ROOT, "include", "effconf_debug.h")).read()
     ddecl = sorted(set(re.findall(r"\b(effconf_debug_[a-z_0-9]+)\s*\(", dhdr)))
-    assert len(ddecl) == 7 and sorted(_lib.DEBUG_SIGNATURES) == ddecl
+    assert len(ddecl) == 8 and sorted(_lib.DEBUG_SIGNATURES) == ddecl
     assert not [n for n in declared if n.startswith("effconf_debug")]
     exported = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
     assert "effconf_debug" not in exported and "debug_neighbour" not in exported
     dlib = ctypes.CDLL(os.path.join(os.path.dirname(_lib.LIB_PATH), "libeffconf_debug.so"))
     for name in declared + ddecl:
         assert hasattr(dlib, name), "libeffconf_debug.so does not export %s" % name
+
+
+@pytest.mark.parametrize("ksize,channels", [(15, 120), (31, 176), (7, 10)])
+def test_depthwise_toeplitz_table_of_the_matrix_pipe_kernel(ksize, channels):
+    """pack_dwconv_mfma (csrc/conv.hip, host code; through the diagnostic library's effconf_debug_pack_dwconv_mfma): lane 4 b + i of dwconv_mfma_kernel holds, per
+    group q of 4 taps, row i of the Toeplitz block A_q[i][k] = w[4 q + k - i] as bf16 hi | lo halves.  Checked against numpy: hi + lo reproduce every folded fp32
+    tap to 2^-16 of its magnitude, entries outside the taps are zero, and - the property the kernel relies on - the blocks rebuild the convolution:
+    out[4 j + i] = sum_q sum_k A_q[i][k] x[4 (j + q) + k] equals sum_m w[m] x[4 j + i + m] for random x."""
+    import ctypes
+    dlib = _lib.load_debug()
+    rng = np.random.default_rng(ksize)
+    w = (rng.standard_normal((ksize, channels)) * np.exp(rng.uniform(-6, 2, size=(1, channels)))).astype(np.float32)
+    nq = (ksize + 6) // 4
+    dst = np.zeros((channels, 4, nq, 2, 4), dtype=np.uint16)
+    _lib.check(dlib.effconf_debug_pack_dwconv_mfma(w.ctypes.data_as(ctypes.c_void_p), ksize, channels, dst.ctypes.data_as(ctypes.c_void_p), dst.size), "pack", dlib)
+    assert dlib.effconf_debug_pack_dwconv_mfma(w.ctypes.data_as(ctypes.c_void_p), 9, channels, dst.ctypes.data_as(ctypes.c_void_p), dst.size) != 0      # unsupported size
+    val = (dst.astype(np.uint32) << 16).view(np.float32)                     # [ch][i][q][hi / lo][k]
+    a = val[:, :, :, 0, :].astype(np.float64) + val[:, :, :, 1, :].astype(np.float64)
+    for i in range(4):
+        for q in range(nq):
+            for k in range(4):
+                tap = 4 * q + k - i
+                if 0 <= tap < ksize:
+                    assert np.all(np.abs(a[:, i, q, k] - w[tap]) <= np.abs(w[tap]) * 2.0 ** -16 + 1e-38), (i, q, k)
+                else:
+                    assert not dst[:, i, q, :, k].any()
+    x = rng.standard_normal(4 * (3 + nq)).astype(np.float64)
+    for ch in (0, channels // 2, channels - 1):
+        for j in range(3):
+            for i in range(4):
+                blocks = sum(a[ch, i, q, k] * x[4 * (j + q) + k] for q in range(nq) for k in range(4))
+                direct = sum(float(w[m, ch]) * x[4 * j + i + m] for m in range(ksize))
+                assert abs(blocks - direct) <= 1e-4 * max(1.0, abs(direct)) * max(1.0, float(np.abs(w[:, ch]).max()))
 
 
 def test_create_rejects_bad_config_and_reports_error():
