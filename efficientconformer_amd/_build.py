@@ -27,7 +27,8 @@ NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 # instructions they demonstrate, so those two are compiled WITHOUT the flag below.  Nothing of this is linked into libeffconf.so.
 DEBUG_REPLACES = {"encoder.hip": "encoder_dbg.o", "mel.hip": "mel_dbg.o"}
 DEBUG_OBJECTS = [("debug.hip", "debug.o", []), ("mel.hip", "mel_pk.o", ["-DMEL_PK_BUILD"])]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result",
+# -fvisibility=hidden: only what include/effconf.h / effconf_debug.h declare (under `#pragma GCC visibility push(default)`) is a dynamic symbol
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-unused-result",
          "-Wno-inline-asm"]   # rowstat.h clobbers m0 on purpose (LDS-DMA destination register)
 
 
@@ -41,8 +42,8 @@ def _hipcc() -> str:
 def _stale() -> bool:
     if not os.path.exists(LIB) or not os.path.exists(LIB_DEBUG):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "effconf.h")]
+    t = min(os.path.getmtime(LIB), os.path.getmtime(LIB_DEBUG))       # a failed link of the diagnostic library must not leave a stale one behind
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", h) for h in ("effconf.h", "effconf_debug.h")]
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
@@ -54,6 +55,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(objdir, exist_ok=True)
 
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "effconf.h"),
+                                                                                       os.path.join(HERE, "..", "include", "effconf_debug.h"),
                                                                                        os.path.abspath(__file__)]
     hdr_t = max(os.path.getmtime(h) for h in headers if os.path.exists(h))
 
@@ -78,7 +80,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     # link to a temporary name, run the ISA guard on it, and only then move it into place: a library that fails the guard never
     # becomes importable (before: the first build raised AFTER writing libeffconf.so and the next import passed silently)
     tmp = LIB + ".tmp"
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs
+    vscript = ["-Wl,--version-script=" + os.path.join(CSRC, "exports.map")]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + vscript + ["-o", tmp] + objs
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n%s" % r.stderr[-4000:])
@@ -88,7 +91,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         os.remove(tmp)
         raise
     os.replace(tmp, LIB)
-    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_DEBUG] + debug_link, capture_output=True, text=True)
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + vscript + ["-o", LIB_DEBUG] + debug_link, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link of the diagnostic library failed:\n%s" % r.stderr[-4000:])
     if verbose:

@@ -10,7 +10,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libeffconf.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class EcBlock(C.Structure):

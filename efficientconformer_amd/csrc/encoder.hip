@@ -9,9 +9,6 @@
 #ifdef EFFCONF_DEBUG_ABI
 #include "../../include/effconf_debug.h"
 #endif
-#ifdef EFFCONF_DEBUG_ABI
-#include "../../include/effconf_debug.h"
-#endif
 
 #include <cmath>
 #include <cstdio>

@@ -133,12 +133,11 @@ class ShardedEncoder:
     `torch.bfloat16` halves the xGMI bytes."""
 
     def close(self):
-        """Hand the wrapped encoder back as it was found (its ragged cut policy); pipelined: run the consumers of the last call first."""
+        """Pipelined: run the consumers of the last call.  (The wrapped encoder is never left modified: its ragged cut policy is switched to the
+        rank-independent "rows" cut only for the duration of one `encode_shard` call - round 5 set it in the constructor and restored it from
+        `__del__`, so a dropped wrapper could reset the policy under a live one: mismatched collectives.)"""
         if self._pending:
             self.flush()
-        if self._saved_cut is not None and hasattr(self.encoder, "ragged_cut"):
-            self.encoder.ragged_cut = self._saved_cut
-        self._saved_cut = None
 
     def __del__(self):
         try:
@@ -146,8 +145,6 @@ class ShardedEncoder:
                 import warnings
                 warnings.warn("efficientconformer_amd.dist.ShardedEncoder dropped with %d gathered chunk(s) whose consumer never ran: call flush() "
                               "(or close()) after the last pipelined forward" % len(self._pending))
-            if getattr(self, "_saved_cut", None) is not None and hasattr(self.encoder, "ragged_cut"):
-                self.encoder.ragged_cut = self._saved_cut
         except Exception:
             pass
 
@@ -161,9 +158,8 @@ class ShardedEncoder:
         # ranges for equal valid frames of the lengths it is handed - different on every rank (mismatched collectives: a hang or a
         # corrupted gather).  Under this class it cuts by row count instead (rank-independent: every shard has the same number of rows),
         # unless the caller pins explicit `sub_batch_bounds` (bench.py: frame-balanced / staggered cuts computed from lengths all ranks know).
-        self._saved_cut = getattr(encoder, "ragged_cut", None)     # restored by close(): the encoder cuts for equal frames again when used on its own
-        if hasattr(encoder, "ragged_cut"):
-            encoder.ragged_cut = "rows"
+        # The policy is asserted PER CALL (encode_shard sets "rows" around the encoder call and restores what it found), never left on the shared encoder:
+        # any number of wrappers of one encoder may come and go in any order.
         import os
         import warnings
         try:
@@ -265,14 +261,22 @@ class ShardedEncoder:
         gb = global_batch if global_batch is not None else xs.shape[0] * world
         chunks: List[GatheredChunk] = []
         self._call += 1
-        if self._hooked:
-            kw = {"range_pad": range_pad} if range_pad is not None else {}
-            if x_len_host is not None:
-                kw["x_len_host"] = x_len_host
-            self.encoder(xs, ls, range_hook=lambda lo, hi, out, out_len: self._gather_range(lo, hi, out, out_len, gb, chunks, consumer), **kw)
-        else:
-            out, out_len = self.encoder(xs, ls)[:2]
-            self._gather_range(0, out.shape[0], out, out_len, gb, chunks, consumer)
+        has_cut = hasattr(self.encoder, "ragged_cut")
+        saved_cut = self.encoder.ragged_cut if has_cut else None
+        try:
+            if has_cut:
+                self.encoder.ragged_cut = "rows"          # rank-independent ranges for THIS call (explicit sub_batch_bounds still win)
+            if self._hooked:
+                kw = {"range_pad": range_pad} if range_pad is not None else {}
+                if x_len_host is not None:
+                    kw["x_len_host"] = x_len_host
+                self.encoder(xs, ls, range_hook=lambda lo, hi, out, out_len: self._gather_range(lo, hi, out, out_len, gb, chunks, consumer), **kw)
+            else:
+                out, out_len = self.encoder(xs, ls)[:2]
+                self._gather_range(0, out.shape[0], out, out_len, gb, chunks, consumer)
+        finally:
+            if has_cut:
+                self.encoder.ragged_cut = saved_cut
         if self.pipelined and any(c < self._call for c, _, _, _ in self._pending):
             # row ranges of an EARLIER call that this call did not revisit (the cuts changed): consume them now, on the caller's stream
             stale = [p for p in self._pending if p[0] < self._call]

@@ -25,8 +25,16 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is compiled with -fvisibility=hidden: the declarations of this header (and of effconf_debug.h) are its ONLY dynamic symbols
+ * (tests/test_abi_and_host.py checks `nm -D`); the internal launch_* / pack_* C++ functions of csrc/kernels.h are not linkable. */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
-#define EFFCONF_ABI_VERSION 2      /* 2: EcConfig gained causal / left_context / right_context */
+/* 2: EcConfig gained causal / left_context / right_context
+ * 3: the effconf_debug_* entries left libeffconf.so for libeffconf_debug.so (round 5), hidden visibility for everything this header does not
+ *    declare, the label-exact "split" mode takes ragged batches and causal / streaming configurations (round 6) */
+#define EFFCONF_ABI_VERSION 3
 
 /* Per-block hyper-parameters, already resolved from the per-stage lists exactly as
  * ConformerEncoder.__init__ does (reference encoders.py:80-95). */
@@ -290,6 +298,9 @@ int effconf_encoder_set_attention_outputs(EcEncoder* enc, float* const* maps, in
 int effconf_host_pack_rows(const float* const* src, const int64_t* len, int32_t n, float* dst, int64_t pitch, int32_t zero_pad,
                            int32_t threads);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -10,6 +10,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 /* effconf_mel_frontend with a diagnostic variant of mel_kernel (csrc/mel.hip: 1 canaries, 2 self-verifying hand-offs,
  * 4 workgroup barriers, 8 the build WITH packed-fp32 VALU instructions = round 1's hazardous kernel; bits combine), `extra_lds` bytes of unused dynamic LDS per workgroup, and 8 u32 counters (dev). */
@@ -45,6 +48,9 @@ int effconf_debug_spin(double microseconds, void* stream);
 int effconf_debug_lds_fill(int32_t mode, int32_t blocks, int32_t waves, const void* src, size_t window, int32_t kib_per_wave, int32_t passes, uint64_t* out, void* stream);
 
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -71,7 +71,7 @@ def main():
             for bounds in (None, [1], [3]):
                 enc.sub_batches, enc.sub_batch_bounds = 2, bounds
                 shr = ShardedEncoder(enc, wire_dtype=wire)
-                ok = ok and enc.ragged_cut == "rows"
+                ok = ok and enc.ragged_cut == "frames"     # the shared encoder keeps ITS policy; "rows" is asserted per encode_shard call (and dropping the previous wrapper cannot reset it)
                 seen, outs = {}, {}
 
                 def consumer(ch):                          # runs with the range's stream current, right behind the collective

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), "libeffconf.so does not export %s" % name
     assert sorted(_lib.SIGNATURES) == declared, "ctypes binding out of sync with include/effconf.h"
-    assert _lib.load().effconf_abi_version() == _lib.ABI_VERSION == 2
+    assert _lib.load().effconf_abi_version() == _lib.ABI_VERSION == 3
     # the diagnostics live in a SEPARATE library (include/effconf_debug.h, libeffconf_debug.so = the product objects + csrc/debug.hip + the packed-fp32 mel
     # build): the product library exports none of them, the diagnostic one exports them and the whole product ABI
     dhdr = open(os.path.join(ROOT, "include", "effconf_debug.h")).read()
@@ -35,6 +35,13 @@ def test_library_exports_every_declared_symbol():
     assert not [n for n in declared if n.startswith("effconf_debug")]
     exported = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
     assert "effconf_debug" not in exported and "debug_neighbour" not in exported
+    # -fvisibility=hidden + the headers' visibility pragma: the dynamic symbol table holds the declared C entries and nothing else
+    # (before round 6: 58 mangled internals - launch_chain, ec_fail, std::map instantiations - were linkable beside them)
+    syms = [ln.split()[-1] for ln in exported.splitlines() if ln.strip() and ln.split()[-2] in "TtWwVvBbDdRr"]
+    assert syms and sorted(set(syms)) == declared, [n for n in syms if n not in declared][:10]
+    dexp = subprocess.run(["nm", "-D", "--defined-only", os.path.join(os.path.dirname(_lib.LIB_PATH), "libeffconf_debug.so")], capture_output=True, text=True).stdout
+    dsyms = sorted(set(ln.split()[-1] for ln in dexp.splitlines() if ln.strip()))
+    assert dsyms == sorted(declared + ddecl), [n for n in dsyms if n not in declared + ddecl][:10]
     dlib = ctypes.CDLL(os.path.join(os.path.dirname(_lib.LIB_PATH), "libeffconf_debug.so"))
     for name in declared + ddecl:
         assert hasattr(dlib, name), "libeffconf_debug.so does not export %s" % name

@@ -73,6 +73,27 @@ def _worker(rank, world, port, q):
         ok = ok and torch.equal(c.out[c.keep], ref[c.rows[c.keep]])
     o4, l4 = ShardedEncoder(Ranged(), pipelined=True)(mel, lens)     # whole-batch call: flushes itself
     ok = ok and torch.equal(o4, full) and torch.equal(l4, full_len)
+    # the wrapped encoder's ragged cut policy: "rows" DURING every encode_shard call - whatever wrappers of the same encoder were
+    # created or dropped before - and the encoder's own policy at all other times
+    import gc
+    class Spying(Ranged):
+        ragged_cut, seen_cut = "frames", []
+
+        def forward(self, m, l, range_hook=None):
+            self.seen_cut.append(self.ragged_cut)
+            return Ranged.forward(self, m, l, range_hook)
+        __call__ = forward
+    shared = Spying()
+    first = ShardedEncoder(shared)
+    second = ShardedEncoder(shared, pipelined=True)
+    del first
+    gc.collect()                                                # round 5: the dropped wrapper's __del__ wrote "frames" back under the live one
+    ok = ok and shared.ragged_cut == "frames"
+    second.encode_shard(xs, ls, mel.shape[0])
+    second.close()
+    third = ShardedEncoder(shared)
+    third.encode_shard(xs, ls, mel.shape[0])
+    ok = ok and shared.seen_cut == ["rows", "rows"] and shared.ragged_cut == "frames"
     q.put((rank, bool(ok), float((out - full).abs().max())))
     dist.barrier()
     dist.destroy_process_group()

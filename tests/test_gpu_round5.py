@@ -178,3 +178,20 @@ def test_ragged_forward_refuses_host_lengths_that_differ_from_the_device_lengths
         enc(audio, ln, x_len_host=lens)
     out3, out_len3, _ = enc(audio, ln, x_len_host=wrong)              # now `wrong` is right
     assert int(out_len3[2]) <= int(out_len[2]) and torch.isfinite(out3.float()).all()
+    # a converted temporary (int32 x_len -> a fresh int64 tensor per call) or a freed-and-reallocated length tensor comes back from the
+    # caching allocator at the SAME address with version 0 - the memo may not treat that as "the tensor I verified".  Same address, different lengths, stale
+    # host copy: must raise on every call, in both forms.
+    l32 = torch.from_numpy(wrong.astype(np.int32)).cuda()
+    enc(audio, l32, x_len_host=wrong)                                 # verified through a temporary: nothing may be remembered for it
+    l32b = torch.from_numpy(lens.astype(np.int32)).cuda()
+    with pytest.raises(ValueError):
+        enc(audio, l32b, x_len_host=wrong)
+    fresh = torch.from_numpy(wrong).cuda()
+    enc(audio, fresh, x_len_host=wrong)
+    ptr = fresh.data_ptr()
+    del fresh
+    again = torch.from_numpy(lens).cuda()                             # typically the allocator hands the block back: same data_ptr, version 0
+    if again.data_ptr() != ptr:
+        pytest.skip("the allocator did not recycle the block; the int32 case above covers the conversion path")
+    with pytest.raises(ValueError):
+        enc(audio, again, x_len_host=wrong)
