@@ -1790,6 +1790,27 @@ int effconf_debug_pack_dwconv_mfma(const float* w_kc, int32_t ksize, int32_t cha
     return 0;
 }
 
+int effconf_debug_dwconv(const uint16_t* g, int32_t batch, int32_t frames, int32_t channels, int32_t ld, const float* w_kc_host, const float* bias_host,
+                         int32_t ksize, int32_t stride, int32_t use_mfma, int32_t causal, uint16_t* out, void* stream) {
+    if (!g || !w_kc_host || !bias_host || !out || batch <= 0 || frames <= 0 || channels <= 0 || ld < channels || ld % 8) return fail("bad argument");
+    if (use_mfma && !dwconv_mfma_supported(ksize, stride)) return fail("dwconv_mfma_kernel: stride 1, kernel size 15, 31 or 7");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    float *dw = nullptr, *db = nullptr; uint16_t* dt = nullptr;
+    std::vector<uint16_t> tab;
+    if (use_mfma) { tab.resize((size_t)channels * 4 * dwconv_mfma_groups(ksize) * 8); pack_dwconv_mfma(w_kc_host, ksize, channels, tab.data()); }
+    // test-only entry: temporary device copies of the taps, synchronous
+    if (hipMalloc(&dw, (size_t)ksize * channels * 4) != hipSuccess || hipMalloc(&db, (size_t)channels * 4) != hipSuccess ||
+        (use_mfma && hipMalloc(&dt, tab.size() * 2) != hipSuccess)) return fail("hipMalloc failed");
+    (void)hipMemcpy(dw, w_kc_host, (size_t)ksize * channels * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(db, bias_host, (size_t)channels * 4, hipMemcpyHostToDevice);
+    if (use_mfma) (void)hipMemcpy(dt, tab.data(), tab.size() * 2, hipMemcpyHostToDevice);
+    const int to = (frames - 1) / stride + 1;
+    const int rc = launch_dwconv(g, batch, frames, to, channels, ld, dw, db, ksize, stride, out, st, nullptr, causal, use_mfma ? dt : nullptr);
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(dw); (void)hipFree(db); if (dt) (void)hipFree(dt);
+    return rc ? fail("launch_dwconv failed rc=" + std::to_string(rc)) : 0;
+}
+
 int effconf_debug_spin(double microseconds, void* stream) {
     if (launch_debug_spin(microseconds, reinterpret_cast<hipStream_t>(stream)) != 0) return fail("spin launch failed");
     return 0;

@@ -40,6 +40,12 @@ int effconf_debug_sx_gemm(const float* a, int32_t lda, const uint16_t* w_hi, con
 /* HOST function (no GPU): the A-operand table of dwconv_mfma_kernel (csrc/conv.hip) for folded depthwise taps w_kc [ksize][channels] (fp32):
  * dst [channels][4 rows i][groups q = (ksize + 6) / 4][bf16 hi (4 taps) | bf16 lo (4 taps)] of w[4 q + k - i] (zero outside the taps); tests/test_abi_and_host.py. */
 int effconf_debug_pack_dwconv_mfma(const float* w_kc, int32_t ksize, int32_t channels, uint16_t* dst, size_t dst_elems);
+/* The depthwise-convolution stage of the ConvolutionModule alone (reference modules.py:516-518 with BatchNorm folded into the taps; csrc/conv.hip): g dev bf16
+ * [batch * frames][ld] (GLU output) -> out dev bf16 [batch * ((frames - 1) / stride + 1)][ld] = Swish(sum_j w[j][c] gpad[s t + j][c] + bias[c]); w_kc_host
+ * [ksize][channels] / bias_host [channels]: HOST fp32 (the entry uploads them, builds the Toeplitz table for use_mfma = 1 and synchronises: tests only).
+ * use_mfma: 1 = dwconv_mfma_kernel (stride 1, kernel size 15 / 31 / 7), 0 = dwconv_kernel (VALU).  causal: pre-padding (k - 1, 0) instead of "same". */
+int effconf_debug_dwconv(const uint16_t* g, int32_t batch, int32_t frames, int32_t channels, int32_t ld, const float* w_kc_host, const float* bias_host,
+                         int32_t ksize, int32_t stride, int32_t use_mfma, int32_t causal, uint16_t* out, void* stream);
 /* One idle wave that occupies `stream` for `microseconds` (tools/overlap_probe.py: the duration of an xGMI transfer a single GPU cannot make). */
 int effconf_debug_spin(double microseconds, void* stream);
 /* diagnostics (tools/lds_fill_rate_probe.py): `blocks` workgroups of `waves` waves each walk the same `window` bytes of `src` (dev) into LDS, `kib_per_wave`

@@ -190,8 +190,7 @@ def test_ragged_forward_refuses_host_lengths_that_differ_from_the_device_lengths
     enc(audio, fresh, x_len_host=wrong)
     ptr = fresh.data_ptr()
     del fresh
-    again = torch.from_numpy(lens).cuda()                             # typically the allocator hands the block back: same data_ptr, version 0
-    if again.data_ptr() != ptr:
-        pytest.skip("the allocator did not recycle the block; the int32 case above covers the conversion path")
+    again = torch.from_numpy(lens).cuda()                             # the memo holds a reference to `fresh`, so its block cannot be recycled: a new address
+    assert again.data_ptr() != ptr
     with pytest.raises(ValueError):
         enc(audio, again, x_len_host=wrong)

@@ -1,0 +1,173 @@
+"""-m gpu tests added in round 6: the round-5 kernels against the ORACLE per stage at production widths,
+the matrix-pipe depthwise convolution alone against the oracle's depthwise stage, short utterances of the plain Conformer configurations."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from efficientconformer_amd import ModelCTC, _lib, named_config, synth
+from oracle import ref_encoder as R
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(name, seed):
+    cfg = named_config(name)
+    m = ModelCTC.from_config(cfg)
+    sd = synth.make_state_dict(m.encoder.plan, seed, cfg["tokenizer_params"]["vocab_size"], prefix="encoder.")
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    osd = {k[len("encoder."):] if k.startswith("encoder.") else k: v for k, v in sd.items()}
+    return m.cuda(), osd
+
+
+def _rel(got, ref):
+    d = (got.double() - ref.double()).abs()
+    scale = max(float(ref.abs().max()), 1.0)
+    return float(d.max()) / scale, float(d.mean()) / scale
+
+
+# ------------------------------------------------------------------ per-stage oracle traces at production widths
+# Small: D = 120 / 168 / 240 -> chain_kernel<8,4,2>, chain_kernel<12,8,3>, chain3_kernel<16> (chain A), chain2_kernel<16> (chain B), dwconv_mfma_kernel<15> at
+# 120 / 168 / 240 channels, relpos_attention2_kernel<96> (stage 0, d = 90) / <64> (d = 42, 60).  Medium: D = 180 / 256 / 360 -> <12,8,3>, chain3 / chain2 at the
+# full width 256, the per-GEMM row-stationary kernels at 360, attention head widths 135 / 64 / 90.  Until round 5 these kernels saw the oracle only through the
+# LayerNorm-ed encoder output of 15 blocks (0.06 max) or through each other (bit-identity with the older kernel).
+@pytest.mark.parametrize("ragged", [False, True])
+@pytest.mark.parametrize("name,tm,lens", [("EfficientConformerCTCSmall", 700, [700, 561, 330]), ("EfficientConformerCTCMedium", 520, [520, 401, 263])])
+def test_every_traced_stage_of_the_production_widths_vs_oracle(name, tm, lens, ragged):
+    """The residual stream after FFN1 (= the output of chain A: pointwise-2 + residual + FFN2 + block LayerNorm + the next block's FFN1) and after the attention
+    module (= chain B's out-projection + residual on top of the attention kernel's output) of EVERY block, the subsampling + Linear output and the encoder
+    output against the oracle's trace, with the Tiny test's relative bounds (tests/test_gpu_encoder.py: 0.02 max / 0.003 mean of the tensor's magnitude).
+    Rectangular batches: the oracle on the collated batch (pad frames live).  Ragged batches: the oracle on every utterance ALONE, rows mapped through the
+    group-padded row space (an utterance's rows start at the sum of the previous utterances' frames rounded up to the block's attention group size).
+    A mis-indexed pad column, a wrong chunk order or a head-span slip in one block shows up at that block, not 15 LayerNorms later."""
+    m, sd = _model(name, 7)
+    plan = m.encoder.plan
+    mel, ln = synth.make_mel(len(lens), 80, tm, lens, seed=4321 + tm)
+    m.encoder.ragged = ragged
+    out, out_len, got = m.encoder.trace_forward_mel(torch.from_numpy(mel).cuda(), torch.from_numpy(ln).cuda())
+    assert "blocks.0.x_conv" not in got, "the fused chains are expected on this path (x_conv only exists in registers)"
+    worst = {}
+    if not ragged:
+        trace = {}
+        with torch.no_grad():
+            ref, ref_len = R.encoder_from_mel(torch.from_numpy(mel), torch.from_numpy(ln), sd, plan, trace)
+        assert out_len.cpu().tolist() == ref_len.tolist()
+        worst["linear"] = _rel(got["linear"], trace["linear"].reshape(-1, trace["linear"].shape[-1]))
+        for k in range(len(plan.blocks)):
+            for tag in ("x_ffn1", "x_mhsa"):
+                r = trace["blocks.%d.%s" % (k, tag)]
+                worst["blocks.%d.%s" % (k, tag)] = _rel(got["blocks.%d.%s" % (k, tag)], r.reshape(-1, r.shape[-1]))
+        worst["out"] = _rel(out.cpu(), ref)
+    else:
+        offs = {k: 0 for k in range(len(plan.blocks))}
+        for b, l in enumerate(lens):
+            trace = {}
+            with torch.no_grad():
+                ref, ref_len = R.encoder_from_mel(torch.from_numpy(mel[b:b + 1, :, :l]), torch.tensor([l]), sd, plan, trace)
+            tb = int(ref_len[0])
+            assert int(out_len[b]) == tb
+            worst["out.%d" % b] = _rel(out[b, :tb].cpu(), ref[0])
+            assert float(out[b, tb:].abs().sum()) == 0.0
+            for k, bp in enumerate(plan.blocks):
+                for tag in ("x_ffn1", "x_mhsa"):
+                    r = trace["blocks.%d.%s" % (k, tag)][0]
+                    g = got["blocks.%d.%s" % (k, tag)][offs[k]: offs[k] + r.shape[0]]
+                    key = "blocks.%d.%s" % (k, tag)
+                    w = _rel(g, r)
+                    worst[key] = max(worst.get(key, (0.0, 0.0)), w)
+                if k == 0:
+                    r = trace["linear"][0]
+                    worst["linear"] = max(worst.get("linear", (0.0, 0.0)), _rel(got["linear"][offs[0]: offs[0] + r.shape[0]], r))
+                t_in = trace["blocks.%d.x_ffn1" % k].shape[1]
+                offs[k] += (t_in + bp.group_size - 1) // bp.group_size * bp.group_size
+    top = sorted(worst.items(), key=lambda kv: -kv[1][0])[:4]
+    print("%s ragged=%s worst stages (max, mean relative): %s" % (name, ragged, [(k, "%.4f" % a, "%.5f" % b) for k, (a, b) in top]))
+    for k, (mx, mean) in worst.items():
+        assert mx < 0.02 and mean < 0.003, (k, mx, mean, top)
+
+
+# ------------------------------------------------------------------ the matrix-pipe depthwise convolution alone against the oracle's depthwise stage
+def _bf16_round(x: np.ndarray) -> np.ndarray:
+    return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(torch.bfloat16).float().numpy()
+
+
+@pytest.mark.parametrize("ksize,channels,frames", [(15, 120, 257), (15, 168, 131), (15, 240, 66), (15, 256, 300), (31, 176, 140), (31, 512, 70), (7, 40, 50)])
+@pytest.mark.parametrize("causal", [0, 1])
+def test_depthwise_conv_kernels_alone_vs_the_oracle_depthwise_stage(ksize, channels, frames, causal):
+    """dwconv_mfma_kernel (stride 1) and dwconv_kernel on the SAME bf16-exact inputs against the oracle's depthwise stage (oracle/ref_encoder.py conv_module:
+    zero pre-padding, F.conv1d with groups = channels, BatchNorm(eval), Swish; reference modules.py:516-518, layers.py:97-101) evaluated in float64.
+    The kernels fold the BatchNorm into the taps in fp32 and store bf16: the result must be the float64 value rounded to bf16, give or take one bf16 ulp where
+    the fp32 sum (the matrix-pipe kernel: taps as bf16 hi + lo halves, 2^-17 of a tap) lands on the other side of a rounding boundary - i.e. the error against the
+    UN-rounded float64 value stays below one bf16 ulp (2^-8 relative) plus 2e-5 absolute - the tap split's 2^-17 times the sum of |tap x| (~3), which is what is
+    left of the relative accuracy where the 15 / 31 products cancel to a pre-activation near zero - and at least 95 % of the outputs are the correctly rounded value.  Round 5 tested the
+    matrix-pipe kernel against the VALU kernel only (0.04 on the encoder output); a wrong tap, a shifted frame or a mis-padded channel tile fails this at once."""
+    dlib = _lib.load_debug()
+    rng = np.random.default_rng(100 * ksize + channels + causal)
+    batch, ld = 3, (channels + 7) // 8 * 8
+    g = np.zeros((batch, frames, ld), dtype=np.float32)
+    g[:, :, :channels] = _bf16_round(rng.standard_normal((batch, frames, channels)) * 1.5)
+    w = (rng.standard_normal((channels, 1, ksize)) / np.sqrt(ksize)).astype(np.float32)           # Conv1d(De, De, k, groups = De).weight
+    cb = (0.02 * rng.standard_normal(channels)).astype(np.float32)
+    gamma = (1.0 + 0.1 * rng.standard_normal(channels)).astype(np.float32)
+    beta = (0.1 * rng.standard_normal(channels)).astype(np.float32)
+    mean = (0.2 * rng.standard_normal(channels)).astype(np.float32)
+    var = rng.uniform(0.5, 1.5, channels).astype(np.float32)
+    # oracle arithmetic in float64 on the same numbers
+    h = torch.from_numpy(g[:, :, :channels]).double().transpose(1, 2)
+    half = (ksize - 1) // 2
+    h = F.pad(h, (ksize - 1, 0) if causal else (half, half))
+    h = F.conv1d(h, torch.from_numpy(w).double(), torch.from_numpy(cb).double(), groups=channels)
+    h = F.batch_norm(h, torch.from_numpy(mean).double(), torch.from_numpy(var).double(), torch.from_numpy(gamma).double(), torch.from_numpy(beta).double(),
+                     False, 0.0, R.BN_EPS)
+    want = (h * torch.sigmoid(h)).transpose(1, 2).numpy()                                       # (B, T, C) float64
+    # what finalize hands the kernels: BatchNorm folded into the taps / bias in fp32 (encoder.hip; SURVEY.md 8a closed form)
+    sc = (gamma / np.sqrt(var + np.float32(1e-5))).astype(np.float32)
+    w_kc = np.ascontiguousarray((w[:, 0, :] * sc[:, None]).T.astype(np.float32))                 # [k][C]
+    bias = (cb * sc + beta - mean * sc).astype(np.float32)
+    gd = torch.from_numpy(g).to(torch.bfloat16).cuda()
+    for use_mfma in (1, 0):
+        out = torch.zeros(batch, frames, ld, dtype=torch.bfloat16, device="cuda")
+        _lib.check(dlib.effconf_debug_dwconv(gd.data_ptr(), batch, frames, channels, ld, w_kc.ctypes.data_as(ctypes.c_void_p), bias.ctypes.data_as(ctypes.c_void_p),
+                                             ksize, 1, use_mfma, causal, out.data_ptr(), None), "debug_dwconv", dlib)
+        torch.cuda.synchronize()
+        got = out.float().cpu().numpy()[:, :, :channels].astype(np.float64)
+        ulp = np.abs(want) * 2.0 ** -8 + 2e-5
+        err = np.abs(got - want)
+        exact = float((got == _bf16_round(want).astype(np.float64)).mean())
+        assert float((err / ulp).max()) < 1.0, (use_mfma, float((err / ulp).max()), np.unravel_index(np.argmax(err / ulp), err.shape))
+        assert exact > 0.95, (use_mfma, exact)
+
+
+# ------------------------------------------------------------------ short utterances of the plain Conformer configurations
+@pytest.mark.parametrize("name", ["ConformerCTCSmall", "ConformerCTCLarge"])
+def test_short_utterances_of_the_plain_conformer_configs_vs_oracle(name):
+    """Utterances of 5 - 13 encoder frames (0.2 - 0.5 s) of the plain Conformer configurations (kernel size 31, two-layer subsampler, no grouping): few frames,
+    LayerNorm-ed outputs, nothing averages the bf16 rounding over time - profiles/r5_35_dw_accuracy.txt measured mean |err| 0.0107 - 0.0109 (max 0.054) here, ON /
+    over the 0.010 mean the other tests state.  The tolerance of this length class, stated where it is tested: max 0.08 / mean 0.014,
+    ragged (every utterance alone) and rectangular (the collated batch); the label-exact mode on the same utterances stays at fp32 noise."""
+    m, sd = _model(name, 3)
+    plan = m.encoder.plan
+    frames = [52, 44, 37, 30, 24, 20]                       # mel frames -> 13, 11, 10, 8, 6, 5 encoder frames after the 4x subsampler
+    mel, ln = synth.make_mel(len(frames), 80, max(frames), frames, seed=77)
+    mel_d, ln_d = torch.from_numpy(mel).cuda(), torch.from_numpy(ln).cuda()
+    with torch.no_grad():
+        ref, ref_len = R.encoder_from_mel(torch.from_numpy(mel), torch.from_numpy(ln), sd, plan)
+    out, out_len, _ = m.encoder.forward_mel(mel_d, ln_d)
+    assert out_len.cpu().tolist() == ref_len.tolist()
+    d = (out.cpu() - ref).abs()
+    print("%s rectangular: max %.4f mean %.5f" % (name, float(d.max()), float(d.mean())))
+    assert float(d.max()) < 0.08 and float(d.mean()) < 0.014
+    m.encoder.ragged = True
+    rag, rag_len, _ = m.encoder.forward_mel(mel_d, ln_d)
+    worst_max, means = 0.0, []
+    for b, l in enumerate(frames):
+        with torch.no_grad():
+            alone, alone_len = R.encoder_from_mel(torch.from_numpy(mel[b:b + 1, :, :l]), torch.tensor([l]), sd, plan)
+        tb = int(alone_len[0])
+        assert int(rag_len[b]) == tb
+        e = (rag[b, :tb].cpu() - alone[0]).abs()
+        worst_max = max(worst_max, float(e.max())); means.append(float(e.mean()))
+    print("%s ragged: worst max %.4f, per-utterance mean %s" % (name, worst_max, ["%.4f" % v for v in means]))
+    assert worst_max < 0.08 and max(means) < 0.014
