@@ -649,7 +649,7 @@ def main():
 
     cfg, model, sd = build_model(args.model)
     if args.ragged < 0:
-        args.ragged = int(args.precision == "bf16" and args.workload == "libri" and not args.no_trim)
+        args.ragged = int(args.precision in ("bf16", "split") and args.workload == "libri" and not args.no_trim)      # round 6: the split mode takes ragged batches
     model.encoder.precision = args.precision
     model = model.to(dev)
     plan = model.encoder.plan

@@ -907,44 +907,60 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
 }
 
 // ------------------------------------------------------------------ fp32-operand "exact" forward (kernels: exact.hip)
-struct XWorkspace { size_t total = 0, conv1, sub, x0, x1, a, h, q, k, v, e, o, p1, g, c, lens, scores = 0; size_t qkv_stride = 0; };
+struct XWorkspace { size_t total = 0, conv1, sub, x0, x1, a, h, q, k, v, e, o, p1, g, c, lens, scores = 0; size_t qkv_stride = 0;
+                    size_t cb = 0, xs = 0, xrect = 0, mel_len = 0, row_off = 0, wg_off = 0, tile_off = 0; };     // sxf.hip forward: positional bias, decimated rows, ragged descriptors
 
+// rows come from the Shapes totals: B * T for rectangular batches, the sums over the utterances for ragged ones (s.Tm = the input's row pitch there)
 XWorkspace make_xworkspace(const EcEncoder* e, const Shapes& s) {
     XWorkspace w;
     size_t off = 0;
     auto take = [&](size_t floats) { size_t o = off; off += al(floats * 4); return o; };
     const size_t B = s.B;
-    size_t mx = 0, mh = 0, mq = 0, me = 0, mp = 0, mg = 0, mc = 0;
+    size_t mx = 0, mh = 0, mq = 0, me = 0, mp = 0, mg = 0, mc = 0, mcb = 0, mxs = 0;
     for (size_t k = 0; k < e->blocks.size(); ++k) {
         const EcBlock& b = e->blocks[k];
-        const size_t T = s.Tin[k], To = s.Tout[k], D = b.dim_model, De = b.dim_expand;
+        const size_t T = s.Tin[k], D = b.dim_model, De = b.dim_expand;
+        const size_t Mi = (size_t)s.Min[k], Mo = (size_t)s.Mout[k], Mqk = (size_t)s.Mq[k];
         const size_t Tp = ec_round_up((int)T, b.group_size);
-        mx = std::max(mx, std::max(B * T * D, B * To * De));
-        mh = std::max(mh, std::max(B * T * D, B * To * De) * b.ff_ratio);
-        mq = std::max(mq, B * Tp * D);
+        mx = std::max(mx, std::max(Mi * D, Mo * De));
+        mh = std::max(mh, std::max(Mi * D, Mo * De) * b.ff_ratio);
+        mq = std::max(mq, Mqk * D);
         me = std::max(me, (2 * Tp - b.group_size) * D);
-        mp = std::max(mp, B * T * 2 * De);
-        mg = std::max(mg, B * T * De);
-        mc = std::max(mc, B * To * De);
+        mcb = std::max(mcb, (2 * Tp / b.group_size) * (size_t)b.num_heads);
+        mp = std::max(mp, Mi * 2 * De);
+        mg = std::max(mg, Mi * De);
+        mc = std::max(mc, Mo * De);
+        if (D != De) mxs = std::max(mxs, Mo * D);
     }
     const int L = e->cfg.sub_layers;
-    const size_t F1 = (e->cfg.n_mels - 1) / 2 + 1, T1 = (s.Tm - 1) / 2 + 1;
-    w.conv1 = take(L == 2 ? B * e->cfg.sub_filters[0] * F1 * T1 : 0);
+    size_t T1r = s.Tm; for (int i = 0; i < L; ++i) T1r = (T1r - 1) / 2 + 1;          // rows per utterance of the rectangular front end (ragged: at the input's pitch)
+    const size_t F1 = (e->cfg.n_mels - 1) / 2 + 1, Tl1 = (s.Tm - 1) / 2 + 1;
+    w.conv1 = take(L == 2 ? B * e->cfg.sub_filters[0] * F1 * Tl1 : 0);
     int F = e->cfg.n_mels; for (int i = 0; i < L; ++i) F = (F - 1) / 2 + 1;
-    w.sub = take(B * s.T1 * (size_t)e->cfg.sub_filters[L - 1] * F);
+    w.sub = take(B * T1r * (size_t)e->cfg.sub_filters[L - 1] * F);
     w.x0 = take(mx); w.x1 = take(mx); w.a = take(mx); w.h = take(mh);
     w.q = take(mq); w.k = take(mq); w.v = take(mq); w.e = take(me); w.o = take(mq);
     w.p1 = take(mp); w.g = take(mg); w.c = take(mc);
     w.lens = take((e->blocks.size() + 1) * B);
     w.qkv_stride = (w.k - w.q) / 4;                 // floats between the Q, K and V buffers (the stacked projection writes all three)
-    if (e->exact_split) {                           // split.hip: (B, H, Tg, Tg) attention scores of one block
+    if (e->exact_split) {                           // split.hip: (B, H, Tg, Tg) attention scores of one block (rectangular batches with attention maps)
         size_t ms = 0;
-        for (size_t k = 0; k < e->blocks.size(); ++k) {
-            const EcBlock& b = e->blocks[k];
-            const int Tg = ec_round_up(s.Tin[k], b.group_size) / b.group_size;
-            ms = std::max(ms, sx_attention_scores_bytes(s.B, b.num_heads, Tg) / 4);
-        }
+        if (!s.ragged)
+            for (size_t k = 0; k < e->blocks.size(); ++k) {
+                const EcBlock& b = e->blocks[k];
+                const int Tg = ec_round_up(s.Tin[k], b.group_size) / b.group_size;
+                ms = std::max(ms, sx_attention_scores_bytes(s.B, b.num_heads, Tg) / 4);
+            }
         w.scores = take(ms);
+        w.cb = take(mcb); w.xs = take(mxs);
+        if (s.ragged) {
+            const size_t nbk = e->blocks.size();
+            w.xrect = take(B * T1r * e->blocks[0].dim_model);
+            w.mel_len = take(B);
+            w.row_off = take((nbk + 1) * (B + 1));
+            w.wg_off = take(nbk * (B + 1));
+            w.tile_off = take(nbk * (B + 1));
+        }
     }
     w.total = off;
     return w;
@@ -1087,6 +1103,171 @@ int forward_core_exact(EcEncoder* e, const float* mel, const int64_t* in_len, in
         EC_TRY(launch_layernorm(x, Mo, De, W.ln_out.g, W.ln_out.b, xo, nullptr, 0, nullptr, nullptr, st));
         if (k != nb - 1) std::swap(x, xalt);
         snprintf(nm, sizeof(nm), "blocks.%d.out", k); trace_add(e, st, nm, xo, Mo, De, De, 0);
+    }
+    return 0;
+}
+
+
+// ------------------------------------------------------------------ split-precision forward on the fused kernels of sxf.hip (round 6)
+// The schedule of forward_core_exact with (i) ONE attention kernel per block that keeps the scores on the CU, (ii) ragged batches - every utterance at its own
+// length in the concatenated, group-padded row space of the bf16 path (the row-local GEMMs / LayerNorms see M rows; attention, depthwise conv and the conv_res
+// decimation index utterances through the descriptors of lengths_ragged_kernel), (iii) causal relative tables / causal depthwise padding and streaming
+// contexts.  Reference: encoders.py:97-142, blocks.py:119-137, attentions.py:506-529, 549-718, 1243-1247, layers.py:97-101.
+bool split_fused_ok(const EcEncoder* e) {
+    if (!e->exact_split) return false;
+    for (const EcBlock& b : e->blocks)
+        if (!sxf_attention_supported(b.group_size * b.dim_model / b.num_heads) || b.dim_model % 4 || b.dim_expand % 4) return false;
+    return true;
+}
+
+int forward_core_split(EcEncoder* e, const float* mel, const int64_t* in_len, int from_audio, const Shapes& s, const XWorkspace& w,
+                       char* ws, float* out, int64_t* out_len, hipStream_t st, int out_frames = 0) {
+    const EcConfig& c = e->cfg;
+    const int B = s.B, nb = (int)e->blocks.size();
+    const bool rg = s.ragged;
+    e->trace.clear(); e->trace_used = 0;
+    e->e_cache_drop(ws);
+    auto F32 = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
+    int* lens = reinterpret_cast<int*>(ws + w.lens);
+    const int *mel_len = nullptr, *row_off = nullptr;
+    if (rg) {
+        int* ml = reinterpret_cast<int*>(ws + w.mel_len); int* ro = reinterpret_cast<int*>(ws + w.row_off);
+        PROF(PC_MISC, 0, 0);
+        EC_TRY(launch_lengths_ragged(in_len, B, from_audio, c.hop_length, c.sub_layers, e->block_stride, e->block_group, e->block_heads, nb, lens, ml,
+                                     ro, reinterpret_cast<int*>(ws + w.wg_off), reinterpret_cast<int*>(ws + w.tile_off), out_len, st));
+        mel_len = ml; row_off = ro;
+    } else {
+        PROF(PC_MISC, 0, 0);
+        EC_TRY(launch_lengths(in_len, B, from_audio, c.hop_length, c.sub_layers, e->block_stride, nb, lens, out_len, st));
+    }
+    if (from_audio) trace_add(e, st, "mel", mel, (int64_t)B * c.n_mels, s.Tm, s.Tm, 0);
+    auto rows_at = [&](int k) { RaggedRows r{}; r.off = row_off + (size_t)k * (B + 1); r.len = lens + (size_t)k * B; r.n = B;
+                                r.rows = (int)(k < nb ? s.Min[k] : s.Mfinal); r.tmax = k < nb ? s.Tin[k] : s.Tout[nb - 1]; return r; };
+    // ---- Conv2dSubsampling (modules.py:232-249) + transpose + Linear (encoders.py:113-116).  Ragged: on the rectangular image at the input's pitch with every
+    //      utterance's frames behind its own end read / written as zeros (the zero padding it sees when run alone), then the valid rows are gathered
+    float* sub = F32(w.sub);
+    const int C0 = c.sub_filters[0];
+    int Fl = c.n_mels, Cl = C0;
+    int T1r = s.Tm; for (int i = 0; i < c.sub_layers; ++i) T1r = (T1r - 1) / 2 + 1;
+    {
+        PROF(PC_SUBCONV, 0, (double)B * c.n_mels * s.Tm * 4);
+        if (c.sub_layers == 1) {
+            EC_TRY(launch_ex_conv2d(mel, B, 1, c.n_mels, s.Tm, xget(e, "subsampling_module.layers.0.0.weight"), e->xsub_scale[0], e->xsub_shift[0], C0, sub, 1, st, mel_len));
+            Fl = (c.n_mels - 1) / 2 + 1;
+        } else {
+            float* img = F32(w.conv1);
+            const int F1 = (c.n_mels - 1) / 2 + 1, Tl1 = (s.Tm - 1) / 2 + 1, C1 = c.sub_filters[1];
+            EC_TRY(launch_ex_conv2d(mel, B, 1, c.n_mels, s.Tm, xget(e, "subsampling_module.layers.0.0.weight"), e->xsub_scale[0], e->xsub_shift[0], C0, img, 0, st, mel_len));
+            EC_TRY(launch_ex_conv2d(img, B, C0, F1, Tl1, xget(e, "subsampling_module.layers.1.0.weight"), e->xsub_scale[1], e->xsub_shift[1], C1, sub, 1, st));
+            Fl = (F1 - 1) / 2 + 1; Cl = C1;
+        }
+    }
+    const int Ksub = Cl * Fl;
+    float* x = F32(w.x0);
+    float* xalt = F32(w.x1);
+    const int D0 = e->blocks[0].dim_model;
+    if (rg) {
+        float* xrect = F32(w.xrect);
+        EC_TRY(xgemm(e, st, sub, Ksub, B * T1r, "linear", D0, Ksub, xrect, D0));
+        PROF(PC_MISC, 0, (double)s.Min[0] * D0 * 8);
+        EC_TRY(launch_gather_rows(xrect, D0, T1r, rows_at(0), x, st));
+    } else {
+        trace_add(e, st, "subsample", sub, (int64_t)B * s.T1, Ksub, Ksub, 0);
+        EC_TRY(xgemm(e, st, sub, Ksub, B * s.T1, "linear", D0, Ksub, x, D0));
+    }
+    trace_add(e, st, "linear", x, s.Min[0], D0, D0, 0);
+    float *a = F32(w.a), *hb = F32(w.h), *q = F32(w.q), *kk = F32(w.k), *v = F32(w.v), *eb = F32(w.e), *o = F32(w.o), *p1 = F32(w.p1), *g = F32(w.g),
+          *cbuf = F32(w.c), *posb = F32(w.cb), *xs = F32(w.xs);
+    char nm[64];
+    int xmask_stride = 1;                      // product of the strides of the blocks before block k
+    auto layernorm = [&](const float* in, int rows, int dim, const LNp& ln, float* dst) {
+        PROF(PC_LAYERNORM, 0, (double)rows * dim * 8);
+        return launch_layernorm(in, rows, dim, ln.g, ln.b, dst, nullptr, 0, nullptr, nullptr, st);
+    };
+    for (int k = 0; k < nb; ++k) {
+        const EcBlock& b = e->blocks[k];
+        const BlockW& W = e->bw[k];
+        const int T = s.Tin[k], To = s.Tout[k], D = b.dim_model, De = b.dim_expand;          // ragged: the LONGEST utterance's frames
+        const int M = (int)s.Min[k], Mo = (int)s.Mout[k];
+        const int G = b.group_size, H = b.num_heads, Tp = ec_round_up(T, G), Tg = Tp / G, d = G * D / H;
+        const std::string p = "blocks." + std::to_string(k);
+        // ---- x += 1/2 FFN1(LN(x))   (blocks.py:122; modules.py:385-392)
+        EC_TRY(layernorm(x, M, D, W.ln_ffn1, a));
+        EC_TRY(xgemm(e, st, a, D, M, p + ".feed_forward_module1.layers.1", D * b.ff_ratio, D, hb, D * b.ff_ratio, 1, nullptr, 1.f, 0, 0, 0, 0, 0, 0, 0, PC_GEMM_FFN));
+        EC_TRY(xgemm(e, st, hb, D * b.ff_ratio, M, p + ".feed_forward_module1.layers.4", D, D * b.ff_ratio, x, D, 2, x, 0.5f, 0, 0, 0, 0, 0, 0, 0, PC_GEMM_FFN));
+        snprintf(nm, sizeof(nm), "blocks.%d.x_ffn1", k); trace_add(e, st, nm, x, M, D, D, 0);
+        // ---- x += MHSA(LN(x))   (blocks.py:125-126; attentions.py:549-718).  Rows of Q / K / V: rectangular (b, t) -> b Tp + t, ragged: the identity (the
+        //      residual stream keeps every utterance group-padded); chunk-padding rows are never written - the attention kernel substitutes them
+        const std::string m = p + ".multi_head_self_attention_module";
+        EC_TRY(layernorm(x, M, D, W.ln_att, a));
+        const int qr = rg ? 0 : T, qp = rg ? 0 : Tp;
+        if (e->xsplit.count(m + ".mhsa.qkv_layer")) {
+            EC_TRY(xgemm(e, st, a, D, M, m + ".mhsa.qkv_layer", 3 * D, D, q, D, 0, nullptr, 1.f, 0, 0, 0, qr, qp, D, w.qkv_stride));
+        } else {
+            EC_TRY(xgemm(e, st, a, D, M, m + ".mhsa.query_layer", D, D, q, D, 0, nullptr, 1.f, 0, 0, 0, qr, qp));
+            EC_TRY(xgemm(e, st, a, D, M, m + ".mhsa.key_layer", D, D, kk, D, 0, nullptr, 1.f, 0, 0, 0, qr, qp));
+            EC_TRY(xgemm(e, st, a, D, M, m + ".mhsa.value_layer", D, D, v, D, 0, nullptr, 1.f, 0, 0, 0, qr, qp));
+        }
+        if (Tp > b.max_pos) return fail("sequence longer than max_pos_encoding");
+        // relative tables: R[m] = sinusoid(Tp - 1 - G/2 - m), m < 2 Tp - G; causal: R[m] = sinusoid(Tp - 1 - m), m < Tp (attentions.py:1243-1251, 1296-1309)
+        const float* tab = e->xtab[std::make_pair(b.max_pos, D)];
+        const int erows = c.causal ? Tp : 2 * Tp - G;
+        EC_TRY(xgemm(e, st, tab + (size_t)(b.max_pos - Tp + (c.causal ? 0 : G / 2)) * D, D, erows, m + ".mhsa.pos_layer", D, D, eb, D));
+        { PROF(PC_MISC, 0, (double)erows * D * 4); EC_TRY(launch_sxf_posbias(eb, W.u, W.v, erows / G, H, G, D, d, posb, st)); }
+        SxfAttnParams ap{};
+        ap.q = q; ap.k = kk; ap.v = v; ap.e = eb; ap.cb = posb; ap.u = W.u; ap.lens = lens + (size_t)k * B;
+        ap.off = rg ? row_off + (size_t)k * (B + 1) : nullptr;
+        ap.B = B; ap.H = H; ap.G = G; ap.D = D; ap.d = d; ap.T = T; ap.Tp = Tp; ap.Tg = Tg; ap.out = o; ap.causal = c.causal;
+        {   // streaming mask of this block (encoders.py:132-136, attentions.py:698): contexts in frames after the subsampling, sliced ::stride after every
+            // strided block before this one and ::G in grouped attention
+            const long long unit = (long long)xmask_stride * G;
+            ap.band_l = (int)std::min<long long>(c.left_context / unit, 1 << 30); ap.band_r = (int)std::min<long long>(c.right_context / unit, 1 << 30);
+        }
+        { PROF(PC_ATTENTION, 2.0 * H * (rg ? s.tg2[k] : (double)B * Tg * Tg) * d * 3.0, (double)s.Mq[k] * D * 4 * 4);
+          EC_TRY(launch_sxf_attention(ap, st)); }
+        snprintf(nm, sizeof(nm), "blocks.%d.att_o", k); trace_add(e, st, nm, o, s.Mq[k], D, D, 0);
+        EC_TRY(xgemm(e, st, o, D, M, m + ".mhsa.output_layer", D, D, x, D, 2, x, 1.0f, qr, qp, 1));
+        snprintf(nm, sizeof(nm), "blocks.%d.x_mhsa", k); trace_add(e, st, nm, x, M, D, D, 0);
+        // ---- x = conv_res(x) + ConvModule(x)   (blocks.py:129; modules.py:511-522)
+        const std::string cm = p + ".convolution_module.layers";
+        EC_TRY(layernorm(x, M, D, W.ln_conv, a));
+        EC_TRY(xgemm(e, st, a, D, M, cm + ".2", 2 * De, D, p1, 2 * De));
+        { PROF(PC_MISC, 0, (double)M * De * 12); EC_TRY(launch_sxf_glu(p1, M, De, g, st)); }
+        RaggedConv rc{};
+        int tcap = To;
+        if (rg) { rc.in_off = row_off + (size_t)k * (B + 1); rc.in_len = lens + (size_t)k * B; rc.out_off = row_off + (size_t)(k + 1) * (B + 1);
+                  rc.out_len = lens + (size_t)(k + 1) * B; rc.n = B; rc.out_rows = Mo;
+                  tcap = ec_round_up(To, k + 1 < nb ? e->blocks[k + 1].group_size : 1); }
+        { PROF(PC_DWCONV, 2.0 * Mo * (double)De * b.kernel_size, (double)M * De * 4 + (double)Mo * De * 4);
+          EC_TRY(launch_sxf_dwconv(g, B, T, To, De, W.dw_w, W.dw_b, b.kernel_size, b.conv_stride, cbuf, st, rg ? &rc : nullptr, c.causal, tcap)); }
+        snprintf(nm, sizeof(nm), "blocks.%d.dw", k); trace_add(e, st, nm, cbuf, Mo, De, De, 0);
+        xmask_stride *= b.conv_stride;
+        if (D != De) {      // 1x1 strided conv on frames 0, s, 2s, ...  (blocks.py:106-110)
+            if (rg) {
+                { PROF(PC_MISC, 0, (double)Mo * D * 8); EC_TRY(launch_sxf_decimate(x, D, b.conv_stride, rc, xs, st)); }
+                EC_TRY(xgemm(e, st, xs, D, Mo, p + ".conv_res.1", De, D, xalt, De));
+            } else {
+                EC_TRY(xgemm(e, st, x, D, Mo, p + ".conv_res.1", De, D, xalt, De, 0, nullptr, 1.f, To, T, b.conv_stride));
+            }
+            std::swap(x, xalt);
+        } else if (b.conv_stride > 1) {
+            return fail("strided block without expansion is not native (no shipped config uses it)");
+        }
+        EC_TRY(xgemm(e, st, cbuf, De, Mo, cm + ".7", De, De, x, De, 2, x, 1.0f));
+        snprintf(nm, sizeof(nm), "blocks.%d.x_conv", k); trace_add(e, st, nm, x, Mo, De, De, 0);
+        // ---- x += 1/2 FFN2(LN(x)); x = LN(x)   (blocks.py:132-135)
+        EC_TRY(layernorm(x, Mo, De, W.ln_ffn2, a));
+        EC_TRY(xgemm(e, st, a, De, Mo, p + ".feed_forward_module2.layers.1", De * b.ff_ratio, De, hb, De * b.ff_ratio, 1, nullptr, 1.f, 0, 0, 0, 0, 0, 0, 0, PC_GEMM_FFN));
+        EC_TRY(xgemm(e, st, hb, De * b.ff_ratio, Mo, p + ".feed_forward_module2.layers.4", De, De * b.ff_ratio, x, De, 2, x, 0.5f, 0, 0, 0, 0, 0, 0, 0, PC_GEMM_FFN));
+        float* xo = (k == nb - 1 && !rg) ? out : xalt;
+        EC_TRY(layernorm(x, Mo, De, W.ln_out, xo));
+        if (!(k == nb - 1 && !rg)) std::swap(x, xalt);
+        snprintf(nm, sizeof(nm), "blocks.%d.out", k); trace_add(e, st, nm, xo, Mo, De, De, 0);
+    }
+    if (rg) {
+        const RaggedRows rl = rows_at(nb);
+        PROF(PC_MISC, 0, (double)s.Mfinal * e->blocks.back().dim_expand * 4 + (double)B * out_frames * e->blocks.back().dim_expand * 4);
+        EC_TRY(launch_emit_rows(x, e->blocks.back().dim_expand, rl.off, rl.len, B, out_frames, out, st));
     }
     return 0;
 }
@@ -1543,6 +1724,9 @@ int effconf_encoder_forward_mel(EcEncoder* e, const float* mel, const int64_t* m
     if (e->exact_on) {
         const XWorkspace xw = make_xworkspace(e, s);
         if (workspace_bytes < xw.total) return fail("workspace too small");
+        // split mode: the fused kernels (sxf.hip); attention maps are a by-product of split.hip's scores-in-memory kernels only
+        if (split_fused_ok(e) && e->att_out.empty())
+            return forward_core_split(e, mel, mel_len, 0, s, xw, reinterpret_cast<char*>(workspace), out, out_len, (hipStream_t)stream);
         return forward_core_exact(e, mel, mel_len, 0, s, xw, reinterpret_cast<char*>(workspace), out, out_len, (hipStream_t)stream);
     }
     const Workspace w = make_workspace(e, s, false);
@@ -1562,7 +1746,9 @@ int effconf_encoder_forward(EcEncoder* e, const float* audio, const int64_t* x_l
         char* ws = reinterpret_cast<char*>(workspace);
         float* mel = reinterpret_cast<float*>(ws + xw.total);
         hipStream_t st = (hipStream_t)stream;
-        EC_TRY(launch_mel(audio, batch, n_samples, e->mel, e->cfg.n_fft, e->cfg.hop_length, e->cfg.n_mels, Tm, e->cfg.normalize, e->cfg.mean, e->cfg.std, mel, st));
+        { PROF(PC_MEL, 0, (double)batch * n_samples * 4 + (double)batch * e->cfg.n_mels * Tm * 4);
+          EC_TRY(launch_mel(audio, batch, n_samples, e->mel, e->cfg.n_fft, e->cfg.hop_length, e->cfg.n_mels, Tm, e->cfg.normalize, e->cfg.mean, e->cfg.std, mel, st)); }
+        if (split_fused_ok(e) && e->att_out.empty()) return forward_core_split(e, mel, x_len, 1, s, xw, ws, out, out_len, st);
         return forward_core_exact(e, mel, x_len, 1, s, xw, ws, out, out_len, st);
     }
     const Workspace w = make_workspace(e, s, true);
@@ -1592,20 +1778,39 @@ size_t effconf_encoder_workspace_bytes_ragged(const EcEncoder* e, const int64_t*
     if (!ragged_host_lengths(e, x_len_host, batch, n, from_audio, &tm)) return 0;
     const Shapes s = make_shapes_ragged(e, tm);
     Shapes full = s; full.Tm = from_audio ? n / e->cfg.hop_length + 1 : n;      // the mel image keeps the input's row pitch
-    return make_workspace(e, full, from_audio != 0).total;
+    size_t bytes = make_workspace(e, full, from_audio != 0).total;
+    if (e->exact_pack) bytes = std::max(bytes, make_xworkspace(e, full).total + (from_audio ? al((size_t)batch * e->cfg.n_mels * full.Tm * 4) : 0));
+    return bytes;
 }
 
 int effconf_encoder_forward_ragged(EcEncoder* e, const float* x, const int64_t* x_len, const int64_t* x_len_host, int32_t batch, int32_t n,
                                    int32_t from_audio, float* out, int32_t out_frames, int64_t* out_len, void* workspace, size_t workspace_bytes,
                                    void* stream) {
     if (!e || !e->finalized) return fail("encoder not finalized");
-    if (e->exact_on) return fail("ragged batches run on the bf16 path (precision = fp32 keeps rectangular batches)");
+    if (e->exact_on && !split_fused_ok(e))
+        return fail("ragged batches run on the bf16 path and in the split mode (exact_fp32 = 2, head widths <= 144); exact_fp32 = 1 keeps rectangular batches");
+    if (e->exact_on && !e->att_out.empty()) return fail("attention maps of a ragged batch: bf16 path only");
     if (!x || !x_len || !x_len_host || !out || !workspace || batch <= 0 || n <= 0 || out_frames <= 0) return fail("bad argument");
     std::vector<int> tm;
     if (!ragged_host_lengths(e, x_len_host, batch, n, from_audio, &tm)) return fail("ragged lengths out of range (audio: n_fft / 2 < len <= n; mel: 1 <= len <= n)");
     Shapes s = make_shapes_ragged(e, tm);
     if (s.Tout.back() > out_frames) return fail("out_frames smaller than the longest utterance's output");
     s.Tm = from_audio ? n / e->cfg.hop_length + 1 : n;        // pitch of the mel image = the input's row pitch (every utterance masks at its own length)
+    if (e->exact_on) {       // split mode on the fused kernels: mel at the tail of the exact workspace
+        const XWorkspace xw = make_xworkspace(e, s);
+        if (workspace_bytes < xw.total + (from_audio ? al((size_t)batch * e->cfg.n_mels * s.Tm * 4) : 0)) return fail("workspace too small");
+        char* wsx = reinterpret_cast<char*>(workspace);
+        hipStream_t stx = (hipStream_t)stream;
+        const float* melx = x;
+        if (from_audio) {
+            float* m = reinterpret_cast<float*>(wsx + xw.total);
+            hipStream_t st = stx;
+            PROF(PC_MEL, 0, (double)batch * n * 4 + (double)batch * e->cfg.n_mels * s.Tm * 4);
+            EC_TRY(launch_mel(x, batch, n, e->mel, e->cfg.n_fft, e->cfg.hop_length, e->cfg.n_mels, s.Tm, e->cfg.normalize, e->cfg.mean, e->cfg.std, m, st, x_len));
+            melx = m;
+        }
+        return forward_core_split(e, melx, x_len, from_audio, s, xw, wsx, out, out_len, stx, out_frames);
+    }
     const Workspace w = make_workspace(e, s, from_audio != 0);
     if (workspace_bytes < w.total) return fail("workspace too small");
     char* ws = reinterpret_cast<char*>(workspace);

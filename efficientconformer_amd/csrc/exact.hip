@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void ex_gemm_kernel(ExGemmParams p) {
 // in (B, Cin, F, T) -> out (B, Co, Fo, To), or flat = 1: (B, To, Co*Fo) with feature index co*Fo + fo (modules.py:247 + encoders.py:113)
 __global__ __launch_bounds__(256) void ex_conv2d_kernel(const float* __restrict__ in, int B, int Cin, int F, int T, const float* __restrict__ w,
                                                         const float* __restrict__ scale, const float* __restrict__ shift, int Co, int Fo, int To,
-                                                        float* __restrict__ out, int flat) {
+                                                        float* __restrict__ out, int flat, const int* __restrict__ tlen) {
     const long long total = (long long)B * Co * Fo * To;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
         int to, fo, co, b;
@@ -83,6 +83,8 @@ __global__ __launch_bounds__(256) void ex_conv2d_kernel(const float* __restrict_
             co = (int)(q % Co);
             b = (int)(q / Co);
         }
+        const int Tv = tlen ? tlen[b] : T;                       // ragged batches: the utterance's own frames (zero behind them)
+        if (tlen && !flat && to >= (Tv - 1) / 2 + 1) { out[(((size_t)b * Co + co) * Fo + fo) * To + to] = 0.f; continue; }
         float acc = 0.f;
         for (int ci = 0; ci < Cin; ++ci) {
             const float* ip = in + ((size_t)b * Cin + ci) * F * T;
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(256) void ex_conv2d_kernel(const float* __restrict_
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
                     const int t = 2 * to - 1 + j;
-                    if (t < 0 || t >= T) continue;
+                    if (t < 0 || t >= Tv) continue;
                     acc = fmaf(ip[(size_t)f * T + t], wp[i * 3 + j], acc);
                 }
             }
@@ -113,13 +115,14 @@ __global__ __launch_bounds__(256) void ex_conv2d_kernel(const float* __restrict_
 // per Small step of the label-exact modes).
 __global__ __launch_bounds__(256) void ex_conv2d_flat1_kernel(const float* __restrict__ in, int B, int F, int T, const float* __restrict__ w,
                                                               const float* __restrict__ scale, const float* __restrict__ shift, int Co, int Fo, int To,
-                                                              float* __restrict__ out) {
+                                                              float* __restrict__ out, const int* __restrict__ tlen) {
     const long long total = (long long)B * To * Fo;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
         const int fo = (int)(idx % Fo);
         const long long q = idx / Fo;
         const int to = (int)(q % To), b = (int)(q / To);
         const float* ip = in + (size_t)b * F * T;
+        const int Tv = tlen ? tlen[b] : T;
         float pt[9];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -127,7 +130,7 @@ __global__ __launch_bounds__(256) void ex_conv2d_flat1_kernel(const float* __res
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const int t = 2 * to - 1 + j;
-                const bool ok = f >= 0 && f < F && t >= 0 && t < T;
+                const bool ok = f >= 0 && f < F && t >= 0 && t < Tv;
                 pt[i * 3 + j] = ok ? ip[(size_t)(ok ? f : 0) * T + (ok ? t : 0)] : 0.f;
             }
         }
@@ -415,13 +418,13 @@ int launch_ex_gemm(const ExGemmParams& p, hipStream_t s) {
 }
 
 int launch_ex_conv2d(const float* in, int B, int Cin, int F, int T, const float* w, const float* scale, const float* shift, int Co,
-                     float* out, int flat, hipStream_t s) {
+                     float* out, int flat, hipStream_t s, const int* tlen) {
     const int Fo = (F - 1) / 2 + 1, To = (T - 1) / 2 + 1;
     if (Cin == 1 && flat) {
-        hipLaunchKernelGGL(ex_conv2d_flat1_kernel, dim3(grid_for((long long)B * To * Fo)), dim3(256), 0, s, in, B, F, T, w, scale, shift, Co, Fo, To, out);
+        hipLaunchKernelGGL(ex_conv2d_flat1_kernel, dim3(grid_for((long long)B * To * Fo)), dim3(256), 0, s, in, B, F, T, w, scale, shift, Co, Fo, To, out, tlen);
         return hipGetLastError() == hipSuccess ? 0 : -1;
     }
-    hipLaunchKernelGGL(ex_conv2d_kernel, dim3(grid_for((long long)B * Co * Fo * To)), dim3(256), 0, s, in, B, Cin, F, T, w, scale, shift, Co, Fo, To, out, flat);
+    hipLaunchKernelGGL(ex_conv2d_kernel, dim3(grid_for((long long)B * Co * Fo * To)), dim3(256), 0, s, in, B, Cin, F, T, w, scale, shift, Co, Fo, To, out, flat, tlen);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -221,8 +221,10 @@ struct ExGemmParams {              // C = epi(A W^T + bias), everything fp32 (v_
     int epi;                       // 0 plain, 1 Swish, 2 residual
 };
 int launch_ex_gemm(const ExGemmParams& p, hipStream_t s);
+// tlen != null (dev [B]): valid input frames per utterance - input frames behind them read as ZERO (the utterance run alone sees the conv's zero padding there)
+// and, in the image layout (flat = 0), outputs behind (tlen - 1) / 2 + 1 are written as zero (the next layer's zero padding)
 int launch_ex_conv2d(const float* in, int B, int Cin, int F, int T, const float* w, const float* scale, const float* shift, int Co,
-                     float* out, int flat, hipStream_t s);
+                     float* out, int flat, hipStream_t s, const int* tlen = nullptr);
 int launch_ex_glu(const float* in, long long M, int N, float* out, hipStream_t s);
 int launch_ex_dwconv(const float* g, int B, int T, int To, int C, const float* w_kc, const float* bias, int ks, int stride, float* out, hipStream_t s);
 struct ExAttnParams {              // natural-layout fp32 Q, K, V [B*Tp][D], E [2Tp-G][D]; out [B*Tp][D]
@@ -246,6 +248,28 @@ struct SxAttnParams { ExAttnParams a; float* scores; int TgP; };
 bool sx_attention_supported(int d);
 size_t sx_attention_scores_bytes(int B, int H, int Tg);
 int launch_sx_attention(const ExAttnParams& p, float* scores, hipStream_t s);     // scores: sx_attention_scores_bytes(B, H, Tg) of scratch
+
+// ---------------------------------------------------------------- split-precision mode on fused kernels  (sxf.hip, round 6): ragged batches, causal / streaming
+struct SxfAttnParams {             // natural-layout fp32 rows [rows][D]: Q, K, V straight from the projection (no + u / + v, no pad-row pass), out likewise
+    const float *q, *k, *v;
+    const float* e;                // E = pos_layer(R) fp32 [causal ? Tp : 2 Tp - G][D] for the LONGEST utterance (Tp = G Tg)
+    const float* cb;               // launch_sxf_posbias: [causal ? Tg : 2 Tg - 1][H]
+    const float* u;                // [D] content bias (attentions.py:474)
+    const int* lens;               // [B] valid frames per utterance at this stage (key mask; ragged: the utterance's frames)
+    const int* off;                // ragged: [B + 1] first row of every utterance (rows padded to the group size); null: utterance b = rows b Tp ..
+    int B, H, G, D, d;
+    int T, Tp, Tg;                 // rectangular: frames / padded frames / grouped frames of every utterance; ragged: Tg of the longest one (E and the grid)
+    float* out;
+    int band_l, band_r, causal;    // key j of query i visible iff -band_l <= j - i <= band_r (grouped positions); causal: E holds the non-negative distances
+};
+bool sxf_attention_supported(int d);
+int launch_sxf_attention(const SxfAttnParams& p, hipStream_t s);
+int launch_sxf_posbias(const float* e, const float* u, const float* vb, int erows_grouped, int H, int G, int D, int d, float* cb, hipStream_t s);
+// fp32 depthwise conv + folded BatchNorm + Swish; rc != null: per-utterance row ranges (tcap_max = the longest utterance's padded output rows)
+int launch_sxf_dwconv(const float* g, int B, int T, int To, int C, const float* w_kc, const float* bias, int ks, int stride, float* out, hipStream_t s,
+                      const RaggedConv* rc = nullptr, int causal = 0, int tcap_max = 0);
+int launch_sxf_decimate(const float* x, int D, int stride, const RaggedConv& rc, float* out, hipStream_t s);
+int launch_sxf_glu(const float* in, long long M, int N, float* out, hipStream_t s);
 
 // ---------------------------------------------------------------- mel frontend  (mel.hip)
 struct MelTables {                 // device tables built once per encoder

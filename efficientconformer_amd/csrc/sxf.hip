@@ -1,0 +1,466 @@
+// Split-precision mode, second generation (round 6): the label-exact forward on FUSED kernels that take ragged batches and causal / streaming
+// configurations.  Arithmetic as in split.hip (fp32 tensors, every product on the fp16 matrix pipe with operands x = h + l / 2048, three MFMAs per
+// product, ~2^-21 relative); reference: models/attentions.py:549-718 (483-547 rel_to_abs, 506-529 causal skew, 1326-1403 masks), modules.py:511-525,
+// layers.py:97-101, blocks.py:106-110.
+//
+//   sxf_attention_kernel   one workgroup = 64 grouped queries of one (utterance, head), all key tiles: S^T = K Qu^T + skew(E Qu^T) on the matrix pipe
+//                          (TRANSPOSED scores: a lane owns a query column, so the softmax statistics are lane-local), online softmax in fp32, O^T += V^T P^T with
+//                          the probabilities going from accumulator registers straight into B fragments - no score ever leaves the CU (split.hip wrote
+//                          (B, H, Tg, Tg) fp32 scores to HBM and read them twice: 15.9 of its 31.4 ms).  Q + v is not formed: (Q + v) E^T = (Q + u) E^T + (v - u) E^T,
+//                          and the second term is one number per (head, relative position) - sxf_posbias_kernel - that rides in a spare k column of E against a
+//                          constant 1 in Q + u.  Ragged batches: per-utterance row offsets / lengths; chunk-padding rows (attentions.py:107-138) are substituted
+//                          while staging (K = V = 0, Q = 0 -> Q + u = u), so no pad-row pass exists.  Streaming contexts / causal: band limits per query,
+//                          causal relative tables indexed Tg - 1 + j - i with j <= i.
+//   sxf_dwconv_kernel      depthwise conv + folded BatchNorm + Swish in fp32 on per-utterance row ranges, "same" or causal pre-padding.
+//   sxf_decimate_kernel    frames 0, s, 2s, .. of every utterance (input of the conv_res 1 x 1 convolution of the transition blocks).
+#include "kernels.h"
+#include "sx_common.h"
+
+namespace {
+
+using namespace sx;
+
+constexpr int SS_LD = 40;                                        // floats per key row of a wave's skew buffer (conflict-free: see the writer below)
+constexpr int VROW = 64 * 2 + 16;                                // bytes per row of the V^T tiles (64 keys)
+
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// exp(x) for x in [-inf, ~0]: sx_expf with the -inf case (excluded keys, the first tile's running maximum) made explicit
+__device__ __forceinline__ float expm(float x) { return x < -1e30f ? 0.f : sx_expf(x); }
+
+template <int KS, int NT>
+struct AttnLds {
+    static constexpr int PK = 16 * KS, ROW = PK * 2 + 16;
+    static constexpr int HALF = 2 * 64 * ROW;                    // one band half / the K tile: hi [64][ROW] | lo [64][ROW]
+    static constexpr int VT = 2 * 32 * NT * VROW;                // V^T hi | lo
+    static constexpr bool VALIAS = 3 * HALF + VT + 4 * 32 * SS_LD * 4 + PK * 4 > 150 * 1024;    // wide heads: V^T shares the K tile + the consumed band half
+    static constexpr int BYTES = 3 * HALF + (VALIAS ? 0 : VT) + 4 * 32 * SS_LD * 4 + PK * 4;
+};
+
+template <int KS, int NT>
+__global__ __launch_bounds__(256) void sxf_attention_kernel(const SxfAttnParams p) {
+    using L = AttnLds<KS, NT>;
+    constexpr int PK = L::PK, ROW = L::ROW, CPR = PK / 4, HALF = L::HALF;
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+    // [band half A][K tile][band half B]: the K tile and the band half a key tile has consumed are contiguous whichever half that is (V^T alias of the wide heads)
+    char* const sEA = sm;
+    char* const sK = sm + HALF;
+    char* const sEB = sm + 2 * HALF;
+    char* const tail = sm + 3 * HALF;
+    char* const sVfix = tail;                                    // !VALIAS
+    float* const sS = reinterpret_cast<float*>(tail + (L::VALIAS ? 0 : L::VT));
+    float* const suv = sS + 4 * 32 * SS_LD;                      // [PK]: u of this head's columns | 1 at column d | 0
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wq = wave >> 1, wk = wave & 1, lr = lane & 31, kh = lane >> 5;
+    const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
+    const int d = p.d, G = p.G, D = p.D;
+    // ---- this utterance: first row, frames that carry projections (rows behind them are chunk padding), key-mask length, grouped length
+    long long row0; int nfr, klen, Tg;
+    if (p.off) { row0 = p.off[b]; nfr = p.lens[b]; klen = nfr; Tg = (nfr + G - 1) / G; }
+    else { row0 = (long long)b * p.Tp; nfr = p.T; klen = p.lens[b]; Tg = p.Tg; }
+    const int i0 = blockIdx.x * 64;
+    if (i0 >= Tg) return;                                        // ragged launches are sized for the longest utterance (whole workgroup leaves)
+    const size_t hb = (size_t)h * d, gd = (size_t)G * D;
+    const float* qbase = p.q + row0 * D + hb;
+    const float* kbase = p.k + row0 * D + hb;
+    const float* vbase = p.v + row0 * D + hb;
+    const float* ebase = p.e + hb;
+    const int erows = p.causal ? p.Tg : 2 * p.Tg - 1;            // rows of E (built for the LONGEST utterance: an utterance's own table is a centred slice of it)
+    // valid elements of grouped row i's head span: natural row G i + (hb + x) / D carries a projection iff it is < nfr
+    auto dspan = [&](int i) { const long long xl = (long long)(nfr - G * i) * D - (long long)hb; return (int)(xl < 0 ? 0 : (xl > d ? d : xl)); };
+    for (int x = tid; x < PK; x += 256) suv[x] = x < d ? p.u[(int)((hb + x) % D)] : (x == d ? 1.0f : 0.f);
+    __syncthreads();
+    // ---- this lane's query as B fragments of Q + u (split), column d = 1 (the positional bias column of the staged E rows)
+    f16x8 quh[KS], qul[KS];
+    {
+        int i = i0 + 32 * wq + lr;
+        i = i < Tg ? i : Tg - 1;
+        const float* qr = qbase + gd * i;
+        const int de = dspan(i);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int x = 16 * s + 8 * kh;
+            const float4 a = ld_span4(qr, x, de), c = ld_span4(qr, x + 4, de);
+            const float4 u0 = *reinterpret_cast<const float4*>(suv + x), u1 = *reinterpret_cast<const float4*>(suv + x + 4);
+            uint32_t uh[4], ul[4];
+            split2(a.x + u0.x, a.y + u0.y, uh[0], ul[0]); split2(a.z + u0.z, a.w + u0.w, uh[1], ul[1]);
+            split2(c.x + u1.x, c.y + u1.y, uh[2], ul[2]); split2(c.z + u1.z, c.w + u1.w, uh[3], ul[3]);
+            quh[s] = as_f16x8(make_uint4(uh[0], uh[1], uh[2], uh[3])); qul[s] = as_f16x8(make_uint4(ul[0], ul[1], ul[2], ul[3]));
+        }
+    }
+    // ---- key tiles this workgroup has to visit.  A tile all of whose keys are masked for all of the workgroup's queries contributes exp(-1e9 - max) = 0
+    //      exactly, PROVIDED every query row has an unmasked key (its own): true for ragged batches and for query tiles in front of the key-mask length;
+    //      pad-frame queries of a rectangular batch can have every key masked - the reference's softmax is then uniform over ALL keys - so those walk everything
+    const int bl = p.band_l < (1 << 24) ? p.band_l : (1 << 24), br = p.causal ? 0 : (p.band_r < (1 << 24) ? p.band_r : (1 << 24));
+    int jt_lo = 0, jt_hi = (Tg + 63) / 64;
+    {
+        const int ilast = (i0 + 63 < Tg ? i0 + 63 : Tg - 1);
+        if (p.off || G * ilast < klen) {
+            const int kmax = (klen + G - 1) / G;                 // first key masked by the padding mask
+            int hi = (kmax + 63) / 64;
+            const int hr = (ilast + br) / 64 + 1;
+            hi = hi < hr ? hi : hr;
+            jt_hi = jt_hi < hi ? jt_hi : hi;
+            if (i0 - bl > 0) jt_lo = (i0 - bl) / 64;
+        }
+    }
+    const float irs = 1.0f / sqrtf((float)d);
+    auto stage_rows = [&](char* dst, auto rowval) __attribute__((always_inline)) {     // 64 fp32 rows -> split fp16 rows [64][ROW] hi | lo
+        for (int c = tid; c < 64 * CPR; c += 256) {
+            const int r = c / CPR, x = (c - r * CPR) * 4;
+            const float4 v = rowval(r, x);
+            uint32_t h0, l0, h1, l1;
+            split2(v.x, v.y, h0, l0); split2(v.z, v.w, h1, l1);
+            *reinterpret_cast<uint2*>(dst + r * ROW + x * 2) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2*>(dst + 64 * ROW + r * ROW + x * 2) = make_uint2(l0, l1);
+        }
+    };
+    // band row w (0 .. 127) of key tile j0 = E row Tgmax - 1 + j0 - i0 - 63 + w, clamped (rows no visible pair touches); column d = the positional bias
+    auto eval = [&](int w, int j0, int x) {
+        int rel = p.Tg - 1 + j0 - i0 - 63 + w;
+        rel = rel < 0 ? 0 : (rel > erows - 1 ? erows - 1 : rel);
+        float4 v = ld_span4(ebase + gd * rel, x, d);
+        if (d >= x && d < x + 4) {
+            const float cb = p.cb[(size_t)rel * p.H + h];
+            if (d == x) v.x = cb; else if (d == x + 1) v.y = cb; else if (d == x + 2) v.z = cb; else v.w = cb;
+        }
+        return v;
+    };
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x16 oacc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
+    float* sSw = sS + wave * 32 * SS_LD;
+    const int iq = i0 + 32 * wq + lr;                            // this lane's query (may lie behind the utterance: computed on clamped data, never stored)
+    int cur = 0;                                                 // 0: band rows 0 .. 63 of the current key tile live in half A
+    stage_rows(sEA, [&](int r, int x) { return eval(r, jt_lo * 64, x); });
+    for (int jt = jt_lo; jt < jt_hi; ++jt, cur ^= 1) {
+        const int j0 = jt * 64;
+        char* const eLo = cur ? sEB : sEA;
+        char* const eHi = cur ? sEA : sEB;
+        char* const sV = L::VALIAS ? (cur ? sK : sEA) : sVfix;   // alias: consumed band half + K tile (contiguous either way)
+        stage_rows(sK, [&](int r, int x) { int j = j0 + r; j = j < Tg ? j : Tg - 1; return ld_span4(kbase + gd * j, x, dspan(j)); });
+        stage_rows(eHi, [&](int r, int x) { return eval(64 + r, j0, x); });
+        auto stage_v = [&]() __attribute__((always_inline)) {
+            // consecutive lanes <-> consecutive KEYS of one column quad: the transposing 2-byte stores of a wave fall on 32 consecutive dwords
+            for (int c = tid; c < 64 * 8 * NT; c += 256) {
+                const int r = c & 63, x = (c >> 6) * 4;
+                int j = j0 + r; j = j < Tg ? j : Tg - 1;         // keys behind the utterance: finite data times zero probabilities
+                const float4 v = ld_span4(vbase + gd * j, x, dspan(j));
+                const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 4; e += 2) {
+                    uint32_t hh, ll;
+                    split2(vv[e], vv[e + 1], hh, ll);
+                    *reinterpret_cast<uint16_t*>(sV + (x + e) * VROW + r * 2) = (uint16_t)(hh & 0xFFFFu);
+                    *reinterpret_cast<uint16_t*>(sV + (x + e + 1) * VROW + r * 2) = (uint16_t)(hh >> 16);
+                    *reinterpret_cast<uint16_t*>(sV + 32 * NT * VROW + (x + e) * VROW + r * 2) = (uint16_t)(ll & 0xFFFFu);
+                    *reinterpret_cast<uint16_t*>(sV + 32 * NT * VROW + (x + e + 1) * VROW + r * 2) = (uint16_t)(ll >> 16);
+                }
+            }
+        };
+        if (!L::VALIAS) stage_v();
+        __syncthreads();
+        // ---- S1^T = K (Q + u)^T on this wave's 32 keys x 32 queries
+        f32x16 s1h, s1x;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s1h[r] = 0.f; s1x[r] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int ko = (16 * s + 8 * kh) * 2;
+            const f16x8 ah = *reinterpret_cast<const f16x8*>(sK + (32 * wk + lr) * ROW + ko), al = *reinterpret_cast<const f16x8*>(sK + 64 * ROW + (32 * wk + lr) * ROW + ko);
+            s1h = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, quh[s], s1h, 0, 0, 0);
+            s1x = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qul[s], s1x, 0, 0, 0);
+            s1x = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, quh[s], s1x, 0, 0, 0);
+        }
+        // ---- band product E_band (Q + u)^T on the 64 band rows this wave's (key, query) pairs touch, realigned by the writer:
+        //      pair (jj, ii) of the wave's tile reads band row jj - ii + 31 of those 64; value of band row wr for query ii goes to S[wr - 31 + ii][ii].
+        //      Banks: writer 40 wr + 41 ii (41 odd: 32 queries on 32 banks, the kh halves 160 = 32 banks apart), reader 40 jj + ii likewise
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int wb = 32 * (wk - wq + 1 + t) + lr;          // band row of the workgroup tile this lane loads as the A operand
+            const char* eb = ((wb >> 6) ? eHi : eLo) + (wb & 63) * ROW;
+            f32x16 ph, px;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { ph[r] = 0.f; px[r] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int ko = (16 * s + 8 * kh) * 2;
+                const f16x8 eh = *reinterpret_cast<const f16x8*>(eb + ko), el = *reinterpret_cast<const f16x8*>(eb + 64 * ROW + ko);
+                ph = __builtin_amdgcn_mfma_f32_32x32x16_f16(eh, quh[s], ph, 0, 0, 0);
+                px = __builtin_amdgcn_mfma_f32_32x32x16_f16(eh, qul[s], px, 0, 0, 0);
+                px = __builtin_amdgcn_mfma_f32_32x32x16_f16(el, quh[s], px, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int jj = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * kh - 31 + lr;
+                if (jj >= 0 && jj < 32) sSw[jj * SS_LD + lr] = fmaf(px[r], LO_INV, ph[r]);
+            }
+        }
+        wave_sync();
+        // ---- scores of this lane's query against its 16 keys: scale, additive mask (attentions.py:692-701: ONE mask = max(padding, streaming)), online softmax
+        float sc[16], tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int jj = (r & 3) + 8 * (r >> 2) + 4 * kh, j = j0 + 32 * wk + jj;
+            float sv = (fmaf(s1x[r], LO_INV, s1h[r]) + sSw[jj * SS_LD + lr]) * irs;
+            if (G * j >= klen || j - iq > br || iq - j > bl) sv += -1e9f;
+            if (j >= Tg) sv = -INFINITY;                         // no such key (ragged: behind this utterance; the last tile's tail)
+            sc[r] = sv;
+            tmax = fmaxf(tmax, sv);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        const float m_new = fmaxf(m_run, tmax);
+        const float m_use = m_new < -1e30f ? 0.f : m_new;
+        const float alpha = expm(m_run - m_use);
+        m_run = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sc[r] = expm(sc[r] - m_use); psum += sc[r]; }
+        l_run = fmaf(l_run, alpha, psum);                        // the two kh halves keep partial sums (same alpha): added once at the end
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
+        // probabilities as B fragments: accumulator registers 8 s .. 8 s + 7 ARE k positions 8 kh .. 8 kh + 7 of k-step s (keys 4 kh + (e & 3) + 8 (e >> 2) + 16 s)
+        f16x8 pbh[2], pbl[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            uint32_t hh[4], ll[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) split2(sc[8 * s + 2 * e], sc[8 * s + 2 * e + 1], hh[e], ll[e]);
+            pbh[s] = as_f16x8(make_uint4(hh[0], hh[1], hh[2], hh[3])); pbl[s] = as_f16x8(make_uint4(ll[0], ll[1], ll[2], ll[3]));
+        }
+        if (L::VALIAS) { __syncthreads(); stage_v(); __syncthreads(); }      // every wave is done with the K tile and the lower band half
+        // ---- O^T += V^T P^T over this wave's 32 keys; the correction accumulator is folded per column tile
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            f32x16 ox;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ox[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const char* vr = sV + (32 * t + lr) * VROW + (32 * wk + 16 * s + 4 * kh) * 2;
+                const uint2 a0 = *reinterpret_cast<const uint2*>(vr), a1 = *reinterpret_cast<const uint2*>(vr + 16);
+                const uint2 b0 = *reinterpret_cast<const uint2*>(vr + 32 * NT * VROW), b1 = *reinterpret_cast<const uint2*>(vr + 32 * NT * VROW + 16);
+                const f16x8 vh = as_f16x8(make_uint4(a0.x, a0.y, a1.x, a1.y)), vl = as_f16x8(make_uint4(b0.x, b0.y, b1.x, b1.y));
+                oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pbh[s], oacc[t], 0, 0, 0);
+                ox = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pbl[s], ox, 0, 0, 0);
+                ox = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, pbh[s], ox, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[t][r] = fmaf(ox[r], LO_INV, oacc[t][r]);
+        }
+        __syncthreads();                                         // the next tile's staging overwrites the K tile, the lower band half and V^T
+    }
+    // ---- merge the two key halves of every query (wave wk = 1 -> wave wk = 0 through LDS), normalise, un-group (attentions.py:707-712)
+    l_run += __shfl_xor(l_run, 32);
+    float* mrg = reinterpret_cast<float*>(sm) + (size_t)wq * (16 * NT + 2) * 64;
+    if (wk == 1) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mrg[(16 * t + r) * 64 + lane] = oacc[t][r];
+        mrg[16 * NT * 64 + lane] = m_run;
+        mrg[(16 * NT + 1) * 64 + lane] = l_run;
+    }
+    __syncthreads();
+    if (wk == 0 && iq < Tg) {
+        const float m1 = mrg[16 * NT * 64 + lane], l1 = mrg[(16 * NT + 1) * 64 + lane];
+        const float mm = fmaxf(m_run, m1);
+        const float a0 = expm(m_run - mm), a1 = expm(m1 - mm);
+        const float inv = sx_rcp(fmaf(l_run, a0, l1 * a1));
+        float* orow = p.out + row0 * D + gd * iq + hb;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int x = 32 * t + 8 * rq + 4 * kh;
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = fmaf(oacc[t][4 * rq + e], a0, mrg[(16 * t + 4 * rq + e) * 64 + lane] * a1) * inv;
+                if (x + 3 < d) {
+                    typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+                    *reinterpret_cast<f32x4_a4*>(orow + x) = f32x4_a4{o[0], o[1], o[2], o[3]};
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (x + e < d) orow[x + e] = o[e];
+                }
+            }
+    }
+}
+
+// cb[r][h] = sum_x (v - u)[(h d + x) mod D] E[r][h d + x]: what (Q + v) E^T has over (Q + u) E^T, one number per (relative position, head); input independent
+__global__ __launch_bounds__(256) void sxf_posbias_kernel(const float* __restrict__ e, const float* __restrict__ u, const float* __restrict__ vb, int erows, int H,
+                                                          int G, int D, int d, float* __restrict__ cb) {
+    const int wid = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wid >= erows * H) return;
+    const int r = wid / H, h = wid % H;
+    const float* er = e + (size_t)r * G * D + (size_t)h * d;
+    float acc = 0.f;
+    for (int x = lane; x < d; x += 64) {
+        const int n = (int)(((size_t)h * d + x) % D);
+        acc = fmaf(vb[n] - u[n], er[x], acc);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) cb[wid] = acc;
+}
+
+// depthwise conv (k taps, "same" or causal zero pre-padding at the UTTERANCE's own ends, stride S) + folded BatchNorm + Swish, fp32 (modules.py:516-518;
+// layers.py:97-101): 8 output frames of one channel per thread from a register window, taps in ascending order (the order of exact.hip's kernels).
+// Utterance b: input rows in_off[b] .. + in_len[b], output rows out_off[b] .. + out_len[b]; output rows up to out_off[b + 1] (group padding) are zero filled.
+// Rectangular batches: offsets b T / b To, lengths T / To (pad frames are live: SURVEY.md 8a).
+template <int KSZ, int S>
+__global__ __launch_bounds__(256) void sxf_dwconv_kernel(const float* __restrict__ g, int B, int T, int To, int C, const float* __restrict__ w_kc,
+                                                         const float* __restrict__ bias, float* __restrict__ out, RaggedConv rc, int ragged, int causal, int ntile) {
+    constexpr int TO = 8, W = S * (TO - 1) + KSZ;
+    const int pre = causal ? KSZ - 1 : (KSZ - 1) / 2;
+    const long long total = (long long)B * ntile * C;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int c = (int)(idx % C);
+        const long long q = idx / C;
+        const int tile = (int)(q % ntile), b = (int)(q / ntile);
+        long long ibase, obase; int tin, tout, tcap;
+        if (ragged) { ibase = rc.in_off[b]; obase = rc.out_off[b]; tin = rc.in_len[b]; tout = rc.out_len[b]; tcap = rc.out_off[b + 1] - rc.out_off[b]; }
+        else { ibase = (long long)b * T; obase = (long long)b * To; tin = T; tout = To; tcap = To; }
+        const int to0 = tile * TO;
+        if (to0 >= tcap) continue;
+        const int t0 = S * to0 - pre;
+        const float* gp = g + ibase * C + c;
+        float x[W], w[KSZ];
+#pragma unroll
+        for (int i = 0; i < W; ++i) {
+            const int t = t0 + i;
+            const bool ok = t >= 0 && t < tin;
+            x[i] = ok ? gp[(size_t)(ok ? t : 0) * C] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < KSZ; ++j) w[j] = w_kc[(size_t)j * C + c];
+        const float bz = bias[c];
+#pragma unroll
+        for (int o = 0; o < TO; ++o) {
+            if (to0 + o >= tcap) break;
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < KSZ; ++j) acc = fmaf(w[j], x[S * o + j], acc);
+            const float y = acc + bz;
+            out[(obase + to0 + o) * C + c] = to0 + o < tout ? y * sx_rcp(1.0f + sx_expf(fminf(-y, 87.0f))) : 0.f;
+        }
+    }
+}
+
+// out[out_off[b] + t][:] = x[in_off[b] + stride t][:] for t < out_len[b], zero rows up to out_off[b + 1]  (blocks.py:106-110: the 1 x 1 strided conv_res reads frames 0, s, 2s, ..)
+__global__ __launch_bounds__(256) void sxf_decimate_kernel(const float* __restrict__ x, int D4, int stride, RaggedConv rc, float* __restrict__ out) {
+    const long long total = (long long)rc.out_rows * D4;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int c = (int)(idx % D4);
+        const int m = (int)(idx / D4);
+        const int b = ragged_find(rc.out_off, rc.n, m);
+        const int t = m - rc.out_off[b];
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t < rc.out_len[b]) v = reinterpret_cast<const float4*>(x)[((size_t)rc.in_off[b] + (size_t)stride * t) * D4 + c];
+        reinterpret_cast<float4*>(out)[idx] = v;
+    }
+}
+
+// a[m][n] * sigmoid(a[m][N + n]) on fp32 rows (GLU over channels, activations.py:37-39) with the accurate transcendental forms of the split kernels
+__global__ __launch_bounds__(256) void sxf_glu_kernel(const float* __restrict__ in, long long M, int N4, float* __restrict__ out) {
+    const long long total = M * N4;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const long long m = idx / N4; const int n = (int)(idx % N4);
+        const float4 a = reinterpret_cast<const float4*>(in)[m * 2 * N4 + n], gt = reinterpret_cast<const float4*>(in)[m * 2 * N4 + N4 + n];
+        float4 o;
+        o.x = a.x * sx_rcp(1.0f + sx_expf(fminf(-gt.x, 87.0f))); o.y = a.y * sx_rcp(1.0f + sx_expf(fminf(-gt.y, 87.0f)));
+        o.z = a.z * sx_rcp(1.0f + sx_expf(fminf(-gt.z, 87.0f))); o.w = a.w * sx_rcp(1.0f + sx_expf(fminf(-gt.w, 87.0f)));
+        reinterpret_cast<float4*>(out)[idx] = o;
+    }
+}
+
+template <int KS, int NT>
+int launch_attn(const SxfAttnParams& p, hipStream_t s) {
+    using L = AttnLds<KS, NT>;
+    static_assert(L::BYTES <= 160 * 1024, "LDS image of the fused split attention");
+    static_assert((16 * NT + 2) * 64 * 4 * 2 <= 3 * L::HALF, "merge buffer");
+    static LdsAttr attr;
+    ensure_dynamic_lds(reinterpret_cast<const void*>(&sxf_attention_kernel<KS, NT>), L::BYTES, attr);
+    hipLaunchKernelGGL((sxf_attention_kernel<KS, NT>), dim3((p.Tg + 63) / 64, p.B * p.H), dim3(256), L::BYTES, s, p);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+template <int KSZ, int S>
+int launch_dw(const float* g, int B, int T, int To, int C, const float* w, const float* bias, float* out, const RaggedConv* rc, int causal, int tcap_max, hipStream_t s) {
+    const int ntile = (tcap_max + 7) / 8;
+    const long long total = (long long)B * ntile * C;
+    if (total <= 0) return 0;
+    const int grid = (int)std::min<long long>((total + 255) / 256, 1 << 20);
+    RaggedConv r{};
+    if (rc) r = *rc;
+    hipLaunchKernelGGL((sxf_dwconv_kernel<KSZ, S>), dim3(grid), dim3(256), 0, s, g, B, T, To, C, w, bias, out, r, rc ? 1 : 0, causal, ntile);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+}  // namespace
+
+bool sxf_attention_supported(int d) { return d >= 1 && d <= 144; }
+
+int launch_sxf_posbias(const float* e, const float* u, const float* vb, int erows, int H, int G, int D, int d, float* cb, hipStream_t s) {
+    const long long waves = (long long)erows * H;
+    if (waves <= 0) return 0;
+    hipLaunchKernelGGL(sxf_posbias_kernel, dim3((unsigned)((waves * 64 + 255) / 256)), dim3(256), 0, s, e, u, vb, erows, H, G, D, d, cb);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_sxf_attention(const SxfAttnParams& p, hipStream_t s) {
+    if (p.B <= 0 || p.Tg <= 0) return 0;
+    if (!sxf_attention_supported(p.d) || (long long)p.B * p.H > 65535 || !p.cb) return -2;
+    const int ks = (p.d + 1 + 15) / 16;                         // head width + the positional bias column
+    switch (ks) {
+        case 1: return launch_attn<1, 1>(p, s);
+        case 2: return launch_attn<2, 1>(p, s);
+        case 3: return p.d <= 32 ? launch_attn<3, 1>(p, s) : launch_attn<3, 2>(p, s);
+        case 4: return launch_attn<4, 2>(p, s);
+        case 5: return p.d <= 64 ? launch_attn<5, 2>(p, s) : launch_attn<5, 3>(p, s);
+        case 6: return launch_attn<6, 3>(p, s);
+        case 7: return p.d <= 96 ? launch_attn<7, 3>(p, s) : launch_attn<7, 4>(p, s);
+        case 8: return launch_attn<8, 4>(p, s);
+        case 9: return p.d <= 128 ? launch_attn<9, 4>(p, s) : launch_attn<9, 5>(p, s);
+        default: return launch_attn<10, 5>(p, s);
+    }
+}
+
+int launch_sxf_dwconv(const float* g, int B, int T, int To, int C, const float* w_kc, const float* bias, int ks, int stride, float* out, hipStream_t s,
+                      const RaggedConv* rc, int causal, int tcap_max) {
+    if (!rc) tcap_max = To;
+    if (ks == 15 && stride == 1) return launch_dw<15, 1>(g, B, T, To, C, w_kc, bias, out, rc, causal, tcap_max, s);
+    if (ks == 15 && stride == 2) return launch_dw<15, 2>(g, B, T, To, C, w_kc, bias, out, rc, causal, tcap_max, s);
+    if (ks == 31 && stride == 1) return launch_dw<31, 1>(g, B, T, To, C, w_kc, bias, out, rc, causal, tcap_max, s);
+    if (ks == 31 && stride == 2) return launch_dw<31, 2>(g, B, T, To, C, w_kc, bias, out, rc, causal, tcap_max, s);
+    if (ks == 7 && stride == 1) return launch_dw<7, 1>(g, B, T, To, C, w_kc, bias, out, rc, causal, tcap_max, s);
+    if (ks == 7 && stride == 2) return launch_dw<7, 2>(g, B, T, To, C, w_kc, bias, out, rc, causal, tcap_max, s);
+    if (ks == 3 && stride == 1) return launch_dw<3, 1>(g, B, T, To, C, w_kc, bias, out, rc, causal, tcap_max, s);
+    if (ks == 3 && stride == 2) return launch_dw<3, 2>(g, B, T, To, C, w_kc, bias, out, rc, causal, tcap_max, s);
+    return -2;
+}
+
+int launch_sxf_decimate(const float* x, int D, int stride, const RaggedConv& rc, float* out, hipStream_t s) {
+    if (D % 4) return -2;
+    const long long total = (long long)rc.out_rows * (D / 4);
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(sxf_decimate_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 1 << 20)), dim3(256), 0, s, x, D / 4, stride, rc, out);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_sxf_glu(const float* in, long long M, int N, float* out, hipStream_t s) {
+    if (N % 4) return -2;
+    const long long total = M * (N / 4);
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(sxf_glu_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 1 << 20)), dim3(256), 0, s, in, M, N / 4, out);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}

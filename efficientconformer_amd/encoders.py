@@ -159,7 +159,8 @@ class ConformerEncoder(nn.Module):
         the fp32 matrix pipe end to end, greedy label sequences identical to the reference's CPU fp32 path wherever its top-2 logit margins
         exceed fp32 summation noise (reference model_ctc.py:99-133), about 10x slower - or "split": the same schedule with every GEMM and the
         attention products on the fp16 matrix pipe with operands split into two fp16 numbers (csrc/split.hip: products accurate to ~2^-21,
-        three MFMAs per product): the fast label-exact mode."""
+        three MFMAs per product): the fast label-exact mode - since round 6 on fused kernels (csrc/sxf.hip: attention without scores in memory) that take
+        ragged batches, `causal` configurations and finite contexts like the bf16 path."""
         return ("bf16", "fp32", "split")[self._exact]
 
     @precision.setter
@@ -367,8 +368,8 @@ class ConformerEncoder(nn.Module):
         attentions = [None] * len(self.plan.blocks)
         host_lens = None
         if self.ragged:            # the host copy of the lengths ONCE, validated before anything is sized from it (without x_len_host: one device sync)
-            if self._exact:
-                raise RuntimeError("ragged batches run on the bf16 path (precision = 'fp32' / 'split' keep rectangular batches)")
+            if self._exact == 1:
+                raise RuntimeError("ragged batches run on the bf16 path and in precision = 'split' (precision = 'fp32' keeps rectangular batches)")
             hl = x_len_host if x_len_host is not None else lens.cpu()
             host_lens = np.ascontiguousarray(np.asarray(hl.cpu() if torch.is_tensor(hl) else hl, dtype=np.int64))
             if host_lens.shape != (batch,):

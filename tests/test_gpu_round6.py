@@ -171,3 +171,60 @@ def test_short_utterances_of_the_plain_conformer_configs_vs_oracle(name):
         worst_max = max(worst_max, float(e.max())); means.append(float(e.mean()))
     print("%s ragged: worst max %.4f, per-utterance mean %s" % (name, worst_max, ["%.4f" % v for v in means]))
     assert worst_max < 0.08 and max(means) < 0.014
+
+
+# ------------------------------------------------------------------ the label-exact split mode on the fused kernels (csrc/sxf.hip): ragged, causal, streaming
+import os
+
+from test_gpu_round3 import _STREAM, _ragged_vs_alone, _stream_model
+
+SPLIT_MAX, SPLIT_MEAN = 2e-4, 2e-5            # the label-exact modes' stated bound against the oracle / the reference goldens (measured ~5e-6 / 1e-6)
+
+
+@pytest.mark.parametrize("gname", _STREAM)
+def test_split_mode_streaming_and_causal_vs_reference_goldens(golden_dir, gname):
+    """`causal` (causal relative tables attentions.py:506-529, 1243-1247; causal depthwise pre-padding layers.py:97-101) and finite
+    left / right contexts (attentions.py:1377-1403) in the split mode, against the REFERENCE run with those settings (tools/make_goldens.py --only-streaming):
+    encoder output within 2e-4 at every frame - pad frames included, whose fully masked rows follow the reference's uniform softmax - and the per-frame argmax
+    identical wherever the reference's top-2 margin exceeds 1e-3.  Until round 5 the exact modes refused `causal` (test_exact_mode_rejects_streaming_contexts)."""
+    g = np.load(os.path.join(golden_dir, gname))
+    m, sd, small = _stream_model(gname, g)
+    m.encoder.precision = "split"
+    lens = g["mel_len"].tolist()
+    mel, ln = synth.make_mel(len(lens), 80, max(lens), lens, seed=int(g["mel_seed"]))
+    out, out_len, _ = m.encoder.forward_mel(torch.from_numpy(mel).cuda(), torch.from_numpy(ln).cuda())
+    assert out_len.cpu().tolist() == g["out_len"].tolist()
+    ref = torch.from_numpy(g["out_rows"] if small else g["out"])
+    got = out.cpu()[:, ::4] if small else out.cpu()
+    d = (got - ref).abs()
+    print("%s split: max %.2e mean %.2e" % (gname, float(d.max()), float(d.mean())))
+    assert float(d.max()) < SPLIT_MAX and float(d.mean()) < SPLIT_MEAN
+    if small:
+        logits, _, _ = m._head(out, out_len, want_logits=True)
+        am = logits.argmax(-1).cpu().numpy()
+        valid = np.arange(am.shape[1])[None, :] < g["out_len"][:, None]
+        safe = (g["margin"] > 1e-3) & valid
+        assert safe.sum() > 20 and np.array_equal(am[safe], g["argmax"][safe])
+
+
+@pytest.mark.parametrize("name,extra,nsub", [("Tiny", {}, 1), ("Tiny", {}, 3), ("Tiny", dict(causal=True), 2), ("Tiny", dict(left_context=20, right_context=4), 2),
+                                             ("Tiny", dict(causal=True, left_context=6), 1), ("EfficientConformerCTCSmall", {}, 2), ("ConformerCTCSmall", {}, 2),
+                                             ("EfficientConformerCTCMedium", {}, 1), ("EfficientConformerCTCSmall", dict(causal=True), 1)])
+def test_split_mode_ragged_batch_equals_utterances_alone_and_the_oracle(name, extra, nsub):
+    """ragged batches in the split mode.  Every utterance of a ragged forward is, bit for bit, the split-mode encoder's output for that
+    utterance ALONE (B = 1, rectangular), and within 2e-4 / 2e-5 of the oracle run on it alone; one and several row ranges; grouped stages with T % 3 = 0, 1, 2;
+    the two-layer subsampler (ConformerCTCSmall); head widths 18 .. 135 (Medium stage 0: the V^T-aliasing instance of the attention kernel); causal and
+    finite contexts.  Reference: encoders.py:97-142 on a batch of one."""
+    cfg = named_config(name)
+    cfg["encoder_params"] = dict(cfg["encoder_params"], **extra)
+    m = ModelCTC.from_config(cfg)
+    sd = synth.make_state_dict(m.encoder.plan, 7, cfg["tokenizer_params"]["vocab_size"], prefix="encoder.")
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    osd = {k[len("encoder."):] if k.startswith("encoder.") else k: v for k, v in sd.items()}
+    m.encoder.precision = "split"
+    if name == "Tiny":
+        lens = np.array([48000, 47840, 41000, 37000, 30160, 22000, 12000, 9000, 3000, 640, 300], dtype=np.int64)     # down to 2 mel frames
+    else:
+        lens = np.array([70000, 52345, 33000, 20000, 8000], dtype=np.int64)
+    audio = torch.from_numpy(synth.make_audio(lens, seed=4))
+    _ragged_vs_alone(m.cuda(), osd, audio, lens, nsub, tol=(SPLIT_MAX, SPLIT_MEAN))
