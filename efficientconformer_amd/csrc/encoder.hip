@@ -908,7 +908,7 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
 
 // ------------------------------------------------------------------ fp32-operand "exact" forward (kernels: exact.hip)
 struct XWorkspace { size_t total = 0, conv1, sub, x0, x1, a, h, q, k, v, e, o, p1, g, c, lens, scores = 0; size_t qkv_stride = 0;
-                    size_t cb = 0, xs = 0, xrect = 0, mel_len = 0, row_off = 0, wg_off = 0, tile_off = 0; };     // sxf.hip forward: positional bias, decimated rows, ragged descriptors
+                    size_t kp = 0, vp = 0, ep = 0, xs = 0, xrect = 0, mel_len = 0, row_off = 0, wg_off = 0, tile_off = 0; };     // sxf.hip forward: operand images (bytes / 4), decimated rows, ragged descriptors
 
 // rows come from the Shapes totals: B * T for rectangular batches, the sums over the utterances for ragged ones (s.Tm = the input's row pitch there)
 XWorkspace make_xworkspace(const EcEncoder* e, const Shapes& s) {
@@ -916,7 +916,7 @@ XWorkspace make_xworkspace(const EcEncoder* e, const Shapes& s) {
     size_t off = 0;
     auto take = [&](size_t floats) { size_t o = off; off += al(floats * 4); return o; };
     const size_t B = s.B;
-    size_t mx = 0, mh = 0, mq = 0, me = 0, mp = 0, mg = 0, mc = 0, mcb = 0, mxs = 0;
+    size_t mx = 0, mh = 0, mq = 0, me = 0, mp = 0, mg = 0, mc = 0, mkp = 0, mvp = 0, mep = 0, mxs = 0;
     for (size_t k = 0; k < e->blocks.size(); ++k) {
         const EcBlock& b = e->blocks[k];
         const size_t T = s.Tin[k], D = b.dim_model, De = b.dim_expand;
@@ -926,7 +926,12 @@ XWorkspace make_xworkspace(const EcEncoder* e, const Shapes& s) {
         mh = std::max(mh, std::max(Mi * D, Mo * De) * b.ff_ratio);
         mq = std::max(mq, Mqk * D);
         me = std::max(me, (2 * Tp - b.group_size) * D);
-        mcb = std::max(mcb, (2 * Tp / b.group_size) * (size_t)b.num_heads);
+        {   // operand images of the fused split attention (kernels.h: SxfAttnParams), in floats
+            const size_t dh = b.group_size * D / b.num_heads, pk = sxf_attention_pk((int)dh), vx = sxf_attention_vx((int)dh), Tg = Tp / b.group_size;
+            mkp = std::max(mkp, (Mqk / b.group_size + 64) * b.num_heads * 2 * pk / 2);
+            mvp = std::max(mvp, B * b.num_heads * 2 * vx * (size_t)ec_round_up((int)Tg, 64) / 2);
+            mep = std::max(mep, 2 * Tg * b.num_heads * 2 * pk / 2);
+        }
         mp = std::max(mp, Mi * 2 * De);
         mg = std::max(mg, Mi * De);
         mc = std::max(mc, Mo * De);
@@ -952,7 +957,7 @@ XWorkspace make_xworkspace(const EcEncoder* e, const Shapes& s) {
                 ms = std::max(ms, sx_attention_scores_bytes(s.B, b.num_heads, Tg) / 4);
             }
         w.scores = take(ms);
-        w.cb = take(mcb); w.xs = take(mxs);
+        w.kp = take(mkp); w.vp = take(mvp); w.ep = take(mep); w.xs = take(mxs);
         if (s.ragged) {
             const size_t nbk = e->blocks.size();
             w.xrect = take(B * T1r * e->blocks[0].dim_model);
@@ -1177,7 +1182,8 @@ int forward_core_split(EcEncoder* e, const float* mel, const int64_t* in_len, in
     }
     trace_add(e, st, "linear", x, s.Min[0], D0, D0, 0);
     float *a = F32(w.a), *hb = F32(w.h), *q = F32(w.q), *kk = F32(w.k), *v = F32(w.v), *eb = F32(w.e), *o = F32(w.o), *p1 = F32(w.p1), *g = F32(w.g),
-          *cbuf = F32(w.c), *posb = F32(w.cb), *xs = F32(w.xs);
+          *cbuf = F32(w.c), *xs = F32(w.xs);
+    uint16_t *kpk = reinterpret_cast<uint16_t*>(ws + w.kp), *vpk = reinterpret_cast<uint16_t*>(ws + w.vp), *epk = reinterpret_cast<uint16_t*>(ws + w.ep);
     char nm[64];
     int xmask_stride = 1;                      // product of the strides of the blocks before block k
     auto layernorm = [&](const float* in, int rows, int dim, const LNp& ln, float* dst) {
@@ -1213,9 +1219,9 @@ int forward_core_split(EcEncoder* e, const float* mel, const int64_t* in_len, in
         const float* tab = e->xtab[std::make_pair(b.max_pos, D)];
         const int erows = c.causal ? Tp : 2 * Tp - G;
         EC_TRY(xgemm(e, st, tab + (size_t)(b.max_pos - Tp + (c.causal ? 0 : G / 2)) * D, D, erows, m + ".mhsa.pos_layer", D, D, eb, D));
-        { PROF(PC_MISC, 0, (double)erows * D * 4); EC_TRY(launch_sxf_posbias(eb, W.u, W.v, erows / G, H, G, D, d, posb, st)); }
+        { PROF(PC_MISC, 0, (double)erows * D * 8); EC_TRY(launch_sxf_pack_e(eb, W.u, W.v, erows / G, H, G, D, d, epk, st)); }
         SxfAttnParams ap{};
-        ap.q = q; ap.k = kk; ap.v = v; ap.e = eb; ap.cb = posb; ap.u = W.u; ap.lens = lens + (size_t)k * B;
+        ap.q = q; ap.k = kk; ap.v = v; ap.kp = kpk; ap.vp = vpk; ap.ep = epk; ap.vpitch = ec_round_up(Tg, 64); ap.u = W.u; ap.lens = lens + (size_t)k * B;
         ap.off = rg ? row_off + (size_t)k * (B + 1) : nullptr;
         ap.B = B; ap.H = H; ap.G = G; ap.D = D; ap.d = d; ap.T = T; ap.Tp = Tp; ap.Tg = Tg; ap.out = o; ap.causal = c.causal;
         {   // streaming mask of this block (encoders.py:132-136, attentions.py:698): contexts in frames after the subsampling, sliced ::stride after every
@@ -1223,6 +1229,7 @@ int forward_core_split(EcEncoder* e, const float* mel, const int64_t* in_len, in
             const long long unit = (long long)xmask_stride * G;
             ap.band_l = (int)std::min<long long>(c.left_context / unit, 1 << 30); ap.band_r = (int)std::min<long long>(c.right_context / unit, 1 << 30);
         }
+        { PROF(PC_MISC, 0, (double)s.Mq[k] * D * 16); EC_TRY(launch_sxf_pack_kv(ap, st)); }
         { PROF(PC_ATTENTION, 2.0 * H * (rg ? s.tg2[k] : (double)B * Tg * Tg) * d * 3.0, (double)s.Mq[k] * D * 4 * 4);
           EC_TRY(launch_sxf_attention(ap, st)); }
         snprintf(nm, sizeof(nm), "blocks.%d.att_o", k); trace_add(e, st, nm, o, s.Mq[k], D, D, 0);

@@ -251,9 +251,9 @@ int launch_sx_attention(const ExAttnParams& p, float* scores, hipStream_t s);   
 
 // ---------------------------------------------------------------- split-precision mode on fused kernels  (sxf.hip, round 6): ragged batches, causal / streaming
 struct SxfAttnParams {             // natural-layout fp32 rows [rows][D]: Q, K, V straight from the projection (no + u / + v, no pad-row pass), out likewise
-    const float *q, *k, *v;
-    const float* e;                // E = pos_layer(R) fp32 [causal ? Tp : 2 Tp - G][D] for the LONGEST utterance (Tp = G Tg)
-    const float* cb;               // launch_sxf_posbias: [causal ? Tg : 2 Tg - 1][H]
+    const float *q, *k, *v;        // k, v: read by launch_sxf_pack_kv only
+    const uint16_t *kp, *vp, *ep;  // operand images (sxf.hip): K [grouped row][H][2][PK], V^T [B][H][2][VX][vpitch], E [causal ? Tg : 2 Tg - 1][H][2][PK] fp16 (h | l)
+    int vpitch;                    // keys per V^T row: a multiple of 64 >= Tg
     const float* u;                // [D] content bias (attentions.py:474)
     const int* lens;               // [B] valid frames per utterance at this stage (key mask; ragged: the utterance's frames)
     const int* off;                // ragged: [B + 1] first row of every utterance (rows padded to the group size); null: utterance b = rows b Tp ..
@@ -263,8 +263,12 @@ struct SxfAttnParams {             // natural-layout fp32 rows [rows][D]: Q, K, 
     int band_l, band_r, causal;    // key j of query i visible iff -band_l <= j - i <= band_r (grouped positions); causal: E holds the non-negative distances
 };
 bool sxf_attention_supported(int d);
+int sxf_attention_pk(int d);       // columns per K / E image row half
+int sxf_attention_vx(int d);       // rows per V^T image plane
+int launch_sxf_pack_kv(const SxfAttnParams& p, hipStream_t s);       // K / V (fp32, this block's projections) -> their images
+// E = pos_layer(R) fp32 [erows_grouped * G][D] -> its image, the positional bias (v - u) E^T in column d
+int launch_sxf_pack_e(const float* e, const float* u, const float* vb, int erows_grouped, int H, int G, int D, int d, uint16_t* ep, hipStream_t s);
 int launch_sxf_attention(const SxfAttnParams& p, hipStream_t s);
-int launch_sxf_posbias(const float* e, const float* u, const float* vb, int erows_grouped, int H, int G, int D, int d, float* cb, hipStream_t s);
 // fp32 depthwise conv + folded BatchNorm + Swish; rc != null: per-utterance row ranges (tcap_max = the longest utterance's padded output rows)
 int launch_sxf_dwconv(const float* g, int B, int T, int To, int C, const float* w_kc, const float* bias, int ks, int stride, float* out, hipStream_t s,
                       const RaggedConv* rc = nullptr, int causal = 0, int tcap_max = 0);

@@ -20,6 +20,7 @@ namespace {
 
 using namespace sx;
 
+constexpr int SS_ROWS = 34;                                      // 32 key rows + a dump row on either side (band rows no pair of the wave's tile reads)
 constexpr int SS_LD = 40;                                        // floats per key row of a wave's skew buffer (conflict-free: see the writer below)
 constexpr int VROW = 64 * 2 + 16;                                // bytes per row of the V^T tiles (64 keys)
 
@@ -29,16 +30,18 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// exp(x) for x in [-inf, ~0]: sx_expf with the -inf case (excluded keys, the first tile's running maximum) made explicit
-__device__ __forceinline__ float expm(float x) { return x < -1e30f ? 0.f : sx_expf(x); }
+// workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding GLOBAL load (s_waitcnt vmcnt(0)), i.e. for the next
+// tile's prefetch the moment it was issued
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int KS, int NT>
 struct AttnLds {
     static constexpr int PK = 16 * KS, ROW = PK * 2 + 16;
     static constexpr int HALF = 2 * 64 * ROW;                    // one band half / the K tile: hi [64][ROW] | lo [64][ROW]
     static constexpr int VT = 2 * 32 * NT * VROW;                // V^T hi | lo
-    static constexpr bool VALIAS = 3 * HALF + VT + 4 * 32 * SS_LD * 4 + PK * 4 > 150 * 1024;    // wide heads: V^T shares the K tile + the consumed band half
-    static constexpr int BYTES = 3 * HALF + (VALIAS ? 0 : VT) + 4 * 32 * SS_LD * 4 + PK * 4;
+    static constexpr int SKEW = 4 * SS_ROWS * SS_LD * 4;         // one skew buffer per wave
+    static constexpr bool VALIAS = 3 * HALF + VT + SKEW + PK * 4 > 150 * 1024;    // wide heads: V^T shares the K tile + the consumed band half
+    static constexpr int BYTES = 3 * HALF + (VALIAS ? 0 : VT) + SKEW + PK * 4;
 };
 
 template <int KS, int NT>
@@ -53,7 +56,7 @@ __global__ __launch_bounds__(256) void sxf_attention_kernel(const SxfAttnParams 
     char* const tail = sm + 3 * HALF;
     char* const sVfix = tail;                                    // !VALIAS
     float* const sS = reinterpret_cast<float*>(tail + (L::VALIAS ? 0 : L::VT));
-    float* const suv = sS + 4 * 32 * SS_LD;                      // [PK]: u of this head's columns | 1 at column d | 0
+    float* const suv = sS + 4 * SS_ROWS * SS_LD;                      // [PK]: u of this head's columns | 1 at column d | 0
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wq = wave >> 1, wk = wave & 1, lr = lane & 31, kh = lane >> 5;
     const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
@@ -68,7 +71,6 @@ __global__ __launch_bounds__(256) void sxf_attention_kernel(const SxfAttnParams 
     const float* qbase = p.q + row0 * D + hb;
     const float* kbase = p.k + row0 * D + hb;
     const float* vbase = p.v + row0 * D + hb;
-    const float* ebase = p.e + hb;
     const int erows = p.causal ? p.Tg : 2 * p.Tg - 1;            // rows of E (built for the LONGEST utterance: an utterance's own table is a centred slice of it)
     // valid elements of grouped row i's head span: natural row G i + (hb + x) / D carries a projection iff it is < nfr
     auto dspan = [&](int i) { const long long xl = (long long)(nfr - G * i) * D - (long long)hb; return (int)(xl < 0 ? 0 : (xl > d ? d : xl)); };
@@ -108,27 +110,42 @@ __global__ __launch_bounds__(256) void sxf_attention_kernel(const SxfAttnParams 
             if (i0 - bl > 0) jt_lo = (i0 - bl) / 64;
         }
     }
-    const float irs = 1.0f / sqrtf((float)d);
-    auto stage_rows = [&](char* dst, auto rowval) __attribute__((always_inline)) {     // 64 fp32 rows -> split fp16 rows [64][ROW] hi | lo
-        for (int c = tid; c < 64 * CPR; c += 256) {
-            const int r = c / CPR, x = (c - r * CPR) * 4;
-            const float4 v = rowval(r, x);
-            uint32_t h0, l0, h1, l1;
-            split2(v.x, v.y, h0, l0); split2(v.z, v.w, h1, l1);
-            *reinterpret_cast<uint2*>(dst + r * ROW + x * 2) = make_uint2(h0, h1);
-            *reinterpret_cast<uint2*>(dst + 64 * ROW + r * ROW + x * 2) = make_uint2(l0, l1);
+    const float c2 = 1.4426950408889634f / sqrtf((float)d);      // scores in log2 units
+    const int kvis = min(Tg, (klen + G - 1) / G);                // keys >= kvis are masked or do not exist
+    // ---- staging.  K, V and E arrive PRE-SPLIT (sxf_pack_kv_kernel / sxf_pack_e_kernel: fp16 (h, l) planes, head spans zero padded to PK columns, chunk-padding rows
+    //      zeroed, V transposed, the positional bias in column d of E): a key tile is KS + KS + 2 NT 16-byte copies per thread, requested for the NEXT tile before
+    //      the current tile's products and written to LDS after them.  (First version: fp32 operands split, masked and transposed HERE, once per (query tile, key tile)
+    //      pair - ~1900 VALU instructions per tile and wave against 72 MFMAs, and 18 dependent L2 round trips: 40 k cycles per tile for 2.3 k of matrix work.)
+    typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+    constexpr int CP = PK / 8;                                   // 16-byte chunks per plane row
+    // band row w (0 .. 127) of key tile j0 = E row Tgmax - 1 + j0 - i0 - 63 + w, clamped (rows no visible pair touches)
+    auto erel = [&](int w, int j0) { int rel = p.Tg - 1 + j0 - i0 - 63 + w; return rel < 0 ? 0 : (rel > erows - 1 ? erows - 1 : rel); };
+    const long long rowg0 = p.off ? row0 / G : (long long)b * p.Tg;      // first GROUPED row of this utterance in the packed K image
+    const uint16_t* kpk = p.kp + ((size_t)rowg0 * p.H + h) * 2 * PK;
+    const uint16_t* epk = p.ep + (size_t)h * 2 * PK;
+    const uint16_t* vpk = p.vp + ((size_t)b * p.H + h) * 2 * 32 * NT * (size_t)p.vpitch;
+    u4v kreg[KS], ereg[KS], vreg[2 * NT];
+    auto fetch_ke = [&](int j0, int wbase, bool want_k) __attribute__((always_inline)) {
+#pragma unroll
+        for (int it = 0; it < KS; ++it) {
+            const int c = tid + 256 * it, r = c / (2 * CP), rem = c - r * 2 * CP;      // rem: chunk of the row's hi | lo pair (contiguous 2 PK halfs)
+            if (want_k) { int j = j0 + r; j = j < Tg ? j : Tg - 1; kreg[it] = *reinterpret_cast<const u4v*>(kpk + (size_t)j * p.H * 2 * PK + rem * 8); }
+            ereg[it] = *reinterpret_cast<const u4v*>(epk + (size_t)erel(wbase + r, j0) * p.H * 2 * PK + rem * 8);
         }
     };
-    // band row w (0 .. 127) of key tile j0 = E row Tgmax - 1 + j0 - i0 - 63 + w, clamped (rows no visible pair touches); column d = the positional bias
-    auto eval = [&](int w, int j0, int x) {
-        int rel = p.Tg - 1 + j0 - i0 - 63 + w;
-        rel = rel < 0 ? 0 : (rel > erows - 1 ? erows - 1 : rel);
-        float4 v = ld_span4(ebase + gd * rel, x, d);
-        if (d >= x && d < x + 4) {
-            const float cb = p.cb[(size_t)rel * p.H + h];
-            if (d == x) v.x = cb; else if (d == x + 1) v.y = cb; else if (d == x + 2) v.z = cb; else v.w = cb;
+    auto fetch_v = [&](int j0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int it = 0; it < 2 * NT; ++it) {
+            const int c = tid + 256 * it, xr = c >> 3, ch = c & 7;                   // xr: plane * 32 NT + column
+            vreg[it] = *reinterpret_cast<const u4v*>(vpk + (size_t)xr * p.vpitch + j0 + ch * 8);
         }
-        return v;
+    };
+    auto put_rows = [&](char* dst, const u4v (&reg)[KS]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int it = 0; it < KS; ++it) {
+            const int c = tid + 256 * it, r = c / (2 * CP), rem = c - r * 2 * CP, pl = rem >= CP ? 1 : 0, ch = rem - pl * CP;
+            *reinterpret_cast<u4v*>(dst + pl * 64 * ROW + r * ROW + ch * 16) = reg[it];
+        }
     };
     float m_run = -INFINITY, l_run = 0.f;
     f32x16 oacc[NT];
@@ -136,37 +153,33 @@ __global__ __launch_bounds__(256) void sxf_attention_kernel(const SxfAttnParams 
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
-    float* sSw = sS + wave * 32 * SS_LD;
+    float* sSw = sS + wave * SS_ROWS * SS_LD + SS_LD;            // row 0 of the wave's 32 key rows (rows -1 and 32 are the dump rows)
     const int iq = i0 + 32 * wq + lr;                            // this lane's query (may lie behind the utterance: computed on clamped data, never stored)
     int cur = 0;                                                 // 0: band rows 0 .. 63 of the current key tile live in half A
-    stage_rows(sEA, [&](int r, int x) { return eval(r, jt_lo * 64, x); });
+    fetch_ke(jt_lo * 64, 0, false);
+    put_rows(sEA, ereg);
+    fetch_ke(jt_lo * 64, 64, true);
+    if (!L::VALIAS) fetch_v(jt_lo * 64);
     for (int jt = jt_lo; jt < jt_hi; ++jt, cur ^= 1) {
         const int j0 = jt * 64;
+        const int jn = (jt + 1 < jt_hi ? jt + 1 : jt) * 64;      // the tile to prefetch (the last tile prefetches itself: never published)
         char* const eLo = cur ? sEB : sEA;
         char* const eHi = cur ? sEA : sEB;
         char* const sV = L::VALIAS ? (cur ? sK : sEA) : sVfix;   // alias: consumed band half + K tile (contiguous either way)
-        stage_rows(sK, [&](int r, int x) { int j = j0 + r; j = j < Tg ? j : Tg - 1; return ld_span4(kbase + gd * j, x, dspan(j)); });
-        stage_rows(eHi, [&](int r, int x) { return eval(64 + r, j0, x); });
-        auto stage_v = [&]() __attribute__((always_inline)) {
-            // consecutive lanes <-> consecutive KEYS of one column quad: the transposing 2-byte stores of a wave fall on 32 consecutive dwords
-            for (int c = tid; c < 64 * 8 * NT; c += 256) {
-                const int r = c & 63, x = (c >> 6) * 4;
-                int j = j0 + r; j = j < Tg ? j : Tg - 1;         // keys behind the utterance: finite data times zero probabilities
-                const float4 v = ld_span4(vbase + gd * j, x, dspan(j));
-                const float vv[4] = {v.x, v.y, v.z, v.w};
+        put_rows(sK, kreg);
+        put_rows(eHi, ereg);
+        auto put_v = [&]() __attribute__((always_inline)) {
 #pragma unroll
-                for (int e = 0; e < 4; e += 2) {
-                    uint32_t hh, ll;
-                    split2(vv[e], vv[e + 1], hh, ll);
-                    *reinterpret_cast<uint16_t*>(sV + (x + e) * VROW + r * 2) = (uint16_t)(hh & 0xFFFFu);
-                    *reinterpret_cast<uint16_t*>(sV + (x + e + 1) * VROW + r * 2) = (uint16_t)(hh >> 16);
-                    *reinterpret_cast<uint16_t*>(sV + 32 * NT * VROW + (x + e) * VROW + r * 2) = (uint16_t)(ll & 0xFFFFu);
-                    *reinterpret_cast<uint16_t*>(sV + 32 * NT * VROW + (x + e + 1) * VROW + r * 2) = (uint16_t)(ll >> 16);
-                }
+            for (int it = 0; it < 2 * NT; ++it) {
+                const int c = tid + 256 * it, xr = c >> 3, ch = c & 7;
+                *reinterpret_cast<u4v*>(sV + xr * VROW + ch * 16) = vreg[it];
             }
         };
-        if (!L::VALIAS) stage_v();
-        __syncthreads();
+        // wide heads (V^T aliased): the K / E registers and the V registers are never live together - V of THIS tile is requested here and lands under the score
+        // products, the next tile's K / E are requested behind the V^T write and land under the P V products (a third of the register file less: no scratch)
+        if (!L::VALIAS) { put_v(); fetch_v(jn); fetch_ke(jn, 64, true); }      // land under this tile's products
+        else fetch_v(j0);
+        lds_barrier();
         // ---- S1^T = K (Q + u)^T on this wave's 32 keys x 32 queries
         f32x16 s1h, s1x;
 #pragma unroll
@@ -197,37 +210,56 @@ __global__ __launch_bounds__(256) void sxf_attention_kernel(const SxfAttnParams 
                 px = __builtin_amdgcn_mfma_f32_32x32x16_f16(eh, qul[s], px, 0, 0, 0);
                 px = __builtin_amdgcn_mfma_f32_32x32x16_f16(el, quh[s], px, 0, 0, 0);
             }
+            // band row wr of the wave's 64 -> key row wr - 31 + lr; t = 0: always < 32, t = 1: always >= 0 - the other side is clamped to the dump row (no branch:
+            // 32 predicated stores were 32 exec-mask round trips per tile)
+            const int jb = 4 * kh - 31 + lr;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int jj = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * kh - 31 + lr;
-                if (jj >= 0 && jj < 32) sSw[jj * SS_LD + lr] = fmaf(px[r], LO_INV, ph[r]);
+                const int wr = 32 * t + (r & 3) + 8 * (r >> 2);
+                const int jj = t == 0 ? max(wr + jb, -1) : min(wr + jb, 32);
+                sSw[jj * SS_LD + lr] = fmaf(px[r], LO_INV, ph[r]);
             }
         }
         wave_sync();
-        // ---- scores of this lane's query against its 16 keys: scale, additive mask (attentions.py:692-701: ONE mask = max(padding, streaming)), online softmax
+        // ---- scores of this lane's query against its 16 keys in log2 units (one multiply by log2(e) / sqrt(d): the exponentials below are bare v_exp_f32),
+        //      additive mask (attentions.py:692-701: ONE mask = max(padding, streaming); -1e9 log2(e) absorbs any score exactly as -1e9 does), online softmax.
+        //      Interior tiles - every key of the wave's 32 exists and is visible to every one of its 32 queries - skip the mask arithmetic (wave-uniform branch)
         float sc[16], tmax = -INFINITY;
+        const int jw0 = j0 + 32 * wk, iw0 = i0 + 32 * wq;
+        const bool edge = jw0 + 31 >= kvis || jw0 + 31 - iw0 > br || iw0 + 31 - jw0 > bl;
+        if (!edge) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int jj = (r & 3) + 8 * (r >> 2) + 4 * kh, j = j0 + 32 * wk + jj;
-            float sv = (fmaf(s1x[r], LO_INV, s1h[r]) + sSw[jj * SS_LD + lr]) * irs;
-            if (G * j >= klen || j - iq > br || iq - j > bl) sv += -1e9f;
-            if (j >= Tg) sv = -INFINITY;                         // no such key (ragged: behind this utterance; the last tile's tail)
-            sc[r] = sv;
-            tmax = fmaxf(tmax, sv);
+            for (int r = 0; r < 16; ++r) {
+                const int jj = (r & 3) + 8 * (r >> 2) + 4 * kh;
+                sc[r] = (fmaf(s1x[r], LO_INV, s1h[r]) + sSw[jj * SS_LD + lr]) * c2;
+                tmax = fmaxf(tmax, sc[r]);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int jj = (r & 3) + 8 * (r >> 2) + 4 * kh, j = jw0 + jj;
+                float sv = (fmaf(s1x[r], LO_INV, s1h[r]) + sSw[jj * SS_LD + lr]) * c2;
+                if (G * j >= klen || j - iq > br || iq - j > bl) sv += -1.4426950e9f;
+                if (j >= Tg) sv = -INFINITY;                     // no such key (ragged: behind this utterance; the last tile's tail)
+                sc[r] = sv;
+                tmax = fmaxf(tmax, sv);
+            }
         }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
         const float m_new = fmaxf(m_run, tmax);
-        const float m_use = m_new < -1e30f ? 0.f : m_new;
-        const float alpha = expm(m_run - m_use);
+        const float m_use = m_new < -1e30f ? 0.f : m_new;       // nothing seen yet (a wave whose keys all lie behind the utterance): exp2(-inf - 0) = 0 below
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
         m_run = m_new;
         float psum = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { sc[r] = expm(sc[r] - m_use); psum += sc[r]; }
+        for (int r = 0; r < 16; ++r) { sc[r] = __builtin_amdgcn_exp2f(sc[r] - m_use); psum += sc[r]; }
         l_run = fmaf(l_run, alpha, psum);                        // the two kh halves keep partial sums (same alpha): added once at the end
+        if (__ballot(alpha != 1.0f)) {                           // the running maximum of some query moved (rare after the first tiles)
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
+                for (int r = 0; r < 16; ++r) oacc[t][r] *= alpha;
+        }
         // probabilities as B fragments: accumulator registers 8 s .. 8 s + 7 ARE k positions 8 kh .. 8 kh + 7 of k-step s (keys 4 kh + (e & 3) + 8 (e >> 2) + 16 s)
         f16x8 pbh[2], pbl[2];
 #pragma unroll
@@ -237,7 +269,7 @@ __global__ __launch_bounds__(256) void sxf_attention_kernel(const SxfAttnParams 
             for (int e = 0; e < 4; ++e) split2(sc[8 * s + 2 * e], sc[8 * s + 2 * e + 1], hh[e], ll[e]);
             pbh[s] = as_f16x8(make_uint4(hh[0], hh[1], hh[2], hh[3])); pbl[s] = as_f16x8(make_uint4(ll[0], ll[1], ll[2], ll[3]));
         }
-        if (L::VALIAS) { __syncthreads(); stage_v(); __syncthreads(); }      // every wave is done with the K tile and the lower band half
+        if (L::VALIAS) { lds_barrier(); put_v(); fetch_ke(jn, 64, true); lds_barrier(); }      // every wave is done with the K tile and the lower band half
         // ---- O^T += V^T P^T over this wave's 32 keys; the correction accumulator is folded per column tile
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -257,7 +289,7 @@ __global__ __launch_bounds__(256) void sxf_attention_kernel(const SxfAttnParams 
 #pragma unroll
             for (int r = 0; r < 16; ++r) oacc[t][r] = fmaf(ox[r], LO_INV, oacc[t][r]);
         }
-        __syncthreads();                                         // the next tile's staging overwrites the K tile, the lower band half and V^T
+        lds_barrier();                                         // the next tile's staging overwrites the K tile, the lower band half and V^T
     }
     // ---- merge the two key halves of every query (wave wk = 1 -> wave wk = 0 through LDS), normalise, un-group (attentions.py:707-712)
     l_run += __shfl_xor(l_run, 32);
@@ -274,7 +306,7 @@ __global__ __launch_bounds__(256) void sxf_attention_kernel(const SxfAttnParams 
     if (wk == 0 && iq < Tg) {
         const float m1 = mrg[16 * NT * 64 + lane], l1 = mrg[(16 * NT + 1) * 64 + lane];
         const float mm = fmaxf(m_run, m1);
-        const float a0 = expm(m_run - mm), a1 = expm(m1 - mm);
+        const float a0 = __builtin_amdgcn_exp2f(m_run - mm), a1 = __builtin_amdgcn_exp2f(m1 - mm);      // mm is finite: this wave saw key 0 .. 31 of some tile
         const float inv = sx_rcp(fmaf(l_run, a0, l1 * a1));
         float* orow = p.out + row0 * D + gd * iq + hb;
 #pragma unroll
@@ -296,9 +328,71 @@ __global__ __launch_bounds__(256) void sxf_attention_kernel(const SxfAttnParams 
     }
 }
 
-// cb[r][h] = sum_x (v - u)[(h d + x) mod D] E[r][h d + x]: what (Q + v) E^T has over (Q + u) E^T, one number per (relative position, head); input independent
-__global__ __launch_bounds__(256) void sxf_posbias_kernel(const float* __restrict__ e, const float* __restrict__ u, const float* __restrict__ vb, int erows, int H,
-                                                          int G, int D, int d, float* __restrict__ cb) {
+// ---- operand images of the attention kernel
+// K image  [grouped row][head][hi PK | lo PK] fp16: head span of the grouped row, zero behind the span (columns >= d) and for natural rows that are chunk
+//          padding (attentions.py:107-138, 671: zeros AFTER the projection); grouped rows of utterance b start at off[b] / G (ragged) or b Tg.
+// V image  [utterance][head][hi | lo][32 NT columns][vpitch keys] fp16: TRANSPOSED (the P V product contracts over keys), zero for pad rows / columns / keys
+//          behind the utterance inside its last 64-key tile.
+// One workgroup = 64 grouped rows of one (utterance, head).
+template <int KS, int NT>
+__global__ __launch_bounds__(256) void sxf_pack_kv_kernel(const SxfAttnParams p) {
+    constexpr int PK = 16 * KS, CPR = PK / 4, VX = 32 * NT;
+    __shared__ __attribute__((aligned(16))) char sT[2 * VX * VROW];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y / p.H, h = blockIdx.y % p.H, d = p.d, G = p.G, D = p.D;
+    long long row0; int nfr, Tg;
+    if (p.off) { row0 = p.off[b]; nfr = p.lens[b]; Tg = (nfr + G - 1) / G; }
+    else { row0 = (long long)b * p.Tp; nfr = p.T; Tg = p.Tg; }
+    const int j0 = blockIdx.x * 64;
+    if (j0 >= Tg) return;
+    const size_t hb = (size_t)h * d, gd = (size_t)G * D;
+    const float* kbase = p.k + row0 * D + hb;
+    const float* vbase = p.v + row0 * D + hb;
+    auto dspan = [&](int i) { const long long xl = (long long)(nfr - G * i) * D - (long long)hb; return (int)(xl < 0 ? 0 : (xl > d ? d : xl)); };
+    const long long rowg0 = p.off ? row0 / G : (long long)b * p.Tg;
+    uint16_t* kout = const_cast<uint16_t*>(p.kp) + ((size_t)(rowg0 + j0) * p.H + h) * 2 * PK;
+#pragma unroll
+    for (int it = 0; it < KS; ++it) {
+        const int c = tid + 256 * it, r = c / CPR, x = (c - r * CPR) * 4, j = j0 + r;
+        if (j >= Tg) continue;
+        const float4 v = ld_span4(kbase + gd * j, x, dspan(j));
+        uint32_t h0, l0, h1, l1;
+        split2(v.x, v.y, h0, l0); split2(v.z, v.w, h1, l1);
+        uint16_t* o = kout + (size_t)r * p.H * 2 * PK + x;
+        *reinterpret_cast<uint2*>(o) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(o + PK) = make_uint2(l0, l1);
+    }
+    // V: consecutive lanes <-> consecutive KEYS of one column quad (the transposing 2-byte stores of a wave fall on 32 consecutive dwords)
+#pragma unroll
+    for (int it = 0; it < 2 * NT; ++it) {
+        const int c = tid + 256 * it, r = c & 63, x = (c >> 6) * 4, j = j0 + r;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (j < Tg) v = ld_span4(vbase + gd * j, x, dspan(j));
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; e += 2) {
+            uint32_t hh, ll;
+            split2(vv[e], vv[e + 1], hh, ll);
+            *reinterpret_cast<uint16_t*>(sT + (x + e) * VROW + r * 2) = (uint16_t)(hh & 0xFFFFu);
+            *reinterpret_cast<uint16_t*>(sT + (x + e + 1) * VROW + r * 2) = (uint16_t)(hh >> 16);
+            *reinterpret_cast<uint16_t*>(sT + VX * VROW + (x + e) * VROW + r * 2) = (uint16_t)(ll & 0xFFFFu);
+            *reinterpret_cast<uint16_t*>(sT + VX * VROW + (x + e + 1) * VROW + r * 2) = (uint16_t)(ll >> 16);
+        }
+    }
+    __syncthreads();
+    uint16_t* vout = const_cast<uint16_t*>(p.vp) + ((size_t)b * p.H + h) * 2 * VX * (size_t)p.vpitch + j0;
+#pragma unroll
+    for (int it = 0; it < 2 * NT; ++it) {
+        const int c = tid + 256 * it, xr = c >> 3, ch = c & 7;
+        *reinterpret_cast<uint4*>(vout + (size_t)xr * p.vpitch + ch * 8) = *reinterpret_cast<const uint4*>(sT + xr * VROW + ch * 16);
+    }
+}
+
+// E image  [grouped relative row][head][hi PK | lo PK] fp16 of E = pos_layer(R) (fp32 [rows][D]); column d carries the positional bias
+//   cb[r][h] = sum_x (v - u)[(h d + x) mod D] E[r][h d + x] = what (Q + v) E^T has over (Q + u) E^T - one number per (relative position, head) - against the
+//   constant 1 in column d of the query fragments.  Input independent.  One wave per (row, head).
+__global__ __launch_bounds__(256) void sxf_pack_e_kernel(const float* __restrict__ e, const float* __restrict__ u, const float* __restrict__ vb, int erows, int H,
+                                                         int G, int D, int d, int PK, uint16_t* __restrict__ ep) {
     const int wid = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (wid >= erows * H) return;
     const int r = wid / H, h = wid % H;
@@ -310,7 +404,14 @@ __global__ __launch_bounds__(256) void sxf_posbias_kernel(const float* __restric
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-    if (lane == 0) cb[wid] = acc;
+    uint16_t* out = ep + (size_t)wid * 2 * PK;
+    for (int x = 2 * lane; x < PK; x += 128) {
+        const float a = x < d ? er[x] : (x == d ? acc : 0.f), c = x + 1 < d ? er[x + 1] : (x + 1 == d ? acc : 0.f);
+        uint32_t hh, ll;
+        split2(a, c, hh, ll);
+        *reinterpret_cast<uint32_t*>(out + x) = hh;
+        *reinterpret_cast<uint32_t*>(out + PK + x) = ll;
+    }
 }
 
 // depthwise conv (k taps, "same" or causal zero pre-padding at the UTTERANCE's own ends, stride S) + folded BatchNorm + Swish, fp32 (modules.py:516-518;
@@ -384,14 +485,34 @@ __global__ __launch_bounds__(256) void sxf_glu_kernel(const float* __restrict__ 
 }
 
 template <int KS, int NT>
-int launch_attn(const SxfAttnParams& p, hipStream_t s) {
+int launch_attn(const SxfAttnParams& p, int what, hipStream_t s) {
     using L = AttnLds<KS, NT>;
     static_assert(L::BYTES <= 160 * 1024, "LDS image of the fused split attention");
     static_assert((16 * NT + 2) * 64 * 4 * 2 <= 3 * L::HALF, "merge buffer");
+    if (what == 1) {                                            // the K / V images of this block
+        hipLaunchKernelGGL((sxf_pack_kv_kernel<KS, NT>), dim3((p.Tg + 63) / 64, p.B * p.H), dim3(256), 0, s, p);
+        return hipGetLastError() == hipSuccess ? 0 : -1;
+    }
     static LdsAttr attr;
     ensure_dynamic_lds(reinterpret_cast<const void*>(&sxf_attention_kernel<KS, NT>), L::BYTES, attr);
     hipLaunchKernelGGL((sxf_attention_kernel<KS, NT>), dim3((p.Tg + 63) / 64, p.B * p.H), dim3(256), L::BYTES, s, p);
     return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int dispatch_attn(const SxfAttnParams& p, int what, hipStream_t s) {
+    const int ks = sxf_attention_pk(p.d) / 16;
+    switch (ks) {
+        case 1: return launch_attn<1, 1>(p, what, s);
+        case 2: return launch_attn<2, 1>(p, what, s);
+        case 3: return p.d <= 32 ? launch_attn<3, 1>(p, what, s) : launch_attn<3, 2>(p, what, s);
+        case 4: return launch_attn<4, 2>(p, what, s);
+        case 5: return p.d <= 64 ? launch_attn<5, 2>(p, what, s) : launch_attn<5, 3>(p, what, s);
+        case 6: return launch_attn<6, 3>(p, what, s);
+        case 7: return p.d <= 96 ? launch_attn<7, 3>(p, what, s) : launch_attn<7, 4>(p, what, s);
+        case 8: return launch_attn<8, 4>(p, what, s);
+        case 9: return p.d <= 128 ? launch_attn<9, 4>(p, what, s) : launch_attn<9, 5>(p, what, s);
+        default: return launch_attn<10, 5>(p, what, s);
+    }
 }
 
 template <int KSZ, int S>
@@ -410,29 +531,26 @@ int launch_dw(const float* g, int B, int T, int To, int C, const float* w, const
 
 bool sxf_attention_supported(int d) { return d >= 1 && d <= 144; }
 
-int launch_sxf_posbias(const float* e, const float* u, const float* vb, int erows, int H, int G, int D, int d, float* cb, hipStream_t s) {
+int sxf_attention_pk(int d) { return (d + 1 + 15) / 16 * 16; }                  // head width + the positional bias column, in 16-wide k-steps
+int sxf_attention_vx(int d) { return (d + 31) / 32 * 32; }
+
+int launch_sxf_pack_e(const float* e, const float* u, const float* vb, int erows, int H, int G, int D, int d, uint16_t* ep, hipStream_t s) {
     const long long waves = (long long)erows * H;
     if (waves <= 0) return 0;
-    hipLaunchKernelGGL(sxf_posbias_kernel, dim3((unsigned)((waves * 64 + 255) / 256)), dim3(256), 0, s, e, u, vb, erows, H, G, D, d, cb);
+    hipLaunchKernelGGL(sxf_pack_e_kernel, dim3((unsigned)((waves * 64 + 255) / 256)), dim3(256), 0, s, e, u, vb, erows, H, G, D, d, sxf_attention_pk(d), ep);
     return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_sxf_pack_kv(const SxfAttnParams& p, hipStream_t s) {
+    if (p.B <= 0 || p.Tg <= 0) return 0;
+    if (!sxf_attention_supported(p.d) || (long long)p.B * p.H > 65535 || !p.kp || !p.vp || p.vpitch % 64 || p.vpitch < p.Tg) return -2;
+    return dispatch_attn(p, 1, s);
 }
 
 int launch_sxf_attention(const SxfAttnParams& p, hipStream_t s) {
     if (p.B <= 0 || p.Tg <= 0) return 0;
-    if (!sxf_attention_supported(p.d) || (long long)p.B * p.H > 65535 || !p.cb) return -2;
-    const int ks = (p.d + 1 + 15) / 16;                         // head width + the positional bias column
-    switch (ks) {
-        case 1: return launch_attn<1, 1>(p, s);
-        case 2: return launch_attn<2, 1>(p, s);
-        case 3: return p.d <= 32 ? launch_attn<3, 1>(p, s) : launch_attn<3, 2>(p, s);
-        case 4: return launch_attn<4, 2>(p, s);
-        case 5: return p.d <= 64 ? launch_attn<5, 2>(p, s) : launch_attn<5, 3>(p, s);
-        case 6: return launch_attn<6, 3>(p, s);
-        case 7: return p.d <= 96 ? launch_attn<7, 3>(p, s) : launch_attn<7, 4>(p, s);
-        case 8: return launch_attn<8, 4>(p, s);
-        case 9: return p.d <= 128 ? launch_attn<9, 4>(p, s) : launch_attn<9, 5>(p, s);
-        default: return launch_attn<10, 5>(p, s);
-    }
+    if (!sxf_attention_supported(p.d) || (long long)p.B * p.H > 65535 || !p.kp || !p.vp || !p.ep || p.vpitch % 64) return -2;
+    return dispatch_attn(p, 0, s);
 }
 
 int launch_sxf_dwconv(const float* g, int B, int T, int To, int C, const float* w_kc, const float* bias, int ks, int stride, float* out, hipStream_t s,
