@@ -591,10 +591,11 @@ def result_skeleton(args, world, value, ms_per_step, gb, extra_cfg):
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": {"bf16": "bf16", "fp32": "f32", "split": "f16x2 (split fp32 operands, fp32 accumulate)"}[args.precision], "data": "synthetic",
-        "config": dict({"workload": "%s: %s, B=%d utterances/GPU, %s lengths, audio in HBM -> encoder out + greedy labels"
+        "config": dict({"workload": "%s: %s, B=%d utterances/GPU%s, %s lengths, audio in HBM -> encoder out + greedy labels"
                                     % (args.model, {"bf16": "bf16 operands / fp32 accumulate", "fp32": "fp32 operands (label-exact mode)",
                                                     "split": "fp32 tensors, every product on the fp16 matrix pipe with split operands x = h + l / 2048 (label-exact mode, 3 MFMAs per product)"}[args.precision],
                                        args.batch,
+                                       " (the largest single-GPU batch measured; SURVEY.md 8d lists B in {4, 32, 128}: --batch 128 is 0.79 x this rate, profiles/r5_31_bench_b128.json)" if args.batch == 256 else "",
                                        ("lognormal 1.5-16 s (LibriSpeech-shaped), sorted desc; " + padding)
                                        if args.workload == "libri" else "10 s"),
                         "global_batch": gb, "streams_per_gpu": args.streams}, **extra_cfg),
@@ -988,6 +989,42 @@ def main():
                                                "note": "event pairs around the same launches with the %d row ranges in flight on %d streams, as in the timed "
                                                        "region: includes the time a kernel queues behind the other stream's kernel" % (nsub, nsub)}
         result["kernel_classes"] = per
+
+    # ---- the reference's COLLATED-batch semantics beside the ragged headline (un-timed leg like the roofline one): utils/preprocessing.py:33-45
+    #      zero-pads a batch to its longest utterance and encoders.py:107-140 runs every pad frame (they leak into valid frames).  `value` runs ragged
+    #      (each utterance = the reference on it ALONE); these are the same batch, same kernels, with the pad frames computed: the whole batch padded to its maximum
+    #      (`no_trim`: round 1's workload) and each row range padded to ITS maximum (`ragged0`: round 2's).  Valid frames / s, wall clock over a few steps.
+    if rank == 0 and world == 1 and args.ragged and not args.no_roofline and not isinstance(model, Transducer) and args.workload == "libri":
+        enc_ = model.encoder
+        saved = (enc_.ragged, enc_.trim_sub_batches, enc_.sub_batch_bounds, enc_.sub_batches, enc_.sub_batch_streams)
+        ref_sem = {}
+        try:
+            rcuts = [args.batch * i // nsub for i in range(nsub + 1)]
+            if args.batch >= 32 * nsub:
+                rcuts = [c_ - c_ % 16 for c_ in rcuts[:-1]] + [args.batch]
+            nrep = max(3, min(args.steps, 8))
+            for name, trim in (("no_trim", False), ("ragged0", True)):
+                enc_.ragged, enc_.sub_batches, enc_.sub_batch_streams = False, nsub, max(args.streams, 1)
+                enc_.trim_sub_batches = bool(trim and nsub > 1)
+                enc_.sub_batch_bounds = rcuts[1:-1] if enc_.trim_sub_batches else None
+                rp = [int(lens_np[rcuts[i]:rcuts[i + 1]].max()) for i in range(nsub)] if enc_.trim_sub_batches else None
+                for _ in range(2):
+                    model.encode_greedy(audio, lens, range_pad=rp)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(nrep):
+                    model.encode_greedy(audio, lens, range_pad=rp)
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t1) / nrep
+                pf = (sum((rcuts[i + 1] - rcuts[i]) * (rp[i] // plan.hop_length + 1) for i in range(nsub)) if rp
+                      else args.batch * (audio_np.shape[1] // plan.hop_length + 1))
+                ref_sem[name] = {"valid_frames_per_s": valid_frames / dt, "ms_per_step": 1000.0 * dt, "padded_fraction": 1.0 - valid_frames / pf}
+            ref_sem["note"] = ("the same batch with the reference's collated-batch semantics (pad frames computed and live): no_trim = the whole batch zero-padded to its longest "
+                               "utterance (utils/preprocessing.py:33-45), ragged0 = each of the %d row ranges padded to ITS longest; %d steps each after the timed region, "
+                               "wall clock; the headline `value` is the ragged batch (every utterance alone, no pad frames)" % (nsub, nrep))
+        finally:
+            enc_.ragged, enc_.trim_sub_batches, enc_.sub_batch_bounds, enc_.sub_batches, enc_.sub_batch_streams = saved
+        result["reference_batch_semantics"] = ref_sem
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:      # reported at N = 1 only (task contract)
         result["cpu_baseline"] = cpu_baseline(sd, plan)

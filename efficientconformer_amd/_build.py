@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libeffconf.so")
 LIB_DEBUG = os.path.join(HERE, "libeffconf_debug.so")
-SOURCES = ["gemm.hip", "gemm256.hip", "rsgemm.hip", "chain.hip", "chain2.hip", "chain3.hip", "norm.hip", "conv.hip", "sublinear.hip", "sublinear2.hip", "conv2.hip", "mel.hip", "ctc.hip", "rnnt.hip", "attention.hip", "attention2.hip", "exact.hip", "split.hip", "sxf.hip", "hostpack.hip", "encoder.hip"]
+SOURCES = ["gemm.hip", "gemm256.hip", "rsgemm.hip", "chain.hip", "chain2.hip", "chain3.hip", "norm.hip", "conv.hip", "sublinear.hip", "sublinear2.hip", "conv2.hip", "mel.hip", "ctc.hip", "rnnt.hip", "attention.hip", "attention2.hip", "exact.hip", "split.hip", "sxf.hip", "sxf_ffn.hip", "hostpack.hip", "encoder.hip"]
 # (source, object, extra flags): further compilations of a source under other flags
 # No packed-fp32 VALU instructions in product kernels: v_pk_{add,mul,fma}_f32 with an op_sel low-lane swizzle return wrong values
 # next to another wave's bf16 MFMA on gfx950 (measured: profiles/r2_mel_packed_fp32_hazard.txt; guard: _isa_guard.py).
@@ -25,7 +25,7 @@ NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 # libeffconf_debug.so (tests / tools only, include/effconf_debug.h) = the product objects with encoder.hip and mel.hip recompiled under -DEFFCONF_DEBUG_ABI
 # (the effconf_debug_* entry points, the diagnostic mel_kernel variants) + debug.hip and the packed-fp32 build of mel.hip - the hazard reproducers need the
 # instructions they demonstrate, so those two are compiled WITHOUT the flag below.  Nothing of this is linked into libeffconf.so.
-DEBUG_REPLACES = {"encoder.hip": "encoder_dbg.o", "mel.hip": "mel_dbg.o"}
+DEBUG_REPLACES = {"encoder.hip": "encoder_dbg.o", "mel.hip": "mel_dbg.o", "sxf_ffn.hip": "sxf_ffn_dbg.o"}
 DEBUG_OBJECTS = [("debug.hip", "debug.o", []), ("mel.hip", "mel_pk.o", ["-DMEL_PK_BUILD"])]
 # -fvisibility=hidden: only what include/effconf.h / effconf_debug.h declare (under `#pragma GCC visibility push(default)`) is a dynamic symbol
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-unused-result",

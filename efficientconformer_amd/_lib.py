@@ -86,6 +86,7 @@ DEBUG_SIGNATURES = {
     "effconf_debug_lds_fill": (C.c_int, [_I32, _I32, _I32, _P, _SZ, _I32, _I32, _P, _P]),
     "effconf_debug_sx_gemm": (C.c_int, [_F32P, _I32, _P, _P, _I32, _F32P, _I32, _I32, _I32, _I32, _F32P, _I32, _F32P, _I32, C.c_float, _P]),
     "effconf_debug_dwconv": (C.c_int, [_P, _I32, _I32, _I32, _I32, _F32P, _F32P, _I32, _I32, _I32, _I32, _P, _P]),
+    "effconf_debug_sxf_ffn": (C.c_int, [_P, _I32, _I32, _F32P, _I32, _F32P, _I32, _I32, _P]),
     "effconf_debug_gemm": (C.c_int, [_P, _I32, _P, _I32, _P, _I32, _I32, _I32, _I32, _I32, _P, _I32, _P, _I32, C.c_float, _P]),
 }
 

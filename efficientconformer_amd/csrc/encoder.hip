@@ -62,6 +62,8 @@ struct BlockW {
     const bf16_t *c_f1b = nullptr, *c_f2b = nullptr; const float *c_f1b2 = nullptr, *c_f2b2 = nullptr;
     int c_qkv_chunks = 0, c_pw1_chunks = 0;
     std::vector<float> h_ln_out_g, h_ln_out_b, h_u, h_v, h_f1b2, h_f2b2;     // host copies for the chains' constant blocks
+    // split mode (sxf_ffn.hip): weight images of the two feed-forward modules, b2 / 2, hidden chunks
+    const uint16_t *xf_img[2] = {nullptr, nullptr}; const float* xf_b2[2] = {nullptr, nullptr}; int xf_nch[2] = {0, 0};
     const float *cc_b = nullptr, *cc_head = nullptr, *cc_tail = nullptr, *cc_full = nullptr;   // constant blocks (chain_const_layout)
 };
 
@@ -101,6 +103,7 @@ struct EcEncoder {
     int chain_max_dim = 256;                 // fused chains only for stage widths <= this (tuning: wider stages on the per-GEMM / tiled kernels)
     int tiled_min_k = 256;                   // with wide_gemm >= 2: layers with K > this leave the row-stationary kernels for LayerNorm + tiled GEMMs
     std::vector<float*> att_out;             // per block: device buffer [B][H][Tg][Tg] for the softmax maps of the next forward, or null
+    int split_ffn = 1;                       // split mode: the feed-forward modules as one kernel each (sxf_ffn.hip) where the width is built; 0 = LayerNorm + two GEMMs (tests)
     int exact_attention = 0;                 // fp32 mode: 0 tiled attention kernel (2: its 16-row shape), 1 one wave per query row (round 2's); bit-identical
     bool head_major_odd = false;             // odd grouped head widths on the head-major Q/K/V layout (tests; the default reads the natural layout unaligned)
     // two-layer subsampler (plain Conformer configs): layer-2 implicit-GEMM weight [N][9*Cp] (tap, c_in), folded bias, Cp
@@ -1197,10 +1200,17 @@ int forward_core_split(EcEncoder* e, const float* mel, const int64_t* in_len, in
         const int M = (int)s.Min[k], Mo = (int)s.Mout[k];
         const int G = b.group_size, H = b.num_heads, Tp = ec_round_up(T, G), Tg = Tp / G, d = G * D / H;
         const std::string p = "blocks." + std::to_string(k);
-        // ---- x += 1/2 FFN1(LN(x))   (blocks.py:122; modules.py:385-392)
-        EC_TRY(layernorm(x, M, D, W.ln_ffn1, a));
-        EC_TRY(xgemm(e, st, a, D, M, p + ".feed_forward_module1.layers.1", D * b.ff_ratio, D, hb, D * b.ff_ratio, 1, nullptr, 1.f, 0, 0, 0, 0, 0, 0, 0, PC_GEMM_FFN));
-        EC_TRY(xgemm(e, st, hb, D * b.ff_ratio, M, p + ".feed_forward_module1.layers.4", D, D * b.ff_ratio, x, D, 2, x, 0.5f, 0, 0, 0, 0, 0, 0, 0, PC_GEMM_FFN));
+        // ---- x += 1/2 FFN1(LN(x))   (blocks.py:122; modules.py:385-392): one kernel where the width is built (sxf_ffn.hip), else LayerNorm + two GEMMs
+        if (W.xf_img[0] && e->split_ffn) {
+            SxfFfnParams fp{};
+            fp.X = x; fp.ldx = D; fp.Y = x; fp.ldy = D; fp.wimg = W.xf_img[0]; fp.b2 = W.xf_b2[0]; fp.M = M; fp.D = D; fp.nchunk = W.xf_nch[0];
+            PROF(PC_GEMM_FFN, 4.0 * M * (double)D * D * b.ff_ratio, (double)M * D * 8 + 16.0 * D * D * b.ff_ratio);
+            EC_TRY(launch_sxf_ffn(fp, st));
+        } else {
+            EC_TRY(layernorm(x, M, D, W.ln_ffn1, a));
+            EC_TRY(xgemm(e, st, a, D, M, p + ".feed_forward_module1.layers.1", D * b.ff_ratio, D, hb, D * b.ff_ratio, 1, nullptr, 1.f, 0, 0, 0, 0, 0, 0, 0, PC_GEMM_FFN));
+            EC_TRY(xgemm(e, st, hb, D * b.ff_ratio, M, p + ".feed_forward_module1.layers.4", D, D * b.ff_ratio, x, D, 2, x, 0.5f, 0, 0, 0, 0, 0, 0, 0, PC_GEMM_FFN));
+        }
         snprintf(nm, sizeof(nm), "blocks.%d.x_ffn1", k); trace_add(e, st, nm, x, M, D, D, 0);
         // ---- x += MHSA(LN(x))   (blocks.py:125-126; attentions.py:549-718).  Rows of Q / K / V: rectangular (b, t) -> b Tp + t, ragged: the identity (the
         //      residual stream keeps every utterance group-padded); chunk-padding rows are never written - the attention kernel substitutes them
@@ -1263,11 +1273,19 @@ int forward_core_split(EcEncoder* e, const float* mel, const int64_t* in_len, in
         EC_TRY(xgemm(e, st, cbuf, De, Mo, cm + ".7", De, De, x, De, 2, x, 1.0f));
         snprintf(nm, sizeof(nm), "blocks.%d.x_conv", k); trace_add(e, st, nm, x, Mo, De, De, 0);
         // ---- x += 1/2 FFN2(LN(x)); x = LN(x)   (blocks.py:132-135)
-        EC_TRY(layernorm(x, Mo, De, W.ln_ffn2, a));
-        EC_TRY(xgemm(e, st, a, De, Mo, p + ".feed_forward_module2.layers.1", De * b.ff_ratio, De, hb, De * b.ff_ratio, 1, nullptr, 1.f, 0, 0, 0, 0, 0, 0, 0, PC_GEMM_FFN));
-        EC_TRY(xgemm(e, st, hb, De * b.ff_ratio, Mo, p + ".feed_forward_module2.layers.4", De, De * b.ff_ratio, x, De, 2, x, 0.5f, 0, 0, 0, 0, 0, 0, 0, PC_GEMM_FFN));
         float* xo = (k == nb - 1 && !rg) ? out : xalt;
-        EC_TRY(layernorm(x, Mo, De, W.ln_out, xo));
+        if (W.xf_img[1] && e->split_ffn) {
+            SxfFfnParams fp{};
+            fp.X = x; fp.ldx = De; fp.Y = xo; fp.ldy = De; fp.wimg = W.xf_img[1]; fp.b2 = W.xf_b2[1]; fp.M = Mo; fp.D = De; fp.nchunk = W.xf_nch[1];
+            fp.ln_g = W.ln_out.g; fp.ln_b = W.ln_out.b;
+            PROF(PC_GEMM_FFN, 4.0 * Mo * (double)De * De * b.ff_ratio, (double)Mo * De * 8 + 16.0 * De * De * b.ff_ratio);
+            EC_TRY(launch_sxf_ffn(fp, st));
+        } else {
+            EC_TRY(layernorm(x, Mo, De, W.ln_ffn2, a));
+            EC_TRY(xgemm(e, st, a, De, Mo, p + ".feed_forward_module2.layers.1", De * b.ff_ratio, De, hb, De * b.ff_ratio, 1, nullptr, 1.f, 0, 0, 0, 0, 0, 0, 0, PC_GEMM_FFN));
+            EC_TRY(xgemm(e, st, hb, De * b.ff_ratio, Mo, p + ".feed_forward_module2.layers.4", De, De * b.ff_ratio, x, De, 2, x, 0.5f, 0, 0, 0, 0, 0, 0, 0, PC_GEMM_FFN));
+            EC_TRY(layernorm(x, Mo, De, W.ln_out, xo));
+        }
         if (!(k == nb - 1 && !rg)) std::swap(x, xalt);
         snprintf(nm, sizeof(nm), "blocks.%d.out", k); trace_add(e, st, nm, xo, Mo, De, De, 0);
     }
@@ -1686,6 +1704,52 @@ int effconf_encoder_finalize(EcEncoder* e) {
                 add_split(m + "qkv_layer", rows, D);
                 e->xw[m + "qkv_layer.bias"] = upload(e, bias);
             }
+            // weight images of the fused FFN kernel (sxf_ffn.hip; kernels.h: SxfFfnParams)
+            for (size_t k = 0; k < e->blocks.size(); ++k)
+                for (int which = 0; which < 2; ++which) {
+                    const int D = which ? e->blocks[k].dim_expand : e->blocks[k].dim_model, F = D * e->blocks[k].ff_ratio;
+                    if (!sxf_ffn_supported(D)) continue;
+                    const std::string pf = "blocks." + std::to_string(k) + (which ? ".feed_forward_module2.layers." : ".feed_forward_module1.layers.");
+                    const HostTensor *g = find(e, pf + "0.weight"), *bt = find(e, pf + "0.bias"), *w1 = find(e, pf + "1.weight"), *b1 = find(e, pf + "1.bias"),
+                                     *w2 = find(e, pf + "4.weight"), *b2 = find(e, pf + "4.bias");
+                    if (!g || !bt || !w1 || !b1 || !w2 || !b2 || (int64_t)w1->data.size() != (int64_t)F * D || (int64_t)w2->data.size() != (int64_t)F * D ||
+                        (int)g->data.size() != D || (int)bt->data.size() != D || (int)b1->data.size() != F || (int)b2->data.size() != D) continue;
+                    int ks1, nt2; sxf_ffn_shape(D, &ks1, &nt2);
+                    const int DP1 = 16 * ks1, DP2 = 32 * nt2, nch = (F + 31) / 32;
+                    const size_t per = (size_t)64 * (DP1 + DP2);
+                    std::vector<uint16_t> img((size_t)nch * per, 0);
+                    auto put = [&](size_t hi_at, size_t lo_at, float wv) {      // same-scale halves at the weight scale 2^10 (sx_common.h split2s; sxf_ffn.hip SW)
+                        const float ws = clampf(wv * 1024.0f);
+                        const _Float16 hh = (_Float16)ws;
+                        img[hi_at] = half_bits((float)hh);
+                        img[lo_at] = half_bits(ws - (float)hh);
+                    };
+                    for (int c = 0; c < nch; ++c) {
+                        const size_t base = (size_t)c * per;
+                        for (int r = 0; r < 32; ++r) {
+                            const int hrow = 32 * c + r;
+                            if (hrow >= F) continue;
+                            double bias = b1->data[hrow];
+                            for (int kk = 0; kk < D; ++kk) {
+                                const double wv = w1->data[(size_t)hrow * D + kk];
+                                bias += wv * bt->data[kk];                                       // W1 beta folded into the bias column
+                                put(base + (size_t)r * DP1 + kk, base + (size_t)32 * DP1 + (size_t)r * DP1 + kk, (float)(wv * g->data[kk]));
+                            }
+                            put(base + (size_t)r * DP1 + D, base + (size_t)32 * DP1 + (size_t)r * DP1 + D, (float)bias);
+                        }
+                        for (int n = 0; n < D; ++n)
+                            for (int pos = 0; pos < 32; ++pos) {
+                                const int sstep = pos >> 4, khh = (pos >> 3) & 1, ee = pos & 7;
+                                const int hid = 32 * c + 16 * sstep + 8 * (ee >> 2) + 4 * khh + (ee & 3);      // accumulator register 8 s + e of lane half kh holds this hidden unit
+                                if (hid >= F) continue;
+                                put(base + (size_t)64 * DP1 + (size_t)n * 32 + pos, base + (size_t)64 * DP1 + (size_t)32 * DP2 + (size_t)n * 32 + pos,
+                                    0.5f * w2->data[(size_t)n * F + hid]);
+                            }
+                    }
+                    std::vector<float> b2h(DP2, 0.f);
+                    for (int n = 0; n < D; ++n) b2h[n] = 0.5f * b2->data[n];
+                    e->bw[k].xf_img[which] = upload(e, img); e->bw[k].xf_b2[which] = upload(e, b2h); e->bw[k].xf_nch[which] = nch;
+                }
         }
         for (const EcBlock& b : e->blocks) {
             auto key = std::make_pair(b.max_pos, b.dim_model);
@@ -2023,6 +2087,19 @@ int effconf_debug_dwconv(const uint16_t* g, int32_t batch, int32_t frames, int32
     return rc ? fail("launch_dwconv failed rc=" + std::to_string(rc)) : 0;
 }
 
+int effconf_debug_sxf_ffn(EcEncoder* e, int32_t block, int32_t which, const float* x, int32_t rows, float* y, int32_t with_norm, int32_t ablate, void* stream) {
+    if (!e || !e->finalized || block < 0 || block >= (int)e->blocks.size() || which < 1 || which > 2 || !x || !y || rows <= 0) return fail("bad argument");
+    const BlockW& W = e->bw[block];
+    if (!W.xf_img[which - 1]) return fail("no fused split FFN image for this block (finalize with exact_fp32 = 2; width not built)");
+    SxfFfnParams fp{};
+    const int D = which == 2 ? e->blocks[block].dim_expand : e->blocks[block].dim_model;
+    fp.X = x; fp.ldx = D; fp.Y = y; fp.ldy = D; fp.wimg = W.xf_img[which - 1]; fp.b2 = W.xf_b2[which - 1]; fp.M = rows; fp.D = D; fp.nchunk = W.xf_nch[which - 1];
+    if (with_norm) { fp.ln_g = W.ln_out.g; fp.ln_b = W.ln_out.b; }
+    fp.ablate = ablate;
+    EC_TRY(launch_sxf_ffn(fp, reinterpret_cast<hipStream_t>(stream)));
+    return 0;
+}
+
 int effconf_debug_spin(double microseconds, void* stream) {
     if (launch_debug_spin(microseconds, reinterpret_cast<hipStream_t>(stream)) != 0) return fail("spin launch failed");
     return 0;
@@ -2117,6 +2194,7 @@ int effconf_encoder_set_option(EcEncoder* e, const char* name, int32_t value) {
     if (!strcmp(name, "tiled_min_k")) { e->tiled_min_k = value; return 0; }
     if (!strcmp(name, "ffn_variant")) { if (value < 0 || value > 2) return fail("ffn_variant: 0, 1 or 2 (fused-FFN workgroup shapes)"); e->ffn_variant = value; return 0; }
     if (!strcmp(name, "head_major_odd")) { e->head_major_odd = value != 0; return 0; }
+    if (!strcmp(name, "split_ffn")) { e->split_ffn = value != 0; return 0; }
     if (!strcmp(name, "exact_attention")) { if (value < 0 || value > 2) return fail("exact_attention: 0 (tiled), 2 (tiled, 16-row workgroups) or 1 (one wave per query row)"); e->exact_attention = value; return 0; }
     if (!strcmp(name, "cache_pos_embeddings")) { e->e_cache_on = value != 0; e->e_cache.clear(); return 0; }
     if (!strcmp(name, "exact_fp32")) {

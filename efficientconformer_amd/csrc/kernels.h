@@ -269,6 +269,22 @@ int launch_sxf_pack_kv(const SxfAttnParams& p, hipStream_t s);       // K / V (f
 // E = pos_layer(R) fp32 [erows_grouped * G][D] -> its image, the positional bias (v - u) E^T in column d
 int launch_sxf_pack_e(const float* e, const float* u, const float* vb, int erows_grouped, int H, int G, int D, int d, uint16_t* ep, hipStream_t s);
 int launch_sxf_attention(const SxfAttnParams& p, hipStream_t s);
+// FeedForwardModule + half-step residual (+ optional block-final LayerNorm) as one split-precision kernel (sxf_ffn.hip)
+struct SxfFfnParams {
+    const float* X; int ldx;       // residual stream in [M][ldx]
+    float* Y; int ldy;             // out (may alias X): x + 1/2 FFN(LN(x)), or LayerNorm of that when ln_g != null
+    const uint16_t* wimg;          // weight image, chunk-major: per 32 hidden units [W1 hi 32 x DP1 | W1 lo | W2 hi DP2 x 32 | W2 lo] fp16 (pack_sxf_ffn in encoder.hip:
+                                   // pre-norm gamma / beta and b1 folded into W1 / its column D, W2 pre-scaled by 1/2 with its k order permuted to the accumulator layout)
+    const float* b2;               // [DP2] b2 / 2, zero padded
+    const float *ln_g, *ln_b;      // optional LayerNorm applied to the result (blocks.py:135), [D]
+    int M, D, nchunk;
+    int ablate;                    // timing-only ablations (tools/sxf_ffn_probe.py through the diagnostic library; 0 in the product): 1 no first product, 2 no Swish,
+                                   // 4 no second product, 8 no weight stream after the first chunk, 16 no per-chunk barrier
+};
+void sxf_ffn_shape(int D, int* ks1, int* nt2);
+bool sxf_ffn_supported(int D);
+size_t sxf_ffn_image_halfs(int D, int F);
+int launch_sxf_ffn(const SxfFfnParams& p, hipStream_t s);
 // fp32 depthwise conv + folded BatchNorm + Swish; rc != null: per-utterance row ranges (tcap_max = the longest utterance's padded output rows)
 int launch_sxf_dwconv(const float* g, int B, int T, int To, int C, const float* w_kc, const float* bias, int ks, int stride, float* out, hipStream_t s,
                       const RaggedConv* rc = nullptr, int causal = 0, int tcap_max = 0);

@@ -31,6 +31,20 @@ __device__ __forceinline__ void split2(float x0, float x1, uint32_t& hi, uint32_
     lo = cl.u;
 }
 
+// Same-scale variant (round 6, sxf_ffn.hip): x S = h + l with BOTH halves at the scale S (a power of two that puts the operand's usual magnitude around
+// 2^5 .. 2^12, so l - 2^-11 of h - is a normal fp16 number for every element that matters: an element so small that its l underflows contributes < 2^-25 S^-1
+// absolutely).  The three products h h' + h l' + l h' then share ONE fp32 accumulator at the scale S S' (undone by an exact multiply at the end): no correction
+// accumulator, no fold - the sum rounds like the fp32 accumulation of the reference's own GEMM.  Inputs are the already scaled values.
+__device__ __forceinline__ void split2s(float x0, float x1, uint32_t& hi, uint32_t& lo) {
+    typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+    union { fp16x2 p; f16x2 h; uint32_t u; } ch;
+    union { f16x2 h; uint32_t u; } cl;
+    ch.p = __builtin_amdgcn_cvt_pkrtz(x0, x1);
+    cl.h = __builtin_convertvector(f32x2v{x0 - (float)ch.h[0], x1 - (float)ch.h[1]}, f16x2);
+    hi = ch.u;
+    lo = cl.u;
+}
+
 // exp(x) for x <= ~0 .. 88 to ~1 ulp on v_exp_f32: the product x log2(e) in two parts (fma residual + the constant's low part), first-order
 // correction of the result; 1 / x by v_rcp_f32 + one Newton step.  (libm's expf and the IEEE division sequence are ~60 instructions per element,
 // which made the epilogues and the softmax of this file VALU-bound.)

@@ -46,6 +46,11 @@ int effconf_debug_pack_dwconv_mfma(const float* w_kc, int32_t ksize, int32_t cha
  * use_mfma: 1 = dwconv_mfma_kernel (stride 1, kernel size 15 / 31 / 7), 0 = dwconv_kernel (VALU).  causal: pre-padding (k - 1, 0) instead of "same". */
 int effconf_debug_dwconv(const uint16_t* g, int32_t batch, int32_t frames, int32_t channels, int32_t ld, const float* w_kc_host, const float* bias_host,
                          int32_t ksize, int32_t stride, int32_t use_mfma, int32_t causal, uint16_t* out, void* stream);
+/* The fused split-precision FeedForwardModule kernel alone (csrc/sxf_ffn.hip; reference modules.py:385-395, blocks.py:122, 132-135) on a handle finalized with
+ * exact_fp32 = 2: y = x + 1/2 FFN_which(LayerNorm(x)) on fp32 rows (rows, D), with_norm != 0: followed by the block-final LayerNorm.  ablate: timing-only switches
+ * of the diagnostic build (1 no first product, 2 no Swish, 4 no second product, 8 no weight stream, 16 no per-chunk barrier; results are wrong by construction);
+ * tools/sxf_ffn_probe.py. */
+int effconf_debug_sxf_ffn(EcEncoder* enc, int32_t block, int32_t which, const float* x, int32_t rows, float* y, int32_t with_norm, int32_t ablate, void* stream);
 /* One idle wave that occupies `stream` for `microseconds` (tools/overlap_probe.py: the duration of an xGMI transfer a single GPU cannot make). */
 int effconf_debug_spin(double microseconds, void* stream);
 /* diagnostics (tools/lds_fill_rate_probe.py): `blocks` workgroups of `waves` waves each walk the same `window` bytes of `src` (dev) into LDS, `kib_per_wave`

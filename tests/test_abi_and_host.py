@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     # build): the product library exports none of them, the diagnostic one exports them and the whole product ABI
     dhdr = open(os.path.join(ROOT, "include", "effconf_debug.h")).read()
     ddecl = sorted(set(re.findall(r"\b(effconf_debug_[a-z_0-9]+)\s*\(", dhdr)))
-    assert len(ddecl) == 9 and sorted(_lib.DEBUG_SIGNATURES) == ddecl
+    assert len(ddecl) == 10 and sorted(_lib.DEBUG_SIGNATURES) == ddecl
     assert not [n for n in declared if n.startswith("effconf_debug")]
     exported = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
     assert "effconf_debug" not in exported and "debug_neighbour" not in exported

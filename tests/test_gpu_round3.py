@@ -487,7 +487,9 @@ def test_attention_maps_vs_the_reference(golden_dir, gname, precision):
     plain, plain_len, none = m.encoder.forward_mel(mel_d, ln_d)
     assert all(a is None for a in none)
     out, out_len, atts = m.encoder.forward_mel(mel_d, ln_d, return_attentions=True)
-    assert torch.equal(out, plain) and torch.equal(out_len, plain_len)
+    # split mode (round 6): the forward with maps runs split.hip's scores-in-memory kernels (the maps are their by-product), the plain forward the fused
+    # kernels of sxf.hip / sxf_ffn.hip - the same arithmetic in another summation order
+    assert (torch.equal(out, plain) if precision != "split" else float((out - plain).abs().max()) < 2e-5) and torch.equal(out_len, plain_len)
     trace = {}
     with torch.no_grad():
         R.encoder_from_mel(torch.from_numpy(mel), torch.from_numpy(ln), sd, m.encoder.plan, trace)

@@ -1,12 +1,18 @@
+#!/bin/bash
+# Usage (GPU box, repo root): tools/prof_split.sh <tag> [pmc]
+# rocprofv3 kernel trace (+ optionally two SQ counter passes) of `bench.py --precision split` -> gpurun_out/<tag>/
 set -u
-repo=$(pwd); out="$repo/gpurun_out/r6_06"; mkdir -p "$out"
+tag=${1:-r6_split}; repo=$(pwd); out="$repo/gpurun_out/$tag"; mkdir -p "$out"
+( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/kt && rocprofv3 --kernel-trace --stats -d /tmp/kt -o run -- python "$repo/bench.py" --precision split --no-cpu-baseline --no-roofline --no-check --steps 5 --warmup 2 > "$out/kt.log" 2>&1 )
+db=$(find /tmp/kt -name "*.db" | head -1)
+python "$repo/tools/rocprof_summary.py" "$db" "$out/kernel_stats.txt" "python bench.py --precision split --no-cpu-baseline --no-roofline --no-check --steps 5 --warmup 2" > /dev/null
+if [ "${2:-}" = "pmc" ]; then
 SQ="SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY"
 ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/sq_f && rocprofv3 --kernel-trace --pmc $SQ -d /tmp/sq_f -o run -- python "$repo/bench.py" --precision split --no-cpu-baseline --no-roofline --no-check --steps 2 --warmup 1 > "$out/sq.log" 2>&1 )
 db=$(find /tmp/sq_f -name "*.db" | head -1)
 python tools/sq_summary.py "$db" "$out/sq_counters.txt" "bench.py --precision split" > /dev/null
-SQ2="SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM"
+SQ2="SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
 ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/sq_g && rocprofv3 --kernel-trace --pmc $SQ2 -d /tmp/sq_g -o run -- python "$repo/bench.py" --precision split --no-cpu-baseline --no-roofline --no-check --steps 2 --warmup 1 > "$out/sq2.log" 2>&1 )
 db=$(find /tmp/sq_g -name "*.db" | head -1)
 python tools/sq_summary.py "$db" "$out/sq_counters2.txt" "bench.py --precision split" > /dev/null
-( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/kt && rocprofv3 --kernel-trace --stats -d /tmp/kt -o run -- python "$repo/bench.py" --precision split --no-cpu-baseline --no-roofline --no-check --steps 5 --warmup 2 > "$out/kt.log" 2>&1 )
-f=$(find /tmp/kt -name "*kernel_stats.csv" | head -1); cp "$f" "$out/kernel_stats.csv"
+fi
