@@ -20,6 +20,10 @@ namespace {
 
 using namespace sx;
 
+// Same-scale operand split (sx_common.h split2s): x S = h + l, one fp32 accumulator per product sum at the scale S S' - Q + u, K, E, V at 2^8, the probabilities
+// at 2^10; the scales leave through constants that exist anyway (the score scale, the softmax normalisation).  The (h, l / 2048) form needed a correction
+// accumulator and a fold per tile: a third of this kernel's VALU instructions.
+constexpr float SQK = 256.0f, SV_ = 256.0f, SP_ = 1024.0f;
 constexpr int SS_ROWS = 34;                                      // 32 key rows + a dump row on either side (band rows no pair of the wave's tile reads)
 constexpr int SS_LD = 40;                                        // floats per key row of a wave's skew buffer (conflict-free: see the writer below)
 constexpr int VROW = 64 * 2 + 16;                                // bytes per row of the V^T tiles (64 keys)
@@ -89,8 +93,8 @@ __global__ __launch_bounds__(256) void sxf_attention_kernel(const SxfAttnParams 
             const float4 a = ld_span4(qr, x, de), c = ld_span4(qr, x + 4, de);
             const float4 u0 = *reinterpret_cast<const float4*>(suv + x), u1 = *reinterpret_cast<const float4*>(suv + x + 4);
             uint32_t uh[4], ul[4];
-            split2(a.x + u0.x, a.y + u0.y, uh[0], ul[0]); split2(a.z + u0.z, a.w + u0.w, uh[1], ul[1]);
-            split2(c.x + u1.x, c.y + u1.y, uh[2], ul[2]); split2(c.z + u1.z, c.w + u1.w, uh[3], ul[3]);
+            split2s((a.x + u0.x) * SQK, (a.y + u0.y) * SQK, uh[0], ul[0]); split2s((a.z + u0.z) * SQK, (a.w + u0.w) * SQK, uh[1], ul[1]);
+            split2s((c.x + u1.x) * SQK, (c.y + u1.y) * SQK, uh[2], ul[2]); split2s((c.z + u1.z) * SQK, (c.w + u1.w) * SQK, uh[3], ul[3]);
             quh[s] = as_f16x8(make_uint4(uh[0], uh[1], uh[2], uh[3])); qul[s] = as_f16x8(make_uint4(ul[0], ul[1], ul[2], ul[3]));
         }
     }
@@ -110,7 +114,7 @@ __global__ __launch_bounds__(256) void sxf_attention_kernel(const SxfAttnParams 
             if (i0 - bl > 0) jt_lo = (i0 - bl) / 64;
         }
     }
-    const float c2 = 1.4426950408889634f / sqrtf((float)d);      // scores in log2 units
+    const float c2 = 1.4426950408889634f / sqrtf((float)d) / (SQK * SQK);      // accumulators (scale 2^16) -> scores in log2 units
     const int kvis = min(Tg, (klen + G - 1) / G);                // keys >= kvis are masked or do not exist
     // ---- staging.  K, V and E arrive PRE-SPLIT (sxf_pack_kv_kernel / sxf_pack_e_kernel: fp16 (h, l) planes, head spans zero padded to PK columns, chunk-padding rows
     //      zeroed, V transposed, the positional bias in column d of E): a key tile is KS + KS + 2 NT 16-byte copies per thread, requested for the NEXT tile before
@@ -217,7 +221,7 @@ __global__ __launch_bounds__(256) void sxf_attention_kernel(const SxfAttnParams 
             for (int r = 0; r < 16; ++r) {
                 const int wr = 32 * t + (r & 3) + 8 * (r >> 2);
                 const int jj = t == 0 ? max(wr + jb, -1) : min(wr + jb, 32);
-                sSw[jj * SS_LD + lr] = fmaf(px[r], LO_INV, ph[r]);
+                sSw[jj * SS_LD + lr] = ph[r] + px[r];
             }
         }
         wave_sync();
@@ -231,14 +235,14 @@ __global__ __launch_bounds__(256) void sxf_attention_kernel(const SxfAttnParams 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int jj = (r & 3) + 8 * (r >> 2) + 4 * kh;
-                sc[r] = (fmaf(s1x[r], LO_INV, s1h[r]) + sSw[jj * SS_LD + lr]) * c2;
+                sc[r] = ((s1h[r] + s1x[r]) + sSw[jj * SS_LD + lr]) * c2;
                 tmax = fmaxf(tmax, sc[r]);
             }
         } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int jj = (r & 3) + 8 * (r >> 2) + 4 * kh, j = jw0 + jj;
-                float sv = (fmaf(s1x[r], LO_INV, s1h[r]) + sSw[jj * SS_LD + lr]) * c2;
+                float sv = ((s1h[r] + s1x[r]) + sSw[jj * SS_LD + lr]) * c2;
                 if (G * j >= klen || j - iq > br || iq - j > bl) sv += -1.4426950e9f;
                 if (j >= Tg) sv = -INFINITY;                     // no such key (ragged: behind this utterance; the last tile's tail)
                 sc[r] = sv;
@@ -266,28 +270,28 @@ __global__ __launch_bounds__(256) void sxf_attention_kernel(const SxfAttnParams 
         for (int s = 0; s < 2; ++s) {
             uint32_t hh[4], ll[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) split2(sc[8 * s + 2 * e], sc[8 * s + 2 * e + 1], hh[e], ll[e]);
+            for (int e = 0; e < 4; ++e) split2s(sc[8 * s + 2 * e] * SP_, sc[8 * s + 2 * e + 1] * SP_, hh[e], ll[e]);
             pbh[s] = as_f16x8(make_uint4(hh[0], hh[1], hh[2], hh[3])); pbl[s] = as_f16x8(make_uint4(ll[0], ll[1], ll[2], ll[3]));
         }
         if (L::VALIAS) { lds_barrier(); put_v(); fetch_ke(jn, 64, true); lds_barrier(); }      // every wave is done with the K tile and the lower band half
-        // ---- O^T += V^T P^T over this wave's 32 keys; the correction accumulator is folded per column tile
+        // ---- O^T += V^T P^T over this wave's 32 keys (one accumulator per column tile at the scale 2^18; kind-major over the tiles: consecutive MFMAs hit
+        //      different accumulators)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            f32x16 ox;
+        for (int s = 0; s < 2; ++s) {
+            f16x8 vh[NT], vl[NT];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) ox[r] = 0.f;
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
+            for (int t = 0; t < NT; ++t) {
                 const char* vr = sV + (32 * t + lr) * VROW + (32 * wk + 16 * s + 4 * kh) * 2;
                 const uint2 a0 = *reinterpret_cast<const uint2*>(vr), a1 = *reinterpret_cast<const uint2*>(vr + 16);
                 const uint2 b0 = *reinterpret_cast<const uint2*>(vr + 32 * NT * VROW), b1 = *reinterpret_cast<const uint2*>(vr + 32 * NT * VROW + 16);
-                const f16x8 vh = as_f16x8(make_uint4(a0.x, a0.y, a1.x, a1.y)), vl = as_f16x8(make_uint4(b0.x, b0.y, b1.x, b1.y));
-                oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pbh[s], oacc[t], 0, 0, 0);
-                ox = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pbl[s], ox, 0, 0, 0);
-                ox = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, pbh[s], ox, 0, 0, 0);
+                vh[t] = as_f16x8(make_uint4(a0.x, a0.y, a1.x, a1.y)); vl[t] = as_f16x8(make_uint4(b0.x, b0.y, b1.x, b1.y));
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[t][r] = fmaf(ox[r], LO_INV, oacc[t][r]);
+            for (int t = 0; t < NT; ++t) oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[t], pbh[s], oacc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[t], pbl[s], oacc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[t], pbh[s], oacc[t], 0, 0, 0);
         }
         lds_barrier();                                         // the next tile's staging overwrites the K tile, the lower band half and V^T
     }
@@ -307,7 +311,7 @@ __global__ __launch_bounds__(256) void sxf_attention_kernel(const SxfAttnParams 
         const float m1 = mrg[16 * NT * 64 + lane], l1 = mrg[(16 * NT + 1) * 64 + lane];
         const float mm = fmaxf(m_run, m1);
         const float a0 = __builtin_amdgcn_exp2f(m_run - mm), a1 = __builtin_amdgcn_exp2f(m1 - mm);      // mm is finite: this wave saw key 0 .. 31 of some tile
-        const float inv = sx_rcp(fmaf(l_run, a0, l1 * a1));
+        const float inv = sx_rcp(fmaf(l_run, a0, l1 * a1)) * (1.0f / (SP_ * SV_));      // the scale of the P V accumulators leaves with the normalisation
         float* orow = p.out + row0 * D + gd * iq + hb;
 #pragma unroll
         for (int t = 0; t < NT; ++t)
@@ -357,7 +361,7 @@ __global__ __launch_bounds__(256) void sxf_pack_kv_kernel(const SxfAttnParams p)
         if (j >= Tg) continue;
         const float4 v = ld_span4(kbase + gd * j, x, dspan(j));
         uint32_t h0, l0, h1, l1;
-        split2(v.x, v.y, h0, l0); split2(v.z, v.w, h1, l1);
+        split2s(v.x * SQK, v.y * SQK, h0, l0); split2s(v.z * SQK, v.w * SQK, h1, l1);
         uint16_t* o = kout + (size_t)r * p.H * 2 * PK + x;
         *reinterpret_cast<uint2*>(o) = make_uint2(h0, h1);
         *reinterpret_cast<uint2*>(o + PK) = make_uint2(l0, l1);
@@ -372,7 +376,7 @@ __global__ __launch_bounds__(256) void sxf_pack_kv_kernel(const SxfAttnParams p)
 #pragma unroll
         for (int e = 0; e < 4; e += 2) {
             uint32_t hh, ll;
-            split2(vv[e], vv[e + 1], hh, ll);
+            split2s(vv[e] * SV_, vv[e + 1] * SV_, hh, ll);
             *reinterpret_cast<uint16_t*>(sT + (x + e) * VROW + r * 2) = (uint16_t)(hh & 0xFFFFu);
             *reinterpret_cast<uint16_t*>(sT + (x + e + 1) * VROW + r * 2) = (uint16_t)(hh >> 16);
             *reinterpret_cast<uint16_t*>(sT + VX * VROW + (x + e) * VROW + r * 2) = (uint16_t)(ll & 0xFFFFu);
@@ -408,7 +412,7 @@ __global__ __launch_bounds__(256) void sxf_pack_e_kernel(const float* __restrict
     for (int x = 2 * lane; x < PK; x += 128) {
         const float a = x < d ? er[x] : (x == d ? acc : 0.f), c = x + 1 < d ? er[x + 1] : (x + 1 == d ? acc : 0.f);
         uint32_t hh, ll;
-        split2(a, c, hh, ll);
+        split2s(a * SQK, c * SQK, hh, ll);
         *reinterpret_cast<uint32_t*>(out + x) = hh;
         *reinterpret_cast<uint32_t*>(out + PK + x) = ll;
     }
