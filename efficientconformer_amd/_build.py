@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libeffconf.so")
 LIB_DEBUG = os.path.join(HERE, "libeffconf_debug.so")
-SOURCES = ["gemm.hip", "gemm256.hip", "rsgemm.hip", "chain.hip", "chain2.hip", "chain3.hip", "norm.hip", "conv.hip", "sublinear.hip", "sublinear2.hip", "conv2.hip", "mel.hip", "ctc.hip", "rnnt.hip", "attention.hip", "attention2.hip", "exact.hip", "split.hip", "sxf.hip", "sxf_ffn.hip", "hostpack.hip", "encoder.hip"]
+SOURCES = ["gemm.hip", "gemm256.hip", "rsgemm.hip", "chain.hip", "chain2.hip", "chain3.hip", "norm.hip", "conv.hip", "sublinear.hip", "sublinear2.hip", "conv2.hip", "mel.hip", "ctc.hip", "rnnt.hip", "attention.hip", "attention2.hip", "exact.hip", "split.hip", "sxf.hip", "sxf_ffn.hip", "sxf_chain.hip", "hostpack.hip", "encoder.hip"]
 # (source, object, extra flags): further compilations of a source under other flags
 # No packed-fp32 VALU instructions in product kernels: v_pk_{add,mul,fma}_f32 with an op_sel low-lane swizzle return wrong values
 # next to another wave's bf16 MFMA on gfx950 (measured: profiles/r2_mel_packed_fp32_hazard.txt; guard: _isa_guard.py).
@@ -27,6 +27,9 @@ NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 # instructions they demonstrate, so those two are compiled WITHOUT the flag below.  Nothing of this is linked into libeffconf.so.
 DEBUG_REPLACES = {"encoder.hip": "encoder_dbg.o", "mel.hip": "mel_dbg.o", "sxf_ffn.hip": "sxf_ffn_dbg.o"}
 DEBUG_OBJECTS = [("debug.hip", "debug.o", []), ("mel.hip", "mel_pk.o", ["-DMEL_PK_BUILD"])]
+# sxf_chain.hip: the source-scheduled F2 + Swish body is ~400 unrolled iterations of a 13-way switch - beyond the default cost bound of `#pragma unroll`, and a loop
+# left rolled indexes its register arrays dynamically (= scratch memory)
+PER_SOURCE = {"sxf_chain.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"]}
 # -fvisibility=hidden: only what include/effconf.h / effconf_debug.h declare (under `#pragma GCC visibility push(default)`) is a dynamic symbol
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-unused-result",
          "-Wno-inline-asm"]   # rowstat.h clobbers m0 on purpose (LDS-DMA destination register)
@@ -70,7 +73,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-4000:]))
         return obj
-    jobs = [(s, s.replace(".hip", ".o"), NO_PACKED_FP32) for s in SOURCES]
+    jobs = [(s, s.replace(".hip", ".o"), NO_PACKED_FP32 + PER_SOURCE.get(s, [])) for s in SOURCES]
     djobs = [(s, o, NO_PACKED_FP32 + ["-DEFFCONF_DEBUG_ABI"]) for s, o in DEBUG_REPLACES.items()] + DEBUG_OBJECTS
     with ThreadPoolExecutor(max_workers=min(8, len(jobs) + len(djobs))) as ex:
         allobjs = list(ex.map(compile_one, jobs + djobs))

@@ -64,6 +64,11 @@ struct BlockW {
     std::vector<float> h_ln_out_g, h_ln_out_b, h_u, h_v, h_f1b2, h_f2b2;     // host copies for the chains' constant blocks
     // split mode (sxf_ffn.hip): weight images of the two feed-forward modules, b2 / 2, hidden chunks
     const uint16_t *xf_img[2] = {nullptr, nullptr}; const float* xf_b2[2] = {nullptr, nullptr}; int xf_nch[2] = {0, 0};
+    // split mode (sxf_chain.hip): images in the accumulator layout's k order - out-proj / pointwise-2 (F2), pointwise-1 with GLU row pairs / Q | K | V (F1, pre-norm
+    // folded), the two feed-forward modules; biases of the F2 products
+    const uint16_t *xc_wo = nullptr, *xc_p1 = nullptr, *xc_p2 = nullptr, *xc_qkv = nullptr, *xc_f[2] = {nullptr, nullptr};
+    const float *xc_bo = nullptr, *xc_bp2 = nullptr; int xc_nch_p1 = 0;
+    bool xc_in = false, xc_out = false;          // the D-wide (out-proj, pointwise-1, FFN1, Q K V) / De-wide (pointwise-2, FFN2) images exist
     const float *cc_b = nullptr, *cc_head = nullptr, *cc_tail = nullptr, *cc_full = nullptr;   // constant blocks (chain_const_layout)
 };
 
@@ -103,6 +108,7 @@ struct EcEncoder {
     int chain_max_dim = 256;                 // fused chains only for stage widths <= this (tuning: wider stages on the per-GEMM / tiled kernels)
     int tiled_min_k = 256;                   // with wide_gemm >= 2: layers with K > this leave the row-stationary kernels for LayerNorm + tiled GEMMs
     std::vector<float*> att_out;             // per block: device buffer [B][H][Tg][Tg] for the softmax maps of the next forward, or null
+    int split_chain = 1;                     // split mode: the row-local work of a block as two kernels (sxf_chain.hip) where the width is built; 0 = per-module kernels (tests)
     int split_ffn = 1;                       // split mode: the feed-forward modules as one kernel each (sxf_ffn.hip) where the width is built; 0 = LayerNorm + two GEMMs (tests)
     int exact_attention = 0;                 // fp32 mode: 0 tiled attention kernel (2: its 16-row shape), 1 one wave per query row (round 2's); bit-identical
     bool head_major_odd = false;             // odd grouped head widths on the head-major Q/K/V layout (tests; the default reads the natural layout unaligned)
@@ -911,6 +917,7 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
 
 // ------------------------------------------------------------------ fp32-operand "exact" forward (kernels: exact.hip)
 struct XWorkspace { size_t total = 0, conv1, sub, x0, x1, a, h, q, k, v, e, o, p1, g, c, lens, scores = 0; size_t qkv_stride = 0;
+                    std::vector<size_t> ep_blk;      // sxf.hip forward: the E image of every block (input-independent: kept warm between forwards, as the bf16 path's)
                     size_t kp = 0, vp = 0, ep = 0, xs = 0, xrect = 0, mel_len = 0, row_off = 0, wg_off = 0, tile_off = 0; };     // sxf.hip forward: operand images (bytes / 4), decimated rows, ragged descriptors
 
 // rows come from the Shapes totals: B * T for rectangular batches, the sums over the utterances for ragged ones (s.Tm = the input's row pitch there)
@@ -961,6 +968,11 @@ XWorkspace make_xworkspace(const EcEncoder* e, const Shapes& s) {
             }
         w.scores = take(ms);
         w.kp = take(mkp); w.vp = take(mvp); w.ep = take(mep); w.xs = take(mxs);
+        for (size_t k = 0; k < e->blocks.size(); ++k) {
+            const EcBlock& b = e->blocks[k];
+            const size_t dh = b.group_size * b.dim_model / b.num_heads, pk = sxf_attention_pk((int)dh), Tg = ec_round_up(s.Tin[k], b.group_size) / b.group_size;
+            w.ep_blk.push_back(take(2 * Tg * b.num_heads * 2 * pk / 2));
+        }
         if (s.ragged) {
             const size_t nbk = e->blocks.size();
             w.xrect = take(B * T1r * e->blocks[0].dim_model);
@@ -1134,7 +1146,14 @@ int forward_core_split(EcEncoder* e, const float* mel, const int64_t* in_len, in
     const int B = s.B, nb = (int)e->blocks.size();
     const bool rg = s.ragged;
     e->trace.clear(); e->trace_used = 0;
-    e->e_cache_drop(ws);
+    // E = pos_layer(R) and its operand image depend on the block and the frame count entering it only: with the caller's workspace left untouched between
+    // forwards (option cache_pos_embeddings, as on the bf16 path) the 2 x blocks small launches are skipped for an unchanged shape
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+    const int e_tag = rg ? -(s.Tin[0] + 1) : s.Tm;
+    const size_t e_layout = w.ep_blk.empty() ? 0 : w.ep_blk[0] ^ ((size_t)1 << 62) ^ ((size_t)c.causal << 61);      // never equal to a bf16 forward's tag on the same workspace
+    const bool e_cached = !capturing && e->e_cache_on && !e->trace_arena && e->e_cache_hit(ws, B, e_tag, e_layout);
+    if (!e_cached) e->e_cache_drop(ws);
     auto F32 = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
     int* lens = reinterpret_cast<int*>(ws + w.lens);
     const int *mel_len = nullptr, *row_off = nullptr;
@@ -1186,13 +1205,17 @@ int forward_core_split(EcEncoder* e, const float* mel, const int64_t* in_len, in
     trace_add(e, st, "linear", x, s.Min[0], D0, D0, 0);
     float *a = F32(w.a), *hb = F32(w.h), *q = F32(w.q), *kk = F32(w.k), *v = F32(w.v), *eb = F32(w.e), *o = F32(w.o), *p1 = F32(w.p1), *g = F32(w.g),
           *cbuf = F32(w.c), *xs = F32(w.xs);
-    uint16_t *kpk = reinterpret_cast<uint16_t*>(ws + w.kp), *vpk = reinterpret_cast<uint16_t*>(ws + w.vp), *epk = reinterpret_cast<uint16_t*>(ws + w.ep);
+    uint16_t *kpk = reinterpret_cast<uint16_t*>(ws + w.kp), *vpk = reinterpret_cast<uint16_t*>(ws + w.vp);
     char nm[64];
     int xmask_stride = 1;                      // product of the strides of the blocks before block k
     auto layernorm = [&](const float* in, int rows, int dim, const LNp& ln, float* dst) {
         PROF(PC_LAYERNORM, 0, (double)rows * dim * 8);
         return launch_layernorm(in, rows, dim, ln.g, ln.b, dst, nullptr, 0, nullptr, nullptr, st);
     };
+    // the row-local work between attention and the depthwise convolution as two kernels per block (sxf_chain.hip); a debug trace wants the intermediate
+    // states, which the chains never write: per-module kernels then
+    const bool chains = e->split_chain && e->split_ffn && !e->trace_arena;
+    bool head_done = false;                    // this block's FFN1 + Q / K / V projections ran at the end of the previous block's chain A
     for (int k = 0; k < nb; ++k) {
         const EcBlock& b = e->blocks[k];
         const BlockW& W = e->bw[k];
@@ -1200,6 +1223,18 @@ int forward_core_split(EcEncoder* e, const float* mel, const int64_t* in_len, in
         const int M = (int)s.Min[k], Mo = (int)s.Mout[k];
         const int G = b.group_size, H = b.num_heads, Tp = ec_round_up(T, G), Tg = Tp / G, d = G * D / H;
         const std::string p = "blocks." + std::to_string(k);
+        const std::string m = p + ".multi_head_self_attention_module";
+        const int qr = rg ? 0 : T, qp = rg ? 0 : Tp;
+        const bool chain_in = chains && W.xc_in, chain_out = chains && W.xc_out;
+        if (head_done) {
+            // nothing: x is the stream after FFN1, Q / K / V are written
+        } else if (chain_in) {
+            SxcAParams cp{};
+            cp.head = 1; cp.y = x; cp.M = M; cp.D = D; cp.w_f1 = W.xc_f[0]; cp.nch_f1 = W.xf_nch[0]; cp.b_f1 = W.xf_b2[0]; cp.w_qkv = W.xc_qkv;
+            cp.q = q; cp.qkv_stride = w.qkv_stride; cp.q_rows = qr; cp.q_pitch = qp;
+            PROF(PC_GEMM_FFN, M * (double)D * D * (4.0 * b.ff_ratio + 6.0), (double)M * D * 24 + D * (double)D * (16.0 * b.ff_ratio + 12.0));
+            EC_TRY(launch_sxc_a(cp, st));
+        } else {
         // ---- x += 1/2 FFN1(LN(x))   (blocks.py:122; modules.py:385-392): one kernel where the width is built (sxf_ffn.hip), else LayerNorm + two GEMMs
         if (W.xf_img[0] && e->split_ffn) {
             SxfFfnParams fp{};
@@ -1214,9 +1249,7 @@ int forward_core_split(EcEncoder* e, const float* mel, const int64_t* in_len, in
         snprintf(nm, sizeof(nm), "blocks.%d.x_ffn1", k); trace_add(e, st, nm, x, M, D, D, 0);
         // ---- x += MHSA(LN(x))   (blocks.py:125-126; attentions.py:549-718).  Rows of Q / K / V: rectangular (b, t) -> b Tp + t, ragged: the identity (the
         //      residual stream keeps every utterance group-padded); chunk-padding rows are never written - the attention kernel substitutes them
-        const std::string m = p + ".multi_head_self_attention_module";
         EC_TRY(layernorm(x, M, D, W.ln_att, a));
-        const int qr = rg ? 0 : T, qp = rg ? 0 : Tp;
         if (e->xsplit.count(m + ".mhsa.qkv_layer")) {
             EC_TRY(xgemm(e, st, a, D, M, m + ".mhsa.qkv_layer", 3 * D, D, q, D, 0, nullptr, 1.f, 0, 0, 0, qr, qp, D, w.qkv_stride));
         } else {
@@ -1224,12 +1257,17 @@ int forward_core_split(EcEncoder* e, const float* mel, const int64_t* in_len, in
             EC_TRY(xgemm(e, st, a, D, M, m + ".mhsa.key_layer", D, D, kk, D, 0, nullptr, 1.f, 0, 0, 0, qr, qp));
             EC_TRY(xgemm(e, st, a, D, M, m + ".mhsa.value_layer", D, D, v, D, 0, nullptr, 1.f, 0, 0, 0, qr, qp));
         }
+        }
+        head_done = false;
         if (Tp > b.max_pos) return fail("sequence longer than max_pos_encoding");
         // relative tables: R[m] = sinusoid(Tp - 1 - G/2 - m), m < 2 Tp - G; causal: R[m] = sinusoid(Tp - 1 - m), m < Tp (attentions.py:1243-1251, 1296-1309)
         const float* tab = e->xtab[std::make_pair(b.max_pos, D)];
         const int erows = c.causal ? Tp : 2 * Tp - G;
-        EC_TRY(xgemm(e, st, tab + (size_t)(b.max_pos - Tp + (c.causal ? 0 : G / 2)) * D, D, erows, m + ".mhsa.pos_layer", D, D, eb, D));
-        { PROF(PC_MISC, 0, (double)erows * D * 8); EC_TRY(launch_sxf_pack_e(eb, W.u, W.v, erows / G, H, G, D, d, epk, st)); }
+        uint16_t* epk = reinterpret_cast<uint16_t*>(ws + w.ep_blk[k]);
+        if (!e_cached) {
+            EC_TRY(xgemm(e, st, tab + (size_t)(b.max_pos - Tp + (c.causal ? 0 : G / 2)) * D, D, erows, m + ".mhsa.pos_layer", D, D, eb, D));
+            PROF(PC_MISC, 0, (double)erows * D * 8); EC_TRY(launch_sxf_pack_e(eb, W.u, W.v, erows / G, H, G, D, d, epk, st));
+        }
         SxfAttnParams ap{};
         ap.q = q; ap.k = kk; ap.v = v; ap.kp = kpk; ap.vp = vpk; ap.ep = epk; ap.vpitch = ec_round_up(Tg, 64); ap.u = W.u; ap.lens = lens + (size_t)k * B;
         ap.off = rg ? row_off + (size_t)k * (B + 1) : nullptr;
@@ -1243,13 +1281,21 @@ int forward_core_split(EcEncoder* e, const float* mel, const int64_t* in_len, in
         { PROF(PC_ATTENTION, 2.0 * H * (rg ? s.tg2[k] : (double)B * Tg * Tg) * d * 3.0, (double)s.Mq[k] * D * 4 * 4);
           EC_TRY(launch_sxf_attention(ap, st)); }
         snprintf(nm, sizeof(nm), "blocks.%d.att_o", k); trace_add(e, st, nm, o, s.Mq[k], D, D, 0);
+        const std::string cm = p + ".convolution_module.layers";
+        if (chain_in) {       // x += O Wo^T + bo;  g = GLU(LN(x) Wp1^T + bp1)
+            SxcBParams cp{};
+            cp.o = o; cp.o_rows = qr; cp.o_pitch = qp; cp.x = x; cp.g = g; cp.M = M; cp.D = D; cp.De = De;
+            cp.w_o = W.xc_wo; cp.b_o = W.xc_bo; cp.w_p1 = W.xc_p1; cp.nch_p1 = W.xc_nch_p1;
+            PROF(PC_GEMM_OTHER, 2.0 * M * D * ((double)D + 2.0 * De), (double)M * (D * 12.0 + De * 4.0) + 4.0 * D * ((double)D + 2.0 * De));
+            EC_TRY(launch_sxc_b(cp, st));
+        } else {
         EC_TRY(xgemm(e, st, o, D, M, m + ".mhsa.output_layer", D, D, x, D, 2, x, 1.0f, qr, qp, 1));
         snprintf(nm, sizeof(nm), "blocks.%d.x_mhsa", k); trace_add(e, st, nm, x, M, D, D, 0);
         // ---- x = conv_res(x) + ConvModule(x)   (blocks.py:129; modules.py:511-522)
-        const std::string cm = p + ".convolution_module.layers";
         EC_TRY(layernorm(x, M, D, W.ln_conv, a));
         EC_TRY(xgemm(e, st, a, D, M, cm + ".2", 2 * De, D, p1, 2 * De));
         { PROF(PC_MISC, 0, (double)M * De * 12); EC_TRY(launch_sxf_glu(p1, M, De, g, st)); }
+        }
         RaggedConv rc{};
         int tcap = To;
         if (rg) { rc.in_off = row_off + (size_t)k * (B + 1); rc.in_len = lens + (size_t)k * B; rc.out_off = row_off + (size_t)(k + 1) * (B + 1);
@@ -1270,10 +1316,27 @@ int forward_core_split(EcEncoder* e, const float* mel, const int64_t* in_len, in
         } else if (b.conv_stride > 1) {
             return fail("strided block without expansion is not native (no shipped config uses it)");
         }
+        float* xo = (k == nb - 1 && !rg) ? out : xalt;
+        if (chain_out) {      // x = xres + C Wp2^T + bp2;  x += 1/2 FFN2(LN(x));  xo = LN(x);  [next block: xo += 1/2 FFN1(LN(xo)); Q | K | V]
+            SxcAParams cp{};
+            cp.tail = 1; cp.c = cbuf; cp.xres = x; cp.y = xo; cp.M = Mo; cp.D = De;
+            cp.w_p2 = W.xc_p2; cp.b_p2 = W.xc_bp2; cp.w_f2 = W.xc_f[1]; cp.nch_f2 = W.xf_nch[1]; cp.b_f2 = W.xf_b2[1]; cp.ln_g = W.ln_out.g; cp.ln_b = W.ln_out.b;
+            double fl = Mo * (double)De * De * (2.0 + 4.0 * b.ff_ratio), by = (double)Mo * De * 16 + De * (double)De * (4.0 + 16.0 * b.ff_ratio);
+            if (k + 1 < nb && e->bw[k + 1].xc_in && e->blocks[k + 1].dim_model == De && (int)s.Min[k + 1] == Mo) {
+                const EcBlock& bn = e->blocks[k + 1];
+                const BlockW& Wn = e->bw[k + 1];
+                const int Tn = s.Tin[k + 1];
+                cp.head = 1; cp.w_f1 = Wn.xc_f[0]; cp.nch_f1 = Wn.xf_nch[0]; cp.b_f1 = Wn.xf_b2[0]; cp.w_qkv = Wn.xc_qkv;
+                cp.q = q; cp.qkv_stride = w.qkv_stride; cp.q_rows = rg ? 0 : Tn; cp.q_pitch = rg ? 0 : ec_round_up(Tn, bn.group_size);
+                fl += Mo * (double)De * De * (4.0 * bn.ff_ratio + 6.0); by += (double)Mo * De * 20 + De * (double)De * (16.0 * bn.ff_ratio + 12.0);
+                head_done = true;
+            }
+            PROF(PC_GEMM_FFN, fl, by);
+            EC_TRY(launch_sxc_a(cp, st));
+        } else {
         EC_TRY(xgemm(e, st, cbuf, De, Mo, cm + ".7", De, De, x, De, 2, x, 1.0f));
         snprintf(nm, sizeof(nm), "blocks.%d.x_conv", k); trace_add(e, st, nm, x, Mo, De, De, 0);
         // ---- x += 1/2 FFN2(LN(x)); x = LN(x)   (blocks.py:132-135)
-        float* xo = (k == nb - 1 && !rg) ? out : xalt;
         if (W.xf_img[1] && e->split_ffn) {
             SxfFfnParams fp{};
             fp.X = x; fp.ldx = De; fp.Y = xo; fp.ldy = De; fp.wimg = W.xf_img[1]; fp.b2 = W.xf_b2[1]; fp.M = Mo; fp.D = De; fp.nchunk = W.xf_nch[1];
@@ -1286,9 +1349,11 @@ int forward_core_split(EcEncoder* e, const float* mel, const int64_t* in_len, in
             EC_TRY(xgemm(e, st, hb, De * b.ff_ratio, Mo, p + ".feed_forward_module2.layers.4", De, De * b.ff_ratio, x, De, 2, x, 0.5f, 0, 0, 0, 0, 0, 0, 0, PC_GEMM_FFN));
             EC_TRY(layernorm(x, Mo, De, W.ln_out, xo));
         }
+        }
         if (!(k == nb - 1 && !rg)) std::swap(x, xalt);
         snprintf(nm, sizeof(nm), "blocks.%d.out", k); trace_add(e, st, nm, xo, Mo, De, De, 0);
     }
+    if (!capturing && !e->trace_arena) e->e_cache_put(ws, B, e_tag, e_layout);
     if (rg) {
         const RaggedRows rl = rows_at(nb);
         PROF(PC_MISC, 0, (double)s.Mfinal * e->blocks.back().dim_expand * 4 + (double)B * out_frames * e->blocks.back().dim_expand * 4);
@@ -1750,6 +1815,112 @@ int effconf_encoder_finalize(EcEncoder* e) {
                     for (int n = 0; n < D; ++n) b2h[n] = 0.5f * b2->data[n];
                     e->bw[k].xf_img[which] = upload(e, img); e->bw[k].xf_b2[which] = upload(e, b2h); e->bw[k].xf_nch[which] = nch;
                 }
+            // weight images of the split chains (sxf_chain.hip; kernels.h: SxcBParams / SxcAParams).  ONE k order everywhere - the accumulator layout's: inside a
+            // 16-block, position 8 kh + e holds feature 8 (e >> 2) + 4 kh + (e & 3) - because every operand of a product is a converted accumulator tile.
+            {
+                auto perm16 = [](int pos) { const int khh = pos >> 3, ee = pos & 7; return 8 * (ee >> 2) + 4 * khh + (ee & 3); };
+                auto put = [&](std::vector<uint16_t>& img, size_t hi_at, size_t lo_at, double wv) {
+                    const float ws = clampf((float)(wv * 1024.0));
+                    const _Float16 hh = (_Float16)ws;
+                    img[hi_at] = half_bits((float)hh);
+                    img[lo_at] = half_bits(ws - (float)hh);
+                };
+                // F1 chunk at `base`: 32 output rows (null = padding) x DP1 columns, h plane then l plane; gamma folded into the weights, W beta + bias in column D
+                auto f1_chunk = [&](std::vector<uint16_t>& img, size_t base, int DP1, int K, const float* const* wrow, const float* bias, const float* g, const float* beta) {
+                    for (int r = 0; r < 32; ++r) {
+                        if (!wrow[r]) continue;
+                        double bsum = bias[r];
+                        for (int col = 0; col < DP1; ++col) {
+                            const int f = (col & ~15) + perm16(col & 15);
+                            if (f < K) {
+                                const double wv = wrow[r][f];
+                                if (beta) bsum += wv * beta[f];
+                                put(img, base + (size_t)r * DP1 + col, base + (size_t)32 * DP1 + (size_t)r * DP1 + col, g ? wv * g[f] : wv);
+                            }
+                        }
+                        for (int col = 0; col < DP1; ++col)
+                            if ((col & ~15) + perm16(col & 15) == K) put(img, base + (size_t)r * DP1 + col, base + (size_t)32 * DP1 + (size_t)r * DP1 + col, bsum);
+                    }
+                };
+                // F2 chunk c at `base`: DP2 output rows x 32 input positions (inputs 32 c ..), h plane then l plane
+                auto f2_chunk = [&](std::vector<uint16_t>& img, size_t base, int DP2, int c, const float* Wm, int N, int K, int ldw, double scale) {
+                    for (int n = 0; n < N; ++n)
+                        for (int pos = 0; pos < 32; ++pos) {
+                            const int kk = 32 * c + (pos & ~15) + perm16(pos & 15);
+                            if (kk < K) put(img, base + (size_t)n * 32 + pos, base + (size_t)32 * DP2 + (size_t)n * 32 + pos, scale * Wm[(size_t)n * ldw + kk]);
+                        }
+                };
+                auto padded = [&](const std::vector<float>& v, int n, float scale) { std::vector<float> o(n, 0.f); for (size_t i = 0; i < v.size() && (int)i < n; ++i) o[i] = scale * v[i]; return o; };
+                for (size_t k = 0; k < e->blocks.size(); ++k) {
+                    const EcBlock& b = e->blocks[k];
+                    BlockW& W = e->bw[k];
+                    const int D = b.dim_model, De = b.dim_expand;
+                    const std::string pb = "blocks." + std::to_string(k);
+                    const std::string mh = pb + ".multi_head_self_attention_module.", cm = pb + ".convolution_module.layers.";
+                    auto ffn_image = [&](int which, int Dw) -> const uint16_t* {       // FeedForwardModule `which` at width Dw: per 32 hidden units an F1 chunk + an F2 chunk
+                        const int F = Dw * b.ff_ratio;
+                        const std::string pf = pb + (which ? ".feed_forward_module2.layers." : ".feed_forward_module1.layers.");
+                        const HostTensor *g = find(e, pf + "0.weight"), *bt = find(e, pf + "0.bias"), *w1 = find(e, pf + "1.weight"), *b1 = find(e, pf + "1.bias"),
+                                         *w2 = find(e, pf + "4.weight");
+                        if (!g || !bt || !w1 || !b1 || !w2 || (int64_t)w1->data.size() != (int64_t)F * Dw || (int64_t)w2->data.size() != (int64_t)F * Dw ||
+                            (int)g->data.size() != Dw || (int)bt->data.size() != Dw || (int)b1->data.size() != F || !W.xf_b2[which]) return nullptr;
+                        int ks, nt; sxf_ffn_shape(Dw, &ks, &nt);
+                        const int DP1 = 16 * ks, DP2 = 32 * nt, nch = (F + 31) / 32;
+                        const size_t per = (size_t)64 * (DP1 + DP2);
+                        std::vector<uint16_t> img((size_t)nch * per, 0);
+                        for (int c = 0; c < nch; ++c) {
+                            const float* rows[32]; float bias[32];
+                            for (int r = 0; r < 32; ++r) { const int h = 32 * c + r; rows[r] = h < F ? w1->data.data() + (size_t)h * Dw : nullptr; bias[r] = h < F ? b1->data[h] : 0.f; }
+                            f1_chunk(img, (size_t)c * per, DP1, Dw, rows, bias, g->data.data(), bt->data.data());
+                            f2_chunk(img, (size_t)c * per + (size_t)64 * DP1, DP2, c, w2->data.data(), Dw, F, F, 0.5);
+                        }
+                        return upload(e, img);
+                    };
+                    if (sxc_supported(D) && sxf_ffn_supported(D)) {
+                        int ks, nt; sxf_ffn_shape(D, &ks, &nt);
+                        const int DP1 = 16 * ks, DP2 = 32 * nt, nte = (De + 31) / 32;
+                        const HostTensor *wo = find(e, mh + "mhsa.output_layer.weight"), *bo = find(e, mh + "mhsa.output_layer.bias"), *lg = find(e, cm + "0.weight"), *lb = find(e, cm + "0.bias"),
+                                         *w1 = find(e, cm + "2.weight"), *b1 = find(e, cm + "2.bias"), *ag = find(e, mh + "norm.weight"), *ab = find(e, mh + "norm.bias");
+                        const HostTensor *wq[3] = {find(e, mh + "mhsa.query_layer.weight"), find(e, mh + "mhsa.key_layer.weight"), find(e, mh + "mhsa.value_layer.weight")};
+                        const HostTensor *bq[3] = {find(e, mh + "mhsa.query_layer.bias"), find(e, mh + "mhsa.key_layer.bias"), find(e, mh + "mhsa.value_layer.bias")};
+                        bool ok = wo && bo && lg && lb && w1 && b1 && ag && ab && (int)wo->data.size() == D * D && (int)bo->data.size() == D && (int)lg->data.size() == D && (int)lb->data.size() == D &&
+                                  (int64_t)w1->data.size() == (int64_t)2 * De * D && (int)b1->data.size() == 2 * De && (int)ag->data.size() == D && (int)ab->data.size() == D;
+                        for (int i = 0; i < 3; ++i) ok = ok && wq[i] && bq[i] && (int)wq[i]->data.size() == D * D && (int)bq[i]->data.size() == D;
+                        if (ok) {
+                            std::vector<uint16_t> io((size_t)nt * 64 * DP2, 0);
+                            for (int c = 0; c < nt; ++c) f2_chunk(io, (size_t)c * 64 * DP2, DP2, c, wo->data.data(), D, D, D, 1.0);
+                            std::vector<uint16_t> ip((size_t)2 * nte * 64 * DP1, 0);
+                            for (int c = 0; c < 2 * nte; ++c) {          // chunk 2 j: value rows 32 j .., chunk 2 j + 1: their gate rows De + 32 j ..
+                                const float* rows[32]; float bias[32];
+                                for (int r = 0; r < 32; ++r) { const int f = 32 * (c >> 1) + r, n = (c & 1) * De + f; rows[r] = f < De ? w1->data.data() + (size_t)n * D : nullptr; bias[r] = f < De ? b1->data[n] : 0.f; }
+                                f1_chunk(ip, (size_t)c * 64 * DP1, DP1, D, rows, bias, lg->data.data(), lb->data.data());
+                            }
+                            std::vector<uint16_t> iq((size_t)3 * nt * 64 * DP1, 0);
+                            for (int c = 0; c < 3 * nt; ++c) {
+                                const int which = c / nt, cc = c % nt;
+                                const float* rows[32]; float bias[32];
+                                for (int r = 0; r < 32; ++r) { const int n = 32 * cc + r; rows[r] = n < D ? wq[which]->data.data() + (size_t)n * D : nullptr; bias[r] = n < D ? bq[which]->data[n] : 0.f; }
+                                f1_chunk(iq, (size_t)c * 64 * DP1, DP1, D, rows, bias, ag->data.data(), ab->data.data());
+                            }
+                            W.xc_wo = upload(e, io); W.xc_bo = upload(e, padded(bo->data, DP2, 1.f)); W.xc_p1 = upload(e, ip); W.xc_nch_p1 = 2 * nte; W.xc_qkv = upload(e, iq);
+                            W.xc_f[0] = ffn_image(0, D);
+                            W.xc_in = W.xc_f[0] != nullptr;
+                        }
+                    }
+                    if (sxc_supported(De) && sxf_ffn_supported(De)) {
+                        int ks, nt; sxf_ffn_shape(De, &ks, &nt);
+                        const int DP2 = 32 * nt;
+                        const HostTensor *w2 = find(e, cm + "7.weight"), *b2 = find(e, cm + "7.bias");
+                        if (w2 && b2 && (int64_t)w2->data.size() == (int64_t)De * De && (int)b2->data.size() == De) {
+                            std::vector<uint16_t> i2((size_t)nt * 64 * DP2, 0);
+                            for (int c = 0; c < nt; ++c) f2_chunk(i2, (size_t)c * 64 * DP2, DP2, c, w2->data.data(), De, De, De, 1.0);
+                            W.xc_p2 = upload(e, i2); W.xc_bp2 = upload(e, padded(b2->data, DP2, 1.f));
+                            W.xc_f[1] = ffn_image(1, De);
+                            W.xc_out = W.xc_f[1] != nullptr;
+                        }
+                    }
+                }
+            }
         }
         for (const EcBlock& b : e->blocks) {
             auto key = std::make_pair(b.max_pos, b.dim_model);
@@ -2195,6 +2366,7 @@ int effconf_encoder_set_option(EcEncoder* e, const char* name, int32_t value) {
     if (!strcmp(name, "ffn_variant")) { if (value < 0 || value > 2) return fail("ffn_variant: 0, 1 or 2 (fused-FFN workgroup shapes)"); e->ffn_variant = value; return 0; }
     if (!strcmp(name, "head_major_odd")) { e->head_major_odd = value != 0; return 0; }
     if (!strcmp(name, "split_ffn")) { e->split_ffn = value != 0; return 0; }
+    if (!strcmp(name, "split_chain")) { e->split_chain = value != 0; return 0; }
     if (!strcmp(name, "exact_attention")) { if (value < 0 || value > 2) return fail("exact_attention: 0 (tiled), 2 (tiled, 16-row workgroups) or 1 (one wave per query row)"); e->exact_attention = value; return 0; }
     if (!strcmp(name, "cache_pos_embeddings")) { e->e_cache_on = value != 0; e->e_cache.clear(); return 0; }
     if (!strcmp(name, "exact_fp32")) {

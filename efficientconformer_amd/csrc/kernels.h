@@ -285,6 +285,34 @@ void sxf_ffn_shape(int D, int* ks1, int* nt2);
 bool sxf_ffn_supported(int D);
 size_t sxf_ffn_image_halfs(int D, int F);
 int launch_sxf_ffn(const SxfFfnParams& p, hipStream_t s);
+// Split-precision row-local chains (sxf_chain.hip): the work of a block between attention and the depthwise convolution as one kernel each.  Weight images: fp16
+// (h | l) planes at the weight scale 2^10, chunk-major, k order = the accumulator layout's (pack_sxc_* in encoder.hip); "F1" = 32 outputs x all inputs per chunk with
+// the bias in column D, "F2" = all outputs x 32 inputs per chunk, an FFN image = both per chunk of 32 hidden units.
+struct SxcBParams {                // chain B: x += O Wo^T + bo;  g = GLU(LN(x) Wp1^T + bp1)
+    const float* o; int o_rows, o_pitch;       // attention output [.][D]; o_rows > 0: row m of x is row (m / o_rows) o_pitch + m % o_rows of o (rectangular batches: frames / padded frames)
+    float* x;                      // residual stream [M][D], updated in place
+    float* g;                      // [M][De]
+    int M, D, De;
+    const uint16_t* w_o; const float* b_o;     // F2 image of the output projection (ceil(D / 32) chunks), bias padded to 32 ceil(D / 32)
+    const uint16_t* w_p1; int nch_p1;          // F1 image of pointwise-1 (conv-module LayerNorm folded in): chunk pairs (32 value rows, their 32 gate rows)
+};
+struct SxcAParams {                // chain A.  tail: x = xres + C Wp2^T + bp2; x += 1/2 FFN2(LN(x)); y = LN(x).  head: y += 1/2 FFN1(LN(y)); Q | K | V = LN(y) Wqkv^T + b
+    int tail, head;                // at least one
+    const float* c;                // tail: conv-module activations [M][D] (depthwise conv output)
+    const float* xres;             // tail: residual input [M][D] (the stream, or conv_res of it)
+    float* y;                      // [M][D]: tail: the block's output (scratch for x on the way); head: updated in place (head alone: the input stream)
+    int M, D;
+    const uint16_t* w_p2; const float* b_p2;   // F2 image of pointwise-2 + bias
+    const uint16_t* w_f2; int nch_f2; const float* b_f2;     // FFN2 image (pre-norm folded), b2 / 2
+    const float *ln_g, *ln_b;      // block-final LayerNorm [D]
+    const uint16_t* w_f1; int nch_f1; const float* b_f1;     // head: FFN1 image of the NEXT block, b2 / 2
+    const uint16_t* w_qkv;         // head: F1 image of Q | K | V (each padded to 32 ceil(D / 32) rows; attention pre-norm folded)
+    float* q; size_t qkv_stride;   // head: Q at q, K at q + qkv_stride, V at q + 2 qkv_stride (fp32 [.][D])
+    int q_rows, q_pitch;           // head: row remap of the Q / K / V rows (as o_rows / o_pitch)
+};
+bool sxc_supported(int D);
+int launch_sxc_b(const SxcBParams& p, hipStream_t s);
+int launch_sxc_a(const SxcAParams& p, hipStream_t s);
 // fp32 depthwise conv + folded BatchNorm + Swish; rc != null: per-utterance row ranges (tcap_max = the longest utterance's padded output rows)
 int launch_sxf_dwconv(const float* g, int B, int T, int To, int C, const float* w_kc, const float* bias, int ks, int stride, float* out, hipStream_t s,
                       const RaggedConv* rc = nullptr, int causal = 0, int tcap_max = 0);

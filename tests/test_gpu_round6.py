@@ -228,3 +228,45 @@ def test_split_mode_ragged_batch_equals_utterances_alone_and_the_oracle(name, ex
         lens = np.array([70000, 52345, 33000, 20000, 8000], dtype=np.int64)
     audio = torch.from_numpy(synth.make_audio(lens, seed=4))
     _ragged_vs_alone(m.cuda(), osd, audio, lens, nsub, tol=(SPLIT_MAX, SPLIT_MEAN))
+
+
+# ------------------------------------------------------------------ split-precision row-local chains (csrc/sxf_chain.hip)
+@pytest.mark.parametrize("name,tm,lens", [("Tiny", 333, [333, 250, 97, 12]), ("EfficientConformerCTCSmall", 420, [420, 333, 201]),
+                                          ("EfficientConformerCTCMedium", 300, [300, 177]), ("ConformerCTCSmall", 260, [260, 121]),
+                                          ("ConformerCTCMedium", 180, [180, 77]), ("EfficientConformerTransducerSmall", 300, [300, 222])])
+@pytest.mark.parametrize("ragged", [False, True])
+def test_split_chains_vs_per_module_kernels_and_the_oracle(name, tm, lens, ragged):
+    """sxf_chain.hip: out-proj + residual + LayerNorm + pointwise-1 + GLU as one kernel, pointwise-2 + residual + FFN2 + block LayerNorm + the next block's FFN1 +
+    attention pre-norm + Q | K | V as another (blocks.py:119-137, modules.py:385-395, 511-522, attentions.py:651-653, 716).  The split mode with the chains (the
+    default) against (i) the same mode on the per-module kernels (`split_chain = 0`: LayerNorm, split GEMM, GLU and FFN kernels - a different summation order, so
+    a few 1e-6, not bit equality) and (ii) the oracle within the split mode's stated 2e-4 / 2e-5; rectangular batches with pad frames (the Q / K / V and
+    attention-output row remap) and ragged ones; widths 24 .. 256 incl. the stage transitions (D != De) and both subsampler forms."""
+    m, sd = _model(name, 11)
+    plan = m.encoder.plan
+    m.encoder.precision = "split"
+    mel, ln = synth.make_mel(len(lens), 80, tm, lens, seed=99 + tm)
+    mel_d, ln_d = torch.from_numpy(mel).cuda(), torch.from_numpy(ln).cuda()
+    m.encoder.ragged = ragged
+    out, out_len, _ = m.encoder.forward_mel(mel_d, ln_d)
+    m.encoder.set_option("split_chain", 0)
+    base, base_len, _ = m.encoder.forward_mel(mel_d, ln_d)
+    m.encoder.set_option("split_chain", 1)
+    assert torch.equal(out_len, base_len)
+    d = (out - base).abs()
+    print("%s ragged=%s chains vs per-module kernels: max %.2e mean %.2e" % (name, ragged, float(d.max()), float(d.mean())))
+    assert float(d.max()) < 1e-4 and float(d.mean()) < 1e-5
+    if ragged:
+        for b, l in enumerate(lens):
+            with torch.no_grad():
+                ref, ref_len = R.encoder_from_mel(torch.from_numpy(mel[b:b + 1, :, :l]), torch.tensor([l]), sd, plan)
+            tb = int(ref_len[0])
+            assert int(out_len[b]) == tb
+            e = (out[b, :tb].cpu() - ref[0]).abs()
+            assert float(e.max()) < SPLIT_MAX and float(e.mean()) < SPLIT_MEAN, (b, float(e.max()), float(e.mean()))
+    else:
+        with torch.no_grad():
+            ref, ref_len = R.encoder_from_mel(torch.from_numpy(mel), torch.from_numpy(ln), sd, plan)
+        assert out_len.cpu().tolist() == ref_len.tolist()
+        e = (out.cpu() - ref).abs()
+        print("%s rectangular vs oracle: max %.2e mean %.2e" % (name, float(e.max()), float(e.mean())))
+        assert float(e.max()) < SPLIT_MAX and float(e.mean()) < SPLIT_MEAN

@@ -6,7 +6,7 @@ import sys
 
 src = sys.argv[1]
 out = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", src, "-o", "/dev/null",
-                      "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True).stderr
+                      "-Rpass-analysis=kernel-resource-usage"] + sys.argv[2:], capture_output=True, text=True).stderr
 cur = None
 rows = []
 for line in out.splitlines():
