@@ -93,7 +93,11 @@ def test_exact_mode_every_stage_vs_oracle(tm, lens, precision):
     assert 1e-4 < _err(b16.cpu(), ref)[0] < 0.08
     m.encoder.precision = precision
     again, _, _ = m.encoder.forward_mel(torch.from_numpy(mel).cuda(), torch.from_numpy(ln).cuda())
-    assert torch.equal(again, out)
+    if precision == "split":      # a traced forward runs the per-module kernels (the chains of csrc/sxf_chain.hip never write the intermediate states): another
+        twice, _, _ = m.encoder.forward_mel(torch.from_numpy(mel).cuda(), torch.from_numpy(ln).cuda())      # summation order, not another result
+        assert torch.equal(again, twice) and _err(again.cpu(), out.cpu())[0] < 2e-5 and _err(again.cpu(), ref)[0] < 2e-4
+    else:
+        assert torch.equal(again, out)
     if precision == "split":      # a handle packed for "split" serves "fp32" too, and the two label-exact modes agree far below the bf16 path's error
         m.encoder.precision = "fp32"
         f32, _, _ = m.encoder.forward_mel(torch.from_numpy(mel).cuda(), torch.from_numpy(ln).cuda())
