@@ -262,9 +262,15 @@ __global__ __launch_bounds__(NT) void rnnt_greedy_kernel(RnntDev w, const float*
 // tanhf / expf, the decisions) is that kernel's code: both produce identical tokens (tests: the reference's goldens and 165 k tokens
 // of tools/rnnt_diag.py).  Round 3, per round of a 256-utterance decode: 206 k -> 112 k cycles (140 -> 46 ms per decode).
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int CW = 8;          // workgroups per cluster
-constexpr int CU = 8;          // utterances per cluster
-constexpr int CKF = 2;         // encoder frames per joint pass
+// Two cluster shapes <CW workgroups, CU utterances, CKF encoder frames per joint pass>, CU * CKF = 16 = the columns of an MFMA tile:
+//   <8, 8, 2>    round 3's: 32 clusters at B = 256, every one of them streams the whole 10.7 MB (Transducer-Medium) per round - 342 MB per round through the
+//                L2s, which is what a round costs; the gate / decoder-projection tiles use 8 of their 16 columns
+//   <16, 16, 1>  round 6 (option cluster_shape = 1): 16 clusters - half the bytes per round and per workgroup, all 16 columns of every tile used; the state of 16
+//                utterances (h, linear_decoder(h), one joint input each) is 3 x 16 x 640 x 4 B = 123 KB of LDS, so no second speculative frame.
+//                MEASURED (profiles/r6_33_rnnt_cluster_shapes.txt): 41.9 ms against 42.4 ms at B = 256 - and B = 64 (8 clusters instead of 32) takes the same
+//                40 ms: a decode is ~1090 lockstep rounds of ~38 us whatever the bytes per round, i.e. the round is a LATENCY chain (three cluster barriers +
+//                exchange reloads + three dependent 160-MFMA accumulator chains), not the L2 stream the byte count suggests.  Kept as an option, not the default
+//                (a blank-only decode costs 3.4 ms instead of 1.9: one frame per joint pass).
 constexpr int CNT = 512;
 constexpr int CLB = 8;         // weight loads kept in flight per thread (H/4 and J/4 must be multiples)
 
@@ -276,6 +282,7 @@ struct ClusterArgs {
     int ncl, by_slice;
 };
 
+
 // Exchange data and the barrier counter are accessed with relaxed agent-scope atomics (sc1 loads / stores served at the coherent
 // level) instead of plain accesses bracketed by agent-scope release / acquire fences: the fences cost a full L2 write-back +
 // invalidate per workgroup per barrier (~40 us each here; three barriers per round made the cluster no faster than one workgroup per
@@ -286,6 +293,7 @@ __device__ __forceinline__ void xstorei(int* p, int v) { __hip_atomic_store(p, v
 __device__ __forceinline__ float xload(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ int xloadi(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+template <int CW>
 __device__ __forceinline__ bool cluster_sync(unsigned* cnt, unsigned& epoch, int* status) {
     __syncthreads();
     epoch += CW;
@@ -363,7 +371,9 @@ __device__ __forceinline__ void xload3(const float* p0, const float* p1, const f
                  : "=&v"(a), "=&v"(b), "=&v"(c) : "v"(p0), "v"(p1), "v"(p2) : "memory");
 }
 
+template <int CW, int CU, int CKF>
 __global__ __launch_bounds__(CNT) void rnnt_cluster_kernel(const ClusterArgs a) {
+    static_assert(CU * CKF == 16 && CU <= 16, "one MFMA column tile of joint inputs");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const RnntDev& w = a.w;
     const int H = w.H, J = w.J, V = w.V;
@@ -411,7 +421,7 @@ __global__ __launch_bounds__(CNT) void rnnt_cluster_kernel(const ClusterArgs a) 
             {
                 const int ntile = 4 * HU / 16;                             // HU % 4 == 0 (cluster_supported)
                 const int j = lane & 15, g = lane >> 4;
-                const float* xl = sh + (j & 7) * H + 4 * g;                // columns 8 .. 15 of B repeat the 8 utterances (results unused)
+                const float* xl = sh + (j % CU) * H + 4 * g;                // columns 8 .. 15 of B repeat the 8 utterances (results unused)
                 auto run = [&](auto ntl_c) __attribute__((always_inline)) {
                     constexpr int NTL = decltype(ntl_c)::value;
                     int nrow[NTL];
@@ -453,7 +463,7 @@ __global__ __launch_bounds__(CNT) void rnnt_cluster_kernel(const ClusterArgs a) 
                 }
                 xstore(xh + u * H + wg * HU + unit, hv);
             }
-            ok = cluster_sync(cnt, epoch, a.status);
+            ok = cluster_sync<CW>(cnt, epoch, a.status);
             for (int i0 = tid; i0 < CU * H / 4; i0 += 3 * CNT) {         // h of every utterance, k-permuted (see mfma_rows16)
                 const int n4 = CU * H / 4, i1 = i0 + CNT, i2 = i0 + 2 * CNT;
                 float4 v[3];
@@ -477,7 +487,7 @@ __global__ __launch_bounds__(CNT) void rnnt_cluster_kernel(const ClusterArgs a) 
                     const int lr = 16 * t + j;
                     nrow[0] = wg * JU + (lr < JU ? lr : JU - 1);
                     f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
-                    mfma_rows16<1>(w.wd16, J, H / 16, nrow, sh + (j & 7) * H + 4 * g, acc);
+                    mfma_rows16<1>(w.wd16, J, H / 16, nrow, sh + (j % CU) * H + 4 * g, acc);
                     if (j < CU) {
                         const int u = j;
                         const bool upd = s_need[u] && s_step[u] < s_T[u];
@@ -489,7 +499,7 @@ __global__ __launch_bounds__(CNT) void rnnt_cluster_kernel(const ClusterArgs a) 
                     }
                 }
             }
-            ok = cluster_sync(cnt, epoch, a.status) && ok;
+            ok = cluster_sync<CW>(cnt, epoch, a.status) && ok;
             for (int i0 = tid; i0 < CU * J / 4; i0 += 3 * CNT) {
                 const int n4 = CU * J / 4, i1 = i0 + CNT, i2 = i0 + 2 * CNT;
                 float4 v[3];
@@ -561,7 +571,7 @@ __global__ __launch_bounds__(CNT) void rnnt_cluster_kernel(const ClusterArgs a) 
             }
             xstore(xav + wg * CU * CKF + tid, bv); xstorei(xai + wg * CU * CKF + tid, bi);
         }
-        ok = cluster_sync(cnt, epoch, a.status) && ok;
+        ok = cluster_sync<CW>(cnt, epoch, a.status) && ok;
         if (tid < CU * CKF) {
             float bv = xload(xav + tid); int bi = xloadi(xai + tid);
             for (int q = 1; q < CW; ++q) {
@@ -602,14 +612,18 @@ __global__ __launch_bounds__(CNT) void rnnt_cluster_kernel(const ClusterArgs a) 
     }
 }
 
-inline size_t cluster_exchange_bytes(int ncl, int H, int J) {
-    return (size_t)ncl * ((size_t)CU * H * 4 + (size_t)CU * J * 4 + (size_t)CW * CU * CKF * 8 + 256) + 256;
-}
-inline bool cluster_supported(const EcRnntConfig& c) {
-    // 16-blocks of k in groups of CMB; whole 16-row tiles of gate rows; at most 4 gate tiles per wave and one vocabulary tile per wave
-    return c.dim_decoder % (16 * CMB) == 0 && c.dim_joint % (16 * CMB) == 0 && c.dim_decoder % (4 * CW) == 0 && c.dim_joint % CW == 0 &&
-           4 * (c.dim_decoder / CW) <= 16 * 8 * 4 && (c.vocab_size + CW - 1) / CW <= 128;
-}
+template <int CW, int CU, int CKF>
+struct ClusterShape {
+    static size_t exchange_bytes(int ncl, int H, int J) { return (size_t)ncl * ((size_t)CU * H * 4 + (size_t)CU * J * 4 + (size_t)CW * CU * CKF * 8 + 256) + 256; }
+    static size_t lds_bytes(int H, int J) { const int HU = H / CW; return (size_t)(CU * H + CU * J + CU * CKF * J + CU * HU + CU * 4 * HU + CU * CKF * 16) * 4; }
+    static bool supported(const EcRnntConfig& c) {
+        // 16-blocks of k in groups of CMB; whole 16-row tiles of gate rows; at most 4 gate tiles per wave and one vocabulary tile per wave; the state in LDS
+        return c.dim_decoder % (16 * CMB) == 0 && c.dim_joint % (16 * CMB) == 0 && c.dim_decoder % (4 * CW) == 0 && c.dim_joint % CW == 0 &&
+               4 * (c.dim_decoder / CW) <= 16 * 8 * 4 && (c.vocab_size + CW - 1) / CW <= 128 && lds_bytes(c.dim_decoder, c.dim_joint) <= 160 * 1024 - 512;
+    }
+};
+using ShapeA = ClusterShape<8, 8, 2>;
+using ShapeB = ClusterShape<16, 16, 1>;
 
 struct HostT { std::vector<int64_t> shape; std::vector<float> data; };
 
@@ -624,7 +638,8 @@ struct EcRnnt {
     float* be = nullptr;
     bool finalized = false;
     int cluster_by_slice = 1;   // cluster decode: workgroup -> XCD mapping (see rnnt_cluster_kernel)
-    int cluster_mode = -1;   // -1 auto (cluster decode for batches >= 2*CU), 0 per-utterance kernel, 1 force cluster
+    int cluster_mode = -1;   // -1 auto (cluster decode for batches >= 2 x the cluster's utterances), 0 per-utterance kernel, 1 force cluster
+    int cluster_shape = 0;   // 0 <8, 8, 2> (default), 1 <16, 16, 1> where supported (measured: no faster - see the shapes' comment - and a blank costs a round of its own)
 };
 
 namespace {
@@ -726,7 +741,7 @@ int effconf_rnnt_finalize(EcRnnt* r) {
     r->dev.wj4 = (const float4*)upload(r, wj4.data(), wj4.size() * 4);
     r->dev.bj = (const float*)upload(r, bj->data.data(), bj->data.size() * 4);
     r->dev.whh16 = r->dev.wd16 = r->dev.wj16 = nullptr;
-    if (cluster_supported(r->cfg)) {
+    if (ShapeA::supported(r->cfg) || ShapeB::supported(r->cfg)) {
         const std::vector<float> a16 = kperm16(whh->data, 4 * H, H), b16 = kperm16(wd->data, J, H), c16 = kperm16(wj->data, V, J);
         r->dev.whh16 = (const float4*)upload(r, a16.data(), a16.size() * 4);
         r->dev.wd16 = (const float4*)upload(r, b16.data(), b16.size() * 4);
@@ -748,14 +763,15 @@ int effconf_rnnt_finalize(EcRnnt* r) {
 
 size_t effconf_rnnt_workspace_bytes(const EcRnnt* r, int32_t batch, int32_t t_out) {
     if (!r || batch < 0 || t_out < 0) return 0;
-    const int ncl = (batch + CU - 1) / CU;
-    return (size_t)batch * t_out * r->cfg.dim_joint * 4 + 256 + cluster_exchange_bytes(ncl, r->cfg.dim_decoder, r->cfg.dim_joint);
+    const size_t ex = std::max(ShapeA::exchange_bytes((batch + 7) / 8, r->cfg.dim_decoder, r->cfg.dim_joint), ShapeB::exchange_bytes((batch + 15) / 16, r->cfg.dim_decoder, r->cfg.dim_joint));
+    return (size_t)batch * t_out * r->cfg.dim_joint * 4 + 256 + ex;
 }
 
 int effconf_rnnt_set_option(EcRnnt* r, const char* name, int32_t value) {
     if (!r || !name) return ec_fail("null argument");
     if (!strcmp(name, "cluster_decode")) { r->cluster_mode = value; return 0; }
     if (!strcmp(name, "cluster_by_slice")) { r->cluster_by_slice = value != 0; return 0; }
+    if (!strcmp(name, "cluster_shape")) { r->cluster_shape = value; return 0; }
     return ec_fail("unknown option");
 }
 
@@ -781,8 +797,9 @@ int effconf_rnnt_greedy(EcRnnt* r, const float* enc_out, const int64_t* out_len,
     // each other's cluster-mates: a spinning workgroup keeps its CU).
     // With the by-slice mapping a cluster is 8 CONSECUTIVE workgroups: whatever part of a launch is resident consists of whole clusters plus
     // at most one split at the dispatch frontier, so decodes sharing the GPU cannot starve each other and a launch may use every CU.
-    const bool cluster = cluster_supported(r->cfg) && (r->cluster_mode == 1 || (r->cluster_mode < 0 && batch >= 2 * CU && ((batch + CU - 1) / CU) * CW <= (r->cluster_by_slice ? 256 : 128)));
-    if (cluster) {
+    auto run_cluster = [&](auto shape, auto cw_c, auto cu_c, auto ckf_c) -> int {
+        using Shape = decltype(shape);
+        constexpr int CW = decltype(cw_c)::value, CU = decltype(cu_c)::value, CKF = decltype(ckf_c)::value;
         const int ncl = (batch + CU - 1) / CU;
         if (ncl * CW > 256) return ec_fail("cluster decode needs every workgroup resident: batch <= 256");
         char* ex = reinterpret_cast<char*>(fe) + (size_t)batch * t_out * J * 4;
@@ -797,12 +814,19 @@ int effconf_rnnt_greedy(EcRnnt* r, const float* enc_out, const int64_t* out_len,
         a.xav = reinterpret_cast<float*>(p); p += (size_t)ncl * CW * CU * CKF * 4;
         a.xai = reinterpret_cast<int*>(p);
         if (hipMemsetAsync(ex, 0, (size_t)ncl * 256 + 256, s) != hipSuccess) return ec_fail("memset failed");
-        const int HU = H / CW;
-        const size_t lds = (size_t)(CU * H + CU * J + CU * CKF * J + CU * HU + CU * 4 * HU + CU * CKF * 16) * 4;
+        const size_t lds = Shape::lds_bytes(H, J);
         static LdsAttr attr;
-        ensure_dynamic_lds(reinterpret_cast<const void*>(&rnnt_cluster_kernel), (int)lds, attr);
-        hipLaunchKernelGGL(rnnt_cluster_kernel, dim3(ncl * CW), dim3(CNT), lds, s, a);
+        ensure_dynamic_lds(reinterpret_cast<const void*>(&rnnt_cluster_kernel<CW, CU, CKF>), (int)lds, attr);
+        hipLaunchKernelGGL((rnnt_cluster_kernel<CW, CU, CKF>), dim3(ncl * CW), dim3(CNT), lds, s, a);
         return hipGetLastError() == hipSuccess ? 0 : ec_fail("rnnt cluster launch failed");
+    };
+    // a cluster shape runs when the batch fills two of its clusters and all its workgroups are resident (by-cluster mapping: at most half of the CUs)
+    auto fits = [&](int cw, int cu) { return batch >= 2 * cu && ((batch + cu - 1) / cu) * cw <= (r->cluster_by_slice ? 256 : 128); };
+    if (r->cluster_mode != 0) {
+        const bool okB = ShapeB::supported(r->cfg) && r->cluster_shape == 1 && (r->cluster_mode == 1 ? ((batch + 15) / 16) * 16 <= 256 : fits(16, 16));
+        const bool okA = ShapeA::supported(r->cfg) && r->cluster_shape != 1 && (r->cluster_mode == 1 || fits(8, 8));
+        if (okB) return run_cluster(ShapeB{}, std::integral_constant<int, 16>{}, std::integral_constant<int, 16>{}, std::integral_constant<int, 1>{});
+        if (okA) return run_cluster(ShapeA{}, std::integral_constant<int, 8>{}, std::integral_constant<int, 8>{}, std::integral_constant<int, 2>{});
     }
     const size_t lds = (size_t)(2 * H + 4 * H + J + KF * J + 2 * KF * (NT / 64)) * 4;
     hipLaunchKernelGGL(rnnt_greedy_kernel, dim3(batch), dim3(NT), lds, s, r->dev, fe, out_len, t_out, tokens, token_len, max_tokens);

@@ -432,7 +432,7 @@ def test_front_door_matches_direct_calls():
 @pytest.mark.parametrize("name,tag,nb", [("TinyTransducer", "rand", 19), ("TinyTransducer", "blank", 16), ("EfficientConformerTransducerMedium", "blank", 24),
                                          ("EfficientConformerTransducerMedium", "rand", 16)])
 def test_rnnt_cluster_decode_equals_per_utterance_decode(golden_dir, name, tag, nb):
-    """Batches of >= 16 utterances decode in clusters of 8 workgroups x 8 utterances (shared weight streams, lockstep rounds,
+    """Batches of >= 16 utterances decode in clusters of 8 workgroups x 8 utterances or 16 x 16 (shared weight streams, lockstep rounds,
     cross-workgroup barriers); tokens must equal the one-workgroup-per-utterance kernel's and, for the golden rows, the reference's."""
     g = np.load(os.path.join(golden_dir, "rnnt_%s.npz" % name))
     m, _ = _transducer(name, int(g["weight_seed"]), float(g["blank_bias_" + tag]))
@@ -444,10 +444,13 @@ def test_rnnt_cluster_decode_equals_per_utterance_decode(golden_dir, name, tag, 
     m.set_decode_option("cluster_decode", 0)
     ref_t, ref_n = m.decode_encoded(f, lens)
     m.set_decode_option("cluster_decode", 1)
-    for by_slice in (0, 1):                           # workgroup -> XCD mapping: a cluster on one XCD / slice k of every cluster on XCD k
-        m.set_decode_option("cluster_by_slice", by_slice)
-        got_t, got_n = m.decode_encoded(f, lens)
-        assert torch.equal(got_n, ref_n) and torch.equal(got_t, ref_t), by_slice
+    for shape in (0, 1):                              # 8 workgroups x 8 utterances x 2 frames per joint pass / 16 x 16 x 1 (round 6: half the weight bytes per round)
+        m.set_decode_option("cluster_shape", shape)
+        for by_slice in (0, 1):                       # workgroup -> XCD mapping: a cluster on one XCD / slice k of every cluster on XCD k
+            m.set_decode_option("cluster_by_slice", by_slice)
+            got_t, got_n = m.decode_encoded(f, lens)
+            assert torch.equal(got_n, ref_n) and torch.equal(got_t, ref_t), (shape, by_slice)
+    m.set_decode_option("cluster_shape", -1)
     offs = g["offsets_" + tag]
     for b in range(f0.shape[0]):                      # the first copies keep the golden lengths
         want = g["tokens_" + tag][offs[b]:offs[b + 1]].tolist()

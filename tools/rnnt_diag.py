@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Time the RNN-T greedy decode paths (per-utterance kernel vs cluster decode, both workgroup -> XCD mappings) on synthetic encoder outputs.
 
-    [RNNT_MODES=cluster:by_slice,...] python tools/rnnt_diag.py [blank_bias=1.2] [batch=128]
+    [RNNT_MODES=cluster:by_slice:shape,...] python tools/rnnt_diag.py [blank_bias=1.2] [batch=128]      shape: 0 = 8 x 8 x 2, 1 = 16 x 16 x 1
 """
 import sys, os, time
 import numpy as np, torch
@@ -22,10 +22,11 @@ g = torch.Generator().manual_seed(0)
 f = torch.randn(B, T, 360, generator=g).cuda()
 lens = torch.tensor(sorted([int(x) for x in np.linspace(60, T, B)], reverse=True)).cuda()
 ref = None
-modes = [tuple(int(v) for v in m.split(':')) for m in os.environ.get('RNNT_MODES', '0:0,1:0,1:1').split(',')]
-for mode, by_slice in modes:
+modes = [tuple(int(v) for v in mm.split(':')) for mm in os.environ.get('RNNT_MODES', '0:0:0,1:1:0,1:1:1').split(',')]
+for mode, by_slice, shape in modes:
     m.set_decode_option("cluster_decode", mode)
     m.set_decode_option("cluster_by_slice", by_slice)
+    m.set_decode_option("cluster_shape", shape)
     t, n = m.decode_encoded(f, lens)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -33,6 +34,6 @@ for mode, by_slice in modes:
         t, n = m.decode_encoded(f, lens)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 3
-    print("B %d blank_bias %.1f cluster %d by_slice %d: %.2f ms, tokens %d (max %d), frames %d" % (B, bb, mode, by_slice, dt * 1e3, int(n.sum()), int(n.max()), int(lens.sum())))
+    print("B %d blank_bias %.1f cluster %d by_slice %d shape %d: %.2f ms, tokens %d (max %d), frames %d" % (B, bb, mode, by_slice, shape, dt * 1e3, int(n.sum()), int(n.max()), int(lens.sum())))
     if ref is None: ref = (t.clone(), n.clone())
     else: print("   identical to the per-utterance kernel:", torch.equal(ref[0], t) and torch.equal(ref[1], n))
