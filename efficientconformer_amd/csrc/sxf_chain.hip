@@ -98,16 +98,18 @@ struct Ring {
         for (int it = 0; it < NPC; ++it)
             if (PIECES % 256 == 0 || tid + 256 * it < PIECES) *reinterpret_cast<u4v*>((is_f2(it) ? s2 : s1) + loff[it]) = wreg[it];
     }
-    // pieces [i0, i1) of unit u published, then those of unit u + 1 requested into the same registers (spread over the k-steps of an F1 product)
-    __device__ __forceinline__ void unit_pieces(char* sm, int u, int i0, int i1) {
+    // pieces [i0, i1) of unit u / of a whole chunk published (spread over the k-steps of an F1 product: a ds_write_b128 occupies the LDS path for ~13 cycles, sixteen
+    // of them in a row were exposed; the REQUESTS stay together behind the product - interleaved with the MFMAs they faulted, profiles/r6_35_side_bisect.txt)
+    __device__ __forceinline__ void publish_unit_pieces(char* sm, int u, int i0, int i1) {
         char *s1 = sm + ((u + 1) & 1) * L::STAGE, *s2 = sm + (u & 1) * L::STAGE;
-        const int c1 = min(u + 2, n - 1), c2 = min(u + 1, n - 1);
 #pragma unroll
         for (int it = 0; it < NPC; ++it)
-            if (it >= i0 && it < i1 && (PIECES % 256 == 0 || tid + 256 * it < PIECES)) {
-                *reinterpret_cast<u4v*>((is_f2(it) ? s2 : s1) + loff[it]) = wreg[it];
-                wreg[it] = *reinterpret_cast<const u4v*>(src + (size_t)(is_f2(it) ? c2 : c1) * ((size_t)PIECES * 16) + (size_t)it * 4096);
-            }
+            if (it >= i0 && it < i1 && (PIECES % 256 == 0 || tid + 256 * it < PIECES)) *reinterpret_cast<u4v*>((is_f2(it) ? s2 : s1) + loff[it]) = wreg[it];
+    }
+    __device__ __forceinline__ void publish_pieces(char* st, int i0, int i1) {
+#pragma unroll
+        for (int it = 0; it < NPC; ++it)
+            if (it >= i0 && it < i1 && (PIECES % 256 == 0 || tid + 256 * it < PIECES)) *reinterpret_cast<u4v*>(st + loff[it]) = wreg[it];
     }
     // the first request of a product (issued early by the caller)
     __device__ __forceinline__ void fetch0() { if (MODE == MODE_FFN && ffn_pipelined(KS)) fetch_unit(-1); else fetch(0); }
@@ -450,14 +452,15 @@ __device__ __forceinline__ void g2_swish(const char* st, int lr, int kh, const f
 template <int KS, int NT>
 __device__ __forceinline__ void stage_ffn_plain(Ring<KS, NT, MODE_FFN>& ring, char* sm, int lr, int kh, const f16x8 (&ah)[KS], const f16x8 (&al)[KS], f32x16 (&oacc)[NT]) {
     using L = CL<KS, NT>;
+    using R = Ring<KS, NT, MODE_FFN>;
     zero_acc<NT>(oacc);
     ring.prime(sm);
     for (int c = 0; c < ring.n; ++c) {
         const char* st = sm + (c & 1) * L::STAGE;
-        if (c + 1 < ring.n) ring.publish(sm + ((c + 1) & 1) * L::STAGE);
-        ring.fetch(c + 2);
+        char* nx = sm + ((c + 1) & 1) * L::STAGE;                // chunk c + 1's slot: last read in iteration c - 1 (a publish past the end lands in a slot nobody reads)
         f32x16 h1, h2, h3;
-        g1<KS, NT>(st, lr, kh, ah, al, h1, h2, h3);
+        g1x<KS, NT>(st, lr, kh, ah, al, h1, h2, h3, [&](int s) __attribute__((always_inline)) { ring.publish_pieces(nx, s * R::NPC / KS, (s + 1) * R::NPC / KS); });
+        ring.fetch(c + 2);
         f16x8 hbh[2], hbl[2];
         swish_frags(h1, h2, h3, hbh, hbl);
         g2<KS, NT>(st, lr, kh, hbh, hbl, oacc);
@@ -476,23 +479,15 @@ __device__ __forceinline__ void stage_ffn_pipe(Ring<KS, NT, MODE_FFN>& ring, cha
     f16x8 hbh[2], hbl[2];
     {
         f32x16 h1, h2, h3;
-#ifndef SXC_SIDE
-        ring.publish_unit(sm, 0); ring.fetch_unit(1);
-        g1x<KS, NT>(sm, lr, kh, ah, al, h1, h2, h3, [&](int) __attribute__((always_inline)) {});
-#else
-        g1x<KS, NT>(sm, lr, kh, ah, al, h1, h2, h3, [&](int s) __attribute__((always_inline)) { ring.unit_pieces(sm, 0, s * R::NPC / KS, (s + 1) * R::NPC / KS); });
-#endif
+        g1x<KS, NT>(sm, lr, kh, ah, al, h1, h2, h3, [&](int s) __attribute__((always_inline)) { ring.publish_unit_pieces(sm, 0, s * R::NPC / KS, (s + 1) * R::NPC / KS); });
+        ring.fetch_unit(1);
         swish_frags(h1, h2, h3, hbh, hbl);
         lds_barrier();
     }
     for (int c = 1; c < ring.n; ++c) {
         f32x16 h1, h2, h3;
-#ifndef SXC_SIDE
-        ring.publish_unit(sm, c); ring.fetch_unit(c + 1);
-        g1x<KS, NT>(sm + (c & 1) * L::STAGE, lr, kh, ah, al, h1, h2, h3, [&](int) __attribute__((always_inline)) {});
-#else
-        g1x<KS, NT>(sm + (c & 1) * L::STAGE, lr, kh, ah, al, h1, h2, h3, [&](int s) __attribute__((always_inline)) { ring.unit_pieces(sm, c, s * R::NPC / KS, (s + 1) * R::NPC / KS); });
-#endif
+        g1x<KS, NT>(sm + (c & 1) * L::STAGE, lr, kh, ah, al, h1, h2, h3, [&](int s) __attribute__((always_inline)) { ring.publish_unit_pieces(sm, c, s * R::NPC / KS, (s + 1) * R::NPC / KS); });
+        ring.fetch_unit(c + 1);
         f16x8 nh[2], nl[2];
         g2_swish<KS, NT>(sm + ((c - 1) & 1) * L::STAGE, lr, kh, hbh, hbl, oacc, h1, h2, h3, nh, nl);
         hbh[0] = nh[0]; hbh[1] = nh[1]; hbl[0] = nl[0]; hbl[1] = nl[1];
@@ -535,7 +530,7 @@ __global__ __launch_bounds__(256, waves_per_simd(KS)) void sxc_b_kernel(const Sx
     extern __shared__ __attribute__((aligned(16))) char sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, kh = lane >> 5;
     const int D = p.D, De = p.De;
-    constexpr bool EARLY = KS <= 8;                               // the next product's first chunk requested BEFORE the epilogue of the current one (wider: 64 more live registers = spills)
+    constexpr bool EARLY = KS < 8;                               // the next product's first chunk requested BEFORE the epilogue of the current one (wider: 64 more live registers = spills)
     const int m = blockIdx.x * 128 + wave * 32 + lr;
     const int row = m < p.M ? m : p.M - 1;
     Ring<KS, NT, MODE_F2> ra;
@@ -582,7 +577,7 @@ __global__ __launch_bounds__(256) void sxc_a_kernel(const SxcAParams p) {
     extern __shared__ __attribute__((aligned(16))) char sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, kh = lane >> 5;
     const int D = p.D;
-    constexpr bool EARLY = KS <= 8;
+    constexpr bool EARLY = KS < 8;
     const int m = blockIdx.x * 128 + wave * 32 + lr;
     const int row = m < p.M ? m : p.M - 1;
     const bool live = m < p.M;
