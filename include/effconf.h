@@ -209,7 +209,8 @@ int32_t effconf_rnnt_max_tokens(const EcRnnt* r, int32_t t_out);
  * slice k of the weights is only ever read through XCD k's L2 and any resident part of a launch consists of whole clusters (decodes that
  * share the GPU cannot starve each other); 0: the members of a cluster share an XCD and must all be resident - auto then stops at 128
  * utterances.  The spin is bounded: a starved cluster gives up with undefined tokens instead of hanging.  All paths produce identical
- * tokens. */
+ * tokens.  "cluster_shape" (round 6): 0 (default) clusters of 8 workgroups x 8 utterances x 2 encoder frames per joint pass, 1 = 16 x 16 x 1 where the
+ * decoder / joint widths leave LDS for it (<= 768; half the weight bytes per round - measured no faster: profiles/r6_33_rnnt_cluster_shapes.txt). */
 int effconf_rnnt_set_option(EcRnnt* r, const char* name, int32_t value);
 int effconf_rnnt_greedy(EcRnnt* r, const float* enc_out, const int64_t* out_len, int32_t batch, int32_t t_out,
                         int32_t* tokens, int32_t* token_len, int32_t max_tokens, void* workspace, size_t workspace_bytes,
@@ -250,18 +251,24 @@ int effconf_rnnt_greedy(EcRnnt* r, const float* enc_out, const int64_t* out_len,
  *   so that greedy CTC label sequences equal the reference's CPU fp32 path (model_ctc.py:99-133) wherever its top-2 logit margins
  *   exceed fp32 summation-order noise; ~10x slower than the default bf16-operand path.  Set to 1 BEFORE effconf_encoder_finalize
  *   (the fp32 tensors are uploaded there; the workspace query then covers both modes); afterwards it toggles the mode per handle.
- *   2 (round 4, csrc/split.hip): the same schedule and fp32 tensors with every GEMM and the attention products on the fp16 matrix pipe, each
- *   operand split into two fp16 numbers x = h + l / 2048 (three MFMAs per product, products accurate to ~2^-21): label sequences identical to
- *   the reference's on every golden, 5.7x the bf16 step.  Set to 2 BEFORE finalize (the split weight images are built there; such a handle then
- *   serves 2, 1 and 0); a handle finalized with 1 refuses 2.
+ *   2 (round 4, csrc/split.hip; round 6, csrc/sxf.hip + sxf_ffn.hip + sxf_chain.hip): fp32 tensors with every GEMM and the attention products on the fp16
+ *   matrix pipe, each operand split into two fp16 numbers (three MFMAs per product, products accurate to ~2^-21): label sequences identical to the
+ *   reference's on every golden and on the bench's oracle samples of Small / Medium / Large.  Round 6: ONE attention kernel per block with the scores on the
+ *   CU, the row-local work of a block as two kernels, ragged batches, causal and streaming configurations - 3.2x the bf16 step on EfficientConformerCTCSmall
+ *   (5.7x in round 5), 2.9x on Medium / Large.  Set to 2 BEFORE finalize (the split weight images are built there; such a handle then serves 2, 1 and 0);
+ *   a handle finalized with 1 refuses 2.
+ * "split_chain" (default 1), "split_ffn" (default 1): split mode on the fused row-local kernels (csrc/sxf_chain.hip; csrc/sxf_ffn.hip when split_chain = 0);
+ *   0 / 0 = LayerNorm, split GEMM, GLU kernels per module (tests: the same results within a few 1e-6, another summation order).  A debug trace
+ *   (effconf_encoder_trace_*) runs the per-module kernels: the chains never write the intermediate states.
  * MODE MATRIX (what a forward accepts; everything else returns an error, never a silent fallback):
  *   bf16 path (exact_fp32 = 0): rectangular batches (effconf_encoder_forward / _forward_mel), ragged batches (effconf_encoder_forward_ragged; head
  *     widths <= 160 padded), streaming contexts / causal configurations (EcConfig; natural Q / K / V layout, head widths <= 160 padded), attention
  *     maps (effconf_encoder_set_attention_outputs; ragged batches since round 4: rectangles sized for the LONGEST utterance, utterance b's own
  *     Tg(b) x Tg(b) block = its map run alone, zeros elsewhere).
- *   label-exact modes (exact_fp32 = 1 | 2): rectangular batches, attention maps, finite left_context / right_context (round 4: the band mask is
- *     part of their attention kernels); NOT ragged batches (effconf_encoder_forward_ragged fails: their frame-mixing kernels index (utterance,
- *     frame) rectangles), NOT causal configurations (the forward fails: no causal relative tables / causal depthwise padding in these modes). */
+ *   split mode (exact_fp32 = 2; round 6): rectangular AND ragged batches, finite left_context / right_context AND causal configurations (causal relative
+ *     tables, causal depthwise padding); attention maps on rectangular batches (they run round 4's scores-in-memory kernels of csrc/split.hip).
+ *   fp32 mode (exact_fp32 = 1): rectangular batches, attention maps, finite left_context / right_context; NOT ragged batches, NOT causal configurations
+ *     (the forward fails). */
 int effconf_encoder_set_option(EcEncoder* enc, const char* name, int32_t value);
 
 /* ---- per-launch event profiler (bench / tuning only) --------------------------------------- */

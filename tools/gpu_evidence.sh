@@ -6,7 +6,7 @@
 #   kernel_stats.txt                 rocprofv3 --kernel-trace --stats of the same command, --no-check --no-roofline (only the timed region's launches)
 #   pmc_hbm_traffic.txt, pmc_traffic.json   two --pmc passes (FETCH_SIZE, WRITE_SIZE), clean as above; second table = serialised kernel durations
 #   sq_counters.txt                  one --pmc pass of SQ counters (MFMA busy / VALU / LDS wait per kernel)
-#   bench_split.json, bench_fp32.json  the two label-exact modes
+#   bench_split.json, bench_fp32.json  the two label-exact modes; <model>_bench_split.json, split_kernel_stats.txt, split_sq_counters.txt (round 6)
 #   <model>_bench.json               bench.py --model ... for the other configurations of BASELINE.json
 #   bench_ragged0.json, bench_notrim.json, bench_b128.json   the round-2 / round-1 workloads and B = 128 on the final tree
 #   overlap_events.txt               tools/overlap_probe.py (one-GPU stand-in of the per-range all-gather): sync / pipelined / no collective
@@ -29,6 +29,11 @@ python tools/sq_summary.py "$db" "$out/sq_counters.txt" "python bench.py --no-cp
 fi
 python bench.py --precision split --steps 10 --warmup 3 --no-cpu-baseline > "$out/bench_split.json" 2>> "$out/bench.err"
 python bench.py --precision fp32 --steps 5 --warmup 2 --no-cpu-baseline > "$out/bench_fp32.json" 2>> "$out/bench.err"
+for m in EfficientConformerCTCMedium EfficientConformerCTCLarge; do      # round 6: the label-exact mode on the other CTC configurations (labels vs the oracle in `check`)
+  python bench.py --precision split --model $m --steps 5 --warmup 2 --no-cpu-baseline > "$out/${m}_bench_split.json" 2>> "$out/bench.err"
+done
+tools/prof_split.sh "${tag}_split" pmc
+cp "$repo/gpurun_out/${tag}_split/kernel_stats.txt" "$out/split_kernel_stats.txt"; cp "$repo/gpurun_out/${tag}_split/sq_counters.txt" "$out/split_sq_counters.txt" 2>/dev/null
 for m in EfficientConformerCTCMedium EfficientConformerCTCLarge ConformerCTCLarge EfficientConformerTransducerMedium; do
   python bench.py --model $m --steps 5 --warmup 2 --no-cpu-baseline > "$out/${m}_bench.json" 2> "$out/${m}_bench.err"
 done
