@@ -1231,7 +1231,7 @@ int forward_core_split(EcEncoder* e, const float* mel, const int64_t* in_len, in
         } else if (chain_in) {
             SxcAParams cp{};
             cp.head = 1; cp.y = x; cp.M = M; cp.D = D; cp.w_f1 = W.xc_f[0]; cp.nch_f1 = W.xf_nch[0]; cp.b_f1 = W.xf_b2[0]; cp.w_qkv = W.xc_qkv;
-            cp.q = q; cp.qkv_stride = w.qkv_stride; cp.q_rows = qr; cp.q_pitch = qp;
+            cp.q = q; cp.qkv_stride = w.qkv_stride; cp.q_rows = qr; cp.q_pitch = qp; cp.qkv_bytes = (2 * w.qkv_stride + (size_t)s.Mq[k] * D) * 4;
             PROF(PC_GEMM_FFN, M * (double)D * D * (4.0 * b.ff_ratio + 6.0), (double)M * D * 24 + D * (double)D * (16.0 * b.ff_ratio + 12.0));
             EC_TRY(launch_sxc_a(cp, st));
         } else {
@@ -1327,7 +1327,7 @@ int forward_core_split(EcEncoder* e, const float* mel, const int64_t* in_len, in
                 const BlockW& Wn = e->bw[k + 1];
                 const int Tn = s.Tin[k + 1];
                 cp.head = 1; cp.w_f1 = Wn.xc_f[0]; cp.nch_f1 = Wn.xf_nch[0]; cp.b_f1 = Wn.xf_b2[0]; cp.w_qkv = Wn.xc_qkv;
-                cp.q = q; cp.qkv_stride = w.qkv_stride; cp.q_rows = rg ? 0 : Tn; cp.q_pitch = rg ? 0 : ec_round_up(Tn, bn.group_size);
+                cp.q = q; cp.qkv_stride = w.qkv_stride; cp.q_rows = rg ? 0 : Tn; cp.q_pitch = rg ? 0 : ec_round_up(Tn, bn.group_size); cp.qkv_bytes = (2 * w.qkv_stride + (size_t)s.Mq[k + 1] * De) * 4;
                 fl += Mo * (double)De * De * (4.0 * bn.ff_ratio + 6.0); by += (double)Mo * De * 20 + De * (double)De * (16.0 * bn.ff_ratio + 12.0);
                 head_done = true;
             }

@@ -308,6 +308,7 @@ struct SxcAParams {                // chain A.  tail: x = xres + C Wp2^T + bp2; 
     const uint16_t* w_f1; int nch_f1; const float* b_f1;     // head: FFN1 image of the NEXT block, b2 / 2
     const uint16_t* w_qkv;         // head: F1 image of Q | K | V (each padded to 32 ceil(D / 32) rows; attention pre-norm folded)
     float* q; size_t qkv_stride;   // head: Q at q, K at q + qkv_stride, V at q + 2 qkv_stride (fp32 [.][D])
+    size_t qkv_bytes;              // head: bytes from q to the end of V's rows (< 4 GB: the stores are range-checked buffer stores)
     int q_rows, q_pitch;           // head: row remap of the Q / K / V rows (as o_rows / o_pitch)
 };
 bool sxc_supported(int D);

@@ -36,6 +36,24 @@ enum { MODE_F1 = 1, MODE_F2 = 2, MODE_FFN = 3 };
 
 typedef uint32_t u4v __attribute__((ext_vector_type(4)));
 
+// NO LANE-DIVERGENT BRANCH in these kernels (round 6, profiles/r6_35_side_bisect.txt): hipcc (ROCm 7.2) places VGPR -> AGPR live-range-split copies
+// (v_accvgpr_write_b32) inside exec-masked regions; a value defined under the full mask, copied while `if (row < M)` or `if (column < D)` had narrowed it and
+// read back after reconvergence is garbage in the lanes that were off - here the Q / K / V row offset of live lanes whose last column quad lies behind D, i.e. a
+// store address beyond the aperture (every ragged forward of the D = 120 stage faulted in the builds that had such a copy; the rectangular ones recomputed the
+// offset under the full mask).  So masked LOADS read a 16-byte block of zeros, masked STORES are buffer stores at an out-of-range offset, partial ring pieces re-read a
+// valid piece and land in a per-thread LDS dump slot: selects on addresses / offsets, no branches (the listing has no s_and_saveexec left).
+__device__ __attribute__((aligned(16))) float sxc_zero4[4] = {0.f, 0.f, 0.f, 0.f};
+// masked stores: raw buffer stores whose offset lies behind the buffer's byte count are dropped by the address unit - no branch, no memory traffic (a shared sink
+// line cost 4 % of the step: every workgroup's masked lanes wrote the same 4 KB)
+struct OutBuf { __amdgpu_buffer_rsrc_t rsrc; uint32_t bytes; };
+__device__ __forceinline__ OutBuf out_buf(float* base, size_t floats) {
+    OutBuf b; b.bytes = (uint32_t)(floats * 4); b.rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)b.bytes, 0x00020000); return b;
+}
+__device__ __forceinline__ void bstore4(const OutBuf& b, uint32_t byte_off, bool on, float x, float y, float z, float w) {
+    u4v v; v[0] = __float_as_uint(x); v[1] = __float_as_uint(y); v[2] = __float_as_uint(z); v[3] = __float_as_uint(w);
+    __builtin_amdgcn_raw_buffer_store_b128(v, b.rsrc, on ? byte_off : b.bytes, 0, 0);
+}
+
 // Which form of the FFN stage a width runs (measured per launch inside the split step, profiles/r6_26 against r6_21): the software pipeline wins where the Swish is
 // long against the products and registers allow its second set of hidden-unit fragments (D = 144 .. 180: 250 -> 226 us); at D >= 240 it loses (376 -> 401 us: 500
 // registers, the extra copies land between the MFMAs); at D <= 120 the plain loop fits 256 registers, so TWO workgroups share a CU and fill each other's stalls
@@ -56,47 +74,52 @@ struct Ring {
     uint32_t loff[NPC];
     u4v wreg[NPC];
     const char* src;
+    char* dump;                                                  // this thread's 16-byte LDS slot behind the ring (pieces past the end of a chunk)
     int n, tid;
-    __device__ __forceinline__ void init(const uint16_t* img, int nchunk, int tid_) {
+    __device__ __forceinline__ bool piece_ok(int it) const { return PIECES % 256 == 0 || it < NPC - 1 || tid + 256 * it < PIECES; }
+    __device__ __forceinline__ void init(const uint16_t* img, int nchunk, int tid_, char* sm) {
         tid = tid_; n = nchunk;
+        dump = sm + 2 * L::STAGE + 16 * tid_;
         src = reinterpret_cast<const char*>(img) + (size_t)tid * 16;
 #pragma unroll
         for (int it = 0; it < NPC; ++it) {
             const int q = tid + 256 * it;
-            int o;
-            if (q < P1) { const int pl = q / (4 * L::DP1), rem = q - pl * 4 * L::DP1, r = rem / (L::DP1 / 8), ch = rem - r * (L::DP1 / 8); o = pl * 32 * L::ROW1 + r * L::ROW1 + ch * 16; }
-            else { const int q2 = q - P1, pl = q2 / (4 * L::DP2), rem = q2 - pl * 4 * L::DP2, nn = rem >> 2, ch = rem & 3; o = L::W1B + pl * L::DP2 * ROW2 + nn * ROW2 + ch * 16; }
-            loff[it] = (uint32_t)o;
+            // both layouts computed, one selected (no branch: see the note at the top; which one is a compile-time fact unless a 256-piece group straddles P1)
+            const int qa = q < P1 ? q : 0, qb = q >= P1 ? q - P1 : 0;
+            const int pla = qa / (4 * L::DP1), rema = qa - pla * 4 * L::DP1, ra = rema / (L::DP1 / 8), cha = rema - ra * (L::DP1 / 8);
+            const int oa = pla * 32 * L::ROW1 + ra * L::ROW1 + cha * 16;
+            const int plb = qb / (4 * L::DP2), remb = qb - plb * 4 * L::DP2, nb = remb >> 2, chb = remb & 3;
+            const int ob = L::W1B + plb * L::DP2 * ROW2 + nb * ROW2 + chb * 16;
+            loff[it] = (uint32_t)(P1 == 0 ? ob : (P2 == 0 ? oa : (q < P1 ? oa : ob)));
         }
     }
     __device__ __forceinline__ void fetch(int c) {
         c = c < n ? c : n - 1;                                    // past the end: the last chunk again (never published)
 #pragma unroll
         for (int it = 0; it < NPC; ++it)
-            if (PIECES % 256 == 0 || tid + 256 * it < PIECES) wreg[it] = *reinterpret_cast<const u4v*>(src + (size_t)c * ((size_t)PIECES * 16) + (size_t)it * 4096);
+            wreg[it] = *reinterpret_cast<const u4v*>(src + (size_t)c * ((size_t)PIECES * 16) + (piece_ok(it) ? (size_t)it * 4096 : (size_t)0));
     }
     __device__ __forceinline__ void publish(char* st) {
 #pragma unroll
         for (int it = 0; it < NPC; ++it)
-            if (PIECES % 256 == 0 || tid + 256 * it < PIECES) *reinterpret_cast<u4v*>(st + loff[it]) = wreg[it];
+            *reinterpret_cast<u4v*>(piece_ok(it) ? st + loff[it] : dump) = wreg[it];
     }
     // first chunk published, second requested; every wave is past the previous product's last barrier when it gets here
     __device__ __forceinline__ void prime(char* sm) { publish(sm); fetch(1); lds_barrier(); }
     // ---- the pipelined FFN stage moves its two weight parts in different phases: unit u = F1 part of chunk u + 1 (ring stage (u + 1) & 1) and F2 part of chunk u
     //      (ring stage u & 1); piece `it` of this thread belongs to the F2 part iff is_f2(it)
-    __device__ __forceinline__ bool is_f2(int it) const { return P1 % 256 == 0 ? 256 * it >= P1 : (tid + 256 * it >= P1); }
+    __device__ __forceinline__ bool is_f2(int it) const { return P1 % 256 == 0 ? 256 * it >= P1 : (tid + 256 * it >= P1); }      // a select on the address, not a branch
     __device__ __forceinline__ void fetch_unit(int u) {
         const int c1 = min(max(u + 1, 0), n - 1), c2 = min(max(u, 0), n - 1);
 #pragma unroll
         for (int it = 0; it < NPC; ++it)
-            if (PIECES % 256 == 0 || tid + 256 * it < PIECES)
-                wreg[it] = *reinterpret_cast<const u4v*>(src + (size_t)(is_f2(it) ? c2 : c1) * ((size_t)PIECES * 16) + (size_t)it * 4096);
+            wreg[it] = *reinterpret_cast<const u4v*>(src + (size_t)(is_f2(it) ? c2 : c1) * ((size_t)PIECES * 16) + (piece_ok(it) ? (size_t)it * 4096 : (size_t)0));
     }
     __device__ __forceinline__ void publish_unit(char* sm, int u) {
         char *s1 = sm + ((u + 1) & 1) * L::STAGE, *s2 = sm + (u & 1) * L::STAGE;
 #pragma unroll
         for (int it = 0; it < NPC; ++it)
-            if (PIECES % 256 == 0 || tid + 256 * it < PIECES) *reinterpret_cast<u4v*>((is_f2(it) ? s2 : s1) + loff[it]) = wreg[it];
+            *reinterpret_cast<u4v*>(piece_ok(it) ? (is_f2(it) ? s2 : s1) + loff[it] : dump) = wreg[it];
     }
     // pieces [i0, i1) of unit u / of a whole chunk published (spread over the k-steps of an F1 product: a ds_write_b128 occupies the LDS path for ~13 cycles, sixteen
     // of them in a row were exposed; the REQUESTS stay together behind the product - interleaved with the MFMAs they faulted, profiles/r6_35_side_bisect.txt)
@@ -104,12 +127,12 @@ struct Ring {
         char *s1 = sm + ((u + 1) & 1) * L::STAGE, *s2 = sm + (u & 1) * L::STAGE;
 #pragma unroll
         for (int it = 0; it < NPC; ++it)
-            if (it >= i0 && it < i1 && (PIECES % 256 == 0 || tid + 256 * it < PIECES)) *reinterpret_cast<u4v*>((is_f2(it) ? s2 : s1) + loff[it]) = wreg[it];
+            if (it >= i0 && it < i1) *reinterpret_cast<u4v*>(piece_ok(it) ? (is_f2(it) ? s2 : s1) + loff[it] : dump) = wreg[it];
     }
     __device__ __forceinline__ void publish_pieces(char* st, int i0, int i1) {
 #pragma unroll
         for (int it = 0; it < NPC; ++it)
-            if (it >= i0 && it < i1 && (PIECES % 256 == 0 || tid + 256 * it < PIECES)) *reinterpret_cast<u4v*>(st + loff[it]) = wreg[it];
+            if (it >= i0 && it < i1) *reinterpret_cast<u4v*>(piece_ok(it) ? st + loff[it] : dump) = wreg[it];
     }
     // the first request of a product (issued early by the caller)
     __device__ __forceinline__ void fetch0() { if (MODE == MODE_FFN && ffn_pipelined(KS)) fetch_unit(-1); else fetch(0); }
@@ -118,21 +141,13 @@ struct Ring {
 // ---- rows <-> accumulator layout
 template <int NT>
 __device__ __forceinline__ void load_acc(const float* xr, int D, int kh, f32x16 (&acc)[NT]) {
-    float4 q[NT][4];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) {
-            const int f = 32 * t + 8 * rq + 4 * kh, fc = f < D ? f : D - 4;
-            q[t][rq] = *reinterpret_cast<const float4*>(xr + fc);
-        }
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-            const bool ok = 32 * t + 8 * rq + 4 * kh < D;
-            acc[t][4 * rq + 0] = ok ? q[t][rq].x : 0.f; acc[t][4 * rq + 1] = ok ? q[t][rq].y : 0.f;
-            acc[t][4 * rq + 2] = ok ? q[t][rq].z : 0.f; acc[t][4 * rq + 3] = ok ? q[t][rq].w : 0.f;
+            const int f = 32 * t + 8 * rq + 4 * kh;
+            const float4 q = *reinterpret_cast<const float4*>(t < NT - 1 || f < D ? xr + f : sxc_zero4);      // quads behind D: zeros (D % 4 == 0; only the last tile has any)
+            acc[t][4 * rq + 0] = q.x; acc[t][4 * rq + 1] = q.y; acc[t][4 * rq + 2] = q.z; acc[t][4 * rq + 3] = q.w;
         }
 }
 
@@ -148,7 +163,7 @@ __device__ __forceinline__ void acc_to_frags(const f32x16 (&acc)[NT], float sub,
         for (int e = 0; e < 8; ++e) {
             const int f = 16 * s + 8 * (e >> 2) + 4 * kh + (e & 3);
             const float a = t < NT ? acc[t < NT ? t : 0][8 * sp + e] : 0.f;
-            v[e] = f < D ? (a - sub) * mul : (f == D ? one : 0.f);
+            v[e] = (t < NT - 1 || f < D) ? (a - sub) * mul : (f == D ? one : 0.f);      // only the last tile's k-steps can reach D
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) split2s(v[2 * e], v[2 * e + 1], hh[e], ll[e]);
@@ -172,7 +187,7 @@ __device__ __forceinline__ void row_stats(const f32x16 (&acc)[NT], int D, int kh
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int f = 32 * t + 8 * (r >> 2) + 4 * kh + (r & 3);
-            const float dlt = f < D ? acc[t][r] - mean : 0.f;
+            const float dlt = (t < NT - 1 || f < D) ? acc[t][r] - mean : 0.f;
             q2 = fmaf(dlt, dlt, q2);
         }
     q2 += __shfl_xor(q2, 32);
@@ -182,34 +197,35 @@ __device__ __forceinline__ void row_stats(const f32x16 (&acc)[NT], int D, int kh
 // acc = acc uns + res + bias (entries behind D: 0); res / bias read at this lane's features
 template <int NT>
 __device__ __forceinline__ void add_residual(f32x16 (&acc)[NT], float uns, const float* res, const float* bias, int D, int kh) {
-    // a tile's eight 16-byte loads at a time (all tiles at once = 256 registers of loads beside the accumulators: spills at width 256)
+    // a tile's eight 16-byte loads at a time (all tiles at once = 256 registers of loads beside the accumulators: spills at width 256); quads behind D read zeros
+    // and their accumulators are zero (zero image rows): they stay 0
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         float4 xq[4], bq[4];
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) {
-            const int f = 32 * t + 8 * rq + 4 * kh, fc = f < D ? f : D - 4;
-            xq[rq] = *reinterpret_cast<const float4*>(res + fc);
-            bq[rq] = *reinterpret_cast<const float4*>(bias + fc);
+            const int f = 32 * t + 8 * rq + 4 * kh;
+            const bool ok = t < NT - 1 || f < D;
+            xq[rq] = *reinterpret_cast<const float4*>(ok ? res + f : sxc_zero4);
+            bq[rq] = *reinterpret_cast<const float4*>(ok ? bias + f : sxc_zero4);
         }
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) {
-            const bool ok = 32 * t + 8 * rq + 4 * kh < D;
             const float4 x4 = xq[rq], b4 = bq[rq];
-            acc[t][4 * rq + 0] = ok ? fmaf(acc[t][4 * rq + 0], uns, x4.x + b4.x) : 0.f; acc[t][4 * rq + 1] = ok ? fmaf(acc[t][4 * rq + 1], uns, x4.y + b4.y) : 0.f;
-            acc[t][4 * rq + 2] = ok ? fmaf(acc[t][4 * rq + 2], uns, x4.z + b4.z) : 0.f; acc[t][4 * rq + 3] = ok ? fmaf(acc[t][4 * rq + 3], uns, x4.w + b4.w) : 0.f;
+            acc[t][4 * rq + 0] = fmaf(acc[t][4 * rq + 0], uns, x4.x + b4.x); acc[t][4 * rq + 1] = fmaf(acc[t][4 * rq + 1], uns, x4.y + b4.y);
+            acc[t][4 * rq + 2] = fmaf(acc[t][4 * rq + 2], uns, x4.z + b4.z); acc[t][4 * rq + 3] = fmaf(acc[t][4 * rq + 3], uns, x4.w + b4.w);
         }
     }
 }
 
 template <int NT>
-__device__ __forceinline__ void store_acc(float* yr, const f32x16 (&acc)[NT], int D, int kh) {
+__device__ __forceinline__ void store_acc(const OutBuf& ob, uint32_t row_off, const f32x16 (&acc)[NT], int D, int kh, bool live) {
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) {
             const int f = 32 * t + 8 * rq + 4 * kh;
-            if (f < D) *reinterpret_cast<float4*>(yr + f) = make_float4(acc[t][4 * rq], acc[t][4 * rq + 1], acc[t][4 * rq + 2], acc[t][4 * rq + 3]);
+            bstore4(ob, row_off + 4 * f, live && (t < NT - 1 || f < D), acc[t][4 * rq], acc[t][4 * rq + 1], acc[t][4 * rq + 2], acc[t][4 * rq + 3]);
         }
 }
 
@@ -220,11 +236,11 @@ __device__ __forceinline__ void apply_ln(f32x16 (&acc)[NT], float mean, float rs
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) {
-            const int f = 32 * t + 8 * rq + 4 * kh, fc = f < D ? f : D - 4;
-            const float4 g4 = *reinterpret_cast<const float4*>(g + fc), b4 = *reinterpret_cast<const float4*>(b + fc);
-            const bool ok = f < D;
-            acc[t][4 * rq + 0] = ok ? (acc[t][4 * rq + 0] - mean) * rstd * g4.x + b4.x : 0.f; acc[t][4 * rq + 1] = ok ? (acc[t][4 * rq + 1] - mean) * rstd * g4.y + b4.y : 0.f;
-            acc[t][4 * rq + 2] = ok ? (acc[t][4 * rq + 2] - mean) * rstd * g4.z + b4.z : 0.f; acc[t][4 * rq + 3] = ok ? (acc[t][4 * rq + 3] - mean) * rstd * g4.w + b4.w : 0.f;
+            const int f = 32 * t + 8 * rq + 4 * kh;
+            const bool ok = t < NT - 1 || f < D;                 // quads behind D: gamma = beta = 0 -> 0 (no select on the result: the compiler sinks such loads into exec-masked regions)
+            const float4 g4 = *reinterpret_cast<const float4*>(ok ? g + f : sxc_zero4), b4 = *reinterpret_cast<const float4*>(ok ? b + f : sxc_zero4);
+            acc[t][4 * rq + 0] = (acc[t][4 * rq + 0] - mean) * rstd * g4.x + b4.x; acc[t][4 * rq + 1] = (acc[t][4 * rq + 1] - mean) * rstd * g4.y + b4.y;
+            acc[t][4 * rq + 2] = (acc[t][4 * rq + 2] - mean) * rstd * g4.z + b4.z; acc[t][4 * rq + 3] = (acc[t][4 * rq + 3] - mean) * rstd * g4.w + b4.w;
         }
 }
 
@@ -534,7 +550,7 @@ __global__ __launch_bounds__(256, waves_per_simd(KS)) void sxc_b_kernel(const Sx
     const int m = blockIdx.x * 128 + wave * 32 + lr;
     const int row = m < p.M ? m : p.M - 1;
     Ring<KS, NT, MODE_F2> ra;
-    ra.init(p.w_o, NT, tid);
+    ra.init(p.w_o, NT, tid, sm);
     ra.fetch0();
     f16x8 ah[KS], al[KS];
     f32x16 acc[NT];
@@ -542,29 +558,30 @@ __global__ __launch_bounds__(256, waves_per_simd(KS)) void sxc_b_kernel(const Sx
     acc_to_frags<KS, NT>(acc, 0.f, SR, SR, D, kh, ah, al);
     stage_f2<KS, NT>(ra, sm, lr, kh, ah, al, acc);
     Ring<KS, NT, MODE_F1> rb;
-    if (EARLY) { rb.init(p.w_p1, p.nch_p1, tid); rb.fetch0(); }
+    if (EARLY) { rb.init(p.w_p1, p.nch_p1, tid, sm); rb.fetch0(); }
     float* xr = p.x + (size_t)row * D;
     add_residual<NT>(acc, UNS_R, xr, p.b_o, D, kh);               // x += O Wo^T + bo
-    if (m < p.M) store_acc<NT>(xr, acc, D, kh);
+    const OutBuf obx = out_buf(p.x, (size_t)p.M * D);
+    store_acc<NT>(obx, (uint32_t)row * D * 4, acc, D, kh, m < p.M);
     float mean, rstd;
     row_stats<NT>(acc, D, kh, mean, rstd);
     acc_to_frags<KS, NT>(acc, mean, rstd * SA, SA, D, kh, ah, al);
-    if (!EARLY) { rb.init(p.w_p1, p.nch_p1, tid); rb.fetch0(); }
-    float* gr = p.g + (size_t)row * De;
+    if (!EARLY) { rb.init(p.w_p1, p.nch_p1, tid, sm); rb.fetch0(); }
+    const OutBuf obg = out_buf(p.g, (size_t)p.M * De);
+    const uint32_t g_off = (uint32_t)row * De * 4;
     float za[16];
     stage_f1<KS, NT>(rb, sm, lr, kh, ah, al, UNS, [&](int c, const float (&z)[16]) __attribute__((always_inline)) {
         if (!(c & 1)) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) za[r] = z[r];
-        } else if (m < p.M) {                                    // GLU (modules.py:514): value half x sigmoid(gate half)
+        } else {                                                 // GLU (modules.py:514): value half x sigmoid(gate half)
 #pragma unroll
             for (int rq = 0; rq < 4; ++rq) {
                 const int f = 32 * (c >> 1) + 8 * rq + 4 * kh;
-                if (f >= De) continue;
                 float4 o4;
                 o4.x = za[4 * rq + 0] * sx_rcp(1.0f + sx_expf(fminf(-z[4 * rq + 0], 87.0f))); o4.y = za[4 * rq + 1] * sx_rcp(1.0f + sx_expf(fminf(-z[4 * rq + 1], 87.0f)));
                 o4.z = za[4 * rq + 2] * sx_rcp(1.0f + sx_expf(fminf(-z[4 * rq + 2], 87.0f))); o4.w = za[4 * rq + 3] * sx_rcp(1.0f + sx_expf(fminf(-z[4 * rq + 3], 87.0f)));
-                *reinterpret_cast<float4*>(gr + f) = o4;
+                bstore4(obg, g_off + 4 * f, m < p.M && f < De, o4.x, o4.y, o4.z, o4.w);
             }
         }
     });
@@ -582,39 +599,41 @@ __global__ __launch_bounds__(256) void sxc_a_kernel(const SxcAParams p) {
     const int row = m < p.M ? m : p.M - 1;
     const bool live = m < p.M;
     float* yr = p.y + (size_t)row * D;
+    const OutBuf oby = out_buf(p.y, (size_t)p.M * D);
+    const uint32_t y_off = (uint32_t)row * D * 4;
     f16x8 ah[KS], al[KS];
     f32x16 acc[NT];
     float mean, rstd;
     if (TAIL) {
         Ring<KS, NT, MODE_F2> ra;
-        ra.init(p.w_p2, NT, tid);
+        ra.init(p.w_p2, NT, tid, sm);
         ra.fetch0();
         load_acc<NT>(p.c + (size_t)row * D, D, kh, acc);
         acc_to_frags<KS, NT>(acc, 0.f, SR, SR, D, kh, ah, al);
         stage_f2<KS, NT>(ra, sm, lr, kh, ah, al, acc);
         Ring<KS, NT, MODE_FFN> rf;
-        if (EARLY) { rf.init(p.w_f2, p.nch_f2, tid); rf.fetch0(); }
+        if (EARLY) { rf.init(p.w_f2, p.nch_f2, tid, sm); rf.fetch0(); }
         add_residual<NT>(acc, UNS_R, p.xres + (size_t)row * D, p.b_p2, D, kh);      // x = xres + C Wp2^T + bp2
-        if (live) store_acc<NT>(yr, acc, D, kh);
+        store_acc<NT>(oby, y_off, acc, D, kh, live);
         row_stats<NT>(acc, D, kh, mean, rstd);
         acc_to_frags<KS, NT>(acc, mean, rstd * SA, SA, D, kh, ah, al);
-        if (!EARLY) { rf.init(p.w_f2, p.nch_f2, tid); rf.fetch0(); }
+        if (!EARLY) { rf.init(p.w_f2, p.nch_f2, tid, sm); rf.fetch0(); }
         stage_ffn<KS, NT>(rf, sm, lr, kh, ah, al, acc);
         Ring<KS, NT, MODE_FFN> rh;
-        if (HEAD && EARLY) { rh.init(p.w_f1, p.nch_f1, tid); rh.fetch0(); }
+        if (HEAD && EARLY) { rh.init(p.w_f1, p.nch_f1, tid, sm); rh.fetch0(); }
         add_residual<NT>(acc, UNS, yr, p.b_f2, D, kh);            // x += 1/2 FFN2(LN(x))  (W2, b2 pre-scaled)
         row_stats<NT>(acc, D, kh, mean, rstd);
         apply_ln<NT>(acc, mean, rstd, p.ln_g, p.ln_b, D, kh);     // y = LN(x): the block's output
-        if (live) store_acc<NT>(yr, acc, D, kh);
+        store_acc<NT>(oby, y_off, acc, D, kh, live);
         if (HEAD) {
             row_stats<NT>(acc, D, kh, mean, rstd);
             acc_to_frags<KS, NT>(acc, mean, rstd * SA, SA, D, kh, ah, al);
-            if (!EARLY) { rh.init(p.w_f1, p.nch_f1, tid); rh.fetch0(); }
+            if (!EARLY) { rh.init(p.w_f1, p.nch_f1, tid, sm); rh.fetch0(); }
             stage_ffn<KS, NT>(rh, sm, lr, kh, ah, al, acc);
         }
     } else {
         Ring<KS, NT, MODE_FFN> rh;
-        rh.init(p.w_f1, p.nch_f1, tid);
+        rh.init(p.w_f1, p.nch_f1, tid, sm);
         rh.fetch0();
         load_acc<NT>(yr, D, kh, acc);
         row_stats<NT>(acc, D, kh, mean, rstd);
@@ -623,21 +642,22 @@ __global__ __launch_bounds__(256) void sxc_a_kernel(const SxcAParams p) {
     }
     if (HEAD) {
         Ring<KS, NT, MODE_F1> rq;
-        if (EARLY) { rq.init(p.w_qkv, 3 * NT, tid); rq.fetch0(); }
+        if (EARLY) { rq.init(p.w_qkv, 3 * NT, tid, sm); rq.fetch0(); }
         add_residual<NT>(acc, UNS, yr, p.b_f1, D, kh);            // y += 1/2 FFN1(LN(y))
-        if (live) store_acc<NT>(yr, acc, D, kh);
+        store_acc<NT>(oby, y_off, acc, D, kh, live);
         row_stats<NT>(acc, D, kh, mean, rstd);
         acc_to_frags<KS, NT>(acc, mean, rstd * SA, SA, D, kh, ah, al);
-        if (!EARLY) { rq.init(p.w_qkv, 3 * NT, tid); rq.fetch0(); }
-        float* qr = p.q + remap_row(row, p.q_rows, p.q_pitch) * D;
+        if (!EARLY) { rq.init(p.w_qkv, 3 * NT, tid, sm); rq.fetch0(); }
+        const OutBuf obq = out_buf(p.q, p.qkv_bytes / 4);
+        const uint32_t q_off = (uint32_t)(remap_row(row, p.q_rows, p.q_pitch) * D * 4);
+        const uint32_t q_step = (uint32_t)(p.qkv_stride * 4);
         stage_f1<KS, NT>(rq, sm, lr, kh, ah, al, UNS, [&](int c, const float (&z)[16]) __attribute__((always_inline)) {
-            if (!live) return;
             const int which = c / NT, cc = c - which * NT;
-            float* dst = qr + (size_t)which * p.qkv_stride;
+            const uint32_t dst = q_off + (uint32_t)which * q_step;
 #pragma unroll
             for (int rq4 = 0; rq4 < 4; ++rq4) {
                 const int f = 32 * cc + 8 * rq4 + 4 * kh;
-                if (f < D) *reinterpret_cast<float4*>(dst + f) = make_float4(z[4 * rq4], z[4 * rq4 + 1], z[4 * rq4 + 2], z[4 * rq4 + 3]);
+                bstore4(obq, dst + 4 * f, live && (cc < NT - 1 || f < D), z[4 * rq4], z[4 * rq4 + 1], z[4 * rq4 + 2], z[4 * rq4 + 3]);
             }
         });
     }
@@ -646,10 +666,10 @@ __global__ __launch_bounds__(256) void sxc_a_kernel(const SxcAParams p) {
 template <int KS, int NT>
 int launch_b(const SxcBParams& p, hipStream_t s) {
     using L = CL<KS, NT>;
-    static_assert(2 * L::STAGE <= 160 * 1024, "weight ring of the split chains");
+    static_assert(2 * L::STAGE + 4096 <= 160 * 1024, "weight ring of the split chains + the dump slots");
     static LdsAttr attr;
-    ensure_dynamic_lds(reinterpret_cast<const void*>(&sxc_b_kernel<KS, NT>), 2 * L::STAGE, attr);
-    hipLaunchKernelGGL((sxc_b_kernel<KS, NT>), dim3((p.M + 127) / 128), dim3(256), 2 * L::STAGE, s, p);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(&sxc_b_kernel<KS, NT>), 2 * L::STAGE + 4096, attr);
+    hipLaunchKernelGGL((sxc_b_kernel<KS, NT>), dim3((p.M + 127) / 128), dim3(256), 2 * L::STAGE + 4096, s, p);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -657,8 +677,8 @@ template <int KS, int NT, bool TAIL, bool HEAD>
 int launch_a2(const SxcAParams& p, hipStream_t s) {
     using L = CL<KS, NT>;
     static LdsAttr attr;
-    ensure_dynamic_lds(reinterpret_cast<const void*>(&sxc_a_kernel<KS, NT, TAIL, HEAD>), 2 * L::STAGE, attr);
-    hipLaunchKernelGGL((sxc_a_kernel<KS, NT, TAIL, HEAD>), dim3((p.M + 127) / 128), dim3(256), 2 * L::STAGE, s, p);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(&sxc_a_kernel<KS, NT, TAIL, HEAD>), 2 * L::STAGE + 4096, attr);
+    hipLaunchKernelGGL((sxc_a_kernel<KS, NT, TAIL, HEAD>), dim3((p.M + 127) / 128), dim3(256), 2 * L::STAGE + 4096, s, p);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
