@@ -57,7 +57,13 @@ __device__ __forceinline__ void bstore4(const OutBuf& b, uint32_t byte_off, bool
 // Which form of the FFN stage a width runs (measured per launch inside the split step, profiles/r6_26 against r6_21): the software pipeline wins where the Swish is
 // long against the products and registers allow its second set of hidden-unit fragments (D = 144 .. 180: 250 -> 226 us); at D >= 240 it loses (376 -> 401 us: 500
 // registers, the extra copies land between the MFMAs); at D <= 120 the plain loop fits 256 registers, so TWO workgroups share a CU and fill each other's stalls
-__host__ __device__ constexpr bool ffn_pipelined(int KS) { return KS <= 12; }
+#ifndef SXC_PIPE_MAX
+#define SXC_PIPE_MAX 12
+#endif
+#ifndef SXC_EARLY_MAX
+#define SXC_EARLY_MAX 7
+#endif
+__host__ __device__ constexpr bool ffn_pipelined(int KS) { return KS <= SXC_PIPE_MAX; }
 __host__ __device__ constexpr int waves_per_simd(int KS) { return KS <= 8 ? 2 : 1; }
 
 template <int KS, int NT>
@@ -546,7 +552,7 @@ __global__ __launch_bounds__(256, waves_per_simd(KS)) void sxc_b_kernel(const Sx
     extern __shared__ __attribute__((aligned(16))) char sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, kh = lane >> 5;
     const int D = p.D, De = p.De;
-    constexpr bool EARLY = KS < 8;                               // the next product's first chunk requested BEFORE the epilogue of the current one (wider: 64 more live registers = spills)
+    constexpr bool EARLY = KS <= SXC_EARLY_MAX;                               // the next product's first chunk requested BEFORE the epilogue of the current one (wider: 64 more live registers = spills)
     const int m = blockIdx.x * 128 + wave * 32 + lr;
     const int row = m < p.M ? m : p.M - 1;
     Ring<KS, NT, MODE_F2> ra;
@@ -594,7 +600,7 @@ __global__ __launch_bounds__(256) void sxc_a_kernel(const SxcAParams p) {
     extern __shared__ __attribute__((aligned(16))) char sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, kh = lane >> 5;
     const int D = p.D;
-    constexpr bool EARLY = KS < 8;
+    constexpr bool EARLY = KS <= SXC_EARLY_MAX;
     const int m = blockIdx.x * 128 + wave * 32 + lr;
     const int row = m < p.M ? m : p.M - 1;
     const bool live = m < p.M;

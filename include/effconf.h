@@ -254,8 +254,8 @@ int effconf_rnnt_greedy(EcRnnt* r, const float* enc_out, const int64_t* out_len,
  *   2 (round 4, csrc/split.hip; round 6, csrc/sxf.hip + sxf_ffn.hip + sxf_chain.hip): fp32 tensors with every GEMM and the attention products on the fp16
  *   matrix pipe, each operand split into two fp16 numbers (three MFMAs per product, products accurate to ~2^-21): label sequences identical to the
  *   reference's on every golden and on the bench's oracle samples of Small / Medium / Large.  Round 6: ONE attention kernel per block with the scores on the
- *   CU, the row-local work of a block as two kernels, ragged batches, causal and streaming configurations - 3.2x the bf16 step on EfficientConformerCTCSmall
- *   (5.7x in round 5), 2.9x on Medium / Large.  Set to 2 BEFORE finalize (the split weight images are built there; such a handle then serves 2, 1 and 0);
+ *   CU, the row-local work of a block as two kernels, ragged batches, causal and streaming configurations - 2.9x the bf16 step on EfficientConformerCTCSmall
+ *   (5.7x in round 5), 2.7x / 2.8x on Medium / Large.  Set to 2 BEFORE finalize (the split weight images are built there; such a handle then serves 2, 1 and 0);
  *   a handle finalized with 1 refuses 2.
  * "split_chain" (default 1), "split_ffn" (default 1): split mode on the fused row-local kernels (csrc/sxf_chain.hip; csrc/sxf_ffn.hip when split_chain = 0);
  *   0 / 0 = LayerNorm, split GEMM, GLU kernels per module (tests: the same results within a few 1e-6, another summation order).  A debug trace
