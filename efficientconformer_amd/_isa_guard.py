@@ -8,7 +8,13 @@ Measured on MI355X (profiles/r2_mel_packed_fp32_hazard.txt): v_pk_add_f32 / v_pk
 the same SIMD.  libeffconf is therefore compiled with `-target-feature -packed-fp32-ops` (efficientconformer_amd/_build.py); this
 script extracts every gfx950 code object from the shared library (clang offload bundles in .hip_fatbin), disassembles it and checks.
 Kernels of csrc/debug.hip (victim_kernel / neighbour_kernel) and the diagnostic mel_kernel build with packed fp32 are exempt:
-they exist to reproduce the hazard."""
+they exist to reproduce the hazard.
+
+Second rule (round 6, profiles/r6_35_side_bisect.txt): the split-precision chain kernels (csrc/sxf_chain.hip: sxc_a_kernel / sxc_b_kernel) must not contain an
+exec-masked region at all.  hipcc (ROCm 7.2) places VGPR -> AGPR live-range-split copies inside such regions; a value copied under a narrowed mask and read back after
+reconvergence is garbage in the lanes that were off - in those kernels a store address (every ragged forward of one stage faulted).  They are written without a
+lane-divergent branch (masked loads from a zero block, masked stores as out-of-range buffer stores); an `s_and_saveexec` / `s_or_saveexec` in their listing means a
+source change brought one back."""
 import os
 import re
 import struct
@@ -37,6 +43,8 @@ MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 HAZARD = re.compile(r"v_pk_(add|mul|fma)_f32\b.*\bop_sel:\[[^\]]*1")
 PACKED = re.compile(r"v_pk_(add|mul|fma)_f32\b")
 EXEMPT = re.compile(r"victim_kernel|neighbour_kernel|mel_pk_build")
+EXECMASK = re.compile(r"\bs_(and|or|andn2|xor)_saveexec_b64\b")
+BRANCH_FREE = re.compile(r"sxc_[ab]_kernel")
 
 
 def code_objects(lib):
@@ -71,12 +79,14 @@ def scan(lib):
             m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
             if m:
                 cur = m.group(1)
-                rows.setdefault(cur, [0, 0])
+                rows.setdefault(cur, [0, 0, 0])
             elif cur is not None:
                 if PACKED.search(line):
                     rows[cur][0] += 1
                     if HAZARD.search(line):
                         rows[cur][1] += 1
+                if EXECMASK.search(line):
+                    rows[cur][2] += 1
     return rows
 
 
@@ -105,11 +115,15 @@ def check(lib, out=None):
                            "refusing to pass the library unscanned" % (len(rows), lib, MIN_KERNELS))
     names = demangle(list(rows))
     bad = 0
-    for k, (packed, hazard) in sorted(rows.items()):
+    for k, (packed, hazard, execmask) in sorted(rows.items()):
         exempt = bool(EXEMPT.search(names[k]))
         if (packed or hazard) and out is not None:
             out.append("%-100s packed-fp32 %5d  op_sel(low) %5d%s" % (names[k][:100], packed, hazard, "  (diagnostic kernel, exempt)" if exempt else ""))
         if hazard and not exempt:
+            bad += 1
+        if execmask and BRANCH_FREE.search(names[k]):
+            if out is not None:
+                out.append("%-100s exec-masked regions %d (must be 0: see the module docstring)" % (names[k][:100], execmask))
             bad += 1
     return len(rows), bad
 
@@ -119,7 +133,7 @@ def main():
     lines = []
     n, bad = check(lib, lines)
     print("\n".join(lines))
-    print("%d kernels scanned, %d product kernels with hazardous packed-fp32 forms" % (n, bad))
+    print("%d kernels scanned, %d product kernels with hazardous packed-fp32 forms / exec-masked regions in the branch-free kernels" % (n, bad))
     return 1 if bad else 0
 
 

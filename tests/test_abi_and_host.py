@@ -344,7 +344,11 @@ def test_no_product_kernel_carries_a_hazardous_packed_fp32_form():
     assert not [n for n in names.values() if mod.EXEMPT.search(n)]
     product = {names[k]: v for k, v in rows.items()}
     assert any("mel_kernel<0>" in n for n in product) and any("chain_kernel" in n for n in product) and any("chain3_kernel" in n for n in product)
-    assert all(packed == 0 and hazard == 0 for packed, hazard in product.values()), {n: v for n, v in product.items() if v[0] or v[1]}
+    assert all(v[0] == 0 and v[1] == 0 for v in product.values()), {n: v for n, v in product.items() if v[0] or v[1]}
+    # round 6: the split-precision chain kernels hold no exec-masked region (a compiler-placed VGPR -> AGPR copy inside one corrupted a store address:
+    # profiles/r6_35_side_bisect.txt); every other kernel may
+    sxc = {n: v for n, v in product.items() if mod.BRANCH_FREE.search(n)}
+    assert len(sxc) >= 20 and all(v[2] == 0 for v in sxc.values()), {n: v for n, v in sxc.items() if v[2]}
     # the diagnostic library: its mel build with packed fp32 (variant 8) is the one that carries the hazardous forms
     drows = mod.scan(os.path.join(os.path.dirname(_lib.LIB_PATH), "libeffconf_debug.so"))
     dnames = mod.demangle(list(drows))

@@ -4,7 +4,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from efficientconformer_amd._isa_guard import main, scan, demangle, check, EXEMPT  # noqa: E402,F401
+from efficientconformer_amd._isa_guard import main, scan, demangle, check, EXEMPT, BRANCH_FREE  # noqa: E402,F401
 
 if __name__ == "__main__":
     sys.exit(main())
