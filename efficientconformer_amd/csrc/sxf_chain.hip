@@ -699,7 +699,7 @@ int launch_a(const SxcAParams& p, hipStream_t s) {
 
 // widths of the shipped configurations (the Tiny test config included); everything else stays on the per-module kernels
 bool sxc_supported(int D) {
-    switch (D) { case 24: case 32: case 48: case 120: case 144: case 168: case 176: case 180: case 240: case 256: return true; default: return false; }
+    switch (D) { case 24: case 32: case 48: case 100: case 120: case 140: case 144: case 168: case 176: case 180: case 200: case 240: case 256: return true; default: return false; }
 }
 
 #define SXC_DISPATCH(FN, P)                                  \
@@ -707,10 +707,13 @@ bool sxc_supported(int D) {
         case 24: return FN<2, 1>(P, s);                      \
         case 32: return FN<3, 1>(P, s);                      \
         case 48: return FN<4, 2>(P, s);                      \
+        case 100: return FN<7, 4>(P, s);                     \
         case 120: return FN<8, 4>(P, s);                     \
+        case 140: return FN<9, 5>(P, s);                     \
         case 144: return FN<10, 5>(P, s);                    \
         case 168: return FN<11, 6>(P, s);                    \
         case 176: case 180: return FN<12, 6>(P, s);          \
+        case 200: return FN<13, 7>(P, s);                    \
         case 240: return FN<16, 8>(P, s);                    \
         case 256: return FN<17, 8>(P, s);                    \
     }                                                        \

@@ -233,14 +233,16 @@ def test_split_mode_ragged_batch_equals_utterances_alone_and_the_oracle(name, ex
 # ------------------------------------------------------------------ split-precision row-local chains (csrc/sxf_chain.hip)
 @pytest.mark.parametrize("name,tm,lens", [("Tiny", 333, [333, 250, 97, 12]), ("EfficientConformerCTCSmall", 420, [420, 333, 201]),
                                           ("EfficientConformerCTCMedium", 300, [300, 177]), ("ConformerCTCSmall", 260, [260, 121]),
-                                          ("ConformerCTCMedium", 180, [180, 77]), ("EfficientConformerTransducerSmall", 300, [300, 222])])
+                                          ("ConformerCTCMedium", 180, [180, 77]), ("EfficientConformerTransducerSmall", 300, [300, 222]),
+                                          ("ConformerTransducerSmall", 200, [200, 133, 61])])
 @pytest.mark.parametrize("ragged", [False, True])
 def test_split_chains_vs_per_module_kernels_and_the_oracle(name, tm, lens, ragged):
     """sxf_chain.hip: out-proj + residual + LayerNorm + pointwise-1 + GLU as one kernel, pointwise-2 + residual + FFN2 + block LayerNorm + the next block's FFN1 +
     attention pre-norm + Q | K | V as another (blocks.py:119-137, modules.py:385-395, 511-522, attentions.py:651-653, 716).  The split mode with the chains (the
     default) against (i) the same mode on the per-module kernels (`split_chain = 0`: LayerNorm, split GEMM, GLU and FFN kernels - a different summation order, so
     a few 1e-6, not bit equality) and (ii) the oracle within the split mode's stated 2e-4 / 2e-5; rectangular batches with pad frames (the Q / K / V and
-    attention-output row remap) and ragged ones; widths 24 .. 256 incl. the stage transitions (D != De) and both subsampler forms."""
+    attention-output row remap) and ragged ones; every width a shipped configuration <= 256 has (24 .. 256: 100 / 140 / 200, 120 / 168 / 240, 144, 176, 180 / 256)
+    incl. the stage transitions (D != De) and both subsampler forms."""
     m, sd = _model(name, 11)
     plan = m.encoder.plan
     m.encoder.precision = "split"
