@@ -526,9 +526,11 @@ bool relpos_attention2_supported(int dpad) { return dpad == 32 || dpad == 64 || 
 //          2 = 32 queries per wave, 2-wave 64-query workgroups (one wave per SIMD: measured slower, kept for experiments)
 int launch_relpos_attention2(const AttnParams& p0, int waves, hipStream_t s) {
     if (p0.B <= 0 || p0.Tg <= 0) return 0;
-    static const int abl = getenv("EFFCONF_ATTN_ABLATE") ? atoi(getenv("EFFCONF_ATTN_ABLATE")) : 0;
     AttnParams p = p0;
+#ifdef EFFCONF_ABLATE      // the timing-only library (tools/build_ablate.py); the product reads no environment variable here (advisor, round 5)
+    static const int abl = getenv("EFFCONF_ATTN_ABLATE") ? atoi(getenv("EFFCONF_ATTN_ABLATE")) : 0;
     p.ablate = abl;
+#endif
     if (p.dpad < p.d || p.q_rowstride != p.e_rowstride) return -2;
     if (p.rag_off && (waves != 1 || !p.rag_wg || p.q_rowstride != p.G * p.D)) return -2;      // ragged: natural layout, 64-query workgroups
 #define ATT2_CASE(DPV) case DPV: return waves == 1 ? launch2<DPV, 4, 1>(p, s) : launch2<DPV, 2, 2>(p, s);

@@ -730,7 +730,11 @@ int launch_chain2_t(const ChainParams& p, hipStream_t s) {
     static LdsAttr attr;
     ensure_dynamic_lds(reinterpret_cast<const void*>(&chain2_kernel<KS, KIND, DMA, false>), lds, attr);
     if constexpr (DMA >= 1) {
+#ifdef EFFCONF_PHASE_PROF    // in-kernel phase profiles: a tuning build (tools/build_ablate.py); the product has neither the getenv nor the profiling instantiation
         static const bool prof = getenv("EFFCONF_CHAIN2_PHASES") != nullptr && atoi(getenv("EFFCONF_CHAIN2_PHASES")) == DMA * 1000 + KS * 10 + KIND;
+#else
+        constexpr bool prof = false;
+#endif
         if (prof) {
             if (!g_chain2_prof) {
                 if (hipMalloc(&g_chain2_prof, 256) != hipSuccess || hipMemset(g_chain2_prof, 0, 256) != hipSuccess) return -1;

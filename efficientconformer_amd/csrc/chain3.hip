@@ -742,7 +742,11 @@ int launch_chain3_t(const ChainParams& p, hipStream_t s) {
     if (lds > 160 * 1024) return -4;
     static LdsAttr attr;
     ensure_dynamic_lds(reinterpret_cast<const void*>(&chain3_kernel<KS, KIND, false>), lds, attr);
+#ifdef EFFCONF_PHASE_PROF    // in-kernel phase profiles: a tuning build (tools/build_ablate.py); the product has neither the getenv nor the profiling instantiation
     static const bool prof = getenv("EFFCONF_CHAIN3_PHASES") != nullptr && atoi(getenv("EFFCONF_CHAIN3_PHASES")) == KIND;
+#else
+    constexpr bool prof = false;
+#endif
     if (prof) {
         if (!g_chain3_prof) {
             if (hipMalloc(&g_chain3_prof, 512) != hipSuccess || hipMemset(g_chain3_prof, 0, 512) != hipSuccess) return -1;

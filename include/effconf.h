@@ -246,7 +246,8 @@ int effconf_rnnt_greedy(EcRnnt* r, const float* enc_out, const int64_t* out_len,
  * "chain_variant" (0 / 1), "chain_full_max" (widest stage that runs chain A as one kernel; set before finalize to widen), "attn_waves"
  *   (4 / 8, attention.hip), "rs_variant" (0 / 1), "ffn_variant" (0 .. 2), "head_major_odd" (0 / 1), "exact_attention" (0 tiled / 2 tiled with 16-row workgroups / 1 one wave per query row; fp32 mode, bit-identical): tuning / test switches of the kernel launchers that were
  *   process-global EFFCONF_* environment variables until round 2; per handle now.  (Still read from the environment, once, as
- *   profiling / test hooks: EFFCONF_POISON_GUARDS at create, EFFCONF_{CHAIN,ATTN,FFN}_PHASES for the in-kernel phase profilers.)
+ *   profiling / test hooks: EFFCONF_POISON_GUARDS at create, EFFCONF_{CHAIN,ATTN,FFN}_PHASES for the in-kernel phase profilers of chain.hip / attention.hip /
+ *   rsgemm.hip.  EFFCONF_CHAIN2_PHASES, EFFCONF_CHAIN3_PHASES and EFFCONF_ATTN_ABLATE exist in the tuning library of tools/build_ablate.py only - round 6.)
  * "exact_fp32" (default 0): fp32-operand precision mode (csrc/exact.hip): every GEMM on fp32 MFMA, fp32 attention / convolutions,
  *   so that greedy CTC label sequences equal the reference's CPU fp32 path (model_ctc.py:99-133) wherever its top-2 logit margins
  *   exceed fp32 summation-order noise; ~10x slower than the default bf16-operand path.  Set to 1 BEFORE effconf_encoder_finalize

@@ -11,11 +11,11 @@ from efficientconformer_amd import _build as B  # noqa: E402
 
 B.build()
 objdir = os.path.join(B.HERE, "build")
-REBUILT = ("encoder.hip", "attention2.hip")
+REBUILT = ("encoder.hip", "attention2.hip", "chain2.hip", "chain3.hip")      # chain2 / chain3: their in-kernel phase profilers (EFFCONF_CHAIN{2,3}_PHASES) exist in this library only
 abl = []
 for src in REBUILT:
     obj = os.path.join(objdir, src.replace(".hip", "_ablate.o"))
-    subprocess.check_call([B._hipcc()] + B.FLAGS + B.NO_PACKED_FP32 + ["-DEFFCONF_ABLATE", "-c", os.path.join(B.CSRC, src), "-o", obj])
+    subprocess.check_call([B._hipcc()] + B.FLAGS + B.NO_PACKED_FP32 + ["-DEFFCONF_ABLATE", "-DEFFCONF_PHASE_PROF", "-c", os.path.join(B.CSRC, src), "-o", obj])
     abl.append(obj)
 objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in B.SOURCES if s not in REBUILT] + abl
 out = os.path.join(objdir, "libeffconf_ablate.so")
