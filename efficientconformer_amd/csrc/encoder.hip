@@ -1259,6 +1259,11 @@ int forward_core_split(EcEncoder* e, const float* mel, const int64_t* in_len, in
         }
         }
         head_done = false;
+        if (e->trace_arena) {       // rows (b, t) -> b Tp + t of the projections (chunk-padding rows are never written: whatever the workspace held)
+            snprintf(nm, sizeof(nm), "blocks.%d.q", k); trace_add(e, st, nm, q, s.Mq[k], D, D, 0);
+            snprintf(nm, sizeof(nm), "blocks.%d.k", k); trace_add(e, st, nm, kk, s.Mq[k], D, D, 0);
+            snprintf(nm, sizeof(nm), "blocks.%d.v", k); trace_add(e, st, nm, v, s.Mq[k], D, D, 0);
+        }
         if (Tp > b.max_pos) return fail("sequence longer than max_pos_encoding");
         // relative tables: R[m] = sinusoid(Tp - 1 - G/2 - m), m < 2 Tp - G; causal: R[m] = sinusoid(Tp - 1 - m), m < Tp (attentions.py:1243-1251, 1296-1309)
         const float* tab = e->xtab[std::make_pair(b.max_pos, D)];

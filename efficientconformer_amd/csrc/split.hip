@@ -72,11 +72,11 @@ __global__ __launch_bounds__(256, 2) void sx_gemm_kernel(const SxGemmParams q) {
     typedef uint32_t u4v __attribute__((ext_vector_type(4)));
     f4v ra[4];
     u4v rh[2], rl[2];
-    float keep = 1.0f;
+    bool keep = true;
     auto gload_a = [&](int k0) __attribute__((always_inline)) {
         const bool ok = k0 + akq < p.K;                          // K % 4 == 0: a float4 is inside or outside as a whole
-        const int ko = ok ? k0 : 0;                              // always a valid address (the row's own first k-tile: finite data), scaled to zero
-        keep = ok ? 1.0f : 0.0f;                                 // applied when the registers are published (a use here would wait for the loads inside the loop); branch-free: the loop body stays ONE basic block
+        const int ko = ok ? k0 : 0;                              // always a mapped address (the row's own first k-tile; with K < 32 the NEXT row's, behind the last row whatever the buffer holds): replaced by zeros
+        keep = ok;                                               // applied as a SELECT when the registers are published (a use here would wait for the loads inside the loop; a multiply by 0 would pass a NaN on); branch-free: the loop body stays ONE basic block
 #pragma unroll
         for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const f4v*>(p.A + (ao[i] + (uint32_t)ko));
     };
@@ -94,8 +94,8 @@ __global__ __launch_bounds__(256, 2) void sx_gemm_kernel(const SxGemmParams q) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             uint32_t h0, l0, h1, l1;
-            split2(ra[i][0] * keep, ra[i][1] * keep, h0, l0);
-            split2(ra[i][2] * keep, ra[i][3] * keep, h1, l1);
+            split2(keep ? ra[i][0] : 0.f, keep ? ra[i][1] : 0.f, h0, l0);
+            split2(keep ? ra[i][2] : 0.f, keep ? ra[i][3] : 0.f, h1, l1);
             ph[i] = u2v{h0, h1}; pl[i] = u2v{l0, l1};
         }
     };

@@ -272,3 +272,35 @@ def test_split_chains_vs_per_module_kernels_and_the_oracle(name, tm, lens, ragge
         e = (out.cpu() - ref).abs()
         print("%s rectangular vs oracle: max %.2e mean %.2e" % (name, float(e.max()), float(e.mean())))
         assert float(e.max()) < SPLIT_MAX and float(e.mean()) < SPLIT_MEAN
+
+
+# ------------------------------------------------------------------ a forward reads no workspace byte it did not write
+@pytest.mark.parametrize("precision,chain", [("bf16", 1), ("split", 1), ("split", 0), ("fp32", 1)])
+@pytest.mark.parametrize("name,tm,lens", [("Tiny", 100, [100, 77, 52]), ("Tiny", 333, [333, 250, 97, 12]), ("EfficientConformerCTCSmall", 420, [420, 333, 201]),
+                                          ("ConformerCTCSmall", 260, [260, 180, 33])])
+def test_forward_on_a_poisoned_fresh_workspace_is_bit_identical(monkeypatch, name, tm, lens, precision, chain):
+    """The caller owns the workspace and may hand over ANY bytes (a recycled allocation of another dtype holds NaN / Inf patterns with probability ~1/32 per
+    half word).  EFFCONF_POISON_WORKSPACE (encoders.py `_workspace`) fills every fresh workspace with a byte: 255 = NaN patterns in fp32 / bf16 / fp16.  A kernel
+    that reads a byte nobody wrote - and scales it by a zero weight or a zero mask instead of selecting - turns that into a NaN in a VALID output: found on the
+    split GEMM's A-tile tail at K < 32 (the last row read the bytes behind the buffer and multiplied them by 0), fixed by a select.  Every mode, rectangular and
+    ragged, the traced (per-module) forward too: output bit-identical to the forward on a zero-filled workspace, and finite."""
+    outs = {}
+    for fill in ("0", "255"):
+        monkeypatch.setenv("EFFCONF_POISON_WORKSPACE", fill)
+        m, _ = _model(name, 7)                                   # a new handle: fresh workspaces, filled with `fill`
+        enc = m.encoder
+        enc.precision = precision
+        if precision == "split":
+            enc.set_option("split_chain", chain)
+        mel, ln = synth.make_mel(len(lens), 80, tm, lens, seed=77 + tm)
+        mel_d, ln_d = torch.from_numpy(mel).cuda(), torch.from_numpy(ln).cuda()
+        for ragged in ([False, True] if precision != "fp32" else [False]):       # the fp32 mode takes rectangular batches only
+            enc.ragged = ragged
+            o, ol, _ = enc.forward_mel(mel_d, ln_d, x_len_host=ln if ragged else None)
+            outs[(fill, ragged)] = (o.clone(), ol.clone())
+            enc._ws.clear()                                      # the next forward allocates (and fills) again
+    for (fill, ragged), (o, ol) in outs.items():
+        assert bool(torch.isfinite(o).all()), (fill, ragged)
+        if fill == "255":
+            z, zl = outs[("0", ragged)]
+            assert torch.equal(ol, zl) and torch.equal(o, z), (ragged, float((o - z).abs().max()))
