@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libeffconf.so")
 LIB_DEBUG = os.path.join(HERE, "libeffconf_debug.so")
-SOURCES = ["gemm.hip", "gemm256.hip", "rsgemm.hip", "chain.hip", "chain2.hip", "chain3.hip", "norm.hip", "conv.hip", "sublinear.hip", "sublinear2.hip", "conv2.hip", "mel.hip", "ctc.hip", "rnnt.hip", "attention.hip", "attention2.hip", "exact.hip", "split.hip", "sxf.hip", "sxf_ffn.hip", "sxf_chain.hip", "hostpack.hip", "encoder.hip"]
+SOURCES = ["gemm.hip", "gemm256.hip", "rsgemm.hip", "chain.hip", "chain2.hip", "chain3.hip", "norm.hip", "conv.hip", "sublinear.hip", "sublinear2.hip", "conv2.hip", "mel.hip", "ctc.hip", "rnnt.hip", "attention.hip", "attention2.hip", "exact.hip", "split.hip", "sxf.hip", "sxf_ffn.hip", "sxf_chain.hip", "sxf_sub.hip", "hostpack.hip", "encoder.hip"]
 # (source, object, extra flags): further compilations of a source under other flags
 # No packed-fp32 VALU instructions in product kernels: v_pk_{add,mul,fma}_f32 with an op_sel low-lane swizzle return wrong values
 # next to another wave's bf16 MFMA on gfx950 (measured: profiles/r2_mel_packed_fp32_hazard.txt; guard: _isa_guard.py).

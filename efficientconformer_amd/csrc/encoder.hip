@@ -109,6 +109,7 @@ struct EcEncoder {
     int tiled_min_k = 256;                   // with wide_gemm >= 2: layers with K > this leave the row-stationary kernels for LayerNorm + tiled GEMMs
     std::vector<float*> att_out;             // per block: device buffer [B][H][Tg][Tg] for the softmax maps of the next forward, or null
     int split_chain = 1;                     // split mode: the row-local work of a block as two kernels (sxf_chain.hip) where the width is built; 0 = per-module kernels (tests)
+    int split_sublin = 1;                    // split mode: Conv2dSubsampling + Linear as one kernel (sxf_sub.hip) for the one-layer subsampler; 0 = conv kernel + GEMM [+ row gather] (tests)
     int split_ffn = 1;                       // split mode: the feed-forward modules as one kernel each (sxf_ffn.hip) where the width is built; 0 = LayerNorm + two GEMMs (tests)
     int exact_attention = 0;                 // fp32 mode: 0 tiled attention kernel (2: its 16-row shape), 1 one wave per query row (round 2's); bit-identical
     bool head_major_odd = false;             // odd grouped head widths on the head-major Q/K/V layout (tests; the default reads the natural layout unaligned)
@@ -152,6 +153,8 @@ struct EcEncoder {
     std::map<std::string, const float*> xw;
     std::map<std::pair<int, int>, const float*> xtab;
     const float *xsub_scale[2] = {nullptr, nullptr}, *xsub_shift[2] = {nullptr, nullptr};
+    // split mode: images of the fused front end (sxf_sub.hip; kernels.h: SxfSubParams) - one-layer subsampler only
+    const uint16_t *xsub_cimg = nullptr, *xsub_wimg = nullptr; const float* xsub_bias = nullptr; int xsub_ncb = 0, xsub_fo = 0;
     // per-launch event profiler (bench / tuning only; off by default)
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev;          // pairs
@@ -1176,7 +1179,20 @@ int forward_core_split(EcEncoder* e, const float* mel, const int64_t* in_len, in
     const int C0 = c.sub_filters[0];
     int Fl = c.n_mels, Cl = C0;
     int T1r = s.Tm; for (int i = 0; i < c.sub_layers; ++i) T1r = (T1r - 1) / 2 + 1;
-    {
+    // one-layer subsampler: convolution + Swish + Linear as ONE kernel on the frames that exist (sxf_sub.hip) - the (frames, C F') activation stays in registers.
+    // A debug trace wants that activation ("subsample"): per-module kernels then
+    const bool sublin = e->split_sublin && e->xsub_wimg && c.sub_layers == 1 && !e->trace_arena;
+    if (sublin) {
+        const int D0 = e->blocks[0].dim_model;
+        SxfSubParams sp{};
+        sp.mel = mel; sp.B = B; sp.F = c.n_mels; sp.Tm = s.Tm; sp.mel_len = mel_len;
+        if (rg) { const RaggedRows r0 = rows_at(0); sp.off = r0.off; sp.len = r0.len; sp.rows_max = ec_round_up(s.Tin[0], e->blocks[0].group_size); }
+        else { sp.To = T1r; sp.rows_max = T1r; }
+        sp.cimg = e->xsub_cimg; sp.wimg = e->xsub_wimg; sp.bias = e->xsub_bias; sp.y = F32(w.x0); sp.N = D0; sp.ncb = e->xsub_ncb; sp.Fo = e->xsub_fo;
+        const double Mr = (double)s.Min[0], Ks = (double)C0 * e->xsub_fo;
+        PROF(PC_SUBCONV, 2.0 * Mr * Ks * (9.0 + D0), (double)B * c.n_mels * s.Tm * 4 + Mr * D0 * 4);
+        EC_TRY(launch_sxf_sublin(sp, st));
+    } else {
         PROF(PC_SUBCONV, 0, (double)B * c.n_mels * s.Tm * 4);
         if (c.sub_layers == 1) {
             EC_TRY(launch_ex_conv2d(mel, B, 1, c.n_mels, s.Tm, xget(e, "subsampling_module.layers.0.0.weight"), e->xsub_scale[0], e->xsub_shift[0], C0, sub, 1, st, mel_len));
@@ -1193,7 +1209,9 @@ int forward_core_split(EcEncoder* e, const float* mel, const int64_t* in_len, in
     float* x = F32(w.x0);
     float* xalt = F32(w.x1);
     const int D0 = e->blocks[0].dim_model;
-    if (rg) {
+    if (sublin) {
+        // x holds the rows already
+    } else if (rg) {
         float* xrect = F32(w.xrect);
         EC_TRY(xgemm(e, st, sub, Ksub, B * T1r, "linear", D0, Ksub, xrect, D0));
         PROF(PC_MISC, 0, (double)s.Min[0] * D0 * 8);
@@ -1718,6 +1736,7 @@ int effconf_encoder_finalize(EcEncoder* e) {
     e->xw.clear(); e->xtab.clear();
     if (e->exact_pack) {       // fp32-operand mode: the reference-layout fp32 tensors themselves, fp32 sinusoid tables, BatchNorm scale / shift
         for (auto& kv : e->host) e->xw[kv.first] = upload(e, kv.second.data);
+        std::vector<float> sub_sc0, sub_sh0;
         for (int l = 0; l < c.sub_layers; ++l) {
             const std::string sp = "subsampling_module.layers." + std::to_string(l);
             const int C = c.sub_filters[l];
@@ -1726,8 +1745,47 @@ int effconf_encoder_finalize(EcEncoder* e) {
             if (!cbias || (int)cbias->data.size() != C || !bn_fold(e, sp + ".1", C, &sc, &sh, &err)) return fail("exact mode: " + err);
             for (int ch = 0; ch < C; ++ch) sh[ch] += cbias->data[ch] * sc[ch];
             e->xsub_scale[l] = upload(e, sc); e->xsub_shift[l] = upload(e, sh);
+            if (l == 0) { sub_sc0 = sc; sub_sh0 = sh; }
         }
         e->xsplit.clear();
+        e->xsub_cimg = e->xsub_wimg = nullptr; e->xsub_bias = nullptr;
+        if (e->exact_split && c.sub_layers == 1) {
+            // images of the fused front end (sxf_sub.hip): conv taps with the BatchNorm scale folded in (shift + scaled conv bias in tap 9), the Linear's weight in
+            // chunks of (output frequency f', 32 channels) with the k order of the accumulator layout; same-scale halves at 2^10 as for the other fused kernels
+            const int Co = c.sub_filters[0], Fo = (c.n_mels - 1) / 2 + 1, N = e->blocks[0].dim_model, nt = sxf_sublin_tiles(N);
+            const HostTensor *cw = find(e, "subsampling_module.layers.0.0.weight"), *lw = find(e, "linear.weight"), *lb = find(e, "linear.bias");
+            if (nt && cw && lw && lb && (int64_t)cw->data.size() == (int64_t)Co * 9 && (int64_t)lw->data.size() == (int64_t)N * Co * Fo && (int)lb->data.size() == N) {
+                auto half_bits = [](float f) { _Float16 h = (_Float16)f; uint16_t u; memcpy(&u, &h, 2); return u; };
+                auto put = [&](std::vector<uint16_t>& img, size_t hi_at, size_t lo_at, double wv) {
+                    float ws = (float)(wv * 1024.0);
+                    ws = ws > 65000.f ? 65000.f : (ws < -65000.f ? -65000.f : ws);
+                    const _Float16 hh = (_Float16)ws;
+                    img[hi_at] = half_bits((float)hh);
+                    img[lo_at] = half_bits(ws - (float)hh);
+                };
+                const int ncb = (Co + 31) / 32, DP2 = 32 * nt;
+                std::vector<uint16_t> cimg((size_t)ncb * 2 * 32 * 16, 0), wimg((size_t)Fo * ncb * 2 * DP2 * 32, 0);
+                for (int co = 0; co < Co; ++co) {
+                    const size_t base = (size_t)(co / 32) * 2 * 32 * 16 + (size_t)(co % 32) * 16;
+                    for (int tap = 0; tap < 9; ++tap) put(cimg, base + tap, base + 32 * 16 + tap, (double)cw->data[(size_t)co * 9 + tap] * sub_sc0[co]);
+                    put(cimg, base + 9, base + 32 * 16 + 9, sub_sh0[co]);
+                }
+                for (int fo = 0; fo < Fo; ++fo)
+                    for (int cb = 0; cb < ncb; ++cb) {
+                        const size_t base = (size_t)(fo * ncb + cb) * 2 * DP2 * 32;
+                        for (int n = 0; n < N; ++n)
+                            for (int pos = 0; pos < 32; ++pos) {
+                                const int sstep = pos >> 4, khh = (pos >> 3) & 1, ee = pos & 7;
+                                const int co = 32 * cb + 16 * sstep + 8 * (ee >> 2) + 4 * khh + (ee & 3);      // accumulator register 8 s + e of lane half kh holds this channel
+                                if (co >= Co) continue;
+                                put(wimg, base + (size_t)n * 32 + pos, base + (size_t)DP2 * 32 + (size_t)n * 32 + pos, lw->data[(size_t)n * Co * Fo + (size_t)co * Fo + fo]);
+                            }
+                    }
+                std::vector<float> bp(DP2, 0.f);
+                for (int n = 0; n < N; ++n) bp[n] = lb->data[n];
+                e->xsub_cimg = upload(e, cimg); e->xsub_wimg = upload(e, wimg); e->xsub_bias = upload(e, bp); e->xsub_ncb = ncb; e->xsub_fo = Fo;
+            }
+        }
         if (e->exact_split) {
             // every 2-D weight (nn.Linear [N][K], 1x1 Conv1d [N][K][1]) as two fp16 images h = fp16(w), l = fp16((w - h) * 2048), K padded
             // with zeros to whole 32-wide k-tiles and stored k-tile major; the three attention projections of a block additionally stacked (q | k | v)
@@ -2371,6 +2429,7 @@ int effconf_encoder_set_option(EcEncoder* e, const char* name, int32_t value) {
     if (!strcmp(name, "ffn_variant")) { if (value < 0 || value > 2) return fail("ffn_variant: 0, 1 or 2 (fused-FFN workgroup shapes)"); e->ffn_variant = value; return 0; }
     if (!strcmp(name, "head_major_odd")) { e->head_major_odd = value != 0; return 0; }
     if (!strcmp(name, "split_ffn")) { e->split_ffn = value != 0; return 0; }
+    if (!strcmp(name, "split_sublin")) { e->split_sublin = value != 0; return 0; }
     if (!strcmp(name, "split_chain")) { e->split_chain = value != 0; return 0; }
     if (!strcmp(name, "exact_attention")) { if (value < 0 || value > 2) return fail("exact_attention: 0 (tiled), 2 (tiled, 16-row workgroups) or 1 (one wave per query row)"); e->exact_attention = value; return 0; }
     if (!strcmp(name, "cache_pos_embeddings")) { e->e_cache_on = value != 0; e->e_cache.clear(); return 0; }

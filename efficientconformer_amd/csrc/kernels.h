@@ -281,6 +281,23 @@ struct SxfFfnParams {
     int ablate;                    // timing-only ablations (tools/sxf_ffn_probe.py through the diagnostic library; 0 in the product): 1 no first product, 2 no Swish,
                                    // 4 no second product, 8 no weight stream after the first chunk, 16 no per-chunk barrier
 };
+// Conv2dSubsampling (one layer) + transpose / flatten + Linear as one split-precision kernel (sxf_sub.hip)
+struct SxfSubParams {
+    const float* mel; int B, F, Tm;   // (B, F, Tm) fp32 mel image, Tm = row pitch
+    const int* mel_len;               // dev [B]: the utterance's own mel frames (ragged batches), or null: Tm
+    const int* off;                   // dev [B + 1]: first output row of every utterance (ragged: group padded), or null: b To
+    const int* len;                   // dev [B]: output frames that exist, or null: To
+    int To;                           // output frames per utterance of a rectangular batch
+    int rows_max;                     // grid: rows of the longest utterance (ragged: incl. its group padding; rectangular: To)
+    const uint16_t* cimg;             // conv taps [ncb][hi | lo][32 channels][16 taps] fp16 at 2^10: tap 3 i + j (frequency, time) x BN scale, tap 9 = BN shift + scaled conv bias
+    const uint16_t* wimg;             // Linear image [Fo ncb chunks][hi | lo][DP2 outputs][32 k] fp16 at 2^10: chunk f' ncb + cb, k position 16 s + 8 kh + e <->
+                                      // channel 32 cb + 16 s + 8 (e >> 2) + 4 kh + (e & 3) (the accumulator layout), weight column channel Fo + f' (encoders.py:114)
+    const float* bias;                // [DP2] Linear bias, zero padded
+    float* y; int N;                  // out [rows][N]
+    int ncb, Fo;                      // channel blocks of 32, output frequencies
+};
+int sxf_sublin_tiles(int N);          // 32-column output tiles of the instance that serves width N (DP2 = 32 x this); 0 = not built
+int launch_sxf_sublin(const SxfSubParams& p, hipStream_t s);
 void sxf_ffn_shape(int D, int* ks1, int* nt2);
 bool sxf_ffn_supported(int D);
 size_t sxf_ffn_image_halfs(int D, int F);

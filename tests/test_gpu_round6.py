@@ -304,3 +304,46 @@ def test_forward_on_a_poisoned_fresh_workspace_is_bit_identical(monkeypatch, nam
         if fill == "255":
             z, zl = outs[("0", ragged)]
             assert torch.equal(ol, zl) and torch.equal(o, z), (ragged, float((o - z).abs().max()))
+
+
+# ------------------------------------------------------------------ split-precision front end as one kernel (csrc/sxf_sub.hip)
+@pytest.mark.parametrize("name,tm,lens", [("Tiny", 333, [333, 250, 97, 12, 3]), ("EfficientConformerCTCSmall", 700, [700, 433, 258, 57]),
+                                          ("EfficientConformerCTCMedium", 300, [300, 177]), ("EfficientConformerCTCLarge", 260, [260, 121]),
+                                          ("EfficientConformerTransducerSmall", 300, [300, 222, 9])])
+@pytest.mark.parametrize("ragged", [False, True])
+def test_split_front_end_kernel_vs_conv_gemm_kernels_and_the_oracle(name, tm, lens, ragged):
+    """sxf_sub.hip: Conv2d(1, C, 3, stride 2) + BatchNorm + Swish + flatten + Linear as ONE kernel whose (frames, C F') activation never leaves the registers
+    (modules.py:232-249, encoders.py:113-116), ragged batches on the frames that exist.  Against (i) the same mode on the per-module front end
+    (`split_sublin = 0`: fp32 VALU convolution, split GEMM, row gather - another summation order: a few 1e-6) and (ii) the oracle within the split mode's stated
+    bound; rectangular batches (pad frames live) and ragged ones (every utterance against the oracle on it ALONE: the convolution's zero padding starts behind
+    its own last mel frame; the group-padding rows behind it are zeros); every instance (1 / 4 / 6 / 12 output tiles: D0 = 24, 100 / 120, 180, 360) and channel
+    counts that are not a multiple of 32 (24, 100, 120, 180, 360); utterances shorter than one tile and a tile count > 1 (700 frames -> 350 rows)."""
+    m, sd = _model(name, 13)
+    plan = m.encoder.plan
+    m.encoder.precision = "split"
+    mel, ln = synth.make_mel(len(lens), 80, tm, lens, seed=5 + tm)
+    mel_d, ln_d = torch.from_numpy(mel).cuda(), torch.from_numpy(ln).cuda()
+    m.encoder.ragged = ragged
+    out, out_len, _ = m.encoder.forward_mel(mel_d, ln_d)
+    m.encoder.set_option("split_sublin", 0)
+    base, base_len, _ = m.encoder.forward_mel(mel_d, ln_d)
+    m.encoder.set_option("split_sublin", 1)
+    assert torch.equal(out_len, base_len)
+    d = (out - base).abs()
+    print("%s ragged=%s fused front end vs conv + GEMM kernels: max %.2e mean %.2e" % (name, ragged, float(d.max()), float(d.mean())))
+    assert float(d.max()) < 1e-4 and float(d.mean()) < 1e-5
+    if ragged:
+        for b, l in enumerate(lens):
+            with torch.no_grad():
+                ref, ref_len = R.encoder_from_mel(torch.from_numpy(mel[b:b + 1, :, :l]), torch.tensor([l]), sd, plan)
+            tb = int(ref_len[0])
+            assert int(out_len[b]) == tb
+            e = (out[b, :tb].cpu() - ref[0]).abs()
+            assert float(e.max()) < SPLIT_MAX and float(e.mean()) < SPLIT_MEAN, (b, float(e.max()), float(e.mean()))
+    else:
+        with torch.no_grad():
+            ref, ref_len = R.encoder_from_mel(torch.from_numpy(mel), torch.from_numpy(ln), sd, plan)
+        assert out_len.cpu().tolist() == ref_len.tolist()
+        e = (out.cpu() - ref).abs()
+        print("%s rectangular vs oracle: max %.2e mean %.2e" % (name, float(e.max()), float(e.mean())))
+        assert float(e.max()) < SPLIT_MAX and float(e.mean()) < SPLIT_MEAN
