@@ -29,7 +29,7 @@ DEBUG_REPLACES = {"encoder.hip": "encoder_dbg.o", "mel.hip": "mel_dbg.o", "sxf_f
 DEBUG_OBJECTS = [("debug.hip", "debug.o", []), ("mel.hip", "mel_pk.o", ["-DMEL_PK_BUILD"])]
 # sxf_chain.hip: the source-scheduled F2 + Swish body is ~400 unrolled iterations of a 13-way switch - beyond the default cost bound of `#pragma unroll`, and a loop
 # left rolled indexes its register arrays dynamically (= scratch memory)
-PER_SOURCE = {"sxf_chain.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"]}
+PER_SOURCE = {"sxf_chain.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"], "sxf_sub.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"]}
 # -fvisibility=hidden: only what include/effconf.h / effconf_debug.h declare (under `#pragma GCC visibility push(default)`) is a dynamic symbol
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-unused-result",
          "-Wno-inline-asm"]   # rowstat.h clobbers m0 on purpose (LDS-DMA destination register)

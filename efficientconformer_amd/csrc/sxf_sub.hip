@@ -26,6 +26,38 @@ constexpr float SP = 64.0f, SA = 256.0f, SW = 1024.0f;           // operand scal
 constexpr float UNS1 = 1.0f / (SP * SW), UNS2 = 1.0f / (SA * SW);
 constexpr int ROW2 = 80;                                         // bytes per Linear image row in LDS: 32 hidden units (64 B) + 16
 
+// Swish (modules.py:240) of a finished first-product chunk -> split B fragments of the second product, as 216 single-instruction steps (the scheme of sxf_chain.hip:
+// exp through v_exp_f32 with the rounding of its argument corrected to first order, 1 / x by v_rcp_f32).  Four values at a time, stage-major inside the four;
+// value r = register r of the accumulators <-> k position 8 kh + (r & 7) of k-step r >> 3.  Every step ends in an empty volatile asm on its result: the steps are
+// pure arithmetic, which instruction selection otherwise sinks behind the last MFMA whatever fences stand in the source.
+struct SwishState { float x[16], y[16], w[16]; uint32_t hh[8], ll[8]; };
+constexpr int SWISH_STEPS = 16 * 13 + 8;
+#define SUB_PIN(v) asm volatile("" : "+v"(v))
+__device__ __forceinline__ void swish_step(int idx, const f32x16& h1, const f32x16& h2, const f32x16& h3, SwishState& q) {
+    const int g = idx / 54, o = idx - 54 * g;
+    if (o >= 52) { const int pr = 2 * g + (o - 52); split2s(q.x[2 * pr], q.x[2 * pr + 1], q.hh[pr], q.ll[pr]); SUB_PIN(q.hh[pr]); SUB_PIN(q.ll[pr]); return; }
+    const int stage = o >> 2, r = 4 * g + (o & 3);
+    switch (stage) {
+        case 0: q.x[r] = h1[r] + h2[r]; SUB_PIN(q.x[r]); break;
+        case 1: q.x[r] = q.x[r] + h3[r]; SUB_PIN(q.x[r]); break;
+        case 2: q.x[r] = q.x[r] * UNS1; SUB_PIN(q.x[r]); break;
+        case 3: q.y[r] = fminf(-q.x[r], 87.0f); SUB_PIN(q.y[r]); break;
+        case 4: q.w[r] = q.y[r] * 1.44269502162933349609375f; SUB_PIN(q.w[r]); break;
+        case 5: q.y[r] = fmaf(q.y[r], 1.44269502162933349609375f, -q.w[r]); SUB_PIN(q.y[r]); break;
+        case 6: q.w[r] = __builtin_amdgcn_exp2f(q.w[r]); SUB_PIN(q.w[r]); break;
+        case 7: q.y[r] = q.y[r] * 0.693147180559945f; SUB_PIN(q.y[r]); break;
+        case 8: q.w[r] = fmaf(q.w[r], q.y[r], q.w[r]); SUB_PIN(q.w[r]); break;
+        case 9: q.w[r] = 1.0f + q.w[r]; SUB_PIN(q.w[r]); break;
+        case 10: q.w[r] = __builtin_amdgcn_rcpf(q.w[r]); SUB_PIN(q.w[r]); break;
+        case 11: q.x[r] = q.x[r] * SA; SUB_PIN(q.x[r]); break;
+        default: q.x[r] = q.x[r] * q.w[r]; SUB_PIN(q.x[r]); break;
+    }
+}
+__device__ __forceinline__ void swish_pack(const SwishState& q, f16x8 (&nh)[2], f16x8 (&nl)[2]) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) { nh[s] = as_f16x8(make_uint4(q.hh[4 * s], q.hh[4 * s + 1], q.hh[4 * s + 2], q.hh[4 * s + 3])); nl[s] = as_f16x8(make_uint4(q.ll[4 * s], q.ll[4 * s + 1], q.ll[4 * s + 2], q.ll[4 * s + 3])); }
+}
+
 template <int NT2>
 struct SubLds {
     static constexpr int DP2 = 32 * NT2, STAGE = 2 * DP2 * ROW2;
@@ -35,7 +67,7 @@ struct SubLds {
 };
 
 template <int NT2>
-__global__ __launch_bounds__(256, (NT2 <= 6 ? 2 : 1)) void sxf_sublin_kernel(const SxfSubParams p) {
+__global__ __launch_bounds__(256, (NT2 <= 4 ? 2 : 1)) void sxf_sublin_kernel(const SxfSubParams p) {
     using L = SubLds<NT2>;
     constexpr int DP2 = L::DP2, NPC = L::NPC;
     extern __shared__ __attribute__((aligned(16))) char sm[];
@@ -94,75 +126,102 @@ __global__ __launch_bounds__(256, (NT2 <= 6 ? 2 : 1)) void sxf_sublin_kernel(con
     for (int tt = 0; tt < NT2; ++tt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[tt][r] = 0.f;
+    // ---- software pipeline over the chunks: the second product of chunk c (24 MFMAs at four output tiles, operands: registers + the ring) runs in ONE basic block
+    //      with the first product + Swish + operand split of chunk c + 1 (3 MFMAs, ~450 VALU / transcendental instructions) - independent work that the scheduler
+    //      interleaves (one matrix instruction, then a slice of the Swish); left in sequence a wave spent 1.8 k cycles on the VALU with the matrix pipe idle and
+    //      0.9 k cycles queueing MFMAs with the VALU idle, per chunk
+    auto patch_frags = [&](f16x8& ah, f16x8& al) __attribute__((always_inline)) {
+        // this lane's patch as split B fragments: taps 3 i + j; lane half 0 holds taps 0 .. 7, half 1 tap 8, the constant of the shift column (tap 9) and zeros
+        float v[8];
+        v[0] = kh ? pr[2][2] : pr[0][0]; v[1] = kh ? 1.0f : pr[0][1]; v[2] = kh ? 0.f : pr[0][2];
+        v[3] = kh ? 0.f : pr[1][0]; v[4] = kh ? 0.f : pr[1][1]; v[5] = kh ? 0.f : pr[1][2];
+        v[6] = kh ? 0.f : pr[2][0]; v[7] = kh ? 0.f : pr[2][1];
+        uint32_t hh[4], ll[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split2s(v[2 * e] * SP, v[2 * e + 1] * SP, hh[e], ll[e]);
+        ah = as_f16x8(make_uint4(hh[0], hh[1], hh[2], hh[3])); al = as_f16x8(make_uint4(ll[0], ll[1], ll[2], ll[3]));
+    };
+    // H^T = Wc_cb P^T (32 channels x 32 frames): one 16-wide k-step, three accumulators (an MFMA on the previous one's result waits for it)
+    auto first_product = [&](int cb, const f16x8& ah, const f16x8& al, f32x16& h1, f32x16& h2, f32x16& h3) __attribute__((always_inline)) {
+        const char* cw = sCW + cb * L::CW + lr * 32 + 16 * kh;
+        const f16x8 wh = *reinterpret_cast<const f16x8*>(cw), wl = *reinterpret_cast<const f16x8*>(cw + 32 * 32);
+        f32x16 z0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z0[r] = 0.f;
+        h1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, ah, z0, 0, 0, 0);
+        h2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, al, z0, 0, 0, 0);
+        h3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, ah, z0, 0, 0, 0);
+    };
+    constexpr int GS = NT2 < 4 ? NT2 : 4, NG = (NT2 + GS - 1) / GS, NU = 2 * NG, NM = 6 * NT2, Q = (SWISH_STEPS + NM - 1) / NM, LASTG = NT2 - (NG - 1) * GS;
+    static_assert(NM * Q >= SWISH_STEPS, "every Swish step has its MFMA");
+    // one pipeline step: Y^T += Wl_c H_c^T (stage c & 1; units = (group of up to four output tiles, k-step), MFMAs kind-major over the tiles: consecutive instructions
+    // hit different accumulators) with the Swish of chunk c + 1 = (., cb1) BETWEEN its MFMAs, the order fixed in the source (a fence per MFMA, its quota of Swish steps
+    // behind it); fragment reads run one unit ahead
+    auto step = [&](int c, int cb1, const f16x8& ah, const f16x8& al, f16x8 (&hbh)[2], f16x8 (&hbl)[2]) __attribute__((always_inline)) {
+        if (c + 1 < nchunk) publish(sm + ((c + 1) & 1) * L::STAGE);      // stage (c + 1) & 1 was read in iteration c - 1: every wave is past the barrier that closed it
+        fetch(c + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 h1, h2, h3;
+        first_product(cb1, ah, al, h1, h2, h3);
+        const char* w2 = sm + (c & 1) * L::STAGE + lr * ROW2 + 16 * kh;
+        f16x8 vh[NU][GS], vl[NU][GS];
+        auto load_unit = [&](int u) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < GS; ++i) {
+                const int tt = (u >> 1) * GS + i, s2 = u & 1;
+                if (tt < NT2) { vh[u][i] = *reinterpret_cast<const f16x8*>(w2 + 32 * tt * ROW2 + 32 * s2); vl[u][i] = *reinterpret_cast<const f16x8*>(w2 + DP2 * ROW2 + 32 * tt * ROW2 + 32 * s2); }
+            }
+        };
+        SwishState q;
+        __builtin_amdgcn_sched_barrier(0);
+        load_unit(0);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int s2 = u & 1, gq = u >> 1, gsz = gq == NG - 1 ? LASTG : GS;
+            const int base = 3 * (2 * GS * gq + s2 * gsz);              // MFMAs before this unit (a function of the loop indices only: every Swish step index below is a constant)
+#pragma unroll
+            for (int kind = 0; kind < 3; ++kind)
+#pragma unroll
+                for (int i = 0; i < GS; ++i) {
+                    const int tt = gq * GS + i;
+                    if (tt < NT2) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (kind == 0 && i == 0 && u + 1 < NU) load_unit(u + 1);
+                        oacc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kind == 2 ? vl[u][i] : vh[u][i], kind == 1 ? hbl[s2] : hbh[s2], oacc[tt], 0, 0, 0);
+                        const int m0 = (base + kind * gsz + i) * Q;
+#pragma unroll
+                        for (int j = 0; j < Q; ++j) if (m0 + j < SWISH_STEPS) swish_step(m0 + j, h1, h2, h3, q);
+                    }
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        swish_pack(q, hbh, hbl);
+        lds_barrier();
+    };
     publish(sm);
     fetch(1);
     lds_barrier();
+    f16x8 ah, al, hbh[2], hbl[2];
+    {   // chunk 0: first product + Swish alone
+        load_row(2, nx[0]); load_row(3, nx[1]);
+        patch_frags(ah, al);
+        f32x16 h1, h2, h3;
+        first_product(0, ah, al, h1, h2, h3);
+        SwishState q;
+#pragma unroll
+        for (int j = 0; j < SWISH_STEPS; ++j) swish_step(j, h1, h2, h3, q);
+        swish_pack(q, hbh, hbl);
+    }
     int c = 0;
     for (int fo = 0; fo < p.Fo; ++fo) {
-        load_row(2 * fo + 2, nx[0]); load_row(2 * fo + 3, nx[1]);       // the next patch's new rows (behind the image: zeros, never used)
-        // ---- this lane's patch as split B fragments: taps 3 i + j; lane half 0 holds taps 0 .. 7, half 1 tap 8, the constant of the shift column (tap 9) and zeros
-        f16x8 ah, al;
-        {
-            float v[8];
-            v[0] = kh ? pr[2][2] : pr[0][0]; v[1] = kh ? 1.0f : pr[0][1]; v[2] = kh ? 0.f : pr[0][2];
-            v[3] = kh ? 0.f : pr[1][0]; v[4] = kh ? 0.f : pr[1][1]; v[5] = kh ? 0.f : pr[1][2];
-            v[6] = kh ? 0.f : pr[2][0]; v[7] = kh ? 0.f : pr[2][1];
-            uint32_t hh[4], ll[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) split2s(v[2 * e] * SP, v[2 * e + 1] * SP, hh[e], ll[e]);
-            ah = as_f16x8(make_uint4(hh[0], hh[1], hh[2], hh[3])); al = as_f16x8(make_uint4(ll[0], ll[1], ll[2], ll[3]));
-        }
-        for (int cb = 0; cb < p.ncb; ++cb, ++c) {
-            const char* st = sm + (c & 1) * L::STAGE;
-            if (c + 1 < nchunk) publish(sm + ((c + 1) & 1) * L::STAGE);      // stage (c + 1) & 1 was read in iteration c - 1: every wave is past the barrier that closed it
-            fetch(c + 2);
-            // ---- H^T = Wc_cb P^T (32 channels x 32 frames): one 16-wide k-step, three accumulators (an MFMA on the previous one's result waits for it)
-            const char* cw = sCW + cb * L::CW + lr * 32 + 16 * kh;
-            const f16x8 wh = *reinterpret_cast<const f16x8*>(cw), wl = *reinterpret_cast<const f16x8*>(cw + 32 * 32);
-            f32x16 z0;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) z0[r] = 0.f;
-            const f32x16 h1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, ah, z0, 0, 0, 0);
-            const f32x16 h2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, al, z0, 0, 0, 0);
-            const f32x16 h3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, ah, z0, 0, 0, 0);
-            // ---- Swish (modules.py:240) on the accumulators -> split B fragments of the second product (register 8 s + e <-> k position 8 kh + e of k-step s)
-            f16x8 hbh[2], hbl[2];
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                uint32_t hh[4], ll[4];
-                float v[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float z = ((h1[8 * s + e] + h2[8 * s + e]) + h3[8 * s + e]) * UNS1;
-                    v[e] = (z * SA) * sx_rcp(1.0f + sx_expf(fminf(-z, 87.0f)));
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) split2s(v[2 * e], v[2 * e + 1], hh[e], ll[e]);
-                hbh[s] = as_f16x8(make_uint4(hh[0], hh[1], hh[2], hh[3])); hbl[s] = as_f16x8(make_uint4(ll[0], ll[1], ll[2], ll[3]));
-            }
-            // ---- Y^T += Wl_chunk H^T: units = (group of up to four output tiles, k-step), MFMAs kind-major over the tiles (consecutive instructions hit different accumulators)
-            const char* w2 = st + lr * ROW2 + 16 * kh;
-            constexpr int GS = NT2 < 4 ? NT2 : 4, NG = (NT2 + GS - 1) / GS, NU = 2 * NG;
-#pragma unroll
-            for (int u = 0; u < NU; ++u) {
-                const int s2 = u & 1;
-                f16x8 vh[GS], vl[GS];
-#pragma unroll
-                for (int i = 0; i < GS; ++i) {
-                    const int tt = (u >> 1) * GS + i;
-                    if (tt < NT2) { vh[i] = *reinterpret_cast<const f16x8*>(w2 + 32 * tt * ROW2 + 32 * s2); vl[i] = *reinterpret_cast<const f16x8*>(w2 + DP2 * ROW2 + 32 * tt * ROW2 + 32 * s2); }
-                }
-#pragma unroll
-                for (int i = 0; i < GS; ++i) { const int tt = (u >> 1) * GS + i; if (tt < NT2) oacc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[i], hbh[s2], oacc[tt], 0, 0, 0); }
-#pragma unroll
-                for (int i = 0; i < GS; ++i) { const int tt = (u >> 1) * GS + i; if (tt < NT2) oacc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[i], hbl[s2], oacc[tt], 0, 0, 0); }
-#pragma unroll
-                for (int i = 0; i < GS; ++i) { const int tt = (u >> 1) * GS + i; if (tt < NT2) oacc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[i], hbh[s2], oacc[tt], 0, 0, 0); }
-            }
-            lds_barrier();
-        }
+        for (int cb = 0; cb + 1 < p.ncb; ++cb, ++c) step(c, cb + 1, ah, al, hbh, hbl);
+        // the last channel block of this f': its partner is the first chunk of f' + 1 - advance the patch (rows requested one f' ahead), request the one after
 #pragma unroll
         for (int j = 0; j < 3; ++j) { pr[0][j] = pr[2][j]; pr[1][j] = nx[0][j]; pr[2][j] = nx[1][j]; }
+        load_row(2 * fo + 4, nx[0]); load_row(2 * fo + 5, nx[1]);       // behind the image: zeros, never used
+        patch_frags(ah, al);
+        step(c, 0, ah, al, hbh, hbl);                                    // behind the last chunk: a product nobody consumes
+        ++c;
     }
     // ---- y = Y + bias for the frames that exist, zeros for the group-padding rows; feature of register (tt, r) = 32 tt + 8 (r >> 2) + 4 kh + (r & 3)
     if (t < nrows) {
