@@ -25,7 +25,7 @@ using namespace sx;
 // accumulator and a fold per tile: a third of this kernel's VALU instructions.
 constexpr float SQK = 256.0f, SV_ = 256.0f, SP_ = 1024.0f;
 constexpr int SS_ROWS = 34;                                      // 32 key rows + a dump row on either side (band rows no pair of the wave's tile reads)
-constexpr int SS_LD = 40;                                        // floats per key row of a wave's skew buffer (conflict-free: see the writer below)
+constexpr int SS_LD = 36;                                        // floats per key row of a wave's skew buffer (conflict-free: see the writer below; ds_*_b32 bank = dword mod 32 inside a 32-lane group)
 constexpr int VROW = 64 * 2 + 16;                                // bytes per row of the V^T tiles (64 keys)
 
 __device__ __forceinline__ void wave_sync() {
@@ -49,7 +49,7 @@ struct AttnLds {
 };
 
 template <int KS, int NT>
-__global__ __launch_bounds__(256) void sxf_attention_kernel(const SxfAttnParams p) {
+__global__ __launch_bounds__(256, (AttnLds<KS, NT>::BYTES <= 80 * 1024 ? 2 : 1)) void sxf_attention_kernel(const SxfAttnParams p) {
     using L = AttnLds<KS, NT>;
     constexpr int PK = L::PK, ROW = L::ROW, CPR = PK / 4, HALF = L::HALF;
     extern __shared__ __attribute__((aligned(16))) char sm[];
