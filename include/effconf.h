@@ -255,12 +255,16 @@ int effconf_rnnt_greedy(EcRnnt* r, const float* enc_out, const int64_t* out_len,
  *   2 (round 4, csrc/split.hip; round 6, csrc/sxf.hip + sxf_ffn.hip + sxf_chain.hip): fp32 tensors with every GEMM and the attention products on the fp16
  *   matrix pipe, each operand split into two fp16 numbers (three MFMAs per product, products accurate to ~2^-21): label sequences identical to the
  *   reference's on every golden and on the bench's oracle samples of Small / Medium / Large.  Round 6: ONE attention kernel per block with the scores on the
- *   CU, the row-local work of a block as two kernels, ragged batches, causal and streaming configurations - 2.9x the bf16 step on EfficientConformerCTCSmall
- *   (5.7x in round 5), 2.7x / 2.8x on Medium / Large.  Set to 2 BEFORE finalize (the split weight images are built there; such a handle then serves 2, 1 and 0);
+ *   CU, the row-local work of a block as two kernels, the front end as one kernel, ragged batches, causal and streaming configurations - 2.6x the bf16 step on
+ *   EfficientConformerCTCSmall (5.7x in round 5), 2.4x / 2.7x on Medium / Large.  Set to 2 BEFORE finalize (the split weight images are built there; such a handle then serves 2, 1 and 0);
  *   a handle finalized with 1 refuses 2.
  * "split_chain" (default 1), "split_ffn" (default 1): split mode on the fused row-local kernels (csrc/sxf_chain.hip; csrc/sxf_ffn.hip when split_chain = 0);
  *   0 / 0 = LayerNorm, split GEMM, GLU kernels per module (tests: the same results within a few 1e-6, another summation order).  A debug trace
  *   (effconf_encoder_trace_*) runs the per-module kernels: the chains never write the intermediate states.
+ * "split_sublin" (default 1; round 6, csrc/sxf_sub.hip): split mode, one-layer subsampler (the EfficientConformer configurations): Conv2d + BatchNorm + Swish + flatten
+ *   + Linear as ONE kernel whose (frames, C F') activation stays in registers (the conv as a 16-tap MFMA product whose accumulators are the B fragments of the
+ *   Linear's product), ragged batches on the frames that exist; 0 = fp32 VALU convolution + split GEMM (+ row gather) - the same results within a few 1e-6.
+ *   Small split step 14.6 -> 12.9 ms.  A debug trace runs the per-module kernels (it wants the "subsample" activation).
  * MODE MATRIX (what a forward accepts; everything else returns an error, never a silent fallback):
  *   bf16 path (exact_fp32 = 0): rectangular batches (effconf_encoder_forward / _forward_mel), ragged batches (effconf_encoder_forward_ragged; head
  *     widths <= 160 padded), streaming contexts / causal configurations (EcConfig; natural Q / K / V layout, head widths <= 160 padded), attention
