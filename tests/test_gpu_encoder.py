@@ -524,6 +524,7 @@ def test_sub_batch_streams_are_bit_identical_to_one_stream():
     assert torch.equal(got, ref) and torch.equal(got_len, ref_len)
 
 
+@pytest.mark.run_last      # one unexplained failure in 4 full-suite runs of round 6's last session, none in 21 reruns (profiles/r6_77_*, r6_83_*): see tests/conftest.py
 def test_sub_batch_streams_are_bit_identical_at_librispeech_batch_sizes():
     """The case the robustness sweep (tools/robustness_sweep.py) used to fail: EfficientConformerCTCSmall, an odd LibriSpeech-sized
     batch with one very short utterance, 2 and 3 row ranges in flight.  The mel frontend runs once for the whole batch and the
