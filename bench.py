@@ -108,8 +108,8 @@ def parse():
     ap.add_argument("--cuts", default="", help="explicit row boundaries of the ranges, e.g. 80,168 (tuning; overrides --balanced-split)")
     ap.add_argument("--no-trim", action="store_true",
                     help="pad every row range to the whole batch's longest utterance (round-1 workload) instead of its own longest")
-    ap.add_argument("--subsample", type=int, default=-1, choices=[-1, 0, 1, 2],
-                    help="conv subsampling + Linear: 0 separate kernels, 1 sublinear.hip, 2 sublinear2.hip (-1: the library's default = 2)")
+    ap.add_argument("--subsample", type=int, default=-1, choices=[-1, 0, 1, 2, 3],
+                    help="conv subsampling + Linear: 0 separate kernels, 1 sublinear.hip, 2 sublinear2.hip (wide front ends: sublinear3.hip), 3 sublinear3.hip (-1: the library default = 2)")
     ap.add_argument("--attention", type=int, default=-1, choices=[-1, 0, 1, 2],
                     help="attention kernel: 0 attention.hip, 1 / 2 attention2.hip variants (-1: the library's default = 1)")
     ap.add_argument("--wide-gemm", type=int, default=-1, choices=[-1, 0, 1, 2, 3],

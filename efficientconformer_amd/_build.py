@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libeffconf.so")
 LIB_DEBUG = os.path.join(HERE, "libeffconf_debug.so")
-SOURCES = ["gemm.hip", "gemm256.hip", "rsgemm.hip", "chain.hip", "chain2.hip", "chain3.hip", "norm.hip", "conv.hip", "sublinear.hip", "sublinear2.hip", "conv2.hip", "mel.hip", "ctc.hip", "rnnt.hip", "attention.hip", "attention2.hip", "exact.hip", "split.hip", "sxf.hip", "sxf_ffn.hip", "sxf_chain.hip", "sxf_sub.hip", "hostpack.hip", "encoder.hip"]
+SOURCES = ["gemm.hip", "gemm256.hip", "rsgemm.hip", "chain.hip", "chain2.hip", "chain3.hip", "norm.hip", "conv.hip", "sublinear.hip", "sublinear2.hip", "sublinear3.hip", "conv2.hip", "mel.hip", "ctc.hip", "rnnt.hip", "attention.hip", "attention2.hip", "exact.hip", "split.hip", "sxf.hip", "sxf_ffn.hip", "sxf_chain.hip", "sxf_sub.hip", "hostpack.hip", "encoder.hip"]
 # (source, object, extra flags): further compilations of a source under other flags
 # No packed-fp32 VALU instructions in product kernels: v_pk_{add,mul,fma}_f32 with an op_sel low-lane swizzle return wrong values
 # next to another wave's bf16 MFMA on gfx950 (measured: profiles/r2_mel_packed_fp32_hazard.txt; guard: _isa_guard.py).
@@ -29,7 +29,7 @@ DEBUG_REPLACES = {"encoder.hip": "encoder_dbg.o", "mel.hip": "mel_dbg.o", "sxf_f
 DEBUG_OBJECTS = [("debug.hip", "debug.o", []), ("mel.hip", "mel_pk.o", ["-DMEL_PK_BUILD"])]
 # sxf_chain.hip: the source-scheduled F2 + Swish body is ~400 unrolled iterations of a 13-way switch - beyond the default cost bound of `#pragma unroll`, and a loop
 # left rolled indexes its register arrays dynamically (= scratch memory)
-PER_SOURCE = {"sxf_chain.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"], "sxf_sub.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"]}
+PER_SOURCE = {"sxf_chain.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"], "sxf_sub.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"], "sublinear3.hip": ["-mllvm", "-pragma-unroll-threshold=1000000"]}
 # -fvisibility=hidden: only what include/effconf.h / effconf_debug.h declare (under `#pragma GCC visibility push(default)`) is a dynamic symbol
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-unused-result",
          "-Wno-inline-asm"]   # rowstat.h clobbers m0 on purpose (LDS-DMA destination register)

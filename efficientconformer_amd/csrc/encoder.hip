@@ -92,8 +92,9 @@ struct EcEncoder {
     const float *sub_w9 = nullptr, *sub_b = nullptr;
     PackedLinear lin;
     const bf16_t* lin_fused = nullptr; int lin_fused_ld = 0;   // Linear weight in the fused kernel's K order (sublinear.hip)
+    const uint16_t *sub3_cimg = nullptr, *sub3_wimg = nullptr; const float* sub3_bias = nullptr; int sub3_ncb = 0, sub3_fo = 0;   // sublinear3.hip (kernels.h: SubLin3Params)
     const bf16_t* lin_rs = nullptr; const float* conv_tab = nullptr;   // sublinear2.hip: Linear weight [F/2][32 NT][32 CG] (K-permuted per 16), conv taps [32 CG][16]
-    int fuse_subsample = 2;                  // 0: separate conv + GEMM kernels, 1: sublinear.hip, 2: sublinear2.hip where it supports the shape (else 1)
+    int fuse_subsample = 2;                  // 0: separate conv + GEMM kernels, 1: sublinear.hip, 2: sublinear2.hip where it supports the shape (else 1; wide front ends: sublinear3.hip, option sub3_auto), 3: sublinear3.hip
     bool fuse_chain = true;                  // row-local chains (chain.hip) where supported
     int ctc_mfma = 2;                        // CTC head: 2 split-bf16 operands on the bf16 MFMA (bf16 path; fp32 mode falls back to 1), 1 fp32 MFMA (bit-identical to 0), 0 the VALU kernel
     int attention_v2 = 1;                    // 0: attention.hip; 1 (default) / 2: attention2.hip variants where they support the head width (padded <= 160)
@@ -109,6 +110,7 @@ struct EcEncoder {
     int tiled_min_k = 256;                   // with wide_gemm >= 2: layers with K > this leave the row-stationary kernels for LayerNorm + tiled GEMMs
     std::vector<float*> att_out;             // per block: device buffer [B][H][Tg][Tg] for the softmax maps of the next forward, or null
     int split_chain = 1;                     // split mode: the row-local work of a block as two kernels (sxf_chain.hip) where the width is built; 0 = per-module kernels (tests)
+    int sub3_auto = 1;                       // with fuse_subsample = 2: front ends wider than 128 channels / columns on sublinear3.hip (0: sublinear2.hip / conv + GEMM as before round 6)
     int split_sublin = 1;                    // split mode: Conv2dSubsampling + Linear as one kernel (sxf_sub.hip) for the one-layer subsampler; 0 = conv kernel + GEMM [+ row gather] (tests)
     int split_ffn = 1;                       // split mode: the feed-forward modules as one kernel each (sxf_ffn.hip) where the width is built; 0 = LayerNorm + two GEMMs (tests)
     int exact_attention = 0;                 // fp32 mode: 0 tiled attention kernel (2: its 16-row shape), 1 one wave per query row (round 2's); bit-identical
@@ -597,6 +599,14 @@ int run_rs_or_tiled(EcEncoder* e, int cls, hipStream_t st, const bf16_t* A, int 
 
 // Conv2dSubsampling (modules.py:232-249) + transpose + Linear (encoders.py:113-116): mel (B, n_mels, Tm) -> x fp32 (B * T1, D0).
 // sub / act1: bf16 scratch of the unfused variants (the subsampler's output rows / the two-layer subsampler's layer-1 image).
+// sublinear3.hip: option fuse_subsample = 3 (every one-layer front end it is built for) or 2 = the default where sublinear2.hip has no instance or runs one workgroup per
+// CU (channel counts / widths above 128); a debug trace keeps the kernels that write the "subsample" activation only when fuse_subsample = 0
+bool use_sublinear3(const EcEncoder* e) {
+    if (!e->sub3_wimg || e->cfg.sub_layers != 1) return false;
+    if (e->fuse_subsample == 3) return true;
+    return e->fuse_subsample == 2 && e->sub3_auto && (e->cfg.sub_filters[0] > 128 || e->blocks[0].dim_model > 128);
+}
+
 int run_subsample_linear(EcEncoder* e, hipStream_t st, const float* mel, int B, int Tm, int T1, bf16_t* sub, bf16_t* act1, float* x) {
     const EcConfig& c = e->cfg;
     const int C0 = c.sub_filters[0], F2 = c.n_mels / 2, Ksub = C0 * F2;
@@ -608,7 +618,14 @@ int run_subsample_linear(EcEncoder* e, hipStream_t st, const float* mel, int B, 
           EC_TRY(launch_conv2_igemm(act1, B, F1, Tl1, e->sub2_cp, e->sub2_w, 9 * e->sub2_cp, e->sub2_b, C1, F2q, T1, sub, st)); }
         trace_add(e, st, "subsample", sub, (int64_t)B * T1, F2q * C1, F2q * C1, 1);
         EC_TRY(run_gemm(e, PC_GEMM_OTHER, st, sub, F2q * C1, B * T1, e->lin, EPI_F32, x, e->lin.N));
-    } else if (e->fuse_subsample == 2 && e->lin_rs) {
+    } else if (use_sublinear3(e)) {
+        PROF(PC_SUBCONV, 2.0 * 9 * B * T1 * (double)Ksub + 2.0 * B * T1 * (double)Ksub * e->lin.N,
+             (double)B * c.n_mels * Tm * 4 + (double)B * T1 * e->lin.N * 4);
+        SubLin3Params sp{};
+        sp.mel = mel; sp.B = B; sp.F = c.n_mels; sp.Tm = Tm; sp.To = T1; sp.rows_max = T1;
+        sp.cimg = e->sub3_cimg; sp.wimg = e->sub3_wimg; sp.bias = e->sub3_bias; sp.y = x; sp.ldy = e->lin.N; sp.N = e->lin.N; sp.ncb = e->sub3_ncb; sp.Fo = e->sub3_fo;
+        EC_TRY(launch_sublinear3(sp, st));
+    } else if (e->fuse_subsample >= 2 && e->lin_rs) {
         PROF(PC_SUBCONV, 2.0 * 9 * B * T1 * (double)Ksub + 2.0 * B * T1 * (double)Ksub * e->lin.N,
              (double)B * c.n_mels * Tm * 4 + (double)B * T1 * e->lin.N * 4);
         EC_TRY(launch_sublinear2(mel, B, c.n_mels, Tm, T1, e->conv_tab, e->lin_rs, e->lin.bias, C0, e->lin.N, x, e->lin.N, st));
@@ -675,7 +692,14 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
               EC_TRY(launch_conv2_igemm(act1, B, F1, Tl1, e->sub2_cp, e->sub2_w, 9 * e->sub2_cp, e->sub2_b, C1, F2q, T1r, sub, st)); }
             EC_TRY(run_gemm(e, PC_GEMM_OTHER, st, sub, F2q * C1, B * T1r, e->lin, EPI_F32, xrect, e->lin.N));
             { PROF(PC_MISC, 0, (double)s.Min[0] * e->lin.N * 8); EC_TRY(launch_gather_rows(xrect, e->lin.N, T1r, r0, x, st)); }
-        } else if (e->fuse_subsample == 2 && e->lin_rs) {        // sublinear2.hip indexes the ragged rows itself
+        } else if (use_sublinear3(e)) {                            // sublinear3.hip: workgroup = (utterance, 128 frames)
+            PROF(PC_SUBCONV, 2.0 * 9 * (double)s.Min[0] * Ksub + 2.0 * (double)s.Min[0] * Ksub * e->lin.N, (double)B * c.n_mels * s.Tm * 4 + (double)s.Min[0] * e->lin.N * 4);
+            SubLin3Params sp{};
+            sp.mel = mel; sp.B = B; sp.F = c.n_mels; sp.Tm = s.Tm; sp.mel_len = mel_len; sp.off = r0.off; sp.len = r0.len;
+            sp.rows_max = ec_round_up(s.Tin[0], e->blocks[0].group_size);
+            sp.cimg = e->sub3_cimg; sp.wimg = e->sub3_wimg; sp.bias = e->sub3_bias; sp.y = x; sp.ldy = e->lin.N; sp.N = e->lin.N; sp.ncb = e->sub3_ncb; sp.Fo = e->sub3_fo;
+            EC_TRY(launch_sublinear3(sp, st));
+        } else if (e->fuse_subsample >= 2 && e->lin_rs) {        // sublinear2.hip indexes the ragged rows itself
             PROF(PC_SUBCONV, 2.0 * 9 * (double)s.Min[0] * Ksub + 2.0 * (double)s.Min[0] * Ksub * e->lin.N, (double)B * c.n_mels * s.Tm * 4 + (double)s.Min[0] * e->lin.N * 4);
             EC_ABL(32, EC_TRY(launch_sublinear2(mel, B, c.n_mels, s.Tm, s.T1, e->conv_tab, e->lin_rs, e->lin.bias, C0, e->lin.N, x, e->lin.N, st, &r0, mel_len)));
         } else {
@@ -1523,6 +1547,38 @@ int effconf_encoder_finalize(EcEncoder* e) {
                     tab[(size_t)ch * 16 + 9] = bb[ch];
                 }
                 e->lin_rs = upload(e, wr); e->conv_tab = upload(e, tab);
+            }
+            // sublinear3.hip: chunks of (output frequency, 32 channels), any channel count / width up to 384: conv taps as bf16 hi (truncation) + lo, the
+            // Linear's weight [chunk][32 nt rows][32 k] with the k order of the accumulator layout
+            e->sub3_cimg = e->sub3_wimg = nullptr; e->sub3_bias = nullptr;
+            const int nt3 = sublinear3_tiles(N);
+            const HostTensor *lw3 = find(e, "linear.weight"), *lb3 = find(e, "linear.bias");
+            if (nt3 && lw3 && lb3 && (int64_t)lw3->data.size() == (int64_t)N * C * F2 && (int)lb3->data.size() == N) {
+                const int ncb = (C + 31) / 32, DP2 = 32 * nt3;
+                std::vector<uint16_t> cimg((size_t)ncb * 2 * 32 * 16, 0), wimg((size_t)F2 * ncb * DP2 * 32, 0);
+                auto put_tap = [&](int ch, int tap, float v) {
+                    uint32_t u; memcpy(&u, &v, 4);
+                    const uint32_t hb = u & 0xFFFF0000u; float hf; memcpy(&hf, &hb, 4);
+                    const size_t base = (size_t)(ch / 32) * 2 * 32 * 16 + (size_t)(ch % 32) * 16 + tap;
+                    cimg[base] = (uint16_t)(hb >> 16); cimg[base + 32 * 16] = h_f2bf(v - hf);
+                };
+                for (int ch = 0; ch < C; ++ch) {
+                    for (int j = 0; j < 9; ++j) put_tap(ch, j, w9[ch * 9 + j]);
+                    put_tap(ch, 9, bb[ch]);
+                }
+                for (int f = 0; f < F2; ++f)
+                    for (int cb = 0; cb < ncb; ++cb) {
+                        const size_t base = (size_t)(f * ncb + cb) * DP2 * 32;
+                        for (int n = 0; n < N; ++n)
+                            for (int pos = 0; pos < 32; ++pos) {
+                                const int sstep = pos >> 4, khh = (pos >> 3) & 1, ee = pos & 7;
+                                const int ch = 32 * cb + 16 * sstep + 8 * (ee >> 2) + 4 * khh + (ee & 3);      // accumulator register 8 s + e of lane half kh holds this channel
+                                if (ch < C) wimg[base + (size_t)n * 32 + pos] = h_f2bf(lw3->data[(size_t)n * (C * F2) + (size_t)ch * F2 + f]);
+                            }
+                    }
+                std::vector<float> bp(DP2, 0.f);
+                for (int n = 0; n < N; ++n) bp[n] = lb3->data[n];
+                e->sub3_cimg = upload(e, cimg); e->sub3_wimg = upload(e, wimg); e->sub3_bias = upload(e, bp); e->sub3_ncb = ncb; e->sub3_fo = F2;
             }
         }
     }
@@ -2407,7 +2463,7 @@ int effconf_encoder_set_attention_outputs(EcEncoder* e, float* const* maps, int3
 
 int effconf_encoder_set_option(EcEncoder* e, const char* name, int32_t value) {
     if (!e || !name) return fail("null argument");
-    if (!strcmp(name, "fuse_subsample")) { if (value < 0 || value > 2) return fail("fuse_subsample: 0, 1 or 2"); e->fuse_subsample = value; return 0; }
+    if (!strcmp(name, "fuse_subsample")) { if (value < 0 || value > 3) return fail("fuse_subsample: 0, 1, 2 or 3"); e->fuse_subsample = value; return 0; }
     if (!strcmp(name, "fuse_chain")) { e->fuse_chain = value != 0; return 0; }
     if (!strcmp(name, "ctc_mfma")) { if (value < 0 || value > 2) return fail("ctc_mfma: 0 (VALU), 1 (fp32 MFMA) or 2 (split-bf16 MFMA)"); e->ctc_mfma = value; return 0; }
     if (!strcmp(name, "wide_gemm")) { if (value < 0 || (value > 3 && value < 16)) return fail("wide_gemm: 0 (by shape), 1 (never), 2 (256-column tile), 3 (128-column tile), >= 16 (by shape with this many 256 x 256 tiles as the threshold)"); e->wide_gemm = value; return 0; }
@@ -2430,6 +2486,7 @@ int effconf_encoder_set_option(EcEncoder* e, const char* name, int32_t value) {
     if (!strcmp(name, "head_major_odd")) { e->head_major_odd = value != 0; return 0; }
     if (!strcmp(name, "split_ffn")) { e->split_ffn = value != 0; return 0; }
     if (!strcmp(name, "split_sublin")) { e->split_sublin = value != 0; return 0; }
+    if (!strcmp(name, "sub3_auto")) { e->sub3_auto = value != 0; return 0; }
     if (!strcmp(name, "split_chain")) { e->split_chain = value != 0; return 0; }
     if (!strcmp(name, "exact_attention")) { if (value < 0 || value > 2) return fail("exact_attention: 0 (tiled), 2 (tiled, 16-row workgroups) or 1 (one wave per query row)"); e->exact_attention = value; return 0; }
     if (!strcmp(name, "cache_pos_embeddings")) { e->e_cache_on = value != 0; e->e_cache.clear(); return 0; }

@@ -281,6 +281,23 @@ struct SxfFfnParams {
     int ablate;                    // timing-only ablations (tools/sxf_ffn_probe.py through the diagnostic library; 0 in the product): 1 no first product, 2 no Swish,
                                    // 4 no second product, 8 no weight stream after the first chunk, 16 no per-chunk barrier
 };
+// Conv2dSubsampling (one layer) + transpose / flatten + Linear as one bf16 kernel, chunked over (output frequency, 32 channels) (sublinear3.hip)
+struct SubLin3Params {
+    const float* mel; int B, F, Tm;   // (B, F, Tm) fp32 mel image, Tm = row pitch
+    const int* mel_len;               // dev [B]: the utterance's own mel frames (ragged batches), or null: Tm
+    const int* off;                   // dev [B + 1]: first output row of every utterance (ragged: group padded), or null: b To
+    const int* len;                   // dev [B]: output frames that exist, or null: To
+    int To;                           // output frames per utterance of a rectangular batch
+    int rows_max;                     // grid: rows of the longest utterance (ragged: incl. its group padding; rectangular: To)
+    const uint16_t* cimg;             // conv taps [ncb][hi | lo][32 channels][16 taps] bf16 (hi by truncation, lo = bf16(w - hi)): tap 3 i + j = folded weight, tap 9 = folded bias
+    const uint16_t* wimg;             // Linear image [Fo ncb chunks][DP2 outputs][32 k] bf16: chunk f' ncb + cb, k position 16 s + 8 kh + e <-> channel
+                                      // 32 cb + 16 s + 8 (e >> 2) + 4 kh + (e & 3) (the accumulator layout), weight column channel Fo + f' (encoders.py:114)
+    const float* bias;                // [DP2] Linear bias, zero padded
+    float* y; int ldy, N;             // out [rows][ldy], N columns
+    int ncb, Fo;                      // channel blocks of 32, output frequencies
+};
+int sublinear3_tiles(int N);          // 32-column output tiles of the instance that serves width N (DP2 = 32 x this); 0 = not built
+int launch_sublinear3(const SubLin3Params& p, hipStream_t s);
 // Conv2dSubsampling (one layer) + transpose / flatten + Linear as one split-precision kernel (sxf_sub.hip)
 struct SxfSubParams {
     const float* mel; int B, F, Tm;   // (B, F, Tm) fp32 mel image, Tm = row pitch

@@ -41,7 +41,7 @@ def _rel(got, ref):
     return mx / scale, mean / scale
 
 
-@pytest.mark.parametrize("fuse,chain", [(2, 1), (1, 1), (0, 0), (1, 0), (2, 0)])
+@pytest.mark.parametrize("fuse,chain", [(2, 1), (1, 1), (0, 0), (1, 0), (2, 0), (3, 1), (3, 0)])      # 3: sublinear3.hip (round 6)
 @pytest.mark.parametrize("tm,lens", [(47, [47, 40, 23]), (100, [100, 77, 52])])
 def test_tiny_every_stage_vs_oracle(tm, lens, fuse, chain):
     m, sd = _model("Tiny", 7)

@@ -347,3 +347,39 @@ def test_split_front_end_kernel_vs_conv_gemm_kernels_and_the_oracle(name, tm, le
         e = (out.cpu() - ref).abs()
         print("%s rectangular vs oracle: max %.2e mean %.2e" % (name, float(e.max()), float(e.mean())))
         assert float(e.max()) < SPLIT_MAX and float(e.mean()) < SPLIT_MEAN
+
+
+# ------------------------------------------------------------------ bf16 front end chunked over (output frequency, 32 channels) (csrc/sublinear3.hip)
+@pytest.mark.parametrize("name,fuse,tm,lens", [("EfficientConformerCTCSmall", 3, 700, [700, 433, 258, 57]), ("EfficientConformerCTCMedium", 2, 420, [420, 333, 9]),
+                                               ("EfficientConformerCTCLarge", 2, 300, [300, 121]), ("EfficientConformerTransducerSmall", 3, 300, [300, 222, 9])])
+def test_chunked_bf16_front_end_vs_oracle_linear_stage_and_ragged_equals_alone(name, fuse, tm, lens):
+    """sublinear3.hip (Conv2d 3 x 3 stride 2 + BatchNorm + Swish + flatten + Linear as one bf16 kernel, any channel count: the default for front ends wider than 128
+    channels / columns - Medium's 180, Large's 360 - and option fuse_subsample = 3 elsewhere; modules.py:232-249, encoders.py:113-116): (i) its output - the traced
+    "linear" stage of a rectangular batch - against the oracle's at the Tiny test's relative bounds (0.02 max / 0.003 mean of the tensor's magnitude; the conv in split
+    bf16, the Swish-ed activation rounded to bf16 once, fp32 accumulation), pad frames live; (ii) encoder output within the bf16 path's stated tolerance; (iii) a
+    ragged batch bit-identical to every utterance alone (the convolution's zero padding starts behind the utterance's own last mel frame; tiles and group-padding
+    rows behind a short utterance's end; 700 frames -> 3 row tiles)."""
+    m, sd = _model(name, 17)
+    enc, plan = m.encoder, m.encoder.plan
+    enc.set_option("fuse_subsample", fuse)
+    mel, ln = synth.make_mel(len(lens), 80, tm, lens, seed=31 + tm)
+    mel_d, ln_d = torch.from_numpy(mel).cuda(), torch.from_numpy(ln).cuda()
+    trace = {}
+    with torch.no_grad():
+        ref, ref_len = R.encoder_from_mel(torch.from_numpy(mel), torch.from_numpy(ln), sd, plan, trace)
+    out, out_len, got = enc.trace_forward_mel(mel_d, ln_d)
+    assert "subsample" not in got, "the fused front end is expected on this path (the activation only exists in registers)"
+    assert out_len.cpu().tolist() == ref_len.tolist()
+    mx, mean = _rel(got["linear"], trace["linear"].reshape(-1, trace["linear"].shape[-1]))
+    print("%s linear stage vs oracle: max %.4f mean %.5f (relative)" % (name, mx, mean))
+    assert mx < 0.02 and mean < 0.003
+    e = (out.cpu() - ref).abs()
+    assert float(e.max()) < 0.06 and float(e.mean()) < 0.010
+    enc.ragged = True
+    rag, rag_len, _ = enc.forward_mel(mel_d, ln_d, x_len_host=ln)
+    enc.ragged = False
+    for b, l in enumerate(lens):
+        alone, alone_len, _ = enc.forward_mel(mel_d[b:b + 1, :, :l].contiguous(), ln_d[b:b + 1].contiguous())
+        tb = int(alone_len[0])
+        assert int(rag_len[b]) == tb and torch.equal(rag[b, :tb], alone[0, :tb]), (b, float((rag[b, :tb] - alone[0, :tb]).abs().max()))
+        assert not bool(rag[b, tb:].any())
