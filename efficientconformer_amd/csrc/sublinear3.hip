@@ -27,20 +27,18 @@ __device__ __forceinline__ uint32_t hi_bits(float x) { return __float_as_uint(x)
 // common.h swishf_): four values at a time, stage-major inside the four; value r = register r of the accumulators <-> k position 8 kh + (r & 7) of k-step r >> 3.
 // Every step ends in an empty volatile asm on its result (sxf_chain.hip: pure arithmetic otherwise sinks behind the last MFMA whatever fences stand in the source).
 struct SwishState { float x[16], w[16]; uint32_t hh[8]; };
-constexpr int SWISH_STEPS = 16 * 7 + 8;
+constexpr int SWISH_STEPS = 16 * 5 + 8;
 #define SUB3_PIN(v) asm volatile("" : "+v"(v))
-__device__ __forceinline__ void swish_step(int idx, const f32x16& h1, const f32x16& h2, const f32x16& h3, SwishState& q) {
-    const int g = idx / 30, o = idx - 30 * g;
-    if (o >= 28) { const int pr = 2 * g + (o - 28); q.hh[pr] = pack_bf2(q.x[2 * pr], q.x[2 * pr + 1]); SUB3_PIN(q.hh[pr]); return; }
+__device__ __forceinline__ void swish_step(int idx, const f32x16& h, SwishState& q) {
+    const int g = idx / 22, o = idx - 22 * g;
+    if (o >= 20) { const int pr = 2 * g + (o - 20); q.hh[pr] = pack_bf2(q.x[2 * pr], q.x[2 * pr + 1]); SUB3_PIN(q.hh[pr]); return; }
     const int stage = o >> 2, r = 4 * g + (o & 3);
     switch (stage) {
-        case 0: q.x[r] = h1[r] + h2[r]; SUB3_PIN(q.x[r]); break;
-        case 1: q.x[r] = q.x[r] + h3[r]; SUB3_PIN(q.x[r]); break;
-        case 2: q.w[r] = q.x[r] * -1.44269504088896f; SUB3_PIN(q.w[r]); break;
-        case 3: q.w[r] = __builtin_amdgcn_exp2f(q.w[r]); SUB3_PIN(q.w[r]); break;
-        case 4: q.w[r] = 1.0f + q.w[r]; SUB3_PIN(q.w[r]); break;
-        case 5: q.w[r] = __builtin_amdgcn_rcpf(q.w[r]); SUB3_PIN(q.w[r]); break;
-        default: q.x[r] = q.x[r] * q.w[r]; SUB3_PIN(q.x[r]); break;
+        case 0: q.w[r] = h[r] * -1.44269504088896f; SUB3_PIN(q.w[r]); break;
+        case 1: q.w[r] = __builtin_amdgcn_exp2f(q.w[r]); SUB3_PIN(q.w[r]); break;
+        case 2: q.w[r] = 1.0f + q.w[r]; SUB3_PIN(q.w[r]); break;
+        case 3: q.w[r] = __builtin_amdgcn_rcpf(q.w[r]); SUB3_PIN(q.w[r]); break;
+        default: q.x[r] = h[r] * q.w[r]; SUB3_PIN(q.x[r]); break;
     }
 }
 __device__ __forceinline__ void swish_pack(const SwishState& q, bf16x8 (&nb)[2]) {
@@ -131,16 +129,17 @@ __global__ __launch_bounds__(256, (NT2 <= 6 ? 2 : 1)) void sublinear3_kernel(con
         }
         ah = as_bf16x8(make_uint4(hh[0], hh[1], hh[2], hh[3])); al = as_bf16x8(make_uint4(ll[0], ll[1], ll[2], ll[3]));
     };
-    // H^T = Wc_cb P^T (32 channels x 32 frames): one 16-wide k-step, three accumulators (an MFMA on the previous one's result waits for it)
-    auto first_product = [&](int cb, const bf16x8& ah, const bf16x8& al, f32x16& h1, f32x16& h2, f32x16& h3) __attribute__((always_inline)) {
+    // H^T = Wc_cb P^T (32 channels x 32 frames): one 16-wide k-step, the three operand-half products on ONE accumulator (three accumulators - no wait between the
+    // MFMAs - cost 48 v_accvgpr_write zeros, 48 v_accvgpr_read and 32 adds per chunk: 40 % of the loop's VALU instructions, profiles/r6_94_*)
+    auto first_product = [&](int cb, const bf16x8& ah, const bf16x8& al, f32x16& h) __attribute__((always_inline)) {
         const char* cw = sCW + cb * L::CW + lr * 32 + 16 * kh;
         const bf16x8 wh = *reinterpret_cast<const bf16x8*>(cw), wl = *reinterpret_cast<const bf16x8*>(cw + 32 * 32);
         f32x16 z0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) z0[r] = 0.f;
-        h1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, ah, z0, 0, 0, 0);
-        h2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, al, z0, 0, 0, 0);
-        h3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, ah, z0, 0, 0, 0);
+        h = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, ah, z0, 0, 0, 0);
+        h = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, al, h, 0, 0, 0);
+        h = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, ah, h, 0, 0, 0);
     };
     constexpr int GS = NT2 < 4 ? NT2 : 4, NG = (NT2 + GS - 1) / GS, NU = 2 * NG, NM = 2 * NT2, Q = (SWISH_STEPS + NM - 1) / NM, LASTG = NT2 - (NG - 1) * GS;
     static_assert(NM * Q >= SWISH_STEPS, "every Swish step has its MFMA");
@@ -150,8 +149,8 @@ __global__ __launch_bounds__(256, (NT2 <= 6 ? 2 : 1)) void sublinear3_kernel(con
         if (c + 1 < nchunk) publish(sm + ((c + 1) & 1) * L::STAGE);      // stage (c + 1) & 1 was read in iteration c - 1: every wave is past the barrier that closed it
         fetch(c + 2);
         __builtin_amdgcn_sched_barrier(0);
-        f32x16 h1, h2, h3;
-        first_product(cb1, ah, al, h1, h2, h3);
+        f32x16 h;
+        first_product(cb1, ah, al, h);
         const char* w2 = sm + (c & 1) * L::STAGE + lr * ROW2 + 16 * kh;
         bf16x8 vw[NU][GS];
         auto load_unit = [&](int u) __attribute__((always_inline)) {
@@ -177,7 +176,7 @@ __global__ __launch_bounds__(256, (NT2 <= 6 ? 2 : 1)) void sublinear3_kernel(con
                     oacc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vw[u][i], hb[s2], oacc[tt], 0, 0, 0);
                     const int m0 = (base + i) * Q;
 #pragma unroll
-                    for (int j = 0; j < Q; ++j) if (m0 + j < SWISH_STEPS) swish_step(m0 + j, h1, h2, h3, q);
+                    for (int j = 0; j < Q; ++j) if (m0 + j < SWISH_STEPS) swish_step(m0 + j, h, q);
                 }
             }
         }
@@ -192,11 +191,11 @@ __global__ __launch_bounds__(256, (NT2 <= 6 ? 2 : 1)) void sublinear3_kernel(con
     {   // chunk 0: first product + Swish alone
         load_row(2, nx[0]); load_row(3, nx[1]);
         patch_frags(ah, al);
-        f32x16 h1, h2, h3;
-        first_product(0, ah, al, h1, h2, h3);
+        f32x16 h;
+        first_product(0, ah, al, h);
         SwishState q;
 #pragma unroll
-        for (int j = 0; j < SWISH_STEPS; ++j) swish_step(j, h1, h2, h3, q);
+        for (int j = 0; j < SWISH_STEPS; ++j) swish_step(j, h, q);
         swish_pack(q, hb);
     }
     int c = 0;

@@ -31,16 +31,14 @@ constexpr int ROW2 = 80;                                         // bytes per Li
 // value r = register r of the accumulators <-> k position 8 kh + (r & 7) of k-step r >> 3.  Every step ends in an empty volatile asm on its result: the steps are
 // pure arithmetic, which instruction selection otherwise sinks behind the last MFMA whatever fences stand in the source.
 struct SwishState { float x[16], y[16], w[16]; uint32_t hh[8], ll[8]; };
-constexpr int SWISH_STEPS = 16 * 13 + 8;
+constexpr int SWISH_STEPS = 16 * 11 + 8;
 #define SUB_PIN(v) asm volatile("" : "+v"(v))
-__device__ __forceinline__ void swish_step(int idx, const f32x16& h1, const f32x16& h2, const f32x16& h3, SwishState& q) {
-    const int g = idx / 54, o = idx - 54 * g;
-    if (o >= 52) { const int pr = 2 * g + (o - 52); split2s(q.x[2 * pr], q.x[2 * pr + 1], q.hh[pr], q.ll[pr]); SUB_PIN(q.hh[pr]); SUB_PIN(q.ll[pr]); return; }
-    const int stage = o >> 2, r = 4 * g + (o & 3);
+__device__ __forceinline__ void swish_step(int idx, const f32x16& h, SwishState& q) {
+    const int g = idx / 46, o = idx - 46 * g;
+    if (o >= 44) { const int pr = 2 * g + (o - 44); split2s(q.x[2 * pr], q.x[2 * pr + 1], q.hh[pr], q.ll[pr]); SUB_PIN(q.hh[pr]); SUB_PIN(q.ll[pr]); return; }
+    const int stage = (o >> 2) + 2, r = 4 * g + (o & 3);
     switch (stage) {
-        case 0: q.x[r] = h1[r] + h2[r]; SUB_PIN(q.x[r]); break;
-        case 1: q.x[r] = q.x[r] + h3[r]; SUB_PIN(q.x[r]); break;
-        case 2: q.x[r] = q.x[r] * UNS1; SUB_PIN(q.x[r]); break;
+        case 2: q.x[r] = h[r] * UNS1; SUB_PIN(q.x[r]); break;
         case 3: q.y[r] = fminf(-q.x[r], 87.0f); SUB_PIN(q.y[r]); break;
         case 4: q.w[r] = q.y[r] * 1.44269502162933349609375f; SUB_PIN(q.w[r]); break;
         case 5: q.y[r] = fmaf(q.y[r], 1.44269502162933349609375f, -q.w[r]); SUB_PIN(q.y[r]); break;
@@ -141,16 +139,17 @@ __global__ __launch_bounds__(256, (NT2 <= 4 ? 2 : 1)) void sxf_sublin_kernel(con
         for (int e = 0; e < 4; ++e) split2s(v[2 * e] * SP, v[2 * e + 1] * SP, hh[e], ll[e]);
         ah = as_f16x8(make_uint4(hh[0], hh[1], hh[2], hh[3])); al = as_f16x8(make_uint4(ll[0], ll[1], ll[2], ll[3]));
     };
-    // H^T = Wc_cb P^T (32 channels x 32 frames): one 16-wide k-step, three accumulators (an MFMA on the previous one's result waits for it)
-    auto first_product = [&](int cb, const f16x8& ah, const f16x8& al, f32x16& h1, f32x16& h2, f32x16& h3) __attribute__((always_inline)) {
+    // H^T = Wc_cb P^T (32 channels x 32 frames): one 16-wide k-step, the three operand-half products on ONE accumulator at the scale SP SW (three accumulators - no
+    // wait between the MFMAs - cost 48 v_accvgpr_write zeros, 48 v_accvgpr_read and 32 adds per chunk, profiles/r6_94_*)
+    auto first_product = [&](int cb, const f16x8& ah, const f16x8& al, f32x16& h) __attribute__((always_inline)) {
         const char* cw = sCW + cb * L::CW + lr * 32 + 16 * kh;
         const f16x8 wh = *reinterpret_cast<const f16x8*>(cw), wl = *reinterpret_cast<const f16x8*>(cw + 32 * 32);
         f32x16 z0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) z0[r] = 0.f;
-        h1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, ah, z0, 0, 0, 0);
-        h2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, al, z0, 0, 0, 0);
-        h3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, ah, z0, 0, 0, 0);
+        h = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, ah, z0, 0, 0, 0);
+        h = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, al, h, 0, 0, 0);
+        h = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, ah, h, 0, 0, 0);
     };
     constexpr int GS = NT2 < 4 ? NT2 : 4, NG = (NT2 + GS - 1) / GS, NU = 2 * NG, NM = 6 * NT2, Q = (SWISH_STEPS + NM - 1) / NM, LASTG = NT2 - (NG - 1) * GS;
     static_assert(NM * Q >= SWISH_STEPS, "every Swish step has its MFMA");
@@ -161,8 +160,8 @@ __global__ __launch_bounds__(256, (NT2 <= 4 ? 2 : 1)) void sxf_sublin_kernel(con
         if (c + 1 < nchunk) publish(sm + ((c + 1) & 1) * L::STAGE);      // stage (c + 1) & 1 was read in iteration c - 1: every wave is past the barrier that closed it
         fetch(c + 2);
         __builtin_amdgcn_sched_barrier(0);
-        f32x16 h1, h2, h3;
-        first_product(cb1, ah, al, h1, h2, h3);
+        f32x16 h;
+        first_product(cb1, ah, al, h);
         const char* w2 = sm + (c & 1) * L::STAGE + lr * ROW2 + 16 * kh;
         f16x8 vh[NU][GS], vl[NU][GS];
         auto load_unit = [&](int u) __attribute__((always_inline)) {
@@ -190,7 +189,7 @@ __global__ __launch_bounds__(256, (NT2 <= 4 ? 2 : 1)) void sxf_sublin_kernel(con
                         oacc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kind == 2 ? vl[u][i] : vh[u][i], kind == 1 ? hbl[s2] : hbh[s2], oacc[tt], 0, 0, 0);
                         const int m0 = (base + kind * gsz + i) * Q;
 #pragma unroll
-                        for (int j = 0; j < Q; ++j) if (m0 + j < SWISH_STEPS) swish_step(m0 + j, h1, h2, h3, q);
+                        for (int j = 0; j < Q; ++j) if (m0 + j < SWISH_STEPS) swish_step(m0 + j, h, q);
                     }
                 }
         }
@@ -205,11 +204,11 @@ __global__ __launch_bounds__(256, (NT2 <= 4 ? 2 : 1)) void sxf_sublin_kernel(con
     {   // chunk 0: first product + Swish alone
         load_row(2, nx[0]); load_row(3, nx[1]);
         patch_frags(ah, al);
-        f32x16 h1, h2, h3;
-        first_product(0, ah, al, h1, h2, h3);
+        f32x16 h;
+        first_product(0, ah, al, h);
         SwishState q;
 #pragma unroll
-        for (int j = 0; j < SWISH_STEPS; ++j) swish_step(j, h1, h2, h3, q);
+        for (int j = 0; j < SWISH_STEPS; ++j) swish_step(j, h, q);
         swish_pack(q, hbh, hbl);
     }
     int c = 0;
