@@ -224,7 +224,9 @@ int effconf_rnnt_greedy(EcRnnt* r, const float* enc_out, const int64_t* out_len,
  * workspace is freed and its address may be reused.  Host calls on one handle must not run concurrently (they only enqueue).
  * "fuse_subsample" (default 2): conv-subsampling + Linear as 0 = separate conv and GEMM kernels, 1 = sublinear.hip (tiled GEMM whose A tile is
  *   produced by a VALU convolution), 2 = sublinear2.hip (row-stationary, the convolution on the MFMA pipe with a bf16 hi / lo operand
- *   split; falls back to 1 where the shape is not supported).
+ *   split; falls back to 1 where the shape is not supported; front ends wider than 128 channels / columns - EfficientConformer Medium, Large - run
+ *   sublinear3.hip instead: option "sub3_auto", default 1), 3 = sublinear3.hip (round 6: the same fusion in chunks of (output frequency, 32 channels), any
+ *   channel count / width up to 384; bit-identical to sublinear2.hip where both exist, slower there).
  * "fuse_chain" (default 1): 0 runs every GEMM of a block as its own kernel instead of the fused row-local chains (chain.hip);
  *   with the debug trace this exposes the intermediate residual-stream states that otherwise only exist in registers.
  * "attention_v2" (default 1): 0 = attention.hip; 1 = attention2.hip (same tiling; V read through ds_read_b64_tr_b16 instead of being
