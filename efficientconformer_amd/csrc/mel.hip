@@ -82,17 +82,20 @@ __device__ __forceinline__ float2 reread(const float2* p) {           // a secon
     return make_float2(q[0], q[1]);
 }
 
-template <int V>
+// MM = rows of the output staging tile (80 for the shipped n_mels = 80: with the exchange buffers at their own pitches and the twiddle table at 256 entries the
+// workgroup's LDS image is 53.6 KB - THREE workgroups per CU instead of two at 63 KB; the kernel is a dependent chain per wave, so occupancy is its speed)
+template <int V, int MM>
 __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ audio, int L, MelTables tb, int hop,
                                                   int n_mels, int Tm, int normalize, float mean, float inv_std,
                                                   float* __restrict__ mel, unsigned int* __restrict__ dbg,
                                                   const int64_t* __restrict__ rag_len = nullptr) {
     constexpr int CAN = (V & 1) ? 512 : 0;                       // canary words on each side of the exchange buffers
-    constexpr int O_SBUF = CAN * 4, O_POST = O_SBUF + 4 * 2 * 8 * P1 * 8, O_STW = O_POST + CAN * 4, O_SWIN = O_STW + NFFT * 8,
-                  O_SOUT = O_SWIN + NFFT * 4, O_SFW = O_SOUT + MAX_MELS * (FRAMES_PER_BLOCK + 1) * 4, O_END = O_SFW + MAX_FBW * 4;
+    constexpr int WBUF = 8 * (P1 + P2) * 8;                      // bytes of one wave's exchange buffers: A [8][P1] | B [8][P2] float2
+    constexpr int O_SBUF = CAN * 4, O_POST = O_SBUF + 4 * WBUF, O_STW = O_POST + CAN * 4, O_SWIN = O_STW + (NFFT / 2) * 8,
+                  O_SOUT = O_SWIN + NFFT * 4, O_SFW = O_SOUT + MM * (FRAMES_PER_BLOCK + 1) * 4, O_END = O_SFW + MAX_FBW * 4;
+    static_assert(8 * P1 >= NFFT && 8 * P2 * 2 >= 264 + NFFT / 2 + 1, "A holds Z[512], B the two power spectra");
     __shared__ __attribute__((aligned(16))) char lds[O_END];
-    float2 (*sbuf)[2][8 * P1] = reinterpret_cast<float2 (*)[2][8 * P1]>(lds + O_SBUF);   // per wave: exchange buffers A (step 1, Z) and B (step 2, power)
-    float2* stw = reinterpret_cast<float2*>(lds + O_STW);        // W512^m
+    float2* stw = reinterpret_cast<float2*>(lds + O_STW);        // W512^m, m < 256 (W^(m + 256) = -W^m: the sign goes on by one XOR per component)
     float* swin = reinterpret_cast<float*>(lds + O_SWIN);
     float (*sout)[FRAMES_PER_BLOCK + 1] = reinterpret_cast<float (*)[FRAMES_PER_BLOCK + 1]>(lds + O_SOUT);
     float* sfw = reinterpret_cast<float*>(lds + O_SFW);          // packed triangular weights (a global load per tap made the
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ audi
         float f[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) { const int i = tid + 256 * j; f[j] = tb.fb_weight[i < tb.fb_nnz ? i : (tb.fb_nnz > 0 ? tb.fb_nnz - 1 : 0)]; }
-        stw[tid] = w; stw[tid + 256] = make_float2(-w.x, -w.y);
+        stw[tid] = w;
         swin[tid] = wn0; swin[tid + 256] = wn1;
         if (fw_lds) {
 #pragma unroll
@@ -136,8 +139,14 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ audi
         fs0[j] = tb.fb_start[mc]; fcnt[j] = m < n_mels ? tb.fb_count[mc] : 0; foff[j] = tb.fb_offset[mc];
     }
     __syncthreads();
-    float2* A = sbuf[wave][0];
-    float2* B = sbuf[wave][1];
+    float2* A = reinterpret_cast<float2*>(lds + O_SBUF + wave * WBUF);      // per wave: exchange buffers A (step 1, Z) and B (step 2, power)
+    float2* B = A + 8 * P1;
+    auto tw = [&](int m) __attribute__((always_inline)) {            // W512^m for m in [0, 512)
+        float2 w = stw[m & 255];
+        const uint32_t sg = (uint32_t)(m & 256) << 23;
+        w.x = __uint_as_float(__float_as_uint(w.x) ^ sg); w.y = __uint_as_float(__float_as_uint(w.y) ^ sg);
+        return w;
+    };
     const float* a = audio + (size_t)b * L;
 
     // gather of one frame pair (reflect at the ends of the padded waveform, torch.stft center=True): unconditional clamped loads
@@ -169,7 +178,7 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ audi
             const int n2 = lane >> 3;
             dft8(v);
 #pragma unroll
-            for (int k1 = 0; k1 < 8; ++k1) { v[k1] = cmul(v[k1], stw[(8 * n2 * k1) & 511]); A[k1 * P1 + lane] = v[k1]; }
+            for (int k1 = 0; k1 < 8; ++k1) { v[k1] = cmul(v[k1], tw((8 * n2 * k1) & 511)); A[k1 * P1 + lane] = v[k1]; }
         }
         hand_off();
         if constexpr ((V & 2) != 0) {
@@ -188,7 +197,7 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ audi
             }
             dft8(v);
 #pragma unroll
-            for (int k2 = 0; k2 < 8; ++k2) { v[k2] = cmul(v[k2], stw[(n3 * (k1 + 8 * k2)) & 511]); B[n3 * P2 + k1 + 8 * k2] = v[k2]; }
+            for (int k2 = 0; k2 < 8; ++k2) { v[k2] = cmul(v[k2], tw((n3 * (k1 + 8 * k2)) & 511)); B[n3 * P2 + k1 + 8 * k2] = v[k2]; }
         }
         hand_off();
         if constexpr ((V & 2) != 0) {
@@ -287,8 +296,12 @@ int launch_mel(const float* audio, int B, int L, const MelTables& t, int n_fft, 
     if (B <= 0) return 0;
     if (n_fft != NFFT || n_mels > MAX_MELS || L <= n_fft / 2) return -2;
     const int tiles = (Tm + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK;
-    hipLaunchKernelGGL(mel_kernel<0>, dim3(B * tiles), dim3(256), 0, s, audio, L, t, hop, n_mels, Tm, normalize, mean,
-                       1.0f / std, mel, (unsigned int*)nullptr, ragged_len);
+    if (n_mels <= 80)
+        hipLaunchKernelGGL((mel_kernel<0, 80>), dim3(B * tiles), dim3(256), 0, s, audio, L, t, hop, n_mels, Tm, normalize, mean,
+                           1.0f / std, mel, (unsigned int*)nullptr, ragged_len);
+    else
+        hipLaunchKernelGGL((mel_kernel<0, MAX_MELS>), dim3(B * tiles), dim3(256), 0, s, audio, L, t, hop, n_mels, Tm, normalize, mean,
+                           1.0f / std, mel, (unsigned int*)nullptr, ragged_len);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -302,8 +315,8 @@ int launch_mel_debug(int variant, int extra_lds, const float* audio, int B, int 
     if (variant & 8) return launch_mel_debug_pk(variant & 7, extra_lds, audio, B, L, t, n_fft, hop, n_mels, Tm, normalize, mean, std, mel, dbg, s);
 #endif
     const int tiles = (Tm + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK;
-#define MEL_DBG_CASE(VV) case VV: { static LdsAttr attr; ensure_dynamic_lds(reinterpret_cast<const void*>(&mel_kernel<VV>), extra_lds, attr); \
-        hipLaunchKernelGGL(mel_kernel<VV>, dim3(B * tiles), dim3(256), extra_lds, s, audio, L, t, hop, n_mels, Tm, normalize, mean, 1.0f / std, mel, dbg, (const int64_t*)nullptr); break; }
+#define MEL_DBG_CASE(VV) case VV: { static LdsAttr attr; ensure_dynamic_lds(reinterpret_cast<const void*>(&mel_kernel<VV, MAX_MELS>), extra_lds, attr); \
+        hipLaunchKernelGGL((mel_kernel<VV, MAX_MELS>), dim3(B * tiles), dim3(256), extra_lds, s, audio, L, t, hop, n_mels, Tm, normalize, mean, 1.0f / std, mel, dbg, (const int64_t*)nullptr); break; }
     switch (variant) {
         MEL_DBG_CASE(0) MEL_DBG_CASE(1) MEL_DBG_CASE(2) MEL_DBG_CASE(3) MEL_DBG_CASE(4) MEL_DBG_CASE(5) MEL_DBG_CASE(6) MEL_DBG_CASE(7)
         default: return -2;
