@@ -90,10 +90,10 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ audi
                                                   float* __restrict__ mel, unsigned int* __restrict__ dbg,
                                                   const int64_t* __restrict__ rag_len = nullptr) {
     constexpr int CAN = (V & 1) ? 512 : 0;                       // canary words on each side of the exchange buffers
-    constexpr int WBUF = 8 * (P1 + P2) * 8;                      // bytes of one wave's exchange buffers: A [8][P1] | B [8][P2] float2
+    constexpr int WBUF = 8 * P1 * 8;                             // bytes of one wave's exchange buffer: A [8][P1] float2 and B [8][P2] float2 are the SAME bytes (see below)
     constexpr int O_SBUF = CAN * 4, O_POST = O_SBUF + 4 * WBUF, O_STW = O_POST + CAN * 4, O_SWIN = O_STW + (NFFT / 2) * 8,
                   O_SOUT = O_SWIN + NFFT * 4, O_SFW = O_SOUT + MM * (FRAMES_PER_BLOCK + 1) * 4, O_END = O_SFW + MAX_FBW * 4;
-    static_assert(8 * P1 >= NFFT && 8 * P2 * 2 >= 264 + NFFT / 2 + 1, "A holds Z[512], B the two power spectra");
+    static_assert(8 * P1 >= NFFT && P1 >= P2 && 8 * P1 * 2 >= 264 + NFFT / 2 + 1, "one buffer holds Z[512], the step-2 layout and the two power spectra");
     __shared__ __attribute__((aligned(16))) char lds[O_END];
     float2* stw = reinterpret_cast<float2*>(lds + O_STW);        // W512^m, m < 256 (W^(m + 256) = -W^m: the sign goes on by one XOR per component)
     float* swin = reinterpret_cast<float*>(lds + O_SWIN);
@@ -140,7 +140,9 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ audi
     }
     __syncthreads();
     float2* A = reinterpret_cast<float2*>(lds + O_SBUF + wave * WBUF);      // per wave: exchange buffers A (step 1, Z) and B (step 2, power)
-    float2* B = A + 8 * P1;
+    // B aliases A: every phase reads its 8 values per lane into registers (all lanes, one instruction at a time) before it writes the next layout, and the LDS
+    // operations of one wave execute in order - with two buffers the workgroup's LDS image was 53.6 KB (three workgroups per CU), with one it is 36 KB (four)
+    float2* B = A;
     auto tw = [&](int m) __attribute__((always_inline)) {            // W512^m for m in [0, 512)
         float2 w = stw[m & 255];
         const uint32_t sg = (uint32_t)(m & 256) << 23;
@@ -224,15 +226,22 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ audi
         // ---- separate the two real spectra, power for bins 0..256 -> B (as floats: [0..256] frame a, [264..520] frame b)
         float* Pa = reinterpret_cast<float*>(B);
         float* Pb = Pa + 264;
+        float2 zz[5], zcc[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {                                // all reads of Z first: the power spectra overwrite it (B aliases A)
+            const int k = lane + 64 * j, kc = k <= NFFT / 2 ? k : NFFT / 2;
+            zz[j] = A[kc]; zcc[j] = A[(NFFT - kc) & (NFFT - 1)];
+            if constexpr ((V & 2) != 0) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                bad[6] += neq(reread(&A[kc]), zz[j]) + neq(reread(&A[(NFFT - kc) & (NFFT - 1)]), zcc[j]);
+            }
+        }
+        hand_off();
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
             const int k = lane + 64 * j;
             if (k <= NFFT / 2) {
-                const float2 z = A[k], zc = A[(NFFT - k) & (NFFT - 1)];
-                if constexpr ((V & 2) != 0) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    bad[6] += neq(reread(&A[k]), z) + neq(reread(&A[(NFFT - k) & (NFFT - 1)]), zc);
-                }
+                const float2 z = zz[j], zc = zcc[j];
                 const float ar = 0.5f * (z.x + zc.x), ai = 0.5f * (z.y - zc.y);     // X_a = (Z[k] + conj Z[N-k]) / 2
                 const float br = 0.5f * (z.y + zc.y), bi = 0.5f * (zc.x - z.x);     // X_b = (Z[k] - conj Z[N-k]) / 2i
                 Pa[k] = ar * ar + ai * ai;
