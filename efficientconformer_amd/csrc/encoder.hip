@@ -107,6 +107,9 @@ struct EcEncoder {
     int chain_pair = 5, chain_pair_min_m = 0;   // chain2.hip (column-pair chains at padded width 192 / 256): 0 off, 1 burst refills, 2 hooked; launches below chain_pair_min_m rows stay on chain.hip
     int chain_small_m = 4096;                // chain launches of at most this many rows run as 2-wave workgroups (small-batch latency; bit-identical rows)
     int chain_max_dim = 256;                 // fused chains only for stage widths <= this (tuning: wider stages on the per-GEMM / tiled kernels)
+    int tiled_auto = 1;                      // wide_gemm = 0: configurations whose widest stage lies in (tiled_min_k, 384] (EfficientConformer Medium: D = 360) send that stage to LayerNorm + the tiled
+                                             // GEMMs (+ 2.3 % on Medium, profiles/r6_100_*; neutral where wider stages exist - Large - which keep the row-stationary kernels there); 0 = as before round 6's last session
+    bool tiled_auto_on = false;              // the rule's outcome for this configuration (finalize)
     int tiled_min_k = 256;                   // with wide_gemm >= 2: layers with K > this leave the row-stationary kernels for LayerNorm + tiled GEMMs
     std::vector<float*> att_out;             // per block: device buffer [B][H][Tg][Tg] for the softmax maps of the next forward, or null
     int split_chain = 1;                     // split mode: the row-local work of a block as two kernels (sxf_chain.hip) where the width is built; 0 = per-module kernels (tests)
@@ -574,7 +577,7 @@ int run_ffn(EcEncoder* e, hipStream_t st, const bf16_t* a, int M, int D, const P
 // (the two paths round differently; tools/robustness_sweep.py) - the gemm.hip / gemm256.hip choice does not (bit-identical kernels).
 bool prefer_tiled(const EcEncoder* e, int M, int N, int K) {
     (void)M; (void)N;
-    return (e->wide_gemm == 2 || e->wide_gemm == 3) && K > e->tiled_min_k && K % 8 == 0;
+    return (e->wide_gemm == 2 || e->wide_gemm == 3 || (e->wide_gemm == 0 && e->tiled_auto && e->tiled_auto_on)) && K > e->tiled_min_k && K % 8 == 0;
 }
 
 // row-stationary single GEMM when K <= 384, else the tiled kernel
@@ -2058,6 +2061,11 @@ int effconf_encoder_finalize(EcEncoder* e) {
     if (hipDeviceSynchronize() != hipSuccess) return fail("upload failed");
     e->host.clear();
     e->e_cache.clear();
+    {   // tiled_auto: the widest stage of the configuration decides (a property of the configuration, never of the batch: one path per handle)
+        int dmax = 0;
+        for (const EcBlock& b : e->blocks) dmax = std::max(dmax, std::max(b.dim_model, b.dim_expand));
+        e->tiled_auto_on = dmax > e->tiled_min_k && dmax <= 384;
+    }
     e->finalized = true;
     return 0;
 }
@@ -2482,6 +2490,7 @@ int effconf_encoder_set_option(EcEncoder* e, const char* name, int32_t value) {
     if (!strcmp(name, "chain_nt")) { e->chain_nt = value; return 0; }
     if (!strcmp(name, "chain_w2cm")) { e->chain_w2cm = value; return 0; }
     if (!strcmp(name, "tiled_min_k")) { e->tiled_min_k = value; return 0; }
+    if (!strcmp(name, "tiled_auto")) { e->tiled_auto = value != 0; return 0; }
     if (!strcmp(name, "ffn_variant")) { if (value < 0 || value > 2) return fail("ffn_variant: 0, 1 or 2 (fused-FFN workgroup shapes)"); e->ffn_variant = value; return 0; }
     if (!strcmp(name, "head_major_odd")) { e->head_major_odd = value != 0; return 0; }
     if (!strcmp(name, "split_ffn")) { e->split_ffn = value != 0; return 0; }

@@ -227,6 +227,9 @@ int effconf_rnnt_greedy(EcRnnt* r, const float* enc_out, const int64_t* out_len,
  *   split; falls back to 1 where the shape is not supported; front ends wider than 128 channels / columns - EfficientConformer Medium, Large - run
  *   sublinear3.hip instead: option "sub3_auto", default 1), 3 = sublinear3.hip (round 6: the same fusion in chunks of (output frequency, 32 channels), any
  *   channel count / width up to 384; bit-identical to sublinear2.hip where both exist, slower there).
+ * "tiled_auto" (default 1; round 6): with "wide_gemm" = 0, a configuration whose widest stage lies in ("tiled_min_k" = 256, 384] - EfficientConformer Medium's
+ *   D = 360 - runs that stage as LayerNorm + tiled GEMMs instead of the row-stationary kernels (+ 2.3 % on Medium; decided per configuration at finalize,
+ *   never per batch: one rounding path per handle).  0 = the row-stationary kernels as before.
  * "fuse_chain" (default 1): 0 runs every GEMM of a block as its own kernel instead of the fused row-local chains (chain.hip);
  *   with the debug trace this exposes the intermediate residual-stream states that otherwise only exist in registers.
  * "attention_v2" (default 1): 0 = attention.hip; 1 = attention2.hip (same tiling; V read through ds_read_b64_tr_b16 instead of being
