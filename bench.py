@@ -569,7 +569,7 @@ def pmc_traffic(args, kernel_prefix):
 # kernel class -> (what it is, bounding roofline, rocprof kernel-name pattern for the PMC traffic)
 CLASS_INFO = {
     "mel": ("mel_kernel (log-mel frontend)", "hbm", r"mel_kernel"),
-    "subsample_conv": ("conv subsampling (sublinear2_kernel / sublinear_kernel: fused 3x3 conv + Linear; subsample_conv_* for two layers)", "mfma", r"sublinear2?_kernel|subsample_conv"),
+    "subsample_conv": ("conv subsampling (sublinear2_kernel / sublinear3_kernel / sublinear_kernel: fused 3x3 conv + Linear, sxf_sublin_kernel in split mode; subsample_conv_* for two layers)", "mfma", r"sublinear[23]?_kernel|sxf_sublin_kernel|subsample_conv"),
     "gemm_ffn": ("FFN-carrying kernels: chain_kernel A (pointwise-2 + FFN2 + block norm + next FFN1 + attention pre-norm + QKV in one pass over "
                  "the rows); ffn_fused_kernel / gemm_kernel where a chain is not supported", "mfma", r"chain_kernel<\d+, \d+, \d+, [123],|chain2_kernel<\d+, [123],|chain3_kernel<\d+, [123],|ffn_fused_kernel"),
     "gemm_other": ("chain_kernel B (attention output projection + conv-module LayerNorm + pointwise-1 + GLU), rs_gemm / gemm_kernel projections", "mfma",
