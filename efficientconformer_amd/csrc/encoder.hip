@@ -577,7 +577,7 @@ int run_ffn(EcEncoder* e, hipStream_t st, const bf16_t* a, int M, int D, const P
 // (the two paths round differently; tools/robustness_sweep.py) - the gemm.hip / gemm256.hip choice does not (bit-identical kernels).
 bool prefer_tiled(const EcEncoder* e, int M, int N, int K) {
     (void)M; (void)N;
-    return (e->wide_gemm == 2 || e->wide_gemm == 3 || (e->wide_gemm == 0 && e->tiled_auto && e->tiled_auto_on)) && K > e->tiled_min_k && K % 8 == 0;
+    return (e->wide_gemm == 2 || e->wide_gemm == 3 || (e->wide_gemm == 0 && (e->tiled_auto == 2 || (e->tiled_auto && e->tiled_auto_on)))) && K > e->tiled_min_k && K % 8 == 0;
 }
 
 // row-stationary single GEMM when K <= 384, else the tiled kernel
@@ -2490,7 +2490,7 @@ int effconf_encoder_set_option(EcEncoder* e, const char* name, int32_t value) {
     if (!strcmp(name, "chain_nt")) { e->chain_nt = value; return 0; }
     if (!strcmp(name, "chain_w2cm")) { e->chain_w2cm = value; return 0; }
     if (!strcmp(name, "tiled_min_k")) { e->tiled_min_k = value; return 0; }
-    if (!strcmp(name, "tiled_auto")) { e->tiled_auto = value != 0; return 0; }
+    if (!strcmp(name, "tiled_auto")) { e->tiled_auto = value; return 0; }      // 2: every layer with K in (tiled_min_k, 384] whatever the widest stage (tuning)
     if (!strcmp(name, "ffn_variant")) { if (value < 0 || value > 2) return fail("ffn_variant: 0, 1 or 2 (fused-FFN workgroup shapes)"); e->ffn_variant = value; return 0; }
     if (!strcmp(name, "head_major_odd")) { e->head_major_odd = value != 0; return 0; }
     if (!strcmp(name, "split_ffn")) { e->split_ffn = value != 0; return 0; }
