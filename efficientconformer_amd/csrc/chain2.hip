@@ -182,14 +182,14 @@ __global__ __launch_bounds__(NW2 * 64, 1) void chain2_kernel(const ChainDev2 cd,
     auto advance = [&]() __attribute__((always_inline)) -> const char* {
         if constexpr (DUTY) {
             // the issuer of chunk gc has nothing younger in its queue than the stores it issued since (chunk gc + 2 comes in iteration gc)
-            if (cw == (gc & 1)) wait_vmcnt_dyn(st1 + st2);
+            if (cw == (gc & 1)) wait_vmcnt_dyn(p.count_stores ? st1 + st2 : 0);      // stores may retire before an older DMA (chain.hip, advance()): drain, do not count them
         } else {
             constexpr int MAXC = NBUF2 - 2;
             int ahead = total - 1 - gc;
             const int rem = ahead;
             ahead = ahead < 0 ? 0 : (ahead > MAXC ? MAXC : ahead);
             if (st1 + st2 == 0) wait_chunks<PER, MAXC>(rem);
-            else wait_vmcnt_dyn(PER * ahead + st1 + st2);
+            else wait_vmcnt_dyn(PER * ahead + (p.count_stores ? st1 + st2 : 0));           // without the stores since: they may retire before an older DMA (chain.hip, advance())
         }
         C2_TICK(1);
         st2 = st1; st1 = 0;

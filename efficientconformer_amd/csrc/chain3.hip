@@ -431,7 +431,7 @@ __global__ __launch_bounds__(NW3 * 64, 1) void chain3_kernel(const ChainDev3 cd,
         const int rem = ahead;
         ahead = ahead < 0 ? 0 : (ahead > MAXC ? MAXC : ahead);
         if (st1 + st2 == 0) wait_chunks<PER, MAXC>(rem);
-        else wait_vmcnt_dyn(PER * ahead + st1 + st2);
+        else wait_vmcnt_dyn(PER * ahead + (p.count_stores ? st1 + st2 : 0));               // without the stores since: they may retire before an older DMA (chain.hip, advance())
         C3_TICK(1);
         st2 = st1; st1 = 0;
         wg_barrier();

@@ -99,6 +99,7 @@ struct EcEncoder {
     int ctc_mfma = 2;                        // CTC head: 2 split-bf16 operands on the bf16 MFMA (bf16 path; fp32 mode falls back to 1), 1 fp32 MFMA (bit-identical to 0), 0 the VALU kernel
     int attention_v2 = 1;                    // 0: attention.hip; 1 (default) / 2: attention2.hip variants where they support the head width (padded <= 160)
     // tuning / test options that used to be process-global environment switches (effconf_encoder_set_option)
+    int chain_count_stores = 0;              // measurement only: the unsafe counted waits of rounds 3 - 6 (kernels.h: ChainParams::count_stores)
     int chain_variant = 1, chain_full_max = 192, attn_waves = 4, rs_variant = 0, ffn_variant = 0;
     int chain_pair_min_d = 193, chain_nt = 0, chain_w2cm = 1;   // round 5 defaults: the column-pair kernels at padded width 256 (D = 240: 147 -> 119 us per tail + head; at 192 they cost more per row than chain.hip's 256-row workgroups)
     int dwconv_mfma = 1;                         // stride-1 depthwise convolutions on the matrix pipe (conv.hip dwconv_mfma_kernel): 1 = kernel size 15 (the Efficient Conformer
@@ -774,7 +775,7 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
             // FFN1 and the Q/K/V projection of this block already ran inside the previous block's tail chain
         } else if (chain_head) {
             ChainParams cp{};
-            cp.variant = e->chain_variant; cp.small_m = e->chain_small_m; cp.pair = e->chain_pair; cp.pair_small_max = e->chain_pair_min_m - 1; cp.pair_min_d = e->chain_pair_min_d; cp.nt = e->chain_nt; cp.w2cm = e->chain_w2cm;
+            cp.variant = e->chain_variant; cp.count_stores = e->chain_count_stores; cp.small_m = e->chain_small_m; cp.pair = e->chain_pair; cp.pair_small_max = e->chain_pair_min_m - 1; cp.pair_min_d = e->chain_pair_min_d; cp.nt = e->chain_nt; cp.w2cm = e->chain_w2cm;
             fill_chain_head(cp, W, D, F1c(b), qT, qTp, p);
             cp.M = M; cp.X = x; cp.ldx = D; cp.Y = x; cp.ldy = D; cp.consts = W.cc_head;
             PROF(PC_GEMM_FFN, 2.0 * M * (double)D * (2.0 * D * b.ff_ratio + 3.0 * D), (double)M * D * 16 + 22.0 * D * D);
@@ -851,7 +852,7 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
             snprintf(nm, sizeof(nm), "blocks.%d.att_o", k); trace_add(e, st, nm, o, M, D, ld8(D), 1);
             if (chain_b) {
                 ChainParams cp{};
-                cp.variant = e->chain_variant; cp.small_m = e->chain_small_m; cp.pair = e->chain_pair; cp.pair_small_max = e->chain_pair_min_m - 1; cp.pair_min_d = e->chain_pair_min_d; cp.nt = e->chain_nt; cp.w2cm = e->chain_w2cm;
+                cp.variant = e->chain_variant; cp.count_stores = e->chain_count_stores; cp.small_m = e->chain_small_m; cp.pair = e->chain_pair; cp.pair_small_max = e->chain_pair_min_m - 1; cp.pair_min_d = e->chain_pair_min_d; cp.nt = e->chain_nt; cp.w2cm = e->chain_w2cm;
                 cp.M = M; cp.D = D; cp.X = x; cp.ldx = D; cp.Y = x; cp.ldy = D; cp.A = o; cp.lda = ld8(D);
                 cp.g0 = ChainGemm{W.c_outp.w, W.c_outp.ldw, W.c_outp.bias, 0};
                 cp.ln[0] = ChainLn{W.ln_conv.g, W.ln_conv.b};
@@ -895,7 +896,7 @@ int forward_core(EcEncoder* e, const float* mel, const int64_t* in_len, int from
                 next_head = W.cc_full && nbk.dim_model <= e->chain_max_dim && e->bw[k + 1].chain_in && chain_full_supported(De, pair_on(e, De, Mo) ? 256 : e->chain_full_max) && (((nbk.group_size * nbk.dim_model / nbk.num_heads) % 2) == 0 || !head_major_odd) && nbk.dim_model == De;
             }
             ChainParams cp{};
-            cp.variant = e->chain_variant; cp.small_m = e->chain_small_m; cp.pair = e->chain_pair; cp.pair_small_max = e->chain_pair_min_m - 1; cp.pair_min_d = e->chain_pair_min_d; cp.nt = e->chain_nt; cp.w2cm = e->chain_w2cm;
+            cp.variant = e->chain_variant; cp.count_stores = e->chain_count_stores; cp.small_m = e->chain_small_m; cp.pair = e->chain_pair; cp.pair_small_max = e->chain_pair_min_m - 1; cp.pair_min_d = e->chain_pair_min_d; cp.nt = e->chain_nt; cp.w2cm = e->chain_w2cm;
             cp.M = Mo; cp.D = De; cp.X = x; cp.ldx = De; cp.Y = xo; cp.ldy = De; cp.A = cbuf; cp.lda = ld8(De);
             cp.g0 = ChainGemm{W.c_pw2.w, W.c_pw2.ldw, W.c_pw2.bias, 0};
             cp.ln[0] = ChainLn{W.ln_ffn2.g, W.ln_ffn2.b};
@@ -2490,6 +2491,7 @@ int effconf_encoder_set_option(EcEncoder* e, const char* name, int32_t value) {
     if (!strcmp(name, "chain_nt")) { e->chain_nt = value; return 0; }
     if (!strcmp(name, "chain_w2cm")) { e->chain_w2cm = value; return 0; }
     if (!strcmp(name, "tiled_min_k")) { e->tiled_min_k = value; return 0; }
+    if (!strcmp(name, "chain_count_stores")) { e->chain_count_stores = value != 0; return 0; }
     if (!strcmp(name, "tiled_auto")) { e->tiled_auto = value; return 0; }      // 2: every layer with K in (tiled_min_k, 384] whatever the widest stage (tuning)
     if (!strcmp(name, "ffn_variant")) { if (value < 0 || value > 2) return fail("ffn_variant: 0, 1 or 2 (fused-FFN workgroup shapes)"); e->ffn_variant = value; return 0; }
     if (!strcmp(name, "head_major_odd")) { e->head_major_odd = value != 0; return 0; }

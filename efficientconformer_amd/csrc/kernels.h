@@ -103,6 +103,8 @@ struct ChainParams {
     bf16_t* glu; int ldg, Ng;           // GLU output [M][ldg], Ng channels
     const float* consts;                // biases / block-norm gamma, beta / u, v as ONE zero padded block laid out by chain_const_layout
     int variant;                        // option "chain_variant": 1 = 4-wave workgroups (two per CU) at KS = 8
+    int count_stores;                   // option "chain_count_stores" (measurement only, default 0): 1 = the counted ring waits of rounds 3 - 6 that also allow the global stores
+                                        // since the last barrier to stay outstanding - UNSAFE: a store can retire before an older LDS-DMA (chain.hip, advance())
     int small_m;                        // option "chain_small_m": launches of at most this many rows use 2-wave workgroups (64 rows): see launch_chain_kind
     int pair_min_d;                     // option "chain_pair_min_d": narrower stages stay on chain.hip
     int w2cm;                           // option "chain_w2cm": chain2.hip streams the FFN second weights from their chunk-major images
