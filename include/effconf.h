@@ -227,6 +227,8 @@ int effconf_rnnt_greedy(EcRnnt* r, const float* enc_out, const int64_t* out_len,
  *   split; falls back to 1 where the shape is not supported; front ends wider than 128 channels / columns - EfficientConformer Medium, Large - run
  *   sublinear3.hip instead: option "sub3_auto", default 1), 3 = sublinear3.hip (round 6: the same fusion in chunks of (output frequency, 32 channels), any
  *   channel count / width up to 384; bit-identical to sublinear2.hip where both exist, slower there).
+ * "chain_count_stores" (default 0; measurement only): 1 = the weight-ring waits of rounds 3 - 6, which also allowed global stores to stay outstanding - UNSAFE (a store can
+ *   retire before an older LDS-DMA; profiles/r6_108_ring_wait_fix.txt): kept to reproduce the finding, never for production.
  * "tiled_auto" (default 1; round 6): with "wide_gemm" = 0, a configuration whose widest stage lies in ("tiled_min_k" = 256, 384] - EfficientConformer Medium's
  *   D = 360 - runs that stage as LayerNorm + tiled GEMMs instead of the row-stationary kernels (+ 2.3 % on Medium; decided per configuration at finalize,
  *   never per batch: one rounding path per handle).  0 = the row-stationary kernels as before.
