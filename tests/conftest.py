@@ -12,8 +12,6 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    config.addinivalue_line("markers", "run_last: collected behind every other test (a test with one unexplained failure on record: under `-x` its failure must not "
-                                       "keep the rest of the suite from running; it still fails the run)")
     try:        # the oracle (torch fp32 on the host) is several times slower with one thread per core of a 128-core box than with 16
         import torch
         torch.set_num_threads(min(16, os.cpu_count() or 16))
@@ -25,8 +23,3 @@ def pytest_configure(config):
 def golden_dir():
     return GOLDEN
 
-
-def pytest_collection_modifyitems(config, items):
-    last = [it for it in items if it.get_closest_marker("run_last")]
-    if last:
-        items[:] = [it for it in items if not it.get_closest_marker("run_last")] + last
