@@ -383,3 +383,31 @@ def test_chunked_bf16_front_end_vs_oracle_linear_stage_and_ragged_equals_alone(n
         tb = int(alone_len[0])
         assert int(rag_len[b]) == tb and torch.equal(rag[b, :tb], alone[0, :tb]), (b, float((rag[b, :tb] - alone[0, :tb]).abs().max()))
         assert not bool(rag[b, tb:].any())
+
+
+# ------------------------------------------------------------------ the bench's configuration reproduces itself
+@pytest.mark.parametrize("precision,iters", [("bf16", 300), ("split", 60)])
+def test_ragged_forward_on_three_streams_reproduces_itself_bit_for_bit(precision, iters):
+    """EfficientConformerCTCSmall, B = 256 LibriSpeech-shaped utterances sorted by length, ragged, 3 row ranges on 3 streams (bench.py's configuration): every forward
+    equals the first one bit for bit.  With the weight-ring waits of rounds 3 - 6 (option chain_count_stores = 1: global stores counted into the allowed vmcnt although a
+    store can retire before an older LDS-DMA) 23 % of these forwards carried one or two utterances - the last of a row range - perturbed by ~1e-2
+    (profiles/r6_108_ring_wait_fix.txt); no parity test could see that, a repetition test does."""
+    m, _ = _model("EfficientConformerCTCSmall", 5)
+    enc = m.encoder
+    enc.precision = precision
+    B = 256
+    lens = synth.libri_lengths(B, seed=1234)[:B]
+    lens = lens[np.argsort(-lens, kind="stable")].copy()
+    audio = torch.from_numpy(synth.make_audio(lens, seed=7)).cuda()
+    ln = torch.from_numpy(lens).cuda()
+    enc.ragged, enc.sub_batches = True, 3
+    ref, ref_len, _ = enc(audio, ln, x_len_host=lens)
+    assert bool(torch.isfinite(ref).all())
+    bad = []
+    for it in range(iters):
+        got, got_len, _ = enc(audio, ln, x_len_host=lens)
+        torch.cuda.synchronize()
+        if not (torch.equal(got, ref) and torch.equal(got_len, ref_len)):
+            d = got != ref
+            bad.append((it, d.flatten(1).any(1).nonzero().flatten().tolist()[:4], float((got - ref).abs().max())))
+    assert not bad, (len(bad), bad[:5])
