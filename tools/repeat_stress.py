@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The bench's own configuration (EfficientConformerCTCSmall, B = 256 LibriSpeech-shaped, ragged, 3 row ranges on 3 streams) run N times: every forward must reproduce the
-first one bit for bit.   python tools/repeat_stress.py [iterations] [name=value library options ...]"""
+first one bit for bit.   python tools/repeat_stress.py [iterations] [model=NAME] [precision=bf16|split] [batch=B] [name=value library options ...]"""
 import sys
 
 import torch
@@ -10,12 +10,19 @@ import bench
 from efficientconformer_amd import synth
 
 n_it = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-opts = [a.split("=") for a in sys.argv[2:]]
-cfg, model, sd = bench.build_model("EfficientConformerCTCSmall")
+name, precision, B = "EfficientConformerCTCSmall", "bf16", 256
+opts = []
+for a in sys.argv[2:]:
+    k, v = a.split("=")
+    if k == "model": name = v
+    elif k == "precision": precision = v
+    elif k == "batch": B = int(v)
+    else: opts.append((k, v))
+cfg, model, sd = bench.build_model(name)
 model = model.cuda()
+model.encoder.precision = precision
 for k, v in opts:
     model.encoder.set_option(k, int(v))
-B = 256
 lens = synth.libri_lengths(B, seed=1234)[:B]
 lens = -((-lens)).astype(lens.dtype)
 order = sorted(range(B), key=lambda i: -int(lens[i]))
@@ -35,4 +42,4 @@ for it in range(n_it):
             d = got != ref
             utt = d.flatten(1).any(1).nonzero().flatten().tolist()
             print("iteration %d: %d elements differ, utterances %s, max |d| %.3e" % (it, int(d.sum()), utt[:8], float((got - ref).abs().max())))
-print("iterations %d, mismatches %d, options %s" % (n_it, bad, opts))
+print("%s %s B=%d: iterations %d, mismatches %d, options %s" % (name, precision, B, n_it, bad, opts))
