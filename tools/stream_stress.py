@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Stress of the one test with an unexplained failure on record (tests/test_gpu_encoder.py::test_sub_batch_streams_are_bit_identical_at_librispeech_batch_sizes):
+"""Stress that made the rare failure of one bit-identity test reproducible and led to the weight-ring wait fix (profiles/r6_108_ring_wait_fix.txt) (tests/test_gpu_encoder.py::test_sub_batch_streams_are_bit_identical_at_librispeech_batch_sizes):
 EfficientConformerCTCSmall, B = 65 with one very short utterance, 2 / 3 row ranges against one stream, N iterations in ONE process, optionally with unrelated torch work on
 another stream in flight.  Prints where the first differences sit (utterance, rows, size).   python tools/stream_stress.py [iterations] [noise 0/1]"""
 import sys
